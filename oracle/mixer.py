@@ -1,0 +1,88 @@
+"""FastVim bidirectional pooled Mamba mixer oracle (test infrastructure; see oracle/__init__.py).
+
+Follows ``Mamba.forward`` of the FastVim mixer, non-fused default path
+(mamba-1p1p1/mamba_ssm/modules/mamba_simple_faster.py:181-457), and with
+``tokens_per_patch > 1`` the Channel-First channel mixer
+(mamba_simple_channel_faster.py:181-408).  Written flip-free: the reference's
+``x.flip(-1)`` + causal conv + scan + ``out_b.flip(-1)`` is restated as an
+anti-causal conv on the original order, row means in original order and a scan
+over pooled positions in descending order.
+"""
+import torch
+import torch.nn.functional as F
+
+from .conv import causal_conv1d_oracle
+from .scan import selective_scan_oracle
+
+
+def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd):
+    """One scan direction.  x_bdl: (B, d_in, L) in compute dtype.
+    Returns out (B, d_in, L) = expand(scan(pool(conv(x)))) + D * conv(x)."""
+    Bsz, d_in, L = x_bdl.shape
+    w = p[f"conv1d{sfx}.weight"].to(cd).reshape(d_in, -1)
+    b = p.get(f"conv1d{sfx}.bias")
+    # mamba_simple_faster.py:274-285 (conv + SiLU on x / on flipped x)
+    xc = causal_conv1d_oracle(x_bdl, w, b, "silu", anticausal=reverse, compute_dtype=cd, out_dtype=cd)
+    # :287-305 pooling across `cols` (channel variant: mamba_simple_channel_faster.py:242-256)
+    grid = xc.reshape(Bsz, d_in, rows, cols, tpp)
+    if collapse == "mean":
+        pooled = grid.mean(3)
+        if scaling != 1:
+            pooled = pooled * scaling
+    elif collapse == "max":
+        pooled = grid.max(3).values
+    else:
+        raise NotImplementedError(collapse)
+    pooled = pooled.reshape(Bsz, d_in, rows * tpp)                       # (B, d_in, Lc)
+    Lc = rows * tpp
+    # :321-337 x_proj -> (dt, B, C); dt_proj without bias (bias goes into the scan)
+    Wx = p[f"x_proj{sfx}.weight"].to(cd)
+    Wdt = p[f"dt_proj{sfx}.weight"].to(cd)
+    R = Wdt.shape[1]
+    N = (Wx.shape[0] - R) // 2
+    x_dbl = pooled.permute(0, 2, 1).reshape(Bsz * Lc, d_in) @ Wx.t()    # (B*Lc, R+2N)
+    dt = (x_dbl[:, :R] @ Wdt.t()).reshape(Bsz, Lc, d_in).permute(0, 2, 1)
+    Bm = x_dbl[:, R:R + N].reshape(Bsz, Lc, N).permute(0, 2, 1)
+    Cm = x_dbl[:, R + N:].reshape(Bsz, Lc, N).permute(0, 2, 1)
+    A = -torch.exp(p[f"A{sfx}_log"].float()).to(cd)                      # :197-198
+    # :343-354 selective scan, D=None, z=None, softplus, delta_bias = dt_proj.bias
+    y = selective_scan_oracle(pooled, dt, A, Bm, Cm, None, None, p[f"dt_proj{sfx}.bias"].float(),
+                              True, False, compute_dtype=cd, out_dtype=cd, reverse=reverse)
+    # :356-358 repeat_interleave(cols) + D * conv_out
+    y = y.reshape(Bsz, d_in, rows, 1, tpp).expand(Bsz, d_in, rows, cols, tpp).reshape(Bsz, d_in, L)
+    return y + p[f"D{sfx}"].float().to(cd)[None, :, None] * xc
+
+
+def fastvim_mixer_oracle(p, hidden, token_size, tokens_per_patch=1, collapse_method="mean",
+                         scaling_factor=1, use_norm_after_ssm=True, ln_eps=1e-5,
+                         compute_dtype=torch.float64, out_dtype=None):
+    """p: dict of tensors keyed like the reference mixer's state_dict
+    (``in_proj.weight``, ``conv1d.weight`` (d_in,1,W), ``conv1d.bias``, ``x_proj.weight``,
+    ``dt_proj.weight``, ``dt_proj.bias``, ``A_log``, ``D``, the same with ``_b``,
+    ``layernorm.weight/bias``, ``out_proj.weight``, optional ``gamma``).
+    hidden: (B, L, d_model) with L = rows*cols*tokens_per_patch.  Returns (B, L, d_model)."""
+    cd = compute_dtype
+    out_dtype = hidden.dtype if out_dtype is None else out_dtype
+    rows, cols = token_size
+    tpp = tokens_per_patch
+    Bsz, L, d = hidden.shape
+    assert L == rows * cols * tpp
+    W_in = p["in_proj.weight"].to(cd)
+    d_in = W_in.shape[0] // 2
+    xz = hidden.to(cd) @ W_in.t()                                        # :189-193
+    if p.get("in_proj.bias") is not None:
+        xz = xz + p["in_proj.bias"].to(cd)
+    x = xz[..., :d_in].permute(0, 2, 1)                                  # (B, d_in, L)
+    z = xz[..., d_in:]                                                   # (B, L, d_in)
+    out_f = _direction(x, p, "", rows, cols, tpp, collapse_method, scaling_factor, False, cd)
+    out_b = _direction(x, p, "_b", rows, cols, tpp, collapse_method, scaling_factor, True, cd)
+    o = ((out_f + out_b) / 2).permute(0, 2, 1)                           # :434-444
+    if use_norm_after_ssm:
+        o = F.layer_norm(o, (d_in,), p["layernorm.weight"].to(cd), p["layernorm.bias"].to(cd), ln_eps)
+    g = o * F.silu(z)
+    y = g @ p["out_proj.weight"].to(cd).t()
+    if p.get("out_proj.bias") is not None:
+        y = y + p["out_proj.bias"].to(cd)
+    if p.get("gamma") is not None:                                       # :455-456
+        y = y * p["gamma"].to(cd)
+    return y.to(out_dtype)

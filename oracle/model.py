@@ -1,0 +1,176 @@
+"""FastVim Block / backbone oracle (test infrastructure; see oracle/__init__.py).
+
+Functional restatement over a reference-keyed ``state_dict`` of
+``PatchEmbed.forward`` (models/fastvim.py:72-103), ``Block.forward`` (:146-212),
+``VisionMamba.forward_features`` / ``forward`` (:484-557).
+"""
+import math
+import zlib
+
+import torch
+import torch.nn.functional as F
+
+from .mixer import fastvim_mixer_oracle
+from .norm import fused_add_norm_oracle
+
+MIXER_KEYS = (
+    "A_log", "D", "A_b_log", "D_b", "in_proj.weight", "layernorm.weight", "layernorm.bias",
+    "conv1d.weight", "conv1d.bias", "x_proj.weight", "dt_proj.weight", "dt_proj.bias",
+    "conv1d_b.weight", "conv1d_b.bias", "x_proj_b.weight", "dt_proj_b.weight", "dt_proj_b.bias",
+    "out_proj.weight",
+)
+
+
+def state_dict_shapes(embed_dim=192, depth=24, img_size=224, patch_size=16, channels=3,
+                      num_classes=1000, d_state=16, d_conv=4, expand=2):
+    """Key -> shape table of the reference FastVim ``state_dict``
+    (checkpoint contract; models/fastvim.py:391-451,
+    mamba_simple_faster.py:78-177)."""
+    d, d_in = embed_dim, expand * embed_dim
+    R = math.ceil(d / 16)
+    ih, iw = (img_size, img_size) if isinstance(img_size, int) else img_size
+    gh, gw = ih // patch_size, iw // patch_size
+    shapes = {
+        "pos_embed": (1, gh * gw, d),
+        "patch_embed.proj.weight": (d, channels, patch_size, patch_size),
+        "patch_embed.proj.bias": (d,),
+        "head.weight": (num_classes, d),
+        "head.bias": (num_classes,),
+        "norm_f.weight": (d,),
+    }
+    for i in range(depth):
+        pre = f"layers.{i}."
+        shapes[pre + "norm.weight"] = (d,)
+        m = pre + "mixer."
+        shapes[m + "in_proj.weight"] = (2 * d_in, d)
+        shapes[m + "out_proj.weight"] = (d, d_in)
+        shapes[m + "layernorm.weight"] = (d_in,)
+        shapes[m + "layernorm.bias"] = (d_in,)
+        for sfx in ("", "_b"):
+            shapes[m + f"A{sfx}_log"] = (d_in, d_state)
+            shapes[m + f"D{sfx}"] = (d_in,)
+            shapes[m + f"conv1d{sfx}.weight"] = (d_in, 1, d_conv)
+            shapes[m + f"conv1d{sfx}.bias"] = (d_in,)
+            shapes[m + f"x_proj{sfx}.weight"] = (R + 2 * d_state, d_in)
+            shapes[m + f"dt_proj{sfx}.weight"] = (d_in, R)
+            shapes[m + f"dt_proj{sfx}.bias"] = (d_in,)
+    return shapes
+
+
+def make_state_dict(seed=0, **cfg):
+    """Deterministic synthetic parameters, re-derivable anywhere from (seed, key):
+    each tensor is drawn from ``Generator().manual_seed(crc32(key) ^ seed)`` with a
+    per-kind scale that keeps activations O(1) through 24 blocks.  Lets the 28 MB
+    FastVim-T state be rebuilt on the GPU box instead of committed."""
+    sd = {}
+    for key, shape in state_dict_shapes(**cfg).items():
+        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
+        r = torch.randn(shape, generator=g, dtype=torch.float32)
+        leaf = key.split("mixer.")[-1] if "mixer." in key else key
+        if leaf.startswith("A") and leaf.endswith("_log"):
+            n = shape[1]
+            t = torch.log(torch.arange(1, n + 1, dtype=torch.float32))[None, :] + 0.05 * r
+        elif leaf in ("D", "D_b"):
+            t = 1.0 + 0.1 * r
+        elif leaf.endswith("norm.weight") or leaf == "norm_f.weight":
+            t = 1.0 + 0.1 * r
+        elif leaf == "layernorm.bias":
+            t = 0.05 * r
+        elif leaf.startswith("dt_proj") and leaf.endswith(".bias"):
+            u = torch.rand(shape, generator=g)
+            dt = torch.exp(u * (math.log(0.1) - math.log(0.001)) + math.log(0.001)).clamp(min=1e-4)
+            t = dt + torch.log(-torch.expm1(-dt))
+        elif leaf.startswith("dt_proj") and leaf.endswith(".weight"):
+            t = r * shape[1] ** -0.5
+        elif leaf.startswith("conv1d") and leaf.endswith(".weight"):
+            t = 0.5 * r
+        elif leaf.endswith(".bias"):
+            t = 0.02 * r
+        elif leaf == "pos_embed":
+            t = 0.02 * r
+        elif leaf == "out_proj.weight":
+            t = r * (shape[1] ** -0.5) * 0.5
+        else:  # linear / conv weights: fan-in scaling
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = r * fan_in ** -0.5
+        sd[key] = t.contiguous()
+    return sd
+
+
+def _sub(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def patch_embed_oracle(sd, x, patch_size, cd):
+    """models/fastvim.py:72-103 with dynamic_img_pad=True, rowwise scan path:
+    Conv2d(k=s=patch) restated as patch-unfold + matmul."""
+    Bsz, C, H, W = x.shape
+    ps = patch_size
+    pad_h, pad_w = (ps - H % ps) % ps, (ps - W % ps) % ps
+    xf = F.pad(x.to(cd), (0, pad_w, 0, pad_h))
+    gh, gw = xf.shape[2] // ps, xf.shape[3] // ps
+    patches = xf.reshape(Bsz, C, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(Bsz, gh * gw, C * ps * ps)
+    Wp = sd["patch_embed.proj.weight"].to(cd).reshape(-1, C * ps * ps)
+    return patches @ Wp.t() + sd["patch_embed.proj.bias"].to(cd), (gh, gw)
+
+
+def fastvim_block_oracle(sd_layer, hidden, residual, layer_idx, token_size, *, norm_eps=1e-5,
+                         rotate_every_block=True, row_scale=None, compute_dtype=torch.float64,
+                         mixer_kwargs=None):
+    """models/fastvim.py:146-212 with fused_add_norm=True, rms_norm=True,
+    residual_in_fp32=True.  ``row_scale`` is the DropPath per-sample scale applied to
+    ``hidden`` before the add (:182-190).  Returns (hidden_out, residual_out)."""
+    cd = compute_dtype
+    h, res = fused_add_norm_oracle(hidden, sd_layer["norm.weight"], None, residual, norm_eps,
+                                   prenorm=True, residual_in_fp32=True, is_rms_norm=True,
+                                   row_scale=row_scale if residual is not None else None,
+                                   compute_dtype=cd)
+    T0, T1 = token_size
+    Bsz, M, d = h.shape
+    rot = rotate_every_block and layer_idx % 2 != 0
+    ts = token_size
+    if rot:                                                               # :192-200
+        h = h.reshape(Bsz, T0, T1, d).transpose(1, 2).reshape(Bsz, M, d)
+        ts = (T1, T0)                                                     # create_block :244-260
+    h = fastvim_mixer_oracle(_sub(sd_layer, "mixer."), h, ts, compute_dtype=cd, **(mixer_kwargs or {}))
+    if rot:                                                               # :204-210
+        h = h.reshape(Bsz, T1, T0, d).transpose(1, 2).reshape(Bsz, M, d)
+    return h, res
+
+
+def fastvim_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, rotate_every_block=True,
+                           final_pool_type="mean", row_scales=None, compute_dtype=torch.float64,
+                           return_features=False, return_hidden=False, mixer_kwargs=None):
+    """models/fastvim.py:484-557 (if_abs_pos_embed=True, fused_add_norm, rms_norm,
+    residual_in_fp32).  ``row_scales``: optional list of depth+1 per-sample DropPath scales
+    ((B,) tensors or None); entry i is applied inside block i, entry ``depth`` before norm_f."""
+    cd = compute_dtype
+    h, token_size = patch_embed_oracle(sd, x, patch_size, cd)
+    h = h + sd["pos_embed"].to(cd)                                        # :500
+    h = h.to(cd if cd == torch.float64 else torch.float32)
+    residual = None
+    hiddens = []
+    for i in range(depth):
+        rs = row_scales[i] if row_scales is not None else None
+        h, residual = fastvim_block_oracle(_sub(sd, f"layers.{i}."), h, residual, i, token_size,
+                                           norm_eps=norm_eps, rotate_every_block=rotate_every_block,
+                                           row_scale=rs, compute_dtype=cd, mixer_kwargs=mixer_kwargs)
+        hiddens.append(h)
+    rs = row_scales[depth] if row_scales is not None else None
+    h = fused_add_norm_oracle(h, sd["norm_f.weight"], None, residual, norm_eps, prenorm=False,
+                              residual_in_fp32=True, is_rms_norm=True, row_scale=rs, compute_dtype=cd)
+    if final_pool_type == "mean":                                         # :541-542
+        feat = h.to(cd).mean(1)
+    elif final_pool_type == "none":
+        feat = h[:, -1, :].to(cd)
+    else:
+        feat = h.to(cd)
+    if return_features:
+        return (feat, hiddens) if return_hidden else feat
+    logits = feat @ sd["head.weight"].to(cd).t() + sd["head.bias"].to(cd)  # :554
+    if final_pool_type == "max":
+        logits = logits.max(1)[0]
+    return (logits, hiddens) if return_hidden else logits

@@ -1,0 +1,249 @@
+"""Generate golden vectors from the imported reference (build container only).
+
+    python tests/golden/gen_golden.py
+
+Imports insitro/FastVim from /root/reference on CPU through ``_ref_import`` and
+freezes inputs + reference outputs as small ``.pt`` fixtures next to this file.
+The fixtures are data (inputs / expected outputs); nothing of the reference's
+source is stored.  ``tests/test_oracle_golden.py`` pins ``oracle/`` against them
+and the ``-m gpu`` tests pin the HIP path against them.
+
+Input distributions follow the reference's own tests:
+mamba-1p1p1/tests/ops/test_selective_scan.py:61-122 and
+fastvim_kernel/mamba-1p1p1/tests/test_compressed_scan.py:54-127.
+"""
+import os
+import sys
+import warnings
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+warnings.filterwarnings("ignore")
+
+from _ref_import import load_reference  # noqa: E402
+
+ref = load_reference()
+from oracle.model import make_state_dict  # noqa: E402  (seeded parameter recipe only)
+
+
+def save(name, obj):
+    path = os.path.join(HERE, name)
+    torch.save(obj, path)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------
+def scan_case(batch, dim, L, N, groups=1, has_D=True, has_z=True, softplus=True, seed=0):
+    torch.manual_seed(seed)
+    A = -0.5 * torch.rand(dim, N)
+    bshape = (batch, N, L) if groups == 1 else (batch, groups, N, L)
+    B = torch.randn(*bshape)
+    C = torch.randn(*bshape)
+    D = torch.randn(dim) if has_D else None
+    z = torch.randn(batch, dim, L) if has_z else None
+    delta_bias = 0.5 * torch.rand(dim)
+    u = torch.randn(batch, dim, L)
+    delta = 0.5 * torch.rand(batch, dim, L)
+    inp = dict(u=u, delta=delta, A=A, B=B, C=C, D=D, z=z, delta_bias=delta_bias)
+    leaves = {k: v.clone().requires_grad_() for k, v in inp.items() if v is not None}
+    out, last = ref.ssi.selective_scan_ref(
+        leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves.get("D"),
+        z=leaves.get("z"), delta_bias=leaves["delta_bias"], delta_softplus=softplus,
+        return_last_state=True)
+    g = torch.randn_like(out)
+    out.backward(g)
+    grads = {k: v.grad.clone() for k, v in leaves.items()}
+    # bf16 I/O case: the reference rounds once at the end (selective_scan_interface.py:205)
+    bf = {k: (v.bfloat16() if k in ("u", "delta", "B", "C", "z") and v is not None else v)
+          for k, v in inp.items()}
+    out_bf16 = ref.ssi.selective_scan_ref(bf["u"], bf["delta"], bf["A"], bf["B"], bf["C"], bf["D"],
+                                          z=bf["z"], delta_bias=bf["delta_bias"],
+                                          delta_softplus=softplus)
+    return dict(inputs=inp, softplus=softplus, out=out.detach(), last_state=last.detach(), g=g,
+                grads=grads, out_bf16=out_bf16)
+
+
+def gen_scan():
+    cases = {}
+    for L in (14, 112, 128, 256):
+        cases[f"b2_d4_L{L}_n8"] = scan_case(2, 4, L, 8)
+    cases["b2_d8_L14_n16"] = scan_case(2, 8, 14, 16)
+    cases["b2_d4_L128_n8_g2"] = scan_case(2, 4, 128, 8, groups=2)
+    cases["b2_d4_L14_n8_noDz"] = scan_case(2, 4, 14, 8, has_D=False, has_z=False)
+    cases["b2_d4_L64_n8_nosoftplus"] = scan_case(2, 4, 64, 8, softplus=False)
+    cases["b1_d2_L2100_n8"] = scan_case(1, 2, 2100, 8)   # > one 2048 chunk of the reference kernel
+    save("scan.pt", cases)
+
+
+def gen_compressed_scan():
+    # the fork's own ref == scan at Lc, repeat_interleave(cf), + D*u_full
+    # (fastvim_kernel/.../faster_mamba_ssm/ops/selective_scan_interface.py:243-248); it cannot be
+    # imported (its module imports the CUDA extension and prints), so the vectors are produced
+    # with the main reference scan + exactly those two torch ops.
+    cases = {}
+    for cf, Lc, has_D in ((1, 6, True), (2, 64, True), (14, 14, True), (8, 32, False)):
+        torch.manual_seed(0)
+        batch, dim, N = 2, 4, 8
+        L = Lc * cf
+        A = -0.5 * torch.rand(dim, N)
+        B = torch.randn(batch, N, Lc)
+        C = torch.randn(batch, N, Lc)
+        D = torch.randn(dim) if has_D else None
+        delta_bias = 0.5 * torch.rand(dim)
+        u_full = torch.randn(batch, dim, L)
+        u_c = u_full.reshape(batch, dim, Lc, cf).mean(-1)
+        delta = 0.5 * torch.rand(batch, dim, Lc)
+        y, last = ref.ssi.selective_scan_ref(u_c, delta, A, B, C, None, None, delta_bias, False, True)
+        out = y.repeat_interleave(cf, dim=2)
+        if D is not None:
+            out = out + u_full * D[:, None]
+        cases[f"cf{cf}_Lc{Lc}_D{int(has_D)}"] = dict(
+            inputs=dict(u_full=u_full, u_c=u_c, delta=delta, A=A, B=B, C=C, D=D, delta_bias=delta_bias),
+            out=out, last_state=last)
+    save("compressed_scan.pt", cases)
+
+
+def gen_conv():
+    cases = {}
+    for name, (Bsz, D, L, W, act, has_bias) in {
+        "b2_d8_L196_silu": (2, 8, 196, 4, "silu", True),
+        "b2_d8_L5_silu": (2, 8, 5, 4, "silu", True),
+        "b1_d4_L2_none": (1, 4, 2, 4, None, False),
+        "b2_d6_L33_w3": (2, 6, 33, 3, "silu", True),
+    }.items():
+        torch.manual_seed(1)
+        x = torch.randn(Bsz, D, L, requires_grad=True)
+        w = torch.randn(D, W, requires_grad=True)
+        b = torch.randn(D, requires_grad=True) if has_bias else None
+        y = ref.causal_conv1d_fn(x, w, b, act)
+        g = torch.randn_like(y)
+        y.backward(g)
+        cases[name] = dict(x=x.detach(), w=w.detach(), b=None if b is None else b.detach(), act=act,
+                           y=y.detach(), g=g, dx=x.grad, dw=w.grad, db=None if b is None else b.grad)
+    save("conv1d.pt", cases)
+
+
+def gen_norm():
+    cases = {}
+    torch.manual_seed(2)
+    for name, (rms, prenorm, has_res, xdt) in {
+        "rms_prenorm_res": (True, True, True, torch.float32),
+        "rms_prenorm_nores": (True, True, False, torch.float32),
+        "rms_final_res": (True, False, True, torch.float32),
+        "ln_prenorm_res": (False, True, True, torch.float32),
+        "rms_prenorm_res_bf16": (True, True, True, torch.bfloat16),
+    }.items():
+        x = torch.randn(2, 20, 48).to(xdt)
+        res = torch.randn(2, 20, 48) if has_res else None
+        w = 1 + 0.1 * torch.randn(48)
+        b = None if rms else 0.1 * torch.randn(48)
+        fn = ref.rms_norm_fn if rms else ref.layer_norm_fn
+        outs = fn(x, w, b, residual=res, prenorm=prenorm, residual_in_fp32=True, eps=1e-5)
+        cases[name] = dict(x=x, residual=res, w=w, b=b, rms=rms, prenorm=prenorm, eps=1e-5, out=outs)
+    save("norm.pt", cases)
+
+
+def _mixer_case(d_model, token_size, Bsz, sd=None, seed=3):
+    torch.manual_seed(seed)
+    m = ref.msf.Mamba(d_model, token_size=list(token_size))
+    if sd is not None:
+        m.load_state_dict(sd, strict=True)
+    else:
+        # move the special inits off their symmetric defaults so every parameter matters
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n in ("D", "D_b", "layernorm.weight"):
+                    p.add_(0.2 * torch.randn_like(p))
+                elif n in ("layernorm.bias", "conv1d.bias", "conv1d_b.bias"):
+                    p.add_(0.1 * torch.randn_like(p))
+                elif n in ("A_log", "A_b_log"):
+                    p.add_(0.1 * torch.randn_like(p))
+    L = token_size[0] * token_size[1]
+    h = torch.randn(Bsz, L, d_model, requires_grad=True)
+    y = m(h)
+    g = torch.randn_like(y)
+    y.backward(g)
+    grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    return m, dict(hidden=h.detach(), out=y.detach(), g=g, dhidden=h.grad.clone(), grads=grads,
+                   token_size=tuple(token_size))
+
+
+def gen_mixer():
+    cases = {}
+    m, c = _mixer_case(32, (4, 4), 2)
+    c["state_dict"] = {k: v.clone() for k, v in m.state_dict().items()}
+    cases["d32_4x4"] = c
+    m, c = _mixer_case(32, (3, 5), 2, seed=4)         # non-square grid
+    c["state_dict"] = {k: v.clone() for k, v in m.state_dict().items()}
+    cases["d32_3x5"] = c
+    # real FastVim-T mixer; parameters from the seeded recipe (not stored)
+    sd = make_state_dict(seed=11, embed_dim=192, depth=1)
+    msd = {k[len("layers.0.mixer."):]: v for k, v in sd.items() if k.startswith("layers.0.mixer.")}
+    m, c = _mixer_case(192, (14, 14), 1, sd=msd, seed=5)
+    keep = ("in_proj.weight", "A_log", "A_b_log", "D", "D_b", "x_proj.weight", "conv1d.weight",
+            "conv1d_b.bias", "dt_proj_b.bias", "layernorm.weight")
+    c["grads"] = {k: v for k, v in c["grads"].items() if k in keep and v.numel() <= 20000}
+    c["param_recipe"] = dict(seed=11, embed_dim=192, depth=1, prefix="layers.0.mixer.")
+    cases["d192_14x14"] = c
+    save("mixer.pt", cases)
+
+
+def gen_model():
+    cases = {}
+    fv = ref.fastvim
+    for name, img in (("tiny_64x64", (64, 64)), ("tiny_48x80", (48, 80))):
+        torch.manual_seed(6)
+        model = fv.VisionMamba(img_size=img, patch_size=16, depth=4, embed_dim=32, channels=3,
+                               num_classes=10, rms_norm=True, residual_in_fp32=True,
+                               fused_add_norm=True, final_pool_type="mean", if_abs_pos_embed=True,
+                               drop_path_rate=0.0)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith(("D", "D_b", "norm.weight", "layernorm.weight", "norm_f.weight")):
+                    p.add_(0.2 * torch.randn_like(p))
+                elif n.endswith(("layernorm.bias", "head.bias", "patch_embed.proj.bias")):
+                    p.add_(0.1 * torch.randn_like(p))
+        model.eval()
+        x = torch.randn(2, 3, *img)
+        hiddens = []
+        hooks = [l.register_forward_hook(lambda mod, i, o: hiddens.append(o[0].detach().clone()))
+                 for l in model.layers]
+        logits = model(x)
+        for hk in hooks:
+            hk.remove()
+        g = torch.randn_like(logits)
+        logits.backward(g)
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()
+                 if n in ("pos_embed", "head.weight", "layers.0.mixer.in_proj.weight",
+                          "layers.1.mixer.A_b_log", "layers.3.mixer.x_proj_b.weight",
+                          "layers.2.norm.weight", "patch_embed.proj.bias", "norm_f.weight",
+                          "layers.1.mixer.conv1d.weight", "layers.2.mixer.dt_proj.bias")}
+        cases[name] = dict(img=img, state_dict={k: v.clone() for k, v in model.state_dict().items()},
+                           x=x, logits=logits.detach(), hiddens=hiddens, g=g, grads=grads,
+                           cfg=dict(patch_size=16, depth=4, embed_dim=32, num_classes=10))
+    save("model_tiny.pt", cases)
+
+    # FastVim-T, bs=2 (BASELINE config 1): parameters and pixels from seeded recipes
+    sd = make_state_dict(seed=7, embed_dim=192, depth=24)
+    model = fv.vim_tiny_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2(drop_path_rate=0.0)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(123))
+    logits = model(x)
+    g = torch.randn(logits.shape, generator=torch.Generator().manual_seed(124))
+    logits.backward(g)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()
+             if n in ("head.bias", "norm_f.weight", "layers.0.norm.weight", "layers.23.mixer.D_b",
+                      "layers.12.mixer.A_log", "layers.5.mixer.dt_proj.bias", "patch_embed.proj.bias",
+                      "layers.7.mixer.conv1d_b.weight", "layers.0.mixer.x_proj.weight")}
+    save("model_fastvim_t.pt", dict(param_seed=7, x_seed=123, g_seed=124, x_probe=x[0, 0, :2, :8].clone(),
+                                     logits=logits.detach(), grads=grads))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model"]
+    for w in which:
+        globals()["gen_" + w]()
