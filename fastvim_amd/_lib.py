@@ -1,0 +1,67 @@
+"""ctypes binding of libfastvim_hip.so (C ABI: include/fastvim_hip.h).
+
+The product path fails loudly when the library is absent -- there is no fallback.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfastvim_hip.so")
+
+FV_F32, FV_BF16, FV_F16 = 0, 1, 2
+_DTYPES = {torch.float32: FV_F32, torch.bfloat16: FV_BF16, torch.float16: FV_F16}
+
+_lib = None
+
+# every symbol include/fastvim_hip.h declares (tests check the .so exports all of them)
+C_ABI_SYMBOLS = (
+    "fv_last_error", "fv_version",
+    "fv_selective_scan_fwd", "fv_selective_scan_bwd_workspace", "fv_selective_scan_bwd",
+)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m fastvim_amd.build` "
+                "(or __graft_entry__.build()). fastvim_amd has no CPU / eager fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.fv_last_error.restype = ctypes.c_char_p
+        _lib.fv_selective_scan_bwd_workspace.restype = ctypes.c_size_t
+    return _lib
+
+
+def dtype_code(dt):
+    try:
+        return _DTYPES[dt]
+    except KeyError:
+        raise RuntimeError(f"fastvim_amd: unsupported dtype {dt}") from None
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fastvim_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().fv_last_error().decode()
+        raise RuntimeError(f"{what}: {msg} (code {rc})")
+
+
+def i32(v):
+    return ctypes.c_int(int(v))

@@ -1,0 +1,62 @@
+"""Build libfastvim_hip.so (gfx950) in-tree with hipcc.  No torch headers involved:
+the library is a plain C-ABI shared object (include/fastvim_hip.h)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "csrc", "_obj")
+LIB = os.path.join(PKG, "libfastvim_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffast-math", "-fno-finite-math-only",
+         "-Wno-unused-result", "-DNDEBUG"]
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _deps_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(PKG, "..", "include", "fastvim_hip.h"))
+    hs.append(os.path.abspath(__file__))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, obj, verbose):
+    cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr)
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_m = _deps_mtime()
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+            jobs.append((src, obj))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(lambda j: _compile(j[0], j[1], verbose), jobs))
+    if jobs or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

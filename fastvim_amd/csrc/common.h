@@ -1,0 +1,86 @@
+// Shared device helpers for the FastVim gfx950 (CDNA4, wave64) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/fastvim_hip.h"
+
+#define FV_WAVE 64
+#define FV_LOG2E 1.4426950408889634f
+
+typedef __hip_bfloat16 bf16_t;
+
+// ---------------------------------------------------------------- errors
+void fv_set_error(const char* fmt, ...);
+#define FV_CHECK(cond, ...)                  \
+  do {                                       \
+    if (!(cond)) {                           \
+      fv_set_error(__VA_ARGS__);             \
+      return FV_ERR_INVALID;                 \
+    }                                        \
+  } while (0)
+#define FV_LAUNCH_CHECK()                                                 \
+  do {                                                                    \
+    hipError_t e_ = hipGetLastError();                                    \
+    if (e_ != hipSuccess) {                                               \
+      fv_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,         \
+                   hipGetErrorString(e_));                                \
+      return FV_ERR_HIP;                                                  \
+    }                                                                     \
+  } while (0)
+
+static inline int fv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- scalar type traits
+template <typename T> struct io;
+template <> struct io<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct io<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) {
+    return __uint_as_float(((uint32_t) * reinterpret_cast<const uint16_t*>(p)) << 16);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = __float2bfloat16(v); }
+};
+template <> struct io<__half> {
+  static __device__ __forceinline__ float ld(const __half* p) { return __half2float(*p); }
+  static __device__ __forceinline__ void st(__half* p, float v) { *p = __float2half(v); }
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+// round-to-nearest-even via the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float v) {
+  bf16_t h = __float2bfloat16(v);
+  return *reinterpret_cast<uint16_t*>(&h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float fv_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fv_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fv_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float fv_silu(float x) { return x / (1.0f + __expf(-x)); }
+// d/dx silu(x) = s * (1 + x * (1 - s))
+__device__ __forceinline__ float fv_silu_grad(float x) {
+  float s = fv_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+// softplus with the reference's threshold (selective_scan_fwd_kernel.cuh:153-156): x > 20 -> x
+__device__ __forceinline__ float fv_softplus(float x) { return x <= 20.0f ? log1pf(__expf(x)) : x; }
+
+// ---------------------------------------------------------------- wave64 collectives
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,610 @@
+// Selective scan in the reference layout (B, D, L), L contiguous -- the drop-in for
+// selective_scan_cuda.fwd/bwd (mamba-1p1p1/csrc/selective_scan/selective_scan.cpp:226-492).
+//
+// gfx950 design (not a translation of the cub BlockScan kernel):
+//  * one wave64 owns one (batch, channel) row at a time; a tile of LT = 64*V time steps is
+//    staged through LDS with element-coalesced global loads (any alignment, any L) and read
+//    back in the blocked arrangement (lane l owns steps [l*V, l*V+V));
+//  * the recurrence x_t = a_t x_{t-1} + b_t is evaluated as a work-efficient three-phase
+//    (Blelloch-style) scan of the affine maps (a, b): per-lane serial reduce over V steps,
+//    a wave-level scan of the 64 lane aggregates, per-lane down-sweep applying the carry;
+//  * the backward pass recomputes the in-tile forward states from tile-boundary states kept
+//    in LDS and runs the adjoint recurrence as the mirrored (high-to-low) three-phase scan;
+//  * dB/dC (sum over channels) are accumulated by the single wave that owns a
+//    (batch, group, split) slice, so there are no float atomics and results are deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int NC = 16;  // states staged per LDS pass
+
+struct Affine {  // x -> a*x + b
+  float a, b;
+};
+// apply `first` then `second`
+__device__ __forceinline__ Affine compose(Affine first, Affine second) {
+  return {first.a * second.a, second.a * first.b + second.b};
+}
+
+// inclusive scan over the 64 lanes, low lane applied first
+__device__ __forceinline__ Affine wave_scan_up(Affine v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    Affine p = {__shfl_up(v.a, o, 64), __shfl_up(v.b, o, 64)};
+    if (lane >= o) v = compose(p, v);
+  }
+  return v;
+}
+// inclusive scan over the 64 lanes, high lane applied first
+__device__ __forceinline__ Affine wave_scan_down(Affine v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    Affine p = {__shfl_down(v.a, o, 64), __shfl_down(v.b, o, 64)};
+    if (lane + o < 64) v = compose(p, v);
+  }
+  return v;
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void stage_row(const T* __restrict__ row, int t0, int L, float* s, int lane,
+                                          float fill) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    int e = i * 64 + lane, t = t0 + e;
+    s[e] = t < L ? io<T>::ld(row + t) : fill;
+  }
+}
+template <typename T, int V>
+__device__ __forceinline__ void unstage_row(T* __restrict__ row, int t0, int L, const float* s, int lane) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    int e = i * 64 + lane, t = t0 + e;
+    if (t < L) io<T>::st(row + t, s[e]);
+  }
+}
+
+struct ScanParams {
+  const void *u, *delta, *B, *C, *z, *dout;
+  const float *A, *D, *delta_bias;
+  void *out, *du, *ddelta, *dz;
+  float *last_state;
+  float *dB_part, *dC_part;              // variable: (S, batch, G, N, L); constant: unused
+  float *pA, *pD, *pbias, *pBc, *pCc;    // per-batch partials (batch, dim[, N])
+  int batch, dim, L, N, G, S;
+  int B_var, C_var, softplus;
+};
+
+// ------------------------------------------------------------------ forward
+template <typename T, int V>
+__global__ __launch_bounds__(64) void scan_bdl_fwd_kernel(ScanParams p) {
+  constexpr int LT = 64 * V;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_u = smem;                 // LT
+  float* s_d = s_u + LT;             // LT
+  float* s_y = s_d + LT;             // LT (also z staging)
+  float* s_B = s_y + LT;             // NC*LT
+  float* s_C = s_B + NC * LT;        // NC*LT
+  float* s_carry = s_C + NC * LT;    // N
+
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;        // b*dim + d
+  const int b = row / p.dim, d = row % p.dim;
+  const int g = d / (p.dim / p.G);
+  const T* u = (const T*)p.u + (size_t)row * p.L;
+  const T* dl = (const T*)p.delta + (size_t)row * p.L;
+  const T* z = p.z ? (const T*)p.z + (size_t)row * p.L : nullptr;
+  T* out = (T*)p.out + (size_t)row * p.L;
+  const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+  const float Dd = p.D ? p.D[d] : 0.f;
+  const float* Arow = p.A + (size_t)d * p.N;
+
+  for (int n = lane; n < p.N; n += 64) s_carry[n] = 0.f;
+
+  for (int t0 = 0; t0 < p.L; t0 += LT) {
+    __syncthreads();
+    stage_row<T, V>(u, t0, p.L, s_u, lane, 0.f);
+    stage_row<T, V>(dl, t0, p.L, s_d, lane, 0.f);
+    __syncthreads();
+    float uj[V], dj[V], yj[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      int e = lane * V + j;
+      uj[j] = s_u[e];
+      float dv = s_d[e] + bias;
+      if (p.softplus) dv = fv_softplus(dv);
+      dj[j] = (t0 + e < p.L) ? dv : 0.f;   // delta = 0 beyond L: a = 1, b = 0 (identity)
+      yj[j] = 0.f;
+    }
+    for (int nc = 0; nc < p.N; nc += NC) {
+      const int nn = min(NC, p.N - nc);
+      __syncthreads();
+      if (p.B_var) {
+        const T* Bg = (const T*)p.B + ((size_t)(b * p.G + g) * p.N + nc) * p.L;
+        for (int k = 0; k < nn; ++k) stage_row<T, V>(Bg + (size_t)k * p.L, t0, p.L, s_B + k * LT, lane, 0.f);
+      }
+      if (p.C_var) {
+        const T* Cg = (const T*)p.C + ((size_t)(b * p.G + g) * p.N + nc) * p.L;
+        for (int k = 0; k < nn; ++k) stage_row<T, V>(Cg + (size_t)k * p.L, t0, p.L, s_C + k * LT, lane, 0.f);
+      }
+      __syncthreads();
+      for (int k = 0; k < nn; ++k) {
+        const int n = nc + k;
+        const float An = Arow[n] * FV_LOG2E;
+        const float Bc = p.B_var ? 0.f : ((const float*)p.B)[(size_t)d * p.N + n];
+        const float Cc = p.C_var ? 0.f : ((const float*)p.C)[(size_t)d * p.N + n];
+        // phase 1: per-lane serial reduce (keeps the local prefixes for the down-sweep)
+        Affine loc[V];
+        Affine run = {1.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          float a = fv_exp2(dj[j] * An);
+          float Bv = p.B_var ? s_B[k * LT + lane * V + j] : Bc;
+          float bb = dj[j] * uj[j] * Bv;
+          run = {run.a * a, a * run.b + bb};
+          loc[j] = run;
+        }
+        // phase 2: wave-level scan of the lane aggregates
+        Affine inc = wave_scan_up(run, lane);
+        Affine exc = {__shfl_up(inc.a, 1, 64), __shfl_up(inc.b, 1, 64)};
+        if (lane == 0) exc = {1.f, 0.f};
+        const float carry = s_carry[n];
+        const float xin = exc.a * carry + exc.b;   // state entering this lane's chunk
+        // phase 3: down-sweep
+        float xlast = 0.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          float x = loc[j].a * xin + loc[j].b;
+          float Cv = p.C_var ? s_C[k * LT + lane * V + j] : Cc;
+          yj[j] += Cv * x;
+          xlast = x;
+        }
+        float tile_end = __shfl(xlast, 63, 64);
+        if (lane == 0) s_carry[n] = tile_end;
+      }
+    }
+    // epilogue: + D*u, * silu(z), coalesced store through LDS
+    __syncthreads();
+    if (z) stage_row<T, V>(z, t0, p.L, s_d, lane, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      int e = lane * V + j;
+      float y = yj[j] + Dd * uj[j];
+      if (z) y *= fv_silu(s_d[e]);
+      s_y[e] = y;
+    }
+    __syncthreads();
+    unstage_row<T, V>(out, t0, p.L, s_y, lane);
+  }
+  __syncthreads();
+  if (p.last_state)
+    for (int n = lane; n < p.N; n += 64) p.last_state[(size_t)row * p.N + n] = s_carry[n];
+}
+
+// ------------------------------------------------------------------ backward
+// One wave per (batch, group, split): loops over its channels; for each channel runs a forward
+// sweep that records the state entering every tile, then walks the tiles high-to-low.
+template <typename T, int V>
+__global__ __launch_bounds__(64) void scan_bdl_bwd_kernel(ScanParams p, int ntiles) {
+  constexpr int LT = 64 * V;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_u = smem;                  // LT
+  float* s_d = s_u + LT;              // LT   delta (post softplus)
+  float* s_g = s_d + LT;              // LT   dout * silu(z)
+  float* s_t = s_g + LT;              // LT   scratch (z / outputs)
+  float* s_B = s_t + LT;              // NC*LT
+  float* s_C = s_B + NC * LT;         // NC*LT
+  float* s_acc = s_C + NC * LT;       // 5*N : dA, dBconst, dCconst accumulators + carry dx + fwd carry
+  float* s_bound = s_acc + 5 * p.N;   // ntiles*N : forward state entering each tile
+
+  const int lane = threadIdx.x;
+  const int cpg = p.dim / p.G;            // channels per group
+  const int cpb = cpg / p.S;              // channels per block
+  int bid = blockIdx.x;
+  const int s = bid % p.S; bid /= p.S;
+  const int g = bid % p.G;
+  const int b = bid / p.G;
+  const int d0 = g * cpg + s * cpb;
+  const size_t part_off = (((size_t)s * p.batch + b) * p.G + g) * p.N * (size_t)p.L;
+
+  float* s_dA = s_acc;
+  float* s_dBc = s_acc + p.N;
+  float* s_dCc = s_acc + 2 * p.N;
+  float* s_dxc = s_acc + 3 * p.N;     // adjoint state entering the tile from above
+  float* s_fc = s_acc + 4 * p.N;      // forward carry during phase 1
+
+  for (int ci = 0; ci < cpb; ++ci) {
+    const int d = d0 + ci;
+    const size_t row = (size_t)b * p.dim + d;
+    const T* u = (const T*)p.u + row * p.L;
+    const T* dl = (const T*)p.delta + row * p.L;
+    const T* z = p.z ? (const T*)p.z + row * p.L : nullptr;
+    const T* dout = (const T*)p.dout + row * p.L;
+    T* du = (T*)p.du + row * p.L;
+    T* ddl = (T*)p.ddelta + row * p.L;
+    T* dz = p.dz ? (T*)p.dz + row * p.L : nullptr;
+    const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+    const float Dd = p.D ? p.D[d] : 0.f;
+    const float* Arow = p.A + (size_t)d * p.N;
+    const T* Bg = p.B_var ? (const T*)p.B + (size_t)(b * p.G + g) * p.N * p.L : nullptr;
+    const T* Cg = p.C_var ? (const T*)p.C + (size_t)(b * p.G + g) * p.N * p.L : nullptr;
+
+    __syncthreads();
+    for (int n = lane; n < 5 * p.N; n += 64) s_acc[n] = 0.f;
+    __syncthreads();
+
+    // ---- phase 1: forward sweep, record the state entering each tile
+    if (ntiles > 1) {
+      for (int ti = 0; ti < ntiles; ++ti) {
+        const int t0 = ti * LT;
+        __syncthreads();
+        for (int n = lane; n < p.N; n += 64) s_bound[ti * p.N + n] = s_fc[n];
+        if (ti == ntiles - 1) break;
+        stage_row<T, V>(u, t0, p.L, s_u, lane, 0.f);
+        stage_row<T, V>(dl, t0, p.L, s_d, lane, 0.f);
+        __syncthreads();
+        float uj[V], dj[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          int e = lane * V + j;
+          uj[j] = s_u[e];
+          float dv = s_d[e] + bias;
+          if (p.softplus) dv = fv_softplus(dv);
+          dj[j] = (t0 + e < p.L) ? dv : 0.f;
+        }
+        for (int nc = 0; nc < p.N; nc += NC) {
+          const int nn = min(NC, p.N - nc);
+          __syncthreads();
+          if (p.B_var)
+            for (int k = 0; k < nn; ++k)
+              stage_row<T, V>(Bg + (size_t)(nc + k) * p.L, t0, p.L, s_B + k * LT, lane, 0.f);
+          __syncthreads();
+          for (int k = 0; k < nn; ++k) {
+            const int n = nc + k;
+            const float An = Arow[n] * FV_LOG2E;
+            const float Bc = p.B_var ? 0.f : ((const float*)p.B)[(size_t)d * p.N + n];
+            Affine run = {1.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+              float a = fv_exp2(dj[j] * An);
+              float Bv = p.B_var ? s_B[k * LT + lane * V + j] : Bc;
+              run = {run.a * a, a * run.b + dj[j] * uj[j] * Bv};
+            }
+            Affine inc = wave_scan_up(run, lane);
+            float endx = inc.a * s_fc[n] + inc.b;
+            endx = __shfl(endx, 63, 64);
+            if (lane == 0) s_fc[n] = endx;
+          }
+        }
+      }
+    } else {
+      for (int n = lane; n < p.N; n += 64) s_bound[n] = 0.f;
+    }
+
+    // ---- phase 2: tiles high-to-low
+    float dD_acc = 0.f, dbias_acc = 0.f;
+    for (int ti = ntiles - 1; ti >= 0; --ti) {
+      const int t0 = ti * LT;
+      __syncthreads();
+      stage_row<T, V>(u, t0, p.L, s_u, lane, 0.f);
+      stage_row<T, V>(dl, t0, p.L, s_d, lane, 0.f);
+      stage_row<T, V>(dout, t0, p.L, s_g, lane, 0.f);
+      if (z) stage_row<T, V>(z, t0, p.L, s_t, lane, 0.f);
+      __syncthreads();
+      float uj[V], dj[V], draw[V], gj[V], zj[V], doj[V], yj[V], duj[V], ddj[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        int e = lane * V + j;
+        bool in = t0 + e < p.L;
+        uj[j] = s_u[e];
+        draw[j] = s_d[e] + bias;
+        float dv = p.softplus ? fv_softplus(draw[j]) : draw[j];
+        dj[j] = in ? dv : 0.f;
+        doj[j] = s_g[e];
+        zj[j] = z ? s_t[e] : 0.f;
+        gj[j] = z ? doj[j] * fv_silu(zj[j]) : doj[j];
+        yj[j] = 0.f;
+        duj[j] = Dd * gj[j];
+        ddj[j] = 0.f;
+        dD_acc += gj[j] * uj[j];
+      }
+      // delta of the first step of the next tile (its `a` multiplies this tile's last adjoint)
+      float dnext = 0.f;
+      {
+        int tn = t0 + LT;
+        if (tn < p.L) {
+          float dv = io<T>::ld(dl + tn) + bias;
+          dnext = p.softplus ? fv_softplus(dv) : dv;
+        }
+      }
+      for (int nc = 0; nc < p.N; nc += NC) {
+        const int nn = min(NC, p.N - nc);
+        __syncthreads();
+        if (p.B_var)
+          for (int k = 0; k < nn; ++k)
+            stage_row<T, V>(Bg + (size_t)(nc + k) * p.L, t0, p.L, s_B + k * LT, lane, 0.f);
+        if (p.C_var)
+          for (int k = 0; k < nn; ++k)
+            stage_row<T, V>(Cg + (size_t)(nc + k) * p.L, t0, p.L, s_C + k * LT, lane, 0.f);
+        __syncthreads();
+        for (int k = 0; k < nn; ++k) {
+          const int n = nc + k;
+          const float Araw = Arow[n];
+          const float An = Araw * FV_LOG2E;
+          const float Bc = p.B_var ? 0.f : ((const float*)p.B)[(size_t)d * p.N + n];
+          const float Cc = p.C_var ? 0.f : ((const float*)p.C)[(size_t)d * p.N + n];
+          // forward in-tile states
+          float aj[V], bj[V], Bv[V], Cv[V], xj[V];
+          Affine loc[V];
+          Affine run = {1.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            aj[j] = fv_exp2(dj[j] * An);
+            Bv[j] = p.B_var ? s_B[k * LT + lane * V + j] : Bc;
+            Cv[j] = p.C_var ? s_C[k * LT + lane * V + j] : Cc;
+            bj[j] = dj[j] * uj[j] * Bv[j];
+            run = {run.a * aj[j], aj[j] * run.b + bj[j]};
+            loc[j] = run;
+          }
+          Affine inc = wave_scan_up(run, lane);
+          Affine exc = {__shfl_up(inc.a, 1, 64), __shfl_up(inc.b, 1, 64)};
+          if (lane == 0) exc = {1.f, 0.f};
+          const float xin = exc.a * s_bound[ti * p.N + n] + exc.b;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            xj[j] = loc[j].a * xin + loc[j].b;
+            yj[j] += Cv[j] * xj[j];
+          }
+          // adjoint recurrence dx_t = a_{t+1} dx_{t+1} + g_t C_t, high-to-low
+          float a_up = __shfl_down(aj[0], 1, 64);            // a of the step after this lane's chunk
+          if (lane == 63) a_up = fv_exp2(dnext * An);
+          Affine rloc[V];
+          Affine rrun = {1.f, 0.f};
+#pragma unroll
+          for (int j = V - 1; j >= 0; --j) {
+            float alpha = (j == V - 1) ? a_up : aj[j + 1];
+            float beta = gj[j] * Cv[j];
+            rrun = {rrun.a * alpha, alpha * rrun.b + beta};
+            rloc[j] = rrun;
+          }
+          Affine rinc = wave_scan_down(rrun, lane);
+          Affine rexc = {__shfl_down(rinc.a, 1, 64), __shfl_down(rinc.b, 1, 64)};
+          if (lane == 63) rexc = {1.f, 0.f};
+          const float dxin = rexc.a * s_dxc[n] + rexc.b;     // adjoint entering from above
+          float dA_l = 0.f, dBc_l = 0.f, dCc_l = 0.f, dx0 = 0.f;
+          float dBt[V], dCt[V];
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            float dx = rloc[j].a * dxin + rloc[j].b;
+            float ax = xj[j] - bj[j];                         // a_t * x_{t-1}
+            duj[j] += dx * dj[j] * Bv[j];
+            ddj[j] += dx * (Bv[j] * uj[j] + Araw * ax);
+            dA_l += dx * dj[j] * ax;
+            dBt[j] = dx * dj[j] * uj[j];
+            dCt[j] = gj[j] * xj[j];
+            dBc_l += dBt[j];
+            dCc_l += dCt[j];
+            if (j == 0) dx0 = dx;
+          }
+          // carry for the tile below: dx entering = dx of this tile's first step, taken
+          // through a of that first step by the next (lower) tile's own a_up.
+          float first_dx = __shfl(dx0, 0, 64);
+          dA_l = wave_sum(dA_l);
+          if (!p.B_var) dBc_l = wave_sum(dBc_l);
+          if (!p.C_var) dCc_l = wave_sum(dCc_l);
+          if (lane == 0) {
+            s_dxc[n] = first_dx;
+            s_dA[n] += dA_l;
+            if (!p.B_var) s_dBc[n] += dBc_l;
+            if (!p.C_var) s_dCc[n] += dCc_l;
+          }
+          // variable dB/dC: this wave owns its (split, batch, group) slice -> plain RMW
+          if (p.B_var) {
+            float* dst = p.dB_part + part_off + (size_t)n * p.L + t0 + lane * V;
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+              if (t0 + lane * V + j < p.L) dst[j] = (ci == 0 ? 0.f : dst[j]) + dBt[j];
+          }
+          if (p.C_var) {
+            float* dst = p.dC_part + part_off + (size_t)n * p.L + t0 + lane * V;
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+              if (t0 + lane * V + j < p.L) dst[j] = (ci == 0 ? 0.f : dst[j]) + dCt[j];
+          }
+        }
+      }
+      // tile epilogue: du, ddelta (through softplus), dz
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        int e = lane * V + j;
+        float dd = ddj[j];
+        if (p.softplus && draw[j] <= 20.f) dd *= fv_sigmoid(draw[j]);
+        if (t0 + e < p.L) dbias_acc += dd;
+        s_u[e] = duj[j];
+        s_d[e] = dd;
+        if (z) {
+          float yf = yj[j] + Dd * uj[j];
+          s_t[e] = doj[j] * yf * fv_silu_grad(zj[j]);
+        }
+      }
+      __syncthreads();
+      unstage_row<T, V>(du, t0, p.L, s_u, lane);
+      unstage_row<T, V>(ddl, t0, p.L, s_d, lane);
+      if (dz) unstage_row<T, V>(dz, t0, p.L, s_t, lane);
+    }
+    // per-(batch, channel) partials; reduced over batch by reduce_leading_kernel
+    dD_acc = wave_sum(dD_acc);
+    dbias_acc = wave_sum(dbias_acc);
+    __syncthreads();
+    if (lane == 0) {
+      if (p.pD) p.pD[row] = dD_acc;
+      if (p.pbias) p.pbias[row] = dbias_acc;
+    }
+    for (int n = lane; n < p.N; n += 64) {
+      p.pA[row * p.N + n] = s_dA[n];
+      if (!p.B_var) p.pBc[row * p.N + n] = s_dBc[n];
+      if (!p.C_var) p.pCc[row * p.N + n] = s_dCc[n];
+    }
+  }
+}
+
+// out[i] = sum_s in[s*n + i], fixed order (deterministic)
+__global__ void reduce_leading_kernel(const float* __restrict__ in, float* __restrict__ out, int S, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += in[(size_t)s * n + i];
+  out[i] = acc;
+}
+
+int pick_V(int L) { return L <= 64 ? 1 : (L <= 128 ? 2 : 4); }
+
+int bwd_splits(int batch, int dim, int G) {
+  int cpg = dim / G;
+  long target = (2048 + (long)batch * G - 1) / ((long)batch * G);
+  int S = 1;
+  for (int s = 1; s <= cpg; ++s)
+    if (cpg % s == 0 && s <= target) S = s;
+  return S;
+}
+
+struct BwdWs {
+  size_t pA, pD, pbias, pBc, pCc, dBp, dCp, total;
+};
+BwdWs bwd_ws(int batch, int dim, int L, int N, int G, int Bv, int Cv) {
+  BwdWs w{};
+  int S = bwd_splits(batch, dim, G);
+  size_t o = 0;
+  auto take = [&](size_t nfloats) { size_t r = o; o += (nfloats * 4 + 255) / 256 * 256; return r; };
+  w.pA = take((size_t)batch * dim * N);
+  w.pD = take((size_t)batch * dim);
+  w.pbias = take((size_t)batch * dim);
+  w.pBc = take(Bv ? 0 : (size_t)batch * dim * N);
+  w.pCc = take(Cv ? 0 : (size_t)batch * dim * N);
+  w.dBp = take((Bv && S > 1) ? (size_t)S * batch * G * N * L : 0);
+  w.dCp = take((Cv && S > 1) ? (size_t)S * batch * G * N * L : 0);
+  w.total = o;
+  return w;
+}
+
+template <typename T>
+int launch_fwd(const ScanParams& p, hipStream_t st) {
+  int V = pick_V(p.L);
+  int LT = 64 * V;
+  size_t smem = (size_t)(3 * LT + 2 * NC * LT + p.N) * 4;
+  dim3 grid(p.batch * p.dim), block(64);
+  if (V == 1) hipLaunchKernelGGL((scan_bdl_fwd_kernel<T, 1>), grid, block, smem, st, p);
+  else if (V == 2) hipLaunchKernelGGL((scan_bdl_fwd_kernel<T, 2>), grid, block, smem, st, p);
+  else hipLaunchKernelGGL((scan_bdl_fwd_kernel<T, 4>), grid, block, smem, st, p);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+template <typename T>
+int launch_bwd(const ScanParams& p, hipStream_t st) {
+  int V = pick_V(p.L);
+  int LT = 64 * V;
+  int ntiles = fv_cdiv(p.L, LT);
+  size_t smem = (size_t)(4 * LT + 2 * NC * LT + 5 * p.N + (size_t)ntiles * p.N) * 4;
+  FV_CHECK(smem <= 160 * 1024, "selective_scan_bwd: seqlen %d x dstate %d needs %zu B of LDS (> 160 KiB)",
+           p.L, p.N, smem);
+  dim3 grid(p.batch * p.G * p.S), block(64);
+  if (V == 1) {
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bdl_bwd_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((scan_bdl_bwd_kernel<T, 1>), grid, block, smem, st, p, ntiles);
+  } else if (V == 2) {
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bdl_bwd_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((scan_bdl_bwd_kernel<T, 2>), grid, block, smem, st, p, ntiles);
+  } else {
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bdl_bwd_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((scan_bdl_bwd_kernel<T, 4>), grid, block, smem, st, p, ntiles);
+  }
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+int reduce_leading(const float* in, float* out, int S, size_t n, hipStream_t st) {
+  if (n == 0) return FV_OK;
+  hipLaunchKernelGGL(reduce_leading_kernel, dim3(fv_cdiv((long)n, 256)), dim3(256), 0, st, in, out, S, n);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+int check_common(int batch, int dim, int L, int N, int G, int dtype) {
+  FV_CHECK(batch > 0 && dim > 0 && L > 0 && N > 0, "selective_scan: empty dimension (batch=%d dim=%d seqlen=%d dstate=%d)", batch, dim, L, N);
+  FV_CHECK(N <= 256, "selective_scan only supports state dimension <= 256");   // selective_scan.cpp:262
+  FV_CHECK(G >= 1 && dim % G == 0, "selective_scan: dim %d not divisible by n_groups %d", dim, G);
+  FV_CHECK(dtype == FV_F32 || dtype == FV_BF16 || dtype == FV_F16, "selective_scan: bad dtype %d", dtype);
+  return FV_OK;
+}
+
+}  // namespace
+
+extern "C" int fv_selective_scan_fwd(const void* u, const void* delta, const float* A, const void* B,
+                                     const void* C, const float* D, const void* z, const float* delta_bias,
+                                     void* out, float* last_state, int batch, int dim, int seqlen, int dstate,
+                                     int n_groups, int B_variable, int C_variable, int delta_softplus,
+                                     int dtype, fv_stream_t stream) {
+  int rc = check_common(batch, dim, seqlen, dstate, n_groups, dtype);
+  if (rc) return rc;
+  FV_CHECK(u && delta && A && B && C && out, "selective_scan_fwd: null pointer");
+  ScanParams p{};
+  p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C; p.D = D; p.z = z; p.delta_bias = delta_bias;
+  p.out = out; p.last_state = last_state;
+  p.batch = batch; p.dim = dim; p.L = seqlen; p.N = dstate; p.G = n_groups; p.S = 1;
+  p.B_var = B_variable; p.C_var = C_variable; p.softplus = delta_softplus;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FV_F32) return launch_fwd<float>(p, st);
+  if (dtype == FV_BF16) return launch_fwd<bf16_t>(p, st);
+  return launch_fwd<__half>(p, st);
+}
+
+extern "C" size_t fv_selective_scan_bwd_workspace(int batch, int dim, int seqlen, int dstate, int n_groups,
+                                                  int B_variable, int C_variable) {
+  if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0 || n_groups <= 0 || dim % n_groups) return 0;
+  return bwd_ws(batch, dim, seqlen, dstate, n_groups, B_variable, C_variable).total;
+}
+
+extern "C" int fv_selective_scan_bwd(const void* u, const void* delta, const float* A, const void* B,
+                                     const void* C, const float* D, const void* z, const float* delta_bias,
+                                     const void* dout, void* du, void* ddelta, float* dA, float* dB, float* dC,
+                                     float* dD, void* dz, float* ddelta_bias, void* workspace, int batch,
+                                     int dim, int seqlen, int dstate, int n_groups, int B_variable,
+                                     int C_variable, int delta_softplus, int dtype, fv_stream_t stream) {
+  int rc = check_common(batch, dim, seqlen, dstate, n_groups, dtype);
+  if (rc) return rc;
+  FV_CHECK(u && delta && A && B && C && dout && du && ddelta && dA && dB && dC && workspace,
+           "selective_scan_bwd: null pointer");
+  FV_CHECK(!z || dz, "selective_scan_bwd: z given but dz is null");
+  BwdWs w = bwd_ws(batch, dim, seqlen, dstate, n_groups, B_variable, C_variable);
+  char* ws = (char*)workspace;
+  ScanParams p{};
+  p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C; p.D = D; p.z = z; p.delta_bias = delta_bias;
+  p.dout = dout; p.du = du; p.ddelta = ddelta; p.dz = dz;
+  p.batch = batch; p.dim = dim; p.L = seqlen; p.N = dstate; p.G = n_groups;
+  p.S = bwd_splits(batch, dim, n_groups);
+  p.B_var = B_variable; p.C_var = C_variable; p.softplus = delta_softplus;
+  p.pA = (float*)(ws + w.pA);
+  p.pD = (float*)(ws + w.pD);
+  p.pbias = (float*)(ws + w.pbias);
+  p.pBc = (float*)(ws + w.pBc);
+  p.pCc = (float*)(ws + w.pCc);
+  p.dB_part = B_variable ? (p.S > 1 ? (float*)(ws + w.dBp) : dB) : nullptr;
+  p.dC_part = C_variable ? (p.S > 1 ? (float*)(ws + w.dCp) : dC) : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FV_F32) rc = launch_bwd<float>(p, st);
+  else if (dtype == FV_BF16) rc = launch_bwd<bf16_t>(p, st);
+  else rc = launch_bwd<__half>(p, st);
+  if (rc) return rc;
+  const size_t dn = (size_t)dim * dstate;
+  if ((rc = reduce_leading(p.pA, dA, batch, dn, st))) return rc;
+  if (dD && (rc = reduce_leading(p.pD, dD, batch, dim, st))) return rc;
+  if (ddelta_bias && (rc = reduce_leading(p.pbias, ddelta_bias, batch, dim, st))) return rc;
+  if (!B_variable && (rc = reduce_leading(p.pBc, dB, batch, dn, st))) return rc;
+  if (!C_variable && (rc = reduce_leading(p.pCc, dC, batch, dn, st))) return rc;
+  const size_t bn = (size_t)batch * n_groups * dstate * seqlen;
+  if (B_variable && p.S > 1 && (rc = reduce_leading(p.dB_part, dB, p.S, bn, st))) return rc;
+  if (C_variable && p.S > 1 && (rc = reduce_leading(p.dC_part, dC, p.S, bn, st))) return rc;
+  return FV_OK;
+}

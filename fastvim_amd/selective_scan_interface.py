@@ -1,0 +1,142 @@
+"""Operator API of the scan: mirror of
+mamba-1p1p1/mamba_ssm/ops/selective_scan_interface.py:12-123 (``SelectiveScanFn``,
+``selective_scan_fn``) on top of the HIP kernels (csrc/scan_bdl.hip).
+
+Same signature, argument meaning, dtype rules and error behaviour (RuntimeError);
+real ``A`` only -- FastVim never builds a complex ``A``
+(mamba_simple_faster.py:197).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, want_last_state):
+    batch, dim, seqlen = u.shape
+    dstate = A.shape[1]
+    B_var, C_var = B.dim() >= 3, C.dim() >= 3
+    n_groups = B.shape[1] if B_var else (C.shape[1] if C_var else 1)
+    out = torch.empty_like(u)
+    last = torch.empty(batch, dim, dstate, device=u.device, dtype=torch.float32) if want_last_state else None
+    with torch.cuda.device(u.device):
+        rc = L.lib().fv_selective_scan_fwd(
+            L.ptr(u), L.ptr(delta), L.ptr(A), L.ptr(B), L.ptr(C), L.ptr(D), L.ptr(z), L.ptr(delta_bias),
+            L.ptr(out), L.ptr(last), L.i32(batch), L.i32(dim), L.i32(seqlen), L.i32(dstate),
+            L.i32(n_groups), L.i32(B_var), L.i32(C_var), L.i32(delta_softplus),
+            L.i32(L.dtype_code(u.dtype)), L.stream_of(u))
+    L.check(rc, "selective_scan_fwd")
+    return out, last
+
+
+def _validate(u, delta, A, B, C, D, z, delta_bias):
+    """Shape/dtype checks of selective_scan.cpp:233-305."""
+    L.require_gpu(u, delta, A, B, C, D, z, delta_bias)
+    if A.is_complex():
+        raise RuntimeError("selective_scan_fn: complex A is not supported by the MI355X build (FastVim uses real A)")
+    if u.dim() != 3 or delta.shape != u.shape:
+        raise RuntimeError("selective_scan_fn: u and delta must both be (batch, dim, seqlen)")
+    if u.dtype not in (torch.float32, torch.float16, torch.bfloat16) or delta.dtype != u.dtype:
+        raise RuntimeError("selective_scan_fn: u/delta must share a dtype in {fp32, fp16, bf16}")
+    batch, dim, seqlen = u.shape
+    if A.dtype != torch.float32 or A.dim() != 2 or A.shape[0] != dim:
+        raise RuntimeError("selective_scan_fn: A must be fp32 (dim, dstate)")
+    dstate = A.shape[1]
+    if dstate > 256:
+        raise RuntimeError("selective_scan only supports state dimension <= 256")
+    for name, M in (("B", B), ("C", C)):
+        if M.dim() == 2:
+            if M.shape != (dim, dstate) or M.dtype != torch.float32:
+                raise RuntimeError(f"selective_scan_fn: constant {name} must be fp32 (dim, dstate)")
+        elif M.dim() == 4:
+            if M.shape[0] != batch or M.shape[2] != dstate or M.shape[3] != seqlen or dim % M.shape[1]:
+                raise RuntimeError(f"selective_scan_fn: variable {name} must be (batch, n_groups, dstate, seqlen)")
+            if M.dtype != u.dtype:
+                raise RuntimeError(f"selective_scan_fn: variable {name} must have u's dtype")
+        else:
+            raise RuntimeError(f"selective_scan_fn: bad {name} rank")
+    if B.dim() == 4 and C.dim() == 4 and B.shape[1] != C.shape[1]:
+        raise RuntimeError("selective_scan_fn: B and C must have the same number of groups")
+    for name, v in (("D", D), ("delta_bias", delta_bias)):
+        if v is not None and (v.dtype != torch.float32 or v.shape != (dim,)):
+            raise RuntimeError(f"selective_scan_fn: {name} must be fp32 (dim,)")
+    if z is not None and (z.shape != u.shape or z.dtype != u.dtype):
+        raise RuntimeError("selective_scan_fn: z must match u")
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                return_last_state=False):
+        # contiguity fixes of selective_scan_interface.py:27-44 (we need fully contiguous rows)
+        u, delta = u.contiguous(), delta.contiguous()
+        A = A.contiguous()
+        B, C = B.contiguous(), C.contiguous()
+        D = D.contiguous() if D is not None else None
+        z = z.contiguous() if z is not None else None
+        delta_bias = delta_bias.contiguous() if delta_bias is not None else None
+        ctx.squeeze_B = ctx.squeeze_C = False
+        if B.dim() == 3:
+            B = B.unsqueeze(1)
+            ctx.squeeze_B = True
+        if C.dim() == 3:
+            C = C.unsqueeze(1)
+            ctx.squeeze_C = True
+        _validate(u, delta, A, B, C, D, z, delta_bias)
+        out, last = _scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+        ctx.delta_softplus = delta_softplus
+        ctx.has_D, ctx.has_z, ctx.has_bias = D is not None, z is not None, delta_bias is not None
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias)
+        if return_last_state:
+            ctx.mark_non_differentiable(last)
+            return out, last
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        u, delta, A, B, C, D, z, delta_bias = ctx.saved_tensors
+        dout = dout.contiguous()
+        batch, dim, seqlen = u.shape
+        dstate = A.shape[1]
+        B_var, C_var = B.dim() == 4, C.dim() == 4
+        n_groups = B.shape[1] if B_var else (C.shape[1] if C_var else 1)
+        dev = u.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        du, ddelta = torch.empty_like(u), torch.empty_like(delta)
+        dz = torch.empty_like(z) if z is not None else None
+        dA = torch.empty(dim, dstate, **f32)
+        dB = torch.empty(B.shape, **f32)
+        dC = torch.empty(C.shape, **f32)
+        dD = torch.empty(dim, **f32)
+        dbias = torch.empty(dim, **f32)
+        lib = L.lib()
+        ws_bytes = lib.fv_selective_scan_bwd_workspace(L.i32(batch), L.i32(dim), L.i32(seqlen), L.i32(dstate),
+                                                       L.i32(n_groups), L.i32(B_var), L.i32(C_var))
+        ws = torch.empty(max(int(ws_bytes), 4), device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            rc = lib.fv_selective_scan_bwd(
+                L.ptr(u), L.ptr(delta), L.ptr(A), L.ptr(B), L.ptr(C), L.ptr(D), L.ptr(z), L.ptr(delta_bias),
+                L.ptr(dout), L.ptr(du), L.ptr(ddelta), L.ptr(dA), L.ptr(dB), L.ptr(dC), L.ptr(dD), L.ptr(dz),
+                L.ptr(dbias), L.ptr(ws), L.i32(batch), L.i32(dim), L.i32(seqlen), L.i32(dstate),
+                L.i32(n_groups), L.i32(B_var), L.i32(C_var), L.i32(ctx.delta_softplus),
+                L.i32(L.dtype_code(u.dtype)), L.stream_of(u))
+        L.check(rc, "selective_scan_bwd")
+        # variable B/C grads are produced in fp32 and cast back (selective_scan.cpp:461-462,488)
+        if B_var:
+            dB = dB.to(B.dtype)
+        if C_var:
+            dC = dC.to(C.dtype)
+        if ctx.squeeze_B:
+            dB = dB.squeeze(1)
+        if ctx.squeeze_C:
+            dC = dC.squeeze(1)
+        return (du, ddelta, dA, dB, dC, dD if ctx.has_D else None, dz,
+                dbias if ctx.has_bias else None, None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """if return_last_state is True, returns (out, last_state); last_state is (batch, dim, dstate)
+    fp32 and carries no gradient (selective_scan_interface.py:105-123)."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
