@@ -19,6 +19,7 @@ _lib = None
 C_ABI_SYMBOLS = (
     "fv_last_error", "fv_version",
     "fv_selective_scan_fwd", "fv_selective_scan_bwd_workspace", "fv_selective_scan_bwd",
+    "fv_mixer_conv_pool_fwd", "fv_mixer_scan_fwd", "fv_mixer_combine_fwd",
 )
 
 

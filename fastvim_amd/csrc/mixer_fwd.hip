@@ -1,0 +1,403 @@
+// Forward kernels of the fused FastVim mixer "middle" (everything between the in_proj GEMM
+// output xz and the out_proj GEMM input), channel-last.  Replaces, for one bidirectional
+// block, the ~35 launches of mamba_simple_faster.py:270-444:
+//
+//   fv_mixer_conv_pool_fwd : both causal (forward dir) and anti-causal (backward dir)
+//                            depthwise conv + SiLU and the mean/max pooling over `cols`
+//                            (mamba_simple_faster.py:272-305) -- one read of x.
+//   fv_mixer_scan_fwd      : dt_proj + softplus + selective scan over the pooled rows for
+//                            both directions (:328-354, :390-410); one lane per channel,
+//                            16 states in registers, serial over the (short) pooled length.
+//   fv_mixer_combine_fwd   : recompute conv, expand the scan output over `cols`, + D*x skip,
+//                            average the two directions, LayerNorm over d_in, * SiLU(z)
+//                            (:356-358, :412-416, :434-441) -- reads x,z once, writes once.
+//
+// The flip()s of the reference never happen: the backward direction is the anti-causal
+// conv on the original order and a scan over pooled rows in descending order.
+#include "rowwalk.h"
+
+namespace {
+
+constexpr int CW = 4;  // conv width (d_conv); the FastVim configs never change it
+
+struct FwdParams {
+  const void* xz;                       // (B, L, 2*d_in)
+  const float *wf, *bf, *wb, *bb;       // conv1d / conv1d_b: (d_in, CW), (d_in)
+  void* xc;                             // (2, B, rows, d_in) pooled conv output [dir 0 = fwd]
+  const float* yc;                      // (2, B, rows, d_in) scan output
+  const float *Df, *Db, *lnw, *lnb;     // (d_in)
+  void* g;                              // (B, L, d_in) gated LayerNorm output
+  float *mean, *rstd;                   // (B*L) LayerNorm statistics (saved for backward)
+  Geo geo;
+  int B, d_in;
+  int pool_max;
+  float pool_scale;                     // scaling_factor / cols (mean) or 1 (max)
+  float eps;
+  int use_norm;
+};
+
+template <int VEC>
+struct ChanParams {   // per-lane conv parameters of its VEC channels
+  float wf[VEC][CW], wb[VEC][CW], bf[VEC], bb[VEC];
+  __device__ __forceinline__ void load(const FwdParams& p, int c0, bool act) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+      for (int k = 0; k < CW; ++k) {
+        wf[v][k] = act ? p.wf[(c0 + v) * CW + k] : 0.f;
+        wb[v][k] = act ? p.wb[(c0 + v) * CW + k] : 0.f;
+      }
+      bf[v] = act && p.bf ? p.bf[c0 + v] : 0.f;
+      bb[v] = act && p.bb ? p.bb[c0 + v] : 0.f;
+    }
+  }
+};
+
+// loads the x half of TJ+2*H tokens around tile [j0, j0+TJ) of row i (zero outside [0,L))
+template <typename T, int VEC, int TJ, int H>
+__device__ __forceinline__ void load_x_tile(const T* xz_b, const Geo& g, int d_in, int i, int j0, int c0,
+                                            bool act, float (&x)[TJ + 2 * H][VEC]) {
+#pragma unroll
+  for (int k = 0; k < TJ + 2 * H; ++k) {
+    int s = i * g.cols + j0 - H + k;
+    bool ok = act && s >= 0 && s < g.L && (j0 - H + k) < g.cols + H;
+    if (ok) {
+      int m = tok_mem(g, s);
+      VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * d_in + c0, x[k]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[k][v] = 0.f;
+    }
+  }
+}
+
+// conv pre-activations of token jj of the tile (x index jj+3 is the token itself)
+template <int VEC, int TJ>
+__device__ __forceinline__ void conv_both(const ChanParams<VEC>& cp, const float (&x)[TJ + 6][VEC], int jj,
+                                          float (&xf)[VEC], float (&xb)[VEC]) {
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    float pf = cp.bf[v], pb = cp.bb[v];
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+      pf = fmaf(cp.wf[v][k], x[jj + k][v], pf);             // x[s-3+k]
+      pb = fmaf(cp.wb[v][k], x[jj + 2 * (CW - 1) - k][v], pb);  // x[s+3-k]
+    }
+    xf[v] = fv_silu(pf);
+    xb[v] = fv_silu(pb);
+  }
+}
+
+// ------------------------------------------------------------------ conv + pool
+template <typename T, int VEC, int TJ>
+__global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(FwdParams p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int c0 = (wv * 64 + lane) * VEC;
+  const bool act = c0 < p.d_in;
+  const Geo g = p.geo;
+  ChanParams<VEC> cp;
+  cp.load(p, c0, act);
+  const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
+  float accf[VEC], accb[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) accf[v] = accb[v] = p.pool_max ? -INFINITY : 0.f;
+  for (int j0 = 0; j0 < g.cols; j0 += TJ) {
+    float x[TJ + 6][VEC];
+    load_x_tile<T, VEC, TJ, 3>(xz_b, g, p.d_in, i, j0, c0, act, x);
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) {
+      if (j0 + jj < g.cols) {
+        float xf[VEC], xb[VEC];
+        conv_both<VEC, TJ>(cp, x, jj, xf, xb);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          accf[v] = p.pool_max ? fmaxf(accf[v], xf[v]) : accf[v] + xf[v];
+          accb[v] = p.pool_max ? fmaxf(accb[v], xb[v]) : accb[v] + xb[v];
+        }
+      }
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      accf[v] *= p.pool_scale;
+      accb[v] *= p.pool_scale;
+    }
+    T* xc = (T*)p.xc;
+    size_t o = ((size_t)b * g.rows + i) * p.d_in + c0;
+    VecIO<T, VEC>::store(xc + o, accf);
+    VecIO<T, VEC>::store(xc + (size_t)p.B * g.rows * p.d_in + o, accb);
+  }
+}
+
+// ------------------------------------------------------------------ combine
+template <typename T, int VEC, int TJ>
+__global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdParams p) {
+  __shared__ float s_red[16 * TJ];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int c0 = (wv * 64 + lane) * VEC;
+  const bool act = c0 < p.d_in;
+  const Geo g = p.geo;
+  ChanParams<VEC> cp;
+  cp.load(p, c0, act);
+  float Df[VEC], Db[VEC], lw[VEC], lb[VEC], ysum[VEC];
+  {
+    size_t o = ((size_t)b * g.rows + i) * p.d_in + c0;
+    size_t dstride = (size_t)p.B * g.rows * p.d_in;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      Df[v] = act ? p.Df[c0 + v] : 0.f;
+      Db[v] = act ? p.Db[c0 + v] : 0.f;
+      lw[v] = act && p.use_norm ? p.lnw[c0 + v] : 1.f;
+      lb[v] = act && p.use_norm ? p.lnb[c0 + v] : 0.f;
+      ysum[v] = act ? p.yc[o + v] + p.yc[dstride + o + v] : 0.f;   // scan outputs, both dirs
+    }
+  }
+  const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
+  T* g_b = (T*)p.g + (size_t)b * g.L * p.d_in;
+  const float inv_d = 1.f / (float)p.d_in;
+  for (int j0 = 0; j0 < g.cols; j0 += TJ) {
+    float x[TJ + 6][VEC];
+    load_x_tile<T, VEC, TJ, 3>(xz_b, g, p.d_in, i, j0, c0, act, x);
+    float o[TJ][VEC], s1[TJ];
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) {
+      float xf[VEC], xb[VEC];
+      conv_both<VEC, TJ>(cp, x, jj, xf, xb);
+      float acc = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        o[jj][v] = act ? 0.5f * (ysum[v] + Df[v] * xf[v] + Db[v] * xb[v]) : 0.f;
+        acc += o[jj][v];
+      }
+      s1[jj] = acc;
+    }
+    float mean[TJ], rstd[TJ];
+    if (p.use_norm) {
+      // mean over d_in, then centred second moment (two exact passes over registers)
+#pragma unroll
+      for (int jj = 0; jj < TJ; ++jj) s1[jj] = wave_sum_uniform(s1[jj]);
+      if (nw > 1) {
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+          for (int jj = 0; jj < TJ; ++jj) s_red[wv * TJ + jj] = s1[jj];
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < TJ; ++jj) {
+          float t = 0.f;
+          for (int w = 0; w < nw; ++w) t += s_red[w * TJ + jj];
+          s1[jj] = t;
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < TJ; ++jj) {
+        mean[jj] = s1[jj] * inv_d;
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float c = act ? o[jj][v] - mean[jj] : 0.f;
+          acc += c * c;
+        }
+        s1[jj] = wave_sum_uniform(acc);
+      }
+      if (nw > 1) {
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+          for (int jj = 0; jj < TJ; ++jj) s_red[wv * TJ + jj] = s1[jj];
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < TJ; ++jj) {
+          float t = 0.f;
+          for (int w = 0; w < nw; ++w) t += s_red[w * TJ + jj];
+          s1[jj] = t;
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < TJ; ++jj) rstd[jj] = rsqrtf(s1[jj] * inv_d + p.eps);
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < TJ; ++jj) { mean[jj] = 0.f; rstd[jj] = 1.f; }
+    }
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) {
+      if (j0 + jj < g.cols) {
+        int m = tok_mem(g, i * g.cols + j0 + jj);
+        if (act) {
+          float z[VEC], out[VEC];
+          VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + p.d_in + c0, z);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+            out[v] = ((o[jj][v] - mean[jj]) * rstd[jj] * lw[v] + lb[v]) * fv_silu(z[v]);
+          VecIO<T, VEC>::store(g_b + (size_t)m * p.d_in + c0, out);
+        }
+        if (p.use_norm && threadIdx.x == 0) {
+          p.mean[(size_t)b * g.L + m] = mean[jj];
+          p.rstd[(size_t)b * g.L + m] = rstd[jj];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dt_proj + scan
+struct ScanClParams {
+  const void* xc;        // (2, B, Lc, d_in)   pooled conv output
+  const void* xdbl;      // (2, B*Lc, R+2N)    [dt_low | B | C]
+  const float* Wdt[2];   // (d_in, R)
+  const float* dtb[2];   // (d_in)
+  const float* Alog[2];  // (d_in, N)
+  float* yc;             // (2, B, Lc, d_in)
+  int B, Lc, d_in, R;
+};
+
+template <typename T, int N, int RMAX>
+__global__ void scan_cl_fwd_kernel(ScanClParams p) {
+  extern __shared__ __attribute__((aligned(16))) float s_dbl[];   // Lc * (R+2N) fp32
+  const int dir = blockIdx.z, b = blockIdx.y;
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = p.R + 2 * N;
+  const T* dbl = (const T*)p.xdbl + ((size_t)dir * p.B + b) * p.Lc * W;
+  for (int e = threadIdx.x; e < p.Lc * W; e += blockDim.x) s_dbl[e] = io<T>::ld(dbl + e);
+  __syncthreads();
+  if (d >= p.d_in) return;
+  float A[N], st[N], wdt[RMAX];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    A[n] = -__expf(p.Alog[dir][(size_t)d * N + n]) * FV_LOG2E;   // A = -exp(A_log) (mamba_simple_faster.py:197)
+    st[n] = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) wdt[r] = r < p.R ? p.Wdt[dir][(size_t)d * p.R + r] : 0.f;
+  const float bias = p.dtb[dir][d];
+  const T* u = (const T*)p.xc + ((size_t)dir * p.B + b) * p.Lc * p.d_in + d;
+  float* y = p.yc + ((size_t)dir * p.B + b) * p.Lc * p.d_in + d;
+  for (int step = 0; step < p.Lc; ++step) {
+    const int l = dir ? p.Lc - 1 - step : step;    // backward direction: descending rows
+    const float* row = s_dbl + l * W;
+    float dt = bias;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < p.R) dt = fmaf(wdt[r], row[r], dt);
+    dt = fv_softplus(dt);
+    const float uv = io<T>::ld(u + (size_t)l * p.d_in);
+    const float du = dt * uv;
+    float acc = 0.f;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      st[n] = fmaf(fv_exp2(dt * A[n]), st[n], du * row[p.R + n]);
+      acc = fmaf(row[p.R + N + n], st[n], acc);
+    }
+    y[(size_t)l * p.d_in] = acc;
+  }
+}
+
+template <typename T, int VEC>
+int launch_fwd_kernels(int which, const FwdParams& p, hipStream_t st) {
+  const int nch = fv_cdiv(p.d_in, 64 * VEC);
+  FV_CHECK(nch <= (VEC == 1 ? 16 : 8), "mixer: d_inner %d too large for the VEC=%d row-walker", p.d_in, VEC);
+  dim3 grid(p.geo.rows, p.B), block(64 * nch);
+  const bool t14 = p.geo.cols % 7 == 0;
+  if (which == 0) {
+    if (t14) hipLaunchKernelGGL((conv_pool_fwd_kernel<T, VEC, 7>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_pool_fwd_kernel<T, VEC, 8>), grid, block, 0, st, p);
+  } else {
+    if (t14) hipLaunchKernelGGL((combine_fwd_kernel<T, VEC, 7>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((combine_fwd_kernel<T, VEC, 8>), grid, block, 0, st, p);
+  }
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+template <typename T>
+int dispatch_vec(int which, const FwdParams& p, hipStream_t st) {
+  if (p.d_in % 384 == 0) return launch_fwd_kernels<T, 6>(which, p, st);
+  if (p.d_in % 256 == 0) return launch_fwd_kernels<T, 4>(which, p, st);
+  return launch_fwd_kernels<T, 1>(which, p, st);
+}
+
+int check_geo(int B, int rows, int cols, int s_i, int s_j, int d_in, int dtype) {
+  FV_CHECK(B > 0 && rows > 0 && cols > 0 && d_in > 0, "mixer: empty dimension");
+  FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer: dtype must be fp32 or bf16");
+  FV_CHECK((s_i == cols && s_j == 1) || (s_i == 1 && s_j == rows),
+           "mixer: token strides (%d,%d) are neither row-major nor transposed for a %dx%d grid", s_i, s_j, rows, cols);
+  return FV_OK;
+}
+
+}  // namespace
+
+extern "C" int fv_mixer_conv_pool_fwd(const void* xz, const float* conv_w, const float* conv_b,
+                                      const float* conv_w_b, const float* conv_b_b, void* xc, int batch,
+                                      int rows, int cols, int tok_stride_row, int tok_stride_col, int d_inner,
+                                      int d_conv, int pool_max, float scaling_factor, int dtype,
+                                      fv_stream_t stream) {
+  int rc = check_geo(batch, rows, cols, tok_stride_row, tok_stride_col, d_inner, dtype);
+  if (rc) return rc;
+  FV_CHECK(d_conv == CW, "mixer: only d_conv == %d is built (got %d)", CW, d_conv);
+  FV_CHECK(xz && conv_w && conv_w_b && xc, "mixer_conv_pool_fwd: null pointer");
+  FwdParams p{};
+  p.xz = xz; p.wf = conv_w; p.bf = conv_b; p.wb = conv_w_b; p.bb = conv_b_b; p.xc = xc;
+  p.geo = {rows, cols, rows * cols, tok_stride_row, tok_stride_col};
+  p.B = batch; p.d_in = d_inner; p.pool_max = pool_max;
+  p.pool_scale = pool_max ? 1.f : scaling_factor / (float)cols;
+  return dtype == FV_F32 ? dispatch_vec<float>(0, p, (hipStream_t)stream)
+                         : dispatch_vec<bf16_t>(0, p, (hipStream_t)stream);
+}
+
+extern "C" int fv_mixer_combine_fwd(const void* xz, const float* yc, const float* conv_w, const float* conv_b,
+                                    const float* conv_w_b, const float* conv_b_b, const float* D,
+                                    const float* D_b, const float* ln_w, const float* ln_b, float ln_eps,
+                                    void* g, float* mean, float* rstd, int batch, int rows, int cols,
+                                    int tok_stride_row, int tok_stride_col, int d_inner, int d_conv, int dtype,
+                                    fv_stream_t stream) {
+  int rc = check_geo(batch, rows, cols, tok_stride_row, tok_stride_col, d_inner, dtype);
+  if (rc) return rc;
+  FV_CHECK(d_conv == CW, "mixer: only d_conv == %d is built (got %d)", CW, d_conv);
+  FV_CHECK(xz && yc && conv_w && conv_w_b && D && D_b && g, "mixer_combine_fwd: null pointer");
+  FV_CHECK(!ln_w || (ln_b && mean && rstd), "mixer_combine_fwd: LayerNorm needs weight, bias, mean, rstd");
+  FwdParams p{};
+  p.xz = xz; p.yc = yc; p.wf = conv_w; p.bf = conv_b; p.wb = conv_w_b; p.bb = conv_b_b;
+  p.Df = D; p.Db = D_b; p.lnw = ln_w; p.lnb = ln_b; p.eps = ln_eps; p.g = g; p.mean = mean; p.rstd = rstd;
+  p.use_norm = ln_w != nullptr;
+  p.geo = {rows, cols, rows * cols, tok_stride_row, tok_stride_col};
+  p.B = batch; p.d_in = d_inner;
+  return dtype == FV_F32 ? dispatch_vec<float>(1, p, (hipStream_t)stream)
+                         : dispatch_vec<bf16_t>(1, p, (hipStream_t)stream);
+}
+
+extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                 const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                 const float* A_log_b, float* yc, int batch, int Lc, int d_inner, int dt_rank,
+                                 int d_state, int dtype, fv_stream_t stream) {
+  FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_fwd: empty dimension");
+  FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_fwd: dtype must be fp32 or bf16");
+  FV_CHECK(d_state == 16, "mixer_scan_fwd: only d_state == 16 is built (got %d)", d_state);
+  FV_CHECK(dt_rank <= 96, "mixer_scan_fwd: dt_rank %d > 96", dt_rank);
+  FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && yc,
+           "mixer_scan_fwd: null pointer");
+  ScanClParams p{};
+  p.xc = xc; p.xdbl = x_dbl; p.yc = yc;
+  p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
+  p.Alog[0] = A_log; p.Alog[1] = A_log_b;
+  p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
+  const int W = dt_rank + 2 * d_state;
+  size_t smem = (size_t)Lc * W * 4;
+  FV_CHECK(smem <= 64 * 1024, "mixer_scan_fwd: pooled length %d too long for the LDS stage", Lc);
+  const int bs = d_inner >= 256 ? 128 : 64;
+  dim3 grid(fv_cdiv(d_inner, bs), batch, 2), block(bs);
+  hipStream_t st = (hipStream_t)stream;
+#define FV_SCAN_LAUNCH(TT, RM) hipLaunchKernelGGL((scan_cl_fwd_kernel<TT, 16, RM>), grid, block, smem, st, p)
+  if (dtype == FV_F32) {
+    if (dt_rank <= 12) FV_SCAN_LAUNCH(float, 12); else if (dt_rank <= 24) FV_SCAN_LAUNCH(float, 24);
+    else if (dt_rank <= 48) FV_SCAN_LAUNCH(float, 48); else FV_SCAN_LAUNCH(float, 96);
+  } else {
+    if (dt_rank <= 12) FV_SCAN_LAUNCH(bf16_t, 12); else if (dt_rank <= 24) FV_SCAN_LAUNCH(bf16_t, 24);
+    else if (dt_rank <= 48) FV_SCAN_LAUNCH(bf16_t, 48); else FV_SCAN_LAUNCH(bf16_t, 96);
+  }
+#undef FV_SCAN_LAUNCH
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}

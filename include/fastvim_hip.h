@@ -68,6 +68,43 @@ int fv_selective_scan_bwd(const void* u, const void* delta, const float* A, cons
                           int seqlen, int dstate, int n_groups, int B_variable, int C_variable,
                           int delta_softplus, int dtype, fv_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Fused FastVim mixer "middle", channel-last (token-major) activations.
+ * Together these replace the body of `Mamba.forward` between in_proj and out_proj
+ *   (mamba-1p1p1/mamba_ssm/modules/mamba_simple_faster.py:270-444) and the fused autograd
+ *   function `FastVim_MambaInnerFnNoOutProj_withoutZ`
+ *   (mamba_ssm/ops/selective_scan_interface.py:452-776), which themselves call
+ *   causal_conv1d_cuda.causal_conv1d_fwd/bwd (PyPI causal-conv1d 1.1.3.post1) and
+ *   selective_scan_cuda.fwd/bwd.
+ *
+ * Layouts:  xz (batch, L, 2*d_inner)  [x | z] per token;  g, do (batch, L, d_inner);
+ *           xc, yc, ... (2, batch, rows, d_inner)  [0] = forward direction, [1] = backward,
+ *           both indexed by the pooled row in ORIGINAL order (no flips are materialised);
+ *           x_dbl (2, batch*rows, dt_rank + 2*d_state) = [dt_low | B | C].
+ * Token grid: the mixer's sequence position (i, j), i < rows, j < cols, is memory token
+ *           i*tok_stride_row + j*tok_stride_col.  (cols, 1) = natural order; (1, rows) = the
+ *           transposed grid odd layers see (models/fastvim.py:192-210) -- no copy is made.
+ * Conv weights are (d_inner, d_conv) fp32 (= conv1d.weight viewed "d 1 w -> d w").
+ * ---------------------------------------------------------------------- */
+int fv_mixer_conv_pool_fwd(const void* xz, const float* conv_w, const float* conv_b,
+                           const float* conv_w_b, const float* conv_b_b, void* xc, int batch, int rows,
+                           int cols, int tok_stride_row, int tok_stride_col, int d_inner, int d_conv,
+                           int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
+
+/* dt_proj + softplus + selective scan (A = -exp(A_log)) for both directions.  yc is fp32. */
+int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                      const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                      const float* A_log_b, float* yc, int batch, int Lc, int d_inner, int dt_rank,
+                      int d_state, int dtype, fv_stream_t stream);
+
+/* g = LayerNorm(((yc_f + D*conv_f(x)) + (yc_b + D_b*conv_b(x))) / 2) * silu(z); ln_w == NULL
+ * skips the norm (use_norm_after_ssm=False).  mean/rstd (batch*L) fp32 are saved for backward. */
+int fv_mixer_combine_fwd(const void* xz, const float* yc, const float* conv_w, const float* conv_b,
+                         const float* conv_w_b, const float* conv_b_b, const float* D, const float* D_b,
+                         const float* ln_w, const float* ln_b, float ln_eps, void* g, float* mean,
+                         float* rstd, int batch, int rows, int cols, int tok_stride_row,
+                         int tok_stride_col, int d_inner, int d_conv, int dtype, fv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
