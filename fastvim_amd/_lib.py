@@ -20,6 +20,8 @@ C_ABI_SYMBOLS = (
     "fv_last_error", "fv_version",
     "fv_selective_scan_fwd", "fv_selective_scan_bwd_workspace", "fv_selective_scan_bwd",
     "fv_mixer_conv_pool_fwd", "fv_mixer_scan_fwd", "fv_mixer_combine_fwd",
+    "fv_mixer_bwd_blocks", "fv_mixer_combine_bwd", "fv_mixer_scan_bwd_chunks",
+    "fv_mixer_scan_bwd_ckpt_floats", "fv_mixer_scan_bwd", "fv_mixer_conv_pool_bwd", "fv_reduce_partials",
 )
 
 
@@ -33,6 +35,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.fv_last_error.restype = ctypes.c_char_p
         _lib.fv_selective_scan_bwd_workspace.restype = ctypes.c_size_t
+        _lib.fv_mixer_scan_bwd_ckpt_floats.restype = ctypes.c_size_t
     return _lib
 
 

@@ -1,0 +1,45 @@
+// Pieces shared by the forward and backward fused-mixer kernels.
+#pragma once
+#include "rowwalk.h"
+
+namespace {
+
+constexpr int CW = 4;  // conv width (d_conv); the FastVim configs never change it
+
+template <int VEC>
+struct ChanParams {   // per-lane conv parameters of its VEC channels
+  float wf[VEC][CW], wb[VEC][CW], bf[VEC], bb[VEC];
+  __device__ __forceinline__ void load(const float* wf_, const float* bf_, const float* wb_, const float* bb_, int c0, bool act) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+      for (int k = 0; k < CW; ++k) {
+        wf[v][k] = act ? wf_[(c0 + v) * CW + k] : 0.f;
+        wb[v][k] = act ? wb_[(c0 + v) * CW + k] : 0.f;
+      }
+      bf[v] = act && bf_ ? bf_[c0 + v] : 0.f;
+      bb[v] = act && bb_ ? bb_[c0 + v] : 0.f;
+    }
+  }
+};
+
+// loads the x half of TJ+2*H tokens around tile [j0, j0+TJ) of row i (zero outside [0,L))
+template <typename T, int VEC, int TJ, int H>
+__device__ __forceinline__ void load_x_tile(const T* xz_b, const Geo& g, int d_in, int i, int j0, int c0,
+                                            bool act, float (&x)[TJ + 2 * H][VEC]) {
+#pragma unroll
+  for (int k = 0; k < TJ + 2 * H; ++k) {
+    int s = i * g.cols + j0 - H + k;
+    bool ok = act && s >= 0 && s < g.L && (j0 - H + k) < g.cols + H;
+    if (ok) {
+      int m = tok_mem(g, s);
+      VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * d_in + c0, x[k]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[k][v] = 0.f;
+    }
+  }
+}
+
+
+}  // namespace

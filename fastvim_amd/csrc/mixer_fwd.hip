@@ -14,11 +14,9 @@
 //
 // The flip()s of the reference never happen: the backward direction is the anti-causal
 // conv on the original order and a scan over pooled rows in descending order.
-#include "rowwalk.h"
+#include "mixer_common.h"
 
 namespace {
-
-constexpr int CW = 4;  // conv width (d_conv); the FastVim configs never change it
 
 struct FwdParams {
   const void* xz;                       // (B, L, 2*d_in)
@@ -35,41 +33,6 @@ struct FwdParams {
   float eps;
   int use_norm;
 };
-
-template <int VEC>
-struct ChanParams {   // per-lane conv parameters of its VEC channels
-  float wf[VEC][CW], wb[VEC][CW], bf[VEC], bb[VEC];
-  __device__ __forceinline__ void load(const FwdParams& p, int c0, bool act) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-#pragma unroll
-      for (int k = 0; k < CW; ++k) {
-        wf[v][k] = act ? p.wf[(c0 + v) * CW + k] : 0.f;
-        wb[v][k] = act ? p.wb[(c0 + v) * CW + k] : 0.f;
-      }
-      bf[v] = act && p.bf ? p.bf[c0 + v] : 0.f;
-      bb[v] = act && p.bb ? p.bb[c0 + v] : 0.f;
-    }
-  }
-};
-
-// loads the x half of TJ+2*H tokens around tile [j0, j0+TJ) of row i (zero outside [0,L))
-template <typename T, int VEC, int TJ, int H>
-__device__ __forceinline__ void load_x_tile(const T* xz_b, const Geo& g, int d_in, int i, int j0, int c0,
-                                            bool act, float (&x)[TJ + 2 * H][VEC]) {
-#pragma unroll
-  for (int k = 0; k < TJ + 2 * H; ++k) {
-    int s = i * g.cols + j0 - H + k;
-    bool ok = act && s >= 0 && s < g.L && (j0 - H + k) < g.cols + H;
-    if (ok) {
-      int m = tok_mem(g, s);
-      VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * d_in + c0, x[k]);
-    } else {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) x[k][v] = 0.f;
-    }
-  }
-}
 
 // conv pre-activations of token jj of the tile (x index jj+3 is the token itself)
 template <int VEC, int TJ>
@@ -97,7 +60,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
   const bool act = c0 < p.d_in;
   const Geo g = p.geo;
   ChanParams<VEC> cp;
-  cp.load(p, c0, act);
+  cp.load(p.wf, p.bf, p.wb, p.bb, c0, act);
   const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
   float accf[VEC], accb[VEC];
 #pragma unroll
@@ -141,7 +104,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
   const bool act = c0 < p.d_in;
   const Geo g = p.geo;
   ChanParams<VEC> cp;
-  cp.load(p, c0, act);
+  cp.load(p.wf, p.bf, p.wb, p.bb, c0, act);
   float Df[VEC], Db[VEC], lw[VEC], lb[VEC], ysum[VEC];
   {
     size_t o = ((size_t)b * g.rows + i) * p.d_in + c0;

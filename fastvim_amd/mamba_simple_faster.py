@@ -1,0 +1,200 @@
+"""FastVim mixer module: mirror of ``Mamba`` in
+mamba-1p1p1/mamba_ssm/modules/mamba_simple_faster.py:27-457 -- same constructor signature,
+parameter names/shapes/initialisation (so reference ``state_dict``s load unchanged), same
+``forward(hidden_states (B, L, D)) -> (B, L, D)``.
+
+The body is not the reference's ~35-launch op chain: one autograd.Function drives the fused
+channel-last HIP kernels (csrc/mixer_fwd.hip, csrc/mixer_bwd.hip) with a hand-written
+backward; activations stay token-major so in_proj/out_proj are plain row-major GEMMs, and the
+odd-layer grid transpose of ``Block`` is a stride pair, not a copy (``transposed_grid``).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import mixer_ops as M
+
+
+def _compute_dtype(t):
+    """bf16/fp16 under torch.autocast (reference: mamba_simple_faster.py:312-318), else the input dtype."""
+    if torch.is_autocast_enabled():
+        return torch.get_autocast_gpu_dtype()
+    return t.dtype
+
+
+class FastVimMixerFn(torch.autograd.Function):
+    """hidden (B, L, d) -> out (B, L, d).  Geometry: the mixer's (rows, cols) pooling grid;
+    ``transposed`` = memory tokens are laid out as the (cols, rows) grid (odd layers)."""
+
+    @staticmethod
+    def forward(ctx, hidden, W_in, b_in, cw, cb, cw_b, cb_b, Wx, Wx_b, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log,
+                D, D_b, ln_w, ln_b, W_out, b_out, rows, cols, transposed, pool_max, scaling, ln_eps, cdt):
+        L.require_gpu(hidden)
+        B, Ltok, d = hidden.shape
+        if Ltok != rows * cols:
+            raise RuntimeError(f"Mamba: sequence length {Ltok} != token grid {rows}x{cols}")
+        d_in = W_in.shape[0] // 2
+        with torch.autocast("cuda", enabled=False):
+            h_c = hidden.to(cdt).contiguous()
+            W_in_c, W_out_c = W_in.to(cdt), W_out.to(cdt)
+            xz = F.linear(h_c, W_in_c, None if b_in is None else b_in.to(cdt))          # (B, L, 2 d_in)
+            cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
+            xc = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling)
+            Wx2 = torch.stack([Wx, Wx_b])                                               # (2, R+2N, d_in) fp32
+            x_dbl = torch.bmm(xc.view(2, B * rows, d_in), Wx2.to(cdt).transpose(1, 2))  # (2, B*Lc, R+2N)
+            yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
+            g, mean, rstd = M.combine_fwd(xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, ln_eps,
+                                          rows, cols, transposed)
+            out = F.linear(g, W_out_c, None if b_out is None else b_out.to(cdt))
+        ctx.save_for_backward(h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b,
+                              ln_w, ln_b, W_out, xz, xc, x_dbl, yc, g, mean, rstd)
+        ctx.geo = (rows, cols, transposed, pool_max, scaling)
+        ctx.has_bias = (b_in is not None, b_out is not None)
+        ctx.cdt = cdt
+        ctx.in_dtype = hidden.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b, ln_w, ln_b, W_out,
+         xz, xc, x_dbl, yc, g, mean, rstd) = ctx.saved_tensors
+        rows, cols, transposed, pool_max, scaling = ctx.geo
+        cdt = ctx.cdt
+        B, Ltok, d = h_c.shape
+        d_in = W_in.shape[0] // 2
+        with torch.autocast("cuda", enabled=False):
+            dout = dout.to(cdt).contiguous()
+            do2 = dout.view(B * Ltok, d)
+            dg = do2 @ W_out.to(cdt)                                                     # (B*L, d_in)
+            dW_out = (do2.t() @ g.view(B * Ltok, d_in)).float()
+            db_out = do2.float().sum(0) if ctx.has_bias[1] else None
+            cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
+            dxz = torch.empty_like(xz)
+            d_o, dyc, p1 = M.combine_bwd(dg, xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, mean, rstd, dxz,
+                                         rows, cols, transposed)
+            dxc, dx_dbl, dA2, dWdt2, dbdt2 = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc)
+            # x_proj adjoint (selective_scan_interface.py:726-734), both directions batched, fp32
+            xc2 = xc.view(2, B * rows, d_in)
+            dWx2 = torch.bmm(dx_dbl.transpose(1, 2), xc2.float())                        # (2, R+2N, d_in)
+            dxc = torch.baddbmm(dxc.view(2, B * rows, d_in), dx_dbl, Wx2)                # + dx_dbl @ Wx
+            p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
+                                 pool_max, scaling)
+            dxz2 = dxz.view(B * Ltok, 2 * d_in)
+            dhidden = (dxz2 @ W_in.to(cdt)).view(B, Ltok, d).to(ctx.in_dtype)
+            dW_in = (dxz2.t() @ h_c.view(B * Ltok, d)).float()
+            db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
+        has_ln = ln_w is not None
+        return (dhidden, dW_in, db_in,
+                p2[:, 0:4].reshape(cw.shape), p2[:, 8] if cb is not None else None,
+                p2[:, 4:8].reshape(cw_b.shape), p2[:, 9] if cb_b is not None else None,
+                dWx2[0], dWx2[1], dWdt2[0], dbdt2[0], dWdt2[1], dbdt2[1], dA2[0], dA2[1],
+                p1[:, 2], p1[:, 3], p1[:, 0] if has_ln else None, p1[:, 1] if has_ln else None,
+                dW_out, db_out, None, None, None, None, None, None, None)
+
+
+class Mamba(nn.Module):
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False,
+                 use_fast_path=False, layer_idx=None, device=None, dtype=None, init_layer_scale=None,
+                 scanpath_type="rowwise", token_size=None, use_norm_after_ssm=True,
+                 use_our_selective_scan=False, collapse_method="mean", scaling_factor=1):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.d_model = d_model
+        self.d_state = d_state
+        self.d_conv = d_conv
+        self.expand = expand
+        self.d_inner = int(self.expand * self.d_model)
+        self.dt_rank = math.ceil(self.d_model / 16) if dt_rank == "auto" else dt_rank
+        self.use_fast_path = use_fast_path            # accepted for config compatibility; one fused path here
+        self.layer_idx = layer_idx
+        self.use_our_selective_scan = use_our_selective_scan
+        self.num_of_rows, self.num_of_col = token_size[0], token_size[1]
+        self.scanpath_type = scanpath_type
+        self.scaling_factor = scaling_factor
+        if collapse_method not in ("mean", "max"):
+            raise NotImplementedError(collapse_method)
+        self.collapse_method = collapse_method
+        self.init_layer_scale = init_layer_scale
+        if init_layer_scale is not None:
+            self.gamma = nn.Parameter(init_layer_scale * torch.ones(d_model), requires_grad=True)
+
+        self.in_proj = nn.Linear(self.d_model, self.d_inner * 2, bias=bias, **factory_kwargs)
+        self.use_norm_after_ssm = use_norm_after_ssm
+        if use_norm_after_ssm:
+            self.layernorm = nn.LayerNorm(self.d_inner, **factory_kwargs)
+
+        def conv():
+            return nn.Conv1d(self.d_inner, self.d_inner, bias=conv_bias, kernel_size=d_conv, groups=self.d_inner,
+                             padding=d_conv - 1, **factory_kwargs)
+
+        self.conv1d = conv()
+        self.activation = "silu"
+        self.act = nn.SiLU()
+        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+
+        # dt projection init preserving variance; bias = softplus^-1(dt), dt ~ logU[dt_min, dt_max]
+        # (mamba_simple_faster.py:110-130)
+        dt_init_std = self.dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(self.dt_proj.weight, dt_init_std)
+        elif dt_init == "random":
+            nn.init.uniform_(self.dt_proj.weight, -dt_init_std, dt_init_std)
+        else:
+            raise NotImplementedError
+        dt = torch.exp(torch.rand(self.d_inner, **factory_kwargs) * (math.log(dt_max) - math.log(dt_min))
+                       + math.log(dt_min)).clamp(min=dt_init_floor)
+        inv_dt = dt + torch.log(-torch.expm1(-dt))
+        with torch.no_grad():
+            self.dt_proj.bias.copy_(inv_dt)
+        self.dt_proj.bias._no_reinit = True
+
+        def s4d_real():
+            A = torch.arange(1, self.d_state + 1, dtype=torch.float32, device=device).repeat(self.d_inner, 1)
+            p = nn.Parameter(torch.log(A).contiguous())       # fp32
+            p._no_weight_decay = True
+            return p
+
+        self.A_log = s4d_real()
+        self.D = nn.Parameter(torch.ones(self.d_inner, device=device))
+        self.D._no_weight_decay = True
+        self.A_b_log = s4d_real()
+        self.conv1d_b = conv()
+        self.x_proj_b = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+        self.dt_proj_b = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+        self.D_b = nn.Parameter(torch.ones(self.d_inner, device=device))
+        self.D_b._no_weight_decay = True
+        self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
+        self.pre_x_shape = (-1, self.d_inner, self.num_of_rows, self.num_of_col)
+
+    def forward(self, hidden_states, inference_params=None, transposed_grid=False):
+        """hidden_states: (B, L, D) -> (B, L, D).
+
+        ``transposed_grid=False``: tokens are in this mixer's own (rows, cols) sequence order, exactly
+        the reference contract.  ``transposed_grid=True``: tokens are in the *transposed* (cols, rows)
+        order -- what ``Block`` holds in memory on odd layers -- and the output comes back in that same
+        order; equivalent to transpose -> mixer -> transpose (models/fastvim.py:192-210) with no copies."""
+        if inference_params is not None:
+            raise NotImplementedError("FastVim mixers have no inference cache (reference: no step())")
+        if self.d_conv != 4 or self.d_state != 16:
+            raise RuntimeError("fastvim_amd kernels are built for d_conv=4, d_state=16 (the FastVim configs)")
+        cdt = _compute_dtype(hidden_states)
+        ln_w = self.layernorm.weight if self.use_norm_after_ssm else None
+        ln_b = self.layernorm.bias if self.use_norm_after_ssm else None
+        ln_eps = self.layernorm.eps if self.use_norm_after_ssm else 0.0
+        out = FastVimMixerFn.apply(
+            hidden_states, self.in_proj.weight, self.in_proj.bias,
+            self.conv1d.weight, self.conv1d.bias, self.conv1d_b.weight, self.conv1d_b.bias,
+            self.x_proj.weight, self.x_proj_b.weight,
+            self.dt_proj.weight, self.dt_proj.bias, self.dt_proj_b.weight, self.dt_proj_b.bias,
+            self.A_log, self.A_b_log, self.D, self.D_b, ln_w, ln_b,
+            self.out_proj.weight, self.out_proj.bias,
+            self.num_of_rows, self.num_of_col, bool(transposed_grid), self.collapse_method == "max",
+            float(self.scaling_factor), float(ln_eps), cdt)
+        if self.init_layer_scale is not None:
+            out = out * self.gamma
+        return out

@@ -57,3 +57,72 @@ def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, 
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_combine_fwd")
     return g, mean, rstd
+
+
+def reduce_partials(part, n_partials):
+    """Fixed-order sum over the leading dim of a (n_partials, ...) fp32 buffer."""
+    out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
+    n = out.numel()
+    rc = L.lib().fv_reduce_partials(L.ptr(part), L.ptr(out), L.i32(n_partials), ctypes.c_size_t(n),
+                                    L.stream_of(part))
+    L.check(rc, "reduce_partials")
+    return out
+
+
+def combine_bwd(dg, xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, mean, rstd, dxz,
+                rows, cols, transposed):
+    B, Ltok, two_d = xz.shape
+    d_in = two_d // 2
+    s_i, s_j = _geo(rows, cols, transposed)
+    lib = L.lib()
+    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows))
+    d_o = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype)
+    dyc = torch.empty(B, rows, d_in, device=xz.device, dtype=torch.float32)
+    part = torch.empty(nb, d_in, 4, device=xz.device, dtype=torch.float32)
+    rc = lib.fv_mixer_combine_bwd(
+        L.ptr(dg), L.ptr(xz), L.ptr(yc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
+        L.ptr(D), L.ptr(D_b), L.ptr(ln_w), L.ptr(ln_b), L.ptr(mean), L.ptr(rstd), L.ptr(dxz), L.ptr(d_o),
+        L.ptr(dyc), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in),
+        L.i32(conv_w.shape[-1]), L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
+    L.check(rc, "mixer_combine_bwd")
+    return d_o, dyc, reduce_partials(part, nb)      # (d_in, 4): [dln_w, dln_b, dD, dD_b]
+
+
+def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc):
+    _, B, Lc, d_in = xc.shape
+    R, N = dt_w.shape[1], A_log.shape[1]
+    W = R + 2 * N
+    dev = xc.device
+    lib = L.lib()
+    nchunks = lib.fv_mixer_scan_bwd_chunks(L.i32(d_in))
+    f32o = dict(device=dev, dtype=torch.float32)
+    dxc = torch.empty(2, B, Lc, d_in, **f32o)
+    dx_dbl = torch.empty(nchunks, 2, B * Lc, W, **f32o)
+    ckpt = torch.empty(max(1, lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N))), **f32o)
+    pA = torch.empty(B, 2, d_in, N, **f32o)
+    pW = torch.empty(B, 2, d_in, R, **f32o)
+    pb = torch.empty(B, 2, d_in, **f32o)
+    rc = lib.fv_mixer_scan_bwd(
+        L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
+        L.ptr(A_log_b), L.ptr(dyc), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(pA), L.ptr(pW), L.ptr(pb),
+        L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
+    L.check(rc, "mixer_scan_bwd")
+    dx_dbl = dx_dbl[0] if nchunks == 1 else reduce_partials(dx_dbl, nchunks)
+    return dxc, dx_dbl, reduce_partials(pA, B), reduce_partials(pW, B), reduce_partials(pb, B)
+
+
+def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed,
+                  pool_max, scaling):
+    B, Ltok, two_d = xz.shape
+    d_in = two_d // 2
+    s_i, s_j = _geo(rows, cols, transposed)
+    lib = L.lib()
+    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows))
+    part = torch.empty(nb, d_in, 10, device=xz.device, dtype=torch.float32)
+    rc = lib.fv_mixer_conv_pool_bwd(
+        L.ptr(xz), L.ptr(d_o), L.ptr(dxc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
+        L.ptr(D), L.ptr(D_b), L.ptr(dxz), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i),
+        L.i32(s_j), L.i32(d_in), L.i32(conv_w.shape[-1]), L.i32(pool_max), f32(scaling),
+        L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
+    L.check(rc, "mixer_conv_pool_bwd")
+    return reduce_partials(part, nb)                # (d_in, 10): [dw(4), dw_b(4), db, db_b]

@@ -105,6 +105,51 @@ int fv_mixer_combine_fwd(const void* xz, const float* yc, const float* conv_w, c
                          float* rstd, int batch, int rows, int cols, int tok_stride_row,
                          int tok_stride_col, int d_inner, int d_conv, int dtype, fv_stream_t stream);
 
+/* ---- backward of the fused mixer middle --------------------------------------------
+ * Number of persistent blocks the two row-walking backward kernels launch; their `partials`
+ * buffers are (fv_mixer_bwd_blocks, d_inner, 4) and (fv_mixer_bwd_blocks, d_inner, 10) fp32. */
+int fv_mixer_bwd_blocks(int batch, int rows);
+
+/* Adjoint of fv_mixer_combine_fwd.  dg: gradient wrt g.  Writes dz into the z half of dxz
+ * (batch, L, 2*d_inner), d_o (batch, L, d_inner) = gradient wrt the averaged pre-norm value,
+ * dyc (batch, rows, d_inner) fp32 = 0.5 * sum_j d_o (gradient wrt BOTH directions' scan
+ * outputs), and per-block partials [d ln_w | d ln_b | dD | dD_b] per channel. */
+int fv_mixer_combine_bwd(const void* dg, const void* xz, const float* yc, const float* conv_w,
+                         const float* conv_b, const float* conv_w_b, const float* conv_b_b, const float* D,
+                         const float* D_b, const float* ln_w, const float* ln_b, const float* mean,
+                         const float* rstd, void* dxz, void* d_o, float* dyc, float* partials, int batch,
+                         int rows, int cols, int tok_stride_row, int tok_stride_col, int d_inner, int d_conv,
+                         int dtype, fv_stream_t stream);
+
+/* Adjoint of fv_mixer_scan_fwd with the dt_proj adjoint fused in (replaces
+ * selective_scan_cuda.bwd + the einsums of selective_scan_interface.py:698-723).
+ *   dyc    (batch, Lc, d_inner) fp32          in
+ *   dxc    (2, batch, Lc, d_inner) fp32       out: gradient wrt xc through the scan input u
+ *   dx_dbl (fv_mixer_scan_bwd_chunks, 2, batch*Lc, dt_rank+2*d_state) fp32 out: sum over chunks
+ *          = gradient wrt x_dbl
+ *   ckpt   fv_mixer_scan_bwd_ckpt_floats() fp32 scratch
+ *   pA (batch, 2, d_inner, d_state), pW (batch, 2, d_inner, dt_rank), pb (batch, 2, d_inner):
+ *          per-batch partials of dA_log, d dt_proj.weight, d dt_proj.bias (sum over batch). */
+int fv_mixer_scan_bwd_chunks(int d_inner);
+size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state);
+int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                      const float* A_log, const float* dt_w_b, const float* dt_bias_b, const float* A_log_b,
+                      const float* dyc, float* dxc, float* dx_dbl, float* ckpt, float* pA, float* pW,
+                      float* pb, int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
+                      fv_stream_t stream);
+
+/* Adjoint of fv_mixer_conv_pool_fwd plus the D-skip path: consumes d_o and the total gradient
+ * wrt the pooled conv output dxc (2, batch, rows, d_inner) fp32; writes dx into the x half of
+ * dxz and per-block partials [d conv_w (4) | d conv_w_b (4) | d conv_b | d conv_b_b] per channel. */
+int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, const float* conv_w,
+                           const float* conv_b, const float* conv_w_b, const float* conv_b_b, const float* D,
+                           const float* D_b, void* dxz, float* partials, int batch, int rows, int cols,
+                           int tok_stride_row, int tok_stride_col, int d_inner, int d_conv, int pool_max,
+                           float scaling_factor, int dtype, fv_stream_t stream);
+
+/* out[i] = sum_{s < n_partials} partials[s*n + i], fixed order (deterministic). */
+int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n, fv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
