@@ -1,0 +1,242 @@
+// Fused (DropPath-scale) + residual-add + RMSNorm / LayerNorm, forward and backward.
+// Replaces the Triton kernels _layer_norm_fwd_1pass_kernel / _layer_norm_bwd_kernel
+// (mamba-1p1p1/mamba_ssm/ops/triton/layernorm.py:66-121, 210-304) behind rms_norm_fn /
+// layer_norm_fn (layernorm.py:492-512).
+//
+// One wave64 per row, 4 channels per lane per step (8 B bf16 / 16 B fp32 accesses), the whole row
+// kept in registers between the statistics pass and the normalise pass; statistics by DPP wave
+// reductions (two exact passes: mean, then centred second moment).  The per-sample DropPath scale
+// of the mixer branch (timm DropPath applied in models/fastvim.py:182-190) is folded into the add,
+// and the output cast to the mixer's compute dtype is folded into the store.
+#include "rowwalk.h"
+
+namespace {
+
+constexpr int MAXK = 8;   // up to 8 * 256 = 2048 channels per row
+
+struct NormParams {
+  const void *x, *res, *dy, *dres_out, *r;
+  const float *w, *b, *row_scale, *mean_in, *rstd_in;
+  void *y, *res_out, *dx, *dres_in;
+  float *mean, *rstd, *pw, *pb;
+  int x_dt, res_dt, y_dt, ro_dt, dy_dt, dro_dt, r_dt, dx_dt, dri_dt;
+  int M, N, rows_per_scale, is_rms;
+  float eps;
+};
+
+__device__ __forceinline__ void ld4(const void* p, int dt, size_t idx, float (&v)[4]) {
+  if (dt == FV_F32) VecIO<float, 4>::load((const float*)p + idx, v);
+  else VecIO<bf16_t, 4>::load((const bf16_t*)p + idx, v);
+}
+__device__ __forceinline__ void st4(void* p, int dt, size_t idx, const float (&v)[4]) {
+  if (dt == FV_F32) VecIO<float, 4>::store((float*)p + idx, v);
+  else VecIO<bf16_t, 4>::store((bf16_t*)p + idx, v);
+}
+
+__global__ __launch_bounds__(256) void add_norm_fwd_kernel(NormParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float inv_n = 1.f / (float)p.N;
+  for (int row = wave; row < p.M; row += nwaves) {
+    const size_t base = (size_t)row * p.N;
+    const float sc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.f;
+    float v[MAXK][4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < p.N) {
+        ld4(p.x, p.x_dt, base + c, v[k]);
+        if (p.res) {
+          float r[4];
+          ld4(p.res, p.res_dt, base + c, r);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[k][e] = fmaf(v[k][e], sc, r[e]);
+        } else if (p.row_scale) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[k][e] *= sc;
+        }
+        if (p.res_out) st4(p.res_out, p.ro_dt, base + c, v[k]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[k][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] = 0.f;
+      }
+    }
+    float mu = 0.f;
+    if (!p.is_rms) mu = wave_sum_uniform(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < p.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float d = v[k][e] - mu;
+          q = fmaf(d, d, q);
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum_uniform(q) * inv_n + p.eps);
+    if (lane == 0) {
+      p.rstd[row] = rstd;
+      if (!p.is_rms && p.mean) p.mean[row] = mu;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < p.N) {
+        float w[4], o[4];
+        VecIO<float, 4>::load(p.w + c, w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu) * rstd * w[e];
+        if (p.b) {
+          float bb[4];
+          VecIO<float, 4>::load(p.b + c, bb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += bb[e];
+        }
+        st4(p.y, p.y_dt, base + c, o);
+      }
+    }
+  }
+}
+
+// backward: dr = rstd * (dxhat - mean(dxhat)[LN only] - xhat * mean(dxhat * xhat)) + dres_out
+//           dx = dr * row_scale, dres_in = dr;  per-wave-group partials of dw (and db)
+__global__ __launch_bounds__(256) void add_norm_bwd_kernel(NormParams p) {
+  __shared__ float s_acc[4][MAXK * 256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float inv_n = 1.f / (float)p.N;
+  float aw[MAXK][4], ab[MAXK][4];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) aw[k][e] = ab[k][e] = 0.f;
+  for (int row = wave; row < p.M; row += nwaves) {
+    const size_t base = (size_t)row * p.N;
+    const float rstd = p.rstd_in[row];
+    const float mu = p.is_rms ? 0.f : p.mean_in[row];
+    float xh[MAXK][4], dxh[MAXK][4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < p.N) {
+        float r[4], dy[4], w[4];
+        ld4(p.r, p.r_dt, base + c, r);
+        ld4(p.dy, p.dy_dt, base + c, dy);
+        VecIO<float, 4>::load(p.w + c, w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[k][e] = (r[e] - mu) * rstd;
+          dxh[k][e] = dy[e] * w[e];
+          aw[k][e] = fmaf(dy[e], xh[k][e], aw[k][e]);
+          ab[k][e] += dy[e];
+          c1 += dxh[k][e];
+          c2 = fmaf(dxh[k][e], xh[k][e], c2);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xh[k][e] = dxh[k][e] = 0.f;
+      }
+    }
+    c2 = wave_sum_uniform(c2) * inv_n;
+    c1 = p.is_rms ? 0.f : wave_sum_uniform(c1) * inv_n;
+    const float sc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < p.N) {
+        float dr[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dr[e] = rstd * (dxh[k][e] - c1 - xh[k][e] * c2);
+        if (p.dres_out) {
+          float g[4];
+          ld4(p.dres_out, p.dro_dt, base + c, g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dr[e] += g[e];
+        }
+        if (p.dres_in) st4(p.dres_in, p.dri_dt, base + c, dr);
+        if (p.dx) {
+          if (p.row_scale)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dr[e] *= sc;
+          st4(p.dx, p.dx_dt, base + c, dr);
+        }
+      }
+    }
+  }
+  // block-level fixed-order reduction of the 4 waves' accumulators -> one partial row per block
+  for (int pass = 0; pass < (p.pb ? 2 : 1); ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < p.N)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_acc[wv][c + e] = pass ? ab[k][e] : aw[k][e];
+    }
+    __syncthreads();
+    float* dst = (pass ? p.pb : p.pw) + (size_t)blockIdx.x * p.N;
+    for (int c = threadIdx.x; c < p.N; c += blockDim.x)
+      dst[c] = (s_acc[0][c] + s_acc[1][c]) + (s_acc[2][c] + s_acc[3][c]);
+  }
+}
+
+int dt_ok(int dt) { return dt == FV_F32 || dt == FV_BF16; }
+
+}  // namespace
+
+extern "C" int fv_add_norm_blocks(int M) {
+  long waves = M < 4096 ? M : 4096;   // persistent: at most 1024 blocks of 4 waves
+  return (int)((waves + 3) / 4);
+}
+
+extern "C" int fv_add_norm_fwd(const void* x, int x_dtype, const void* residual, int residual_dtype,
+                               const float* weight, const float* bias, const float* row_scale,
+                               int rows_per_scale, void* y, int y_dtype, void* residual_out,
+                               int residual_out_dtype, float* mean, float* rstd, int M, int N, float eps,
+                               int is_rms_norm, fv_stream_t stream) {
+  FV_CHECK(M > 0 && N > 0, "add_norm_fwd: empty input");
+  FV_CHECK(N % 4 == 0 && N <= MAXK * 256, "add_norm_fwd: hidden size %d must be a multiple of 4 and <= %d", N, MAXK * 256);
+  FV_CHECK(x && weight && y && rstd, "add_norm_fwd: null pointer");
+  FV_CHECK(dt_ok(x_dtype) && dt_ok(y_dtype) && (!residual || dt_ok(residual_dtype)) &&
+               (!residual_out || dt_ok(residual_out_dtype)), "add_norm_fwd: dtypes must be fp32 or bf16");
+  FV_CHECK(is_rms_norm || mean, "add_norm_fwd: LayerNorm needs a mean buffer");
+  FV_CHECK(!row_scale || rows_per_scale > 0, "add_norm_fwd: rows_per_scale must be positive");
+  NormParams p{};
+  p.x = x; p.res = residual; p.w = weight; p.b = bias; p.row_scale = row_scale; p.y = y; p.res_out = residual_out;
+  p.mean = mean; p.rstd = rstd;
+  p.x_dt = x_dtype; p.res_dt = residual_dtype; p.y_dt = y_dtype; p.ro_dt = residual_out_dtype;
+  p.M = M; p.N = N; p.rows_per_scale = rows_per_scale; p.is_rms = is_rms_norm; p.eps = eps;
+  hipLaunchKernelGGL(add_norm_fwd_kernel, dim3(fv_add_norm_blocks(M)), dim3(256), 0, (hipStream_t)stream, p);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+extern "C" int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidual_out, int dresidual_out_dtype,
+                               const void* r, int r_dtype, const float* weight, const float* mean,
+                               const float* rstd, const float* row_scale, int rows_per_scale, void* dx,
+                               int dx_dtype, void* dresidual_in, int dresidual_in_dtype, float* partial_dw,
+                               float* partial_db, int M, int N, int is_rms_norm, fv_stream_t stream) {
+  FV_CHECK(M > 0 && N > 0, "add_norm_bwd: empty input");
+  FV_CHECK(N % 4 == 0 && N <= MAXK * 256, "add_norm_bwd: hidden size %d must be a multiple of 4 and <= %d", N, MAXK * 256);
+  FV_CHECK(dy && r && weight && rstd && partial_dw, "add_norm_bwd: null pointer");
+  FV_CHECK(is_rms_norm || mean, "add_norm_bwd: LayerNorm needs the saved mean");
+  FV_CHECK(dt_ok(dy_dtype) && dt_ok(r_dtype) && (!dresidual_out || dt_ok(dresidual_out_dtype)) &&
+               (!dx || dt_ok(dx_dtype)) && (!dresidual_in || dt_ok(dresidual_in_dtype)),
+           "add_norm_bwd: dtypes must be fp32 or bf16");
+  NormParams p{};
+  p.dy = dy; p.dres_out = dresidual_out; p.r = r; p.w = weight; p.mean_in = mean; p.rstd_in = rstd;
+  p.row_scale = row_scale; p.dx = dx; p.dres_in = dresidual_in; p.pw = partial_dw; p.pb = partial_db;
+  p.dy_dt = dy_dtype; p.dro_dt = dresidual_out_dtype; p.r_dt = r_dtype; p.dx_dt = dx_dtype; p.dri_dt = dresidual_in_dtype;
+  p.M = M; p.N = N; p.rows_per_scale = rows_per_scale; p.is_rms = is_rms_norm;
+  hipLaunchKernelGGL(add_norm_bwd_kernel, dim3(fv_add_norm_blocks(M)), dim3(256), 0, (hipStream_t)stream, p);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}

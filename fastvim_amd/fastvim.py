@@ -1,0 +1,375 @@
+"""FastVim backbone: mirror of models/fastvim.py (``PatchEmbed`` :25-103, ``Block`` :106-217,
+``create_block`` :220-291, init fns :295-339, ``VisionMamba`` :342-557, factories :696-967).
+
+Same constructor kwargs, attribute names, ``state_dict`` keys and factory entry points, so it drops
+into the reference's Lightning / Hydra ``_target_`` training loops.  Differences are internal:
+
+* ``Block`` never transposes the token grid; odd layers pass ``transposed_grid=True`` to the mixer,
+  whose kernels walk the grid with swapped token strides (models/fastvim.py:192-210 does two
+  full-length copies per odd layer);
+* DropPath on the mixer branch is a per-sample scale folded into the fused add+RMSNorm kernel;
+* timm / mmdet / mmseg are not imported (``MM_FastVim`` det/seg glue is out of scope).
+"""
+import math
+from functools import partial
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
+from .mamba_simple_faster import Mamba, _compute_dtype
+
+
+def to_2tuple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
+    return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)
+
+
+def lecun_normal_(tensor):
+    # timm.layers.lecun_normal_: variance_scaling_(scale=1, mode="fan_in", distribution="truncated_normal")
+    fan_in = nn.init._calculate_fan_in_and_fan_out(tensor)[0]
+    std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+    return nn.init.trunc_normal_(tensor, std=std, a=-2 * std, b=2 * std)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.layers.DropPath).  ``row_scale`` returns the (B,) scale
+    vector instead of multiplying, so the fused add+norm kernel can apply it."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.scale_by_keep = scale_by_keep
+
+    def row_scale(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return mask
+
+    def forward(self, x):
+        s = self.row_scale(x)
+        if s is None:
+            return x
+        return x * s.to(x.dtype).view(-1, *([1] * (x.ndim - 1)))
+
+    def extra_repr(self):
+        return f"drop_prob={round(self.drop_prob, 3):0.3f}"
+
+
+class PatchEmbed(nn.Module):
+    """2D Image to Patch Embedding (models/fastvim.py:25-103)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True,
+                 strict_img_size=True, dynamic_img_pad=False, scanpath_type="rowwise"):
+        super().__init__()
+        self.img_size = to_2tuple(img_size)
+        self.patch_size = to_2tuple(patch_size)
+        gh, gw = self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1]
+        if scanpath_type == "colwise":      # Pool_row in the paper
+            self.grid_size = (gw, gh)
+        elif scanpath_type == "rowwise":    # Pool_col in the paper
+            self.grid_size = (gh, gw)
+        else:
+            raise ValueError(scanpath_type)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.scanpath_type = scanpath_type
+        self.flatten = flatten
+        self.strict_img_size = strict_img_size
+        self.dynamic_img_pad = dynamic_img_pad
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        if self.strict_img_size:
+            assert H == self.img_size[0], f"Input height ({H}) doesn't match model ({self.img_size[0]})."
+            assert W == self.img_size[1], f"Input width ({W}) doesn't match model ({self.img_size[1]})."
+        elif not self.dynamic_img_pad:
+            assert H % self.patch_size[0] == 0, f"Input height ({H}) should be divisible by patch size ({self.patch_size[0]})."
+            assert W % self.patch_size[1] == 0, f"Input width ({W}) should be divisible by patch size ({self.patch_size[1]})."
+        if self.dynamic_img_pad:
+            pad_h = (self.patch_size[0] - H % self.patch_size[0]) % self.patch_size[0]
+            pad_w = (self.patch_size[1] - W % self.patch_size[1]) % self.patch_size[1]
+            x = F.pad(x, (0, pad_w, 0, pad_h))
+        x = self.proj(x)
+        if self.scanpath_type == "colwise":
+            x = x.transpose(2, 3)
+        if self.flatten:
+            x = x.flatten(2).transpose(1, 2)  # BCHW -> BNC
+        return self.norm(x)
+
+
+class Block(nn.Module):
+    """Add -> (RMS/Layer)Norm -> Mixer, returning (hidden_states, residual)  (models/fastvim.py:106-217)."""
+
+    def __init__(self, dim, mixer_cls, norm_cls=nn.LayerNorm, fused_add_norm=False, residual_in_fp32=False,
+                 drop_path=0.0, rotate_every_block=True, layer_idx=None, token_size=None):
+        super().__init__()
+        self.residual_in_fp32 = residual_in_fp32
+        self.fused_add_norm = fused_add_norm
+        self.mixer = mixer_cls(dim)
+        self.norm = norm_cls(dim)
+        self.rotate_every_block = rotate_every_block
+        self.layer_idx = layer_idx
+        self.token_size = token_size
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        if self.fused_add_norm:
+            assert isinstance(self.norm, (nn.LayerNorm, RMSNorm)), \
+                "Only LayerNorm and RMSNorm are supported for fused_add_norm"
+
+    def forward(self, hidden_states: Tensor, residual: Optional[Tensor] = None, inference_params=None):
+        cdt = _compute_dtype(hidden_states)
+        is_rms = isinstance(self.norm, RMSNorm)
+        if self.fused_add_norm:
+            scale = None
+            if residual is not None and isinstance(self.drop_path, DropPath):
+                scale = self.drop_path.row_scale(hidden_states)
+            hidden_states, residual = layer_norm_fn(
+                hidden_states, self.norm.weight, self.norm.bias, residual=residual, eps=self.norm.eps,
+                prenorm=True, residual_in_fp32=self.residual_in_fp32, is_rms_norm=is_rms,
+                row_scale=scale, out_dtype=cdt)
+        else:
+            residual = hidden_states if residual is None else residual + self.drop_path(hidden_states)
+            hidden_states = layer_norm_fn(residual.to(self.norm.weight.dtype), self.norm.weight, self.norm.bias,
+                                          eps=self.norm.eps, is_rms_norm=is_rms, out_dtype=cdt)
+            if self.residual_in_fp32:
+                residual = residual.to(torch.float32)
+        # odd layers pool across the other grid axis: the mixer (built with the swapped token_size)
+        # reads the un-transposed tokens through swapped strides
+        rot = self.rotate_every_block is True and self.layer_idx % 2 != 0
+        hidden_states = self.mixer(hidden_states, inference_params=inference_params, transposed_grid=rot)
+        return hidden_states, residual
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        raise NotImplementedError("FastVim mixers have no inference cache")
+
+
+def create_block(d_model, ssm_cfg=None, norm_epsilon=1e-5, drop_path=0.0, rms_norm=False, residual_in_fp32=False,
+                 fused_add_norm=False, layer_idx=None, device=None, dtype=None, init_layer_scale=None,
+                 scanpath_type="rowwise", use_norm_after_ssm=True, rotate_every_block=True,
+                 collapse_method="mean", token_size=None, use_our_selective_scan=False, scaling_factor=1):
+    if ssm_cfg is None:
+        ssm_cfg = {}
+    factory_kwargs = {"device": device, "dtype": dtype}
+    rot = rotate_every_block is True and layer_idx % 2 != 0
+    mixer_cls = partial(
+        Mamba, layer_idx=layer_idx, init_layer_scale=init_layer_scale, scanpath_type=scanpath_type,
+        use_norm_after_ssm=use_norm_after_ssm,
+        token_size=[token_size[1], token_size[0]] if rot else list(token_size),   # models/fastvim.py:244-274
+        collapse_method=collapse_method, use_our_selective_scan=use_our_selective_scan,
+        scaling_factor=scaling_factor, **ssm_cfg, **factory_kwargs)
+    norm_cls = partial(nn.LayerNorm if not rms_norm else RMSNorm, eps=norm_epsilon, **factory_kwargs)
+    block = Block(d_model, mixer_cls, norm_cls=norm_cls, drop_path=drop_path, fused_add_norm=fused_add_norm,
+                  residual_in_fp32=residual_in_fp32, rotate_every_block=rotate_every_block, layer_idx=layer_idx,
+                  token_size=token_size)
+    block.layer_idx = layer_idx
+    return block
+
+
+def _init_weights(module, n_layer, initializer_range=0.02, rescale_prenorm_residual=True, n_residuals_per_layer=1):
+    """models/fastvim.py:295-324 (GPT-2 style scaled init of the residual-branch output projections)."""
+    if isinstance(module, nn.Linear):
+        if module.bias is not None and not getattr(module.bias, "_no_reinit", False):
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.Embedding):
+        nn.init.normal_(module.weight, std=initializer_range)
+    if rescale_prenorm_residual:
+        for name, p in module.named_parameters():
+            if name in ["out_proj.weight", "fc2.weight"]:
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                with torch.no_grad():
+                    p /= math.sqrt(n_residuals_per_layer * n_layer)
+
+
+def segm_init_weights(m):
+    if isinstance(m, nn.Linear):
+        trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.Conv2d):
+        lecun_normal_(m.weight)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d)):
+        nn.init.zeros_(m.bias)
+        nn.init.ones_(m.weight)
+
+
+class VisionMamba(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, stride=16, depth=24, embed_dim=192, channels=3,
+                 num_classes=1000, ssm_cfg=None, drop_rate=0.0, drop_path_rate=0.1, norm_epsilon: float = 1e-5,
+                 rms_norm: bool = True, initializer_cfg=None, fused_add_norm=False, residual_in_fp32=False,
+                 device=None, dtype=None, final_pool_type="none", if_abs_pos_embed=True, init_layer_scale=None,
+                 embed_layer=PatchEmbed, scanpath_type="rowwise", use_norm_after_ssm=True,
+                 rotate_every_block=True, collapse_method="mean", use_our_selective_scan=False,
+                 scaling_factor=1, **kwargs):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        kwargs.update(factory_kwargs)
+        super().__init__()
+        self.residual_in_fp32 = residual_in_fp32
+        self.fused_add_norm = fused_add_norm
+        self.final_pool_type = final_pool_type
+        self.if_abs_pos_embed = if_abs_pos_embed
+        self.rotate_every_block = rotate_every_block
+        self.num_classes = num_classes
+        self.d_model = self.num_features = self.embed_dim = embed_dim
+        self.patch_size = patch_size
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=channels,
+                                      embed_dim=embed_dim, strict_img_size=False, dynamic_img_pad=True,
+                                      scanpath_type=scanpath_type)
+        self.num_patches = self.patch_embed.num_patches
+        self.token_size = self.patch_embed.grid_size
+        if if_abs_pos_embed:
+            self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, self.embed_dim))
+            self.pos_drop = nn.Dropout(p=drop_rate)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]   # stochastic depth decay rule
+        inter_dpr = [0.0] + dpr                                              # layer i uses inter_dpr[i] (:433)
+        self.drop_path = DropPath(drop_path_rate) if drop_path_rate > 0.0 else nn.Identity()
+        self.layers = nn.ModuleList([
+            create_block(embed_dim, ssm_cfg=ssm_cfg, norm_epsilon=norm_epsilon, rms_norm=rms_norm,
+                         residual_in_fp32=residual_in_fp32, fused_add_norm=fused_add_norm, layer_idx=i,
+                         drop_path=inter_dpr[i], init_layer_scale=init_layer_scale, scanpath_type=scanpath_type,
+                         use_norm_after_ssm=use_norm_after_ssm, rotate_every_block=rotate_every_block,
+                         collapse_method=collapse_method, token_size=self.token_size,
+                         use_our_selective_scan=use_our_selective_scan, scaling_factor=scaling_factor,
+                         **factory_kwargs)
+            for i in range(depth)])
+        self.norm_f = (nn.LayerNorm if not rms_norm else RMSNorm)(embed_dim, eps=norm_epsilon, **factory_kwargs)
+
+        self.patch_embed.apply(segm_init_weights)
+        self.head.apply(segm_init_weights)
+        if if_abs_pos_embed:
+            trunc_normal_(self.pos_embed, std=0.02)
+        self.apply(partial(_init_weights, n_layer=depth, **(initializer_cfg if initializer_cfg is not None else {})))
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_embed"}
+
+    def forward_features(self, x, inference_params=None, out_indices=None):
+        B, _, H, W = x.shape
+        x = self.patch_embed(x)
+        if self.if_abs_pos_embed:
+            H, W = math.ceil(H / self.patch_size), math.ceil(W / self.patch_size)
+            if H != self.token_size[0] or W != self.token_size[1]:
+                # the reference's resize call is broken for this case: construct
+                # the model with the target img_size instead
+                raise RuntimeError(f"input grid {H}x{W} differs from the model's {self.token_size}; "
+                                   "build VisionMamba with the matching img_size")
+            x = x + self.pos_embed
+            x = self.pos_drop(x)
+        outs = []
+        residual = None
+        hidden_states = x
+        for layer_idx, layer in enumerate(self.layers):
+            hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
+            if out_indices is not None and layer_idx in out_indices:
+                outs.append(hidden_states)
+        if out_indices is not None:
+            assert len(outs) == len(out_indices)
+            return outs, (H, W)
+        is_rms = isinstance(self.norm_f, RMSNorm)
+        if not self.fused_add_norm:
+            residual = hidden_states if residual is None else residual + self.drop_path(hidden_states)
+            hidden_states = layer_norm_fn(residual.to(self.norm_f.weight.dtype), self.norm_f.weight, self.norm_f.bias,
+                                          eps=self.norm_f.eps, is_rms_norm=is_rms)
+        else:
+            scale = self.drop_path.row_scale(hidden_states) if isinstance(self.drop_path, DropPath) else None
+            hidden_states = layer_norm_fn(hidden_states, self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps,
+                                          residual=residual, prenorm=False, residual_in_fp32=self.residual_in_fp32,
+                                          is_rms_norm=is_rms, row_scale=scale)
+        if self.final_pool_type == "none":
+            return hidden_states[:, -1, :]
+        elif self.final_pool_type == "mean":
+            return hidden_states.mean(dim=1)
+        elif self.final_pool_type in ("max", "all"):
+            return hidden_states
+        raise NotImplementedError
+
+    def forward(self, x, return_features=False, inference_params=None):
+        x = self.forward_features(x, inference_params)
+        if return_features:
+            return x
+        x = self.head(x)
+        if self.final_pool_type == "max":
+            x = x.max(dim=1)[0]
+        return x
+
+
+def _factory(embed_dim, depth, img_size, patch_size, stride, kwargs):
+    return VisionMamba(img_size=img_size, patch_size=patch_size, stride=stride, embed_dim=embed_dim, depth=depth,
+                       rms_norm=True, residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean",
+                       if_abs_pos_embed=True, **kwargs)
+
+
+def _load_transfer_checkpoint(model, path, img_size, patch_size):
+    """Checkpoint contract of models/fastvim.py:779-815: Lightning ``state_dict`` with a ``backbone.``
+    prefix; square ``pos_embed`` bicubically resized to the new grid."""
+    checkpoint = torch.load(path, map_location="cpu")["state_dict"]
+    sd = {k.replace("backbone.", ""): v for k, v in checkpoint.items()}
+    if "pos_embed" in sd:
+        orig = int(math.sqrt(sd["pos_embed"].shape[1]))
+        new = int(img_size // patch_size)
+        if orig != new:
+            e = sd["pos_embed"].shape[-1]
+            t = sd["pos_embed"].reshape(-1, orig, orig, e).permute(0, 3, 1, 2)
+            t = F.interpolate(t, size=(new, new), mode="bicubic", align_corners=False)
+            sd["pos_embed"] = t.permute(0, 2, 3, 1).flatten(1, 2)
+    return model.load_state_dict(sd, strict=False)
+
+
+def vim_tiny_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2(
+        pretrained=False, img_size=224, patch_size=16, stride=16, **kwargs):
+    assert not pretrained, "no network: load weights with load_state_dict"
+    return _factory(192, 24, img_size, patch_size, stride, kwargs)
+
+
+def vim_small_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2(
+        pretrained=False, img_size=224, patch_size=16, stride=16, **kwargs):
+    assert not pretrained, "no network: load weights with load_state_dict"
+    return _factory(384, 24, img_size, patch_size, stride, kwargs)
+
+
+def vim_base_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2(
+        pretrained=False, img_size=224, patch_size=16, stride=16, pretrained_checkpoint_path=None, **kwargs):
+    assert not pretrained, "no network: load weights with load_state_dict"
+    model = _factory(768, 24, img_size, patch_size, stride, kwargs)
+    if pretrained_checkpoint_path is not None:
+        _load_transfer_checkpoint(model, pretrained_checkpoint_path, img_size, patch_size)
+    return model
+
+
+def vim_large_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2(
+        pretrained=False, img_size=224, patch_size=16, stride=16, pretrained_checkpoint_path=None, **kwargs):
+    assert not pretrained, "no network: load weights with load_state_dict"
+    model = _factory(1024, 48, img_size, patch_size, stride, kwargs)
+    if pretrained_checkpoint_path is not None:
+        _load_transfer_checkpoint(model, pretrained_checkpoint_path, img_size, patch_size)
+    return model
+
+
+def vim_huge_patch14_224_final_pool_mean_abs_pos_embed_with_noclstok_div2(
+        pretrained=False, img_size=224, patch_size=14, stride=14, pretrained_checkpoint_path=None, **kwargs):
+    assert not pretrained, "no network: load weights with load_state_dict"
+    model = _factory(1280, 64, img_size, patch_size, stride, kwargs)
+    if pretrained_checkpoint_path is not None:
+        _load_transfer_checkpoint(model, pretrained_checkpoint_path, img_size, patch_size)
+    return model
+
+
+# short aliases for the three configs BASELINE.json names
+FastVimT = vim_tiny_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2
+FastVimS = vim_small_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2
+FastVimB = vim_base_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2

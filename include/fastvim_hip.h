@@ -150,6 +150,28 @@ int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, co
 /* out[i] = sum_{s < n_partials} partials[s*n + i], fixed order (deterministic). */
 int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n, fv_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Fused (per-sample scale) + residual add + RMSNorm / LayerNorm over the last dim.
+ * Replaces the Triton kernels behind rms_norm_fn / layer_norm_fn
+ *   (mamba-1p1p1/mamba_ssm/ops/triton/layernorm.py:66-121 fwd, 210-304 bwd; host 124-191, 307-399).
+ *   r = x * row_scale[row / rows_per_scale] + residual   (row_scale, residual nullable)
+ *   residual_out = r (nullable);  y = norm(r) * weight (+ bias)
+ * x, residual, y, residual_out: (M, N) with independent storage dtypes (FV_F32 / FV_BF16);
+ * weight, bias: (N) fp32; mean (LayerNorm only), rstd: (M) fp32.  N % 4 == 0, N <= 2048.
+ * ---------------------------------------------------------------------- */
+int fv_add_norm_blocks(int M);   /* rows of the (blocks, N) partial_dw / partial_db buffers */
+int fv_add_norm_fwd(const void* x, int x_dtype, const void* residual, int residual_dtype,
+                    const float* weight, const float* bias, const float* row_scale, int rows_per_scale,
+                    void* y, int y_dtype, void* residual_out, int residual_out_dtype, float* mean,
+                    float* rstd, int M, int N, float eps, int is_rms_norm, fv_stream_t stream);
+/* r: the saved residual_out.  dresidual_in = d r (nullable), dx = d r * row_scale (nullable);
+ * partial_dw/partial_db: per-block partial sums, reduce with fv_reduce_partials. */
+int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidual_out, int dresidual_out_dtype,
+                    const void* r, int r_dtype, const float* weight, const float* mean, const float* rstd,
+                    const float* row_scale, int rows_per_scale, void* dx, int dx_dtype, void* dresidual_in,
+                    int dresidual_in_dtype, float* partial_dw, float* partial_db, int M, int N,
+                    int is_rms_norm, fv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""GPU parity of the FastVim backbone (fastvim_amd.fastvim.VisionMamba on the HIP kernels) against
+golden vectors captured from the reference models/fastvim.py and against the fp64 oracle."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _err(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+def _tiny(img, **kw):
+    from fastvim_amd.fastvim import VisionMamba
+    return VisionMamba(img_size=img, patch_size=16, depth=4, embed_dim=32, channels=3, num_classes=10,
+                       rms_norm=True, residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean",
+                       if_abs_pos_embed=True, **kw)
+
+
+@pytest.mark.parametrize("case", ["tiny_64x64", "tiny_48x80"])
+def test_tiny_model_vs_reference_golden(case):
+    c = load_golden("model_tiny.pt")[case]
+    m = _tiny(c["img"], drop_path_rate=0.0).cuda().eval()
+    m.load_state_dict(c["state_dict"], strict=True)
+    hid = []
+    hooks = [l.register_forward_hook(lambda mod, i, o: hid.append(o[0].detach())) for l in m.layers]
+    logits = m(c["x"].cuda())
+    for h in hooks:
+        h.remove()
+    assert _err(logits, c["logits"]) <= 2e-5 * max(1.0, c["logits"].abs().max().item()), _err(logits, c["logits"])
+    for h, href in zip(hid, c["hiddens"]):
+        assert _err(h, href) <= 2e-5 * max(1.0, href.abs().max().item())
+    logits.backward(c["g"].cuda())
+    params = dict(m.named_parameters())
+    for k, gref in c["grads"].items():
+        e = _err(params[k].grad, gref)
+        assert e <= 2e-4 * max(1.0, gref.abs().max().item()), (k, e, gref.abs().max().item())
+
+
+def test_fastvim_t_vs_reference_golden_fp32():
+    """BASELINE config 1 input (FastVim-T 224x224 bs=2, seeded weights) on the GPU, fp32."""
+    from fastvim_amd.fastvim import FastVimT
+    from oracle import make_state_dict
+    c = load_golden("model_fastvim_t.pt")
+    m = FastVimT(drop_path_rate=0.0).cuda().eval()
+    m.load_state_dict(make_state_dict(seed=c["param_seed"], embed_dim=192, depth=24), strict=True)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(c["x_seed"]))
+    assert torch.equal(x[0, 0, :2, :8], c["x_probe"])
+    logits = m(x.cuda())
+    s = max(1.0, c["logits"].abs().max().item())
+    assert _err(logits, c["logits"]) <= 1e-4 * s, (_err(logits, c["logits"]), s)
+    g = torch.randn(logits.shape, generator=torch.Generator().manual_seed(c["g_seed"]))
+    logits.backward(g.cuda())
+    params = dict(m.named_parameters())
+    for k, gref in c["grads"].items():
+        e = _err(params[k].grad, gref)
+        assert e <= 1e-3 * max(1.0, gref.abs().max().item()), (k, e, gref.abs().max().item())
+
+
+def test_fastvim_t_bf16_autocast_close_to_fp32_reference():
+    from fastvim_amd.fastvim import FastVimT
+    from oracle import make_state_dict
+    c = load_golden("model_fastvim_t.pt")
+    m = FastVimT(drop_path_rate=0.0).cuda().eval()
+    m.load_state_dict(make_state_dict(seed=c["param_seed"], embed_dim=192, depth=24), strict=True)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(c["x_seed"]))
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        logits = m(x.cuda())
+    ref = c["logits"]
+    rel = (logits.float().cpu() - ref).norm() / ref.norm()
+    assert rel <= 3e-2, rel   # 24 blocks of bf16 activations; fp32 residual stream keeps it ~1e-2
+
+
+def test_training_mode_droppath_vs_oracle():
+    """train() with stochastic depth: same per-sample scales fed to the model and the oracle."""
+    from fastvim_amd import fastvim as fv
+    from oracle import fastvim_forward_oracle
+    torch.manual_seed(0)
+    m = _tiny((64, 64), drop_path_rate=0.5).cuda().train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(4, 3, 64, 64)
+    scales = [None] + [torch.tensor([0.0, 2.0, 2.0, 0.0]).roll(i) for i in range(4)]   # depth+1 entries
+    it = iter(scales[1:])
+    orig = fv.DropPath.row_scale
+    fv.DropPath.row_scale = lambda self, t: next(it).to(t.device)
+    try:
+        logits = m(x.cuda())
+    finally:
+        fv.DropPath.row_scale = orig
+    sdc = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ref = fastvim_forward_oracle(sdc, x, patch_size=16, depth=4, row_scales=scales, compute_dtype=F64)
+    assert _err(logits, ref) <= 2e-5 * max(1.0, ref.abs().max().item()), _err(logits, ref)
+
+
+def test_full_size_step_finite_and_deterministic():
+    """BASELINE config 2: FastVim-T bs=128 bf16 fwd+bwd -- finite, bitwise reproducible."""
+    from fastvim_amd.fastvim import FastVimT
+    torch.manual_seed(0)
+    m = FastVimT(drop_path_rate=0.0).cuda().train()
+    x = torch.randn(128, 3, 224, 224, device="cuda")
+    y = torch.randint(0, 1000, (128,), device="cuda")
+    res = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(m(x).float(), y)
+        loss.backward()
+        res.append((loss.detach().clone(), m.layers[3].mixer.A_log.grad.clone(), m.pos_embed.grad.clone()))
+    assert all(torch.isfinite(t).all() for t in res[0])
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
