@@ -21,7 +21,7 @@ from . import mixer_ops as M
 def _compute_dtype(t):
     """bf16/fp16 under torch.autocast (reference: mamba_simple_faster.py:312-318), else the input dtype."""
     if torch.is_autocast_enabled():
-        return torch.get_autocast_gpu_dtype()
+        return torch.get_autocast_dtype('cuda')
     return t.dtype
 
 

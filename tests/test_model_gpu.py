@@ -82,10 +82,13 @@ def test_training_mode_droppath_vs_oracle():
     m = _tiny((64, 64), drop_path_rate=0.5).cuda().train()
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     x = torch.randn(4, 3, 64, 64)
-    scales = [None] + [torch.tensor([0.0, 2.0, 2.0, 0.0]).roll(i) for i in range(4)]   # depth+1 entries
-    it = iter(scales[1:])
+    # entry i feeds block i (None where the block has no DropPath: layers 0 and 1, rate 0), entry 4 norm_f
+    scales = [None, None] + [torch.tensor([0.0, 2.0, 2.0, 0.0]).roll(i) for i in range(3)]
+    mods = [m.layers[2].drop_path, m.layers[3].drop_path, m.drop_path]
+    assert all(isinstance(d, fv.DropPath) for d in mods) and isinstance(m.layers[1].drop_path, torch.nn.Identity)
+    table = {id(d): s for d, s in zip(mods, scales[2:])}
     orig = fv.DropPath.row_scale
-    fv.DropPath.row_scale = lambda self, t: next(it).to(t.device)
+    fv.DropPath.row_scale = lambda self, t: table[id(self)].to(t.device)
     try:
         logits = m(x.cuda())
     finally:
