@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FastVim-T 224x224 bs=128/GPU bf16 training step (fwd + loss + bwd
+[+ gradient all-reduce] + AdamW) on MI355X, images/sec whole-job.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline":     the dominant hand-written kernel, timed live with HIP events on the launch stream,
+                  against its algorithmic HBM bytes (DESIGN.md section "Kernels and rooflines");
+  "cpu_baseline": the CPU oracle (a port of the reference's pure-PyTorch path, selective_scan_ref
+                  included) timed on this host on a bounded sample of the same workload.
+Synthetic data: ImageNet-shaped N(0,1) pixels, Mixup-like soft targets; random-init weights.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def build_model(name, img_size, drop_path):
+    from fastvim_amd import fastvim as fv
+    factory = {"T": fv.FastVimT, "S": fv.FastVimS, "B": fv.FastVimB}[name]
+    return factory(img_size=img_size, drop_path_rate=drop_path)
+
+
+def param_groups(model, weight_decay):
+    """AdamW groups of the reference recipe (imagenet_classification/utils.py:52-69): no decay for
+    1-D tensors, ``_no_weight_decay`` params and ``no_weight_decay()`` names."""
+    skip = model.no_weight_decay()
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.ndim <= 1 or n.endswith(".bias") or n in skip or getattr(p, "_no_weight_decay", False):
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
+
+
+def soft_targets(batch, num_classes, gen, device, smoothing=0.1):
+    """Mixup/label-smoothing shaped targets (supervised_imagenet.py:69-83 uses timm Mixup)."""
+    y1 = torch.randint(0, num_classes, (batch,), generator=gen)
+    y2 = torch.randint(0, num_classes, (batch,), generator=gen)
+    lam = 0.8
+    off = smoothing / num_classes
+    t = torch.full((batch, num_classes), off)
+    t.scatter_add_(1, y1[:, None], torch.full((batch, 1), lam * (1 - smoothing)))
+    t.scatter_add_(1, y2[:, None], torch.full((batch, 1), (1 - lam) * (1 - smoothing)))
+    return t.to(device)
+
+
+# --------------------------------------------------------------------------- kernel roofline
+def time_kernel(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()                      # torch current stream == the stream the C-ABI launches on
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / iters   # seconds per launch
+
+
+def kernel_table(B, rows, cols, d, depth, dtype):
+    """Time every hand-written full-length kernel of one mixer block at the benchmark shape and
+    price it against its ALGORITHMIC bytes (formulas in DESIGN.md)."""
+    from fastvim_amd import mixer_ops as M
+    from fastvim_amd.layernorm import layer_norm_fn
+    dev = "cuda"
+    d_in, L, R, N = 2 * d, rows * cols, -(-d // 16), 16
+    e = 2 if dtype == torch.bfloat16 else 4
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s, dt=dtype: torch.randn(*s, device=dev, generator=g).to(dt)
+    xz = rn(B, L, 2 * d_in)
+    cw, cwb = rn(d_in, 4, dt=torch.float32) * 0.5, rn(d_in, 4, dt=torch.float32) * 0.5
+    cb, cbb = rn(d_in, dt=torch.float32) * 0.1, rn(d_in, dt=torch.float32) * 0.1
+    D, Db = torch.ones(d_in, device=dev), torch.ones(d_in, device=dev)
+    lnw, lnb = torch.ones(d_in, device=dev), torch.zeros(d_in, device=dev)
+    Wdt = rn(d_in, R, dt=torch.float32) * R ** -0.5
+    bdt = torch.full((d_in,), -4.0, device=dev)
+    A_log = torch.log(torch.arange(1, N + 1, device=dev, dtype=torch.float32)).repeat(d_in, 1).contiguous()
+    xc = M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0)
+    x_dbl = rn(2, B * rows, R + 2 * N)
+    yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log)
+    gout, mean, rstd = M.combine_fwd(xz, yc, cw, cb, cwb, cbb, D, Db, lnw, lnb, 1e-5, rows, cols, False)
+    dg = rn(B, L, d_in)
+    dxz = torch.empty_like(xz)
+    d_o, dyc, _ = M.combine_bwd(dg, xz, yc, cw, cb, cwb, cbb, D, Db, lnw, lnb, mean, rstd, dxz, rows, cols, False)
+    dxc = torch.randn(2, B, rows, d_in, device=dev, generator=g)
+    hid, res = rn(B, L, d), torch.randn(B, L, d, device=dev, generator=g)
+    nw = torch.ones(d, device=dev)
+    U = B * L * d_in * e                      # one full-length (B, L, d_in) tensor
+    small = B * rows * d_in
+    table = {
+        "conv_pool_fwd": (lambda: M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0),
+                          U + 2 * small * e, 1),
+        "scan_fwd": (lambda: M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log),
+                     2 * (small * e + B * rows * (R + 2 * N) * e + small * 4), 1),
+        "combine_fwd": (lambda: M.combine_fwd(xz, yc, cw, cb, cwb, cbb, D, Db, lnw, lnb, 1e-5, rows, cols, False),
+                        3 * U + 2 * small * 4 + 2 * B * L * 4, 1),
+        "combine_bwd": (lambda: M.combine_bwd(dg, xz, yc, cw, cb, cwb, cbb, D, Db, lnw, lnb, mean, rstd, dxz,
+                                              rows, cols, False),
+                        5 * U + 3 * small * 4 + 2 * B * L * 4, 1),
+        "scan_bwd": (lambda: M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc),
+                     2 * (small * e + B * rows * (R + 2 * N) * (e + 4) + small * 4) + small * 4, 1),
+        "conv_pool_bwd": (lambda: M.conv_pool_bwd(xz, d_o, dxc, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 0, 1.0),
+                          3 * U + 2 * small * 4, 1),
+        "add_rmsnorm_fwd": (lambda: layer_norm_fn(hid, nw, None, residual=res, eps=1e-5, prenorm=True,
+                                                  residual_in_fp32=True, is_rms_norm=True),
+                            B * L * d * (2 * e + 8), 1),
+    }
+    out = {}
+    for name, (fn, nbytes, per_block) in table.items():
+        t = time_kernel(fn)
+        out[name] = {"us": round(t * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3),
+                     "GBps": round(nbytes / t / 1e9, 1), "launches_per_step": per_block * depth,
+                     "us_per_step": round(t * 1e6 * per_block * depth, 1)}
+    return out
+
+
+# --------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (port of the reference's pure-PyTorch FastVim path incl. selective_scan_ref)
+    running the SAME workload -- FastVim-T 224x224 fwd+bwd, fp32 -- on a bounded sample."""
+    from oracle import fastvim_forward_oracle, make_state_dict, selective_scan_ref_port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.requires_grad_() for k, v in make_state_dict(seed=0, embed_dim=192, depth=24).items()}
+    bs = 2
+    x = torch.randn(bs, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    t = torch.softmax(torch.randn(bs, 1000, generator=torch.Generator().manual_seed(1)), -1)
+
+    def step():
+        logits = fastvim_forward_oracle(sd, x, compute_dtype=torch.float32)
+        loss = torch.sum(-t * F.log_softmax(logits, -1), -1).mean()
+        loss.backward()
+
+    step()                                   # warm (allocator, thread pools)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget * 0.6 or n >= 4:
+            break
+    ips = n * bs / el
+    # the scan op alone at the benchmark shape (B, d_in, Lc, N) = (128, 384, 14, 16)
+    g = torch.Generator().manual_seed(0)
+    u, dl = torch.randn(128, 384, 14, generator=g), 0.5 * torch.rand(128, 384, 14, generator=g)
+    A = -0.5 * torch.rand(384, 16, generator=g)
+    Bm, Cm = torch.randn(128, 16, 14, generator=g), torch.randn(128, 16, 14, generator=g)
+    db = 0.5 * torch.rand(384, generator=g)
+    selective_scan_ref_port(u, dl, A, Bm, Cm, None, None, db, True)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        selective_scan_ref_port(u, dl, A, Bm, Cm, None, None, db, True)
+    scan_ms = (time.perf_counter() - t1) / 3 * 1e3
+    return {"value": round(ips, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"FastVim-T 224x224 fp32 fwd+bwd, bs={bs}, {n} steps through the CPU oracle "
+                      f"(pure-PyTorch port incl. selective_scan_ref); scan op alone at (128,384,14,16): "
+                      f"{scan_ms:.1f} ms/call",
+            "scan_ref_ms_128x384x14x16": round(scan_ms, 2)}
+
+
+# --------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="T", choices=["T", "S", "B"])
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    from fastvim_amd.ddp import FlatGradAllReduce
+
+    torch.manual_seed(1234)                    # identical init on every rank (DDP broadcast equivalent)
+    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
+    model = build_model(args.model, args.img, drop_path).to(dev).train()
+    gen = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(args.batch, 3, args.img, args.img, generator=gen).to(dev)
+    tgt = soft_targets(args.batch, 1000, gen, dev)
+    flat = FlatGradAllReduce(model.parameters())
+    opt = torch.optim.AdamW(param_groups(model, 0.05), lr=1e-3, betas=(0.9, 0.999), fused=True, capturable=True)
+    amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(5678 + rank)             # per-rank DropPath streams
+
+    def fwd_bwd():
+        flat.zero_()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+            logits = model(x)
+        loss = torch.sum(-tgt * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()   # SoftTargetCrossEntropy
+        loss.backward()
+        return loss.detach()
+
+    use_graph = not args.no_graph
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd_bwd()
+                if world == 1:
+                    opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss_buf = fwd_bwd()
+            if world == 1:
+                opt.step()
+
+        def step():
+            graph.replay()
+            if world > 1:
+                flat.allreduce_mean_()
+                opt.step()
+            return loss_buf
+    else:
+        def step():
+            l = fwd_bwd()
+            flat.allreduce_mean_()
+            opt.step()
+            return l
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    loss_val = float(loss)
+    if not (loss_val == loss_val):
+        raise SystemExit("non-finite loss in the timed region")
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        gs = args.img // 16
+        d = {"T": 192, "S": 384, "B": 768}[args.model]
+        out = {
+            "metric": "images/sec FastVim-%s %dpx bs=%d/GPU fwd+bwd (+all-reduce +AdamW), whole job" % (args.model, args.img, args.batch),
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "images_per_sec_per_gpu": round(value / world, 1),
+            "config": {"workload": f"FastVim-{args.model} {args.img}x{args.img} bs={args.batch}/GPU {args.dtype} "
+                                   f"training step, synthetic ImageNet tensors (BASELINE configs[1])",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "hip_graph": use_graph, "optimizer_in_step": True, "final_loss": round(loss_val, 4)},
+        }
+        if not args.no_kernels:
+            kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
+            dom = max((k for k in kt if k not in ("scan_fwd", "scan_bwd")), key=lambda k: kt[k]["us_per_step"])
+            out["kernels"] = kt
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kt[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
+                               "traffic": None, "avg_us": kt[dom]["us"],
+                               "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
