@@ -5,10 +5,7 @@
 //
 //   fv_mixer_combine_bwd   : d(gate), d(LayerNorm), d(average) -> dz, do, per-row pooled
 //                            dyc = 0.5*sum_j do, partials of dLN.weight/bias, dD, dD_b.
-//   fv_mixer_scan_bwd      : adjoint recurrence of the pooled scan for both directions with the
-//                            dt_proj adjoint fused in: writes d(x_dbl) = [d dt_low | dB | dC]
-//                            (reduced over channels in-kernel, deterministically), d(xc) through
-//                            the scan, and per-batch partials of dA_log, d dt_proj.weight/bias.
+//   (fv_mixer_scan_bwd, the adjoint of dt_proj + scan, lives in scan_cl.hip)
 //   fv_mixer_conv_pool_bwd : adjoint of mean-pool + SiLU + both depthwise convs -> dx, and
 //                            partials of the conv weight/bias gradients.
 //   fv_reduce_partials     : fixed-order sum of per-block partials (no float atomics anywhere).
@@ -297,204 +294,30 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_bwd_kernel(Bw
   }
 }
 
-// ------------------------------------------------------------------ scan backward
-struct ScanBwdParams {
-  const void* xc;        // (2, B, Lc, d_in)
-  const void* xdbl;      // (2, B*Lc, R+2N)
-  const float* Wdt[2];
-  const float* dtb[2];
-  const float* Alog[2];
-  const float* dyc;      // (B, Lc, d_in)  gradient wrt the scan output (same for both directions)
-  float* dxc;            // (2, B, Lc, d_in)  gradient wrt xc through the scan (u path)
-  float* dxdbl;          // (nchunks, 2, B*Lc, R+2N) reduced over the chunk's channels
-  float* ckpt;           // (2, B, nseg, d_in, N) states entering each segment
-  float* pA;             // (B, 2, d_in, N)   dA_log partials
-  float* pW;             // (B, 2, d_in, R)   d dt_proj.weight partials
-  float* pb;             // (B, 2, d_in)      d dt_proj.bias partials
-  int B, Lc, d_in, R;
-};
-
-// Reduce PV per-lane values over the 64 lanes of the wave ("reduce-scatter" butterfly): on
-// return lane l holds the totals of value indices [l*PV/64, (l+1)*PV/64) in v[0..PV/64).
-template <int PV>
-__device__ __forceinline__ void wave_reduce_scatter(float (&v)[PV], int lane) {
-#pragma unroll
-  for (int off = 32, h = PV / 2; off >= 1; off >>= 1, h >>= 1) {
-    const bool up = lane & off;
-#pragma unroll
-    for (int e = 0; e < h; ++e) {
-      float keep = up ? v[e + h] : v[e];
-      float send = up ? v[e] : v[e + h];
-      v[e] = keep + __shfl_xor(send, off, 64);
+// out[i] = sum_s in[s*n + i] in a fixed order.  Block = 32 outputs x 8 row-slices: slice q sums rows
+// q, q+8, ... (independent 128-B coalesced loads), then the 8 slice sums are added in order.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              int S, size_t n, int accumulate) {
+  __shared__ float s_acc[8][33];
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < n) {
+    int s = q;
+    for (; s + 8 < S; s += 16) {
+      a0 += in[(size_t)s * n + i];
+      a1 += in[(size_t)(s + 8) * n + i];
     }
+    if (s < S) a0 += in[(size_t)s * n + i];
   }
-}
-
-template <typename T, int N, int RMAX, int PV>
-__global__ __launch_bounds__(512) void scan_cl_bwd_kernel(ScanBwdParams p) {
-  constexpr int K = 4;          // steps per recompute segment
-  constexpr int Q = PV / 64;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int W = p.R + 2 * N;
-  float* s_dbl = smem;                         // Lc * W
-  float* s_part = smem + p.Lc * W;             // K * NW * PV
-  const int dir = blockIdx.z, b = blockIdx.y, chunk = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NW = blockDim.x >> 6;
-  const int d = chunk * blockDim.x + tid;
-  const bool act = d < p.d_in;
-  const int dd = act ? d : 0;
-  const T* dbl = (const T*)p.xdbl + ((size_t)dir * p.B + b) * p.Lc * W;
-  for (int e = tid; e < p.Lc * W; e += blockDim.x) s_dbl[e] = io<T>::ld(dbl + e);
+  s_acc[q][c] = a0 + a1;
   __syncthreads();
-
-  float A2[N], Araw[N], st[N], wdt[RMAX];
+  if (q == 0 && i < n) {
+    float t = 0.f;
 #pragma unroll
-  for (int n = 0; n < N; ++n) {
-    Araw[n] = -__expf(p.Alog[dir][(size_t)dd * N + n]);
-    A2[n] = Araw[n] * FV_LOG2E;
-    st[n] = 0.f;
+    for (int k = 0; k < 8; ++k) t += s_acc[k][c];
+    out[i] = accumulate ? out[i] + t : t;
   }
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) wdt[r] = (r < p.R) ? p.Wdt[dir][(size_t)dd * p.R + r] : 0.f;
-  const float bias = p.dtb[dir][dd];
-  const int nseg = (p.Lc + K - 1) / K;
-  const T* u = (const T*)p.xc + ((size_t)dir * p.B + b) * p.Lc * p.d_in + dd;
-  float* ck = p.ckpt + (((size_t)dir * p.B + b) * nseg * p.d_in + dd) * N;
-  const size_t ck_seg = (size_t)p.d_in * N;
-
-  auto delta_raw = [&](const float* row) {
-    float dt = bias;
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < p.R) dt = fmaf(wdt[r], row[r], dt);
-    return dt;
-  };
-
-  // ---- pass 1: forward sweep, checkpoint the state entering every segment but the first
-  for (int step = 0; step < (nseg - 1) * K; ++step) {
-    const int l = dir ? p.Lc - 1 - step : step;
-    const float* row = s_dbl + l * W;
-    const float dt = fv_softplus(delta_raw(row));
-    const float du = dt * io<T>::ld(u + (size_t)l * p.d_in);
-#pragma unroll
-    for (int n = 0; n < N; ++n) st[n] = fmaf(fv_exp2(dt * A2[n]), st[n], du * row[p.R + n]);
-    if ((step + 1) % K == 0 && act) {
-      float* dst = ck + (size_t)((step + 1) / K) * ck_seg;
-#pragma unroll
-      for (int n = 0; n < N; ++n) dst[n] = st[n];
-    }
-  }
-
-  // ---- pass 2: segments high-to-low
-  float dxa[N], dA[N], dW[RMAX], dbias = 0.f;
-#pragma unroll
-  for (int n = 0; n < N; ++n) dxa[n] = dA[n] = 0.f;
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) dW[r] = 0.f;
-
-  for (int seg = nseg - 1; seg >= 0; --seg) {
-    const int s0 = seg * K;
-    const int ns = min(K, p.Lc - s0);
-    float cur[N];
-    if (seg > 0 && act) {
-      const float* src = ck + (size_t)seg * ck_seg;
-#pragma unroll
-      for (int n = 0; n < N; ++n) cur[n] = src[n];
-    } else {
-#pragma unroll
-      for (int n = 0; n < N; ++n) cur[n] = 0.f;
-    }
-    float xs[K][N], dtr[K], dtv[K], uv[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (k < ns) {
-        const int l = dir ? p.Lc - 1 - (s0 + k) : s0 + k;
-        const float* row = s_dbl + l * W;
-        dtr[k] = delta_raw(row);
-        dtv[k] = fv_softplus(dtr[k]);
-        uv[k] = io<T>::ld(u + (size_t)l * p.d_in);
-        const float du = dtv[k] * uv[k];
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-          cur[n] = fmaf(fv_exp2(dtv[k] * A2[n]), cur[n], du * row[p.R + n]);
-          xs[k][n] = cur[n];
-        }
-      } else {
-        dtr[k] = dtv[k] = uv[k] = 0.f;
-#pragma unroll
-        for (int n = 0; n < N; ++n) xs[k][n] = 0.f;
-      }
-    }
-#pragma unroll
-    for (int k = K - 1; k >= 0; --k) {
-      if (k < ns) {     // uniform across the block
-        const int l = dir ? p.Lc - 1 - (s0 + k) : s0 + k;
-        const float* row = s_dbl + l * W;
-        const float gq = act ? p.dyc[((size_t)b * p.Lc + l) * p.d_in + dd] : 0.f;
-        float vals[PV];
-#pragma unroll
-        for (int e = 0; e < PV; ++e) vals[e] = 0.f;
-        float du_acc = 0.f, ddt_acc = 0.f;
-        const float dtu = dtv[k] * uv[k];
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-          const float Bn = row[p.R + n], Cn = row[p.R + N + n];
-          const float a = fv_exp2(dtv[k] * A2[n]);
-          const float dx = fmaf(gq, Cn, dxa[n]);
-          const float ax = xs[k][n] - dtu * Bn;          // a_t * x_{t-1}
-          du_acc = fmaf(dx, Bn, du_acc);
-          ddt_acc += dx * fmaf(Araw[n], ax, Bn * uv[k]);
-          dA[n] = fmaf(dx * dtv[k], ax, dA[n]);
-          vals[RMAX + n] = dx * dtu;                      // dB
-          vals[RMAX + N + n] = gq * xs[k][n];             // dC
-          dxa[n] = a * dx;
-        }
-        float ddraw = ddt_acc;
-        if (dtr[k] <= 20.f) ddraw *= fv_sigmoid(dtr[k]);
-        if (!act) ddraw = 0.f;
-        dbias += ddraw;
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          if (r < p.R) {
-            dW[r] = fmaf(ddraw, row[r], dW[r]);
-            vals[r] = ddraw * wdt[r];                     // d dt_low
-          }
-        }
-        if (act) p.dxc[(((size_t)dir * p.B + b) * p.Lc + l) * p.d_in + d] = dtv[k] * du_acc;
-        wave_reduce_scatter<PV>(vals, lane);
-#pragma unroll
-        for (int q = 0; q < Q; ++q) s_part[(k * NW + wv) * PV + lane * Q + q] = vals[q];
-      }
-    }
-    __syncthreads();
-    // cross-wave sum in fixed order; value slot layout: [0,RMAX) dt_low | [RMAX,+N) dB | [RMAX+N,+N) dC
-    for (int e = tid; e < ns * W; e += blockDim.x) {
-      const int k = e / W, c = e - k * W;
-      const int slot = c < p.R ? c : (RMAX + (c - p.R));
-      float t = 0.f;
-      for (int w = 0; w < NW; ++w) t += s_part[(k * NW + w) * PV + slot];
-      const int l = dir ? p.Lc - 1 - (s0 + k) : s0 + k;
-      p.dxdbl[(((size_t)chunk * 2 + dir) * p.B + b) * p.Lc * W + (size_t)l * W + c] = t;
-    }
-    __syncthreads();
-  }
-  if (act) {
-    const size_t o = ((size_t)b * 2 + dir) * p.d_in + d;
-#pragma unroll
-    for (int n = 0; n < N; ++n) p.pA[o * N + n] = dA[n] * Araw[n];   // A = -exp(A_log): dA_log = dA * A
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < p.R) p.pW[o * p.R + r] = dW[r];
-    p.pb[o] = dbias;
-  }
-}
-
-__global__ void reduce_partials_kernel(const float* __restrict__ in, float* __restrict__ out, int S, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += in[(size_t)s * n + i];
-  out[i] = acc;
 }
 
 template <typename T, int VEC>
@@ -587,60 +410,12 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
                          : dispatch_bwd<bf16_t>(1, p, nb, (hipStream_t)stream);
 }
 
-extern "C" int fv_mixer_scan_bwd_chunks(int d_inner) { return fv_cdiv(d_inner, 512); }
-
-extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state) {
-  return (size_t)2 * batch * ((Lc + 3) / 4) * d_inner * d_state;
-}
-
-extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
-                                 const float* A_log, const float* dt_w_b, const float* dt_bias_b,
-                                 const float* A_log_b, const float* dyc, float* dxc, float* dx_dbl, float* ckpt,
-                                 float* pA, float* pW, float* pb, int batch, int Lc, int d_inner, int dt_rank,
-                                 int d_state, int dtype, fv_stream_t stream) {
-  FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_bwd: empty dimension");
-  FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_bwd: dtype must be fp32 or bf16");
-  FV_CHECK(d_state == 16, "mixer_scan_bwd: only d_state == 16 is built (got %d)", d_state);
-  FV_CHECK(dt_rank <= 96, "mixer_scan_bwd: dt_rank %d > 96", dt_rank);
-  FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && dyc && dxc && dx_dbl &&
-               ckpt && pA && pW && pb, "mixer_scan_bwd: null pointer");
-  ScanBwdParams p{};
-  p.xc = xc; p.xdbl = x_dbl; p.dyc = dyc; p.dxc = dxc; p.dxdbl = dx_dbl; p.ckpt = ckpt;
-  p.pA = pA; p.pW = pW; p.pb = pb;
-  p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
-  p.Alog[0] = A_log; p.Alog[1] = A_log_b;
-  p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
-  const int nchunks = fv_mixer_scan_bwd_chunks(d_inner);
-  const int per = fv_cdiv(d_inner, nchunks);
-  const int bs = fv_cdiv(per, 64) * 64;
-  const int NW = bs / 64;
-  const int W = dt_rank + 2 * d_state;
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(nchunks, batch, 2), block(bs);
-#define FV_LAUNCH_SB(TT, RM, PVV)                                                           \
-  do {                                                                                      \
-    size_t smem = ((size_t)Lc * W + (size_t)4 * NW * PVV) * 4;                              \
-    FV_CHECK(smem <= 64 * 1024, "mixer_scan_bwd: pooled length %d too long for the LDS stage", Lc); \
-    hipLaunchKernelGGL((scan_cl_bwd_kernel<TT, 16, RM, PVV>), grid, block, smem, st, p);    \
-  } while (0)
-  if (dtype == FV_F32) {
-    if (dt_rank <= 12) FV_LAUNCH_SB(float, 12, 64); else if (dt_rank <= 24) FV_LAUNCH_SB(float, 24, 64);
-    else if (dt_rank <= 48) FV_LAUNCH_SB(float, 48, 128); else FV_LAUNCH_SB(float, 96, 128);
-  } else {
-    if (dt_rank <= 12) FV_LAUNCH_SB(bf16_t, 12, 64); else if (dt_rank <= 24) FV_LAUNCH_SB(bf16_t, 24, 64);
-    else if (dt_rank <= 48) FV_LAUNCH_SB(bf16_t, 48, 128); else FV_LAUNCH_SB(bf16_t, 96, 128);
-  }
-#undef FV_LAUNCH_SB
-  FV_LAUNCH_CHECK();
-  return FV_OK;
-}
-
 extern "C" int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n,
                                   fv_stream_t stream) {
   FV_CHECK(partials && out && n_partials > 0, "reduce_partials: bad arguments");
   if (n == 0) return FV_OK;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(fv_cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream,
-                     partials, out, n_partials, n);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(fv_cdiv((long)n, 32)), dim3(256), 0, (hipStream_t)stream,
+                     partials, out, n_partials, n, 0);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

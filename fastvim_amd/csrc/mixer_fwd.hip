@@ -5,9 +5,7 @@
 //   fv_mixer_conv_pool_fwd : both causal (forward dir) and anti-causal (backward dir)
 //                            depthwise conv + SiLU and the mean/max pooling over `cols`
 //                            (mamba_simple_faster.py:272-305) -- one read of x.
-//   fv_mixer_scan_fwd      : dt_proj + softplus + selective scan over the pooled rows for
-//                            both directions (:328-354, :390-410); one lane per channel,
-//                            16 states in registers, serial over the (short) pooled length.
+//   (fv_mixer_scan_fwd, the dt_proj + scan over the pooled rows, lives in scan_cl.hip)
 //   fv_mixer_combine_fwd   : recompute conv, expand the scan output over `cols`, + D*x skip,
 //                            average the two directions, LayerNorm over d_in, * SiLU(z)
 //                            (:356-358, :412-416, :434-441) -- reads x,z once, writes once.
@@ -206,58 +204,6 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
   }
 }
 
-// ------------------------------------------------------------------ dt_proj + scan
-struct ScanClParams {
-  const void* xc;        // (2, B, Lc, d_in)   pooled conv output
-  const void* xdbl;      // (2, B*Lc, R+2N)    [dt_low | B | C]
-  const float* Wdt[2];   // (d_in, R)
-  const float* dtb[2];   // (d_in)
-  const float* Alog[2];  // (d_in, N)
-  float* yc;             // (2, B, Lc, d_in)
-  int B, Lc, d_in, R;
-};
-
-template <typename T, int N, int RMAX>
-__global__ void scan_cl_fwd_kernel(ScanClParams p) {
-  extern __shared__ __attribute__((aligned(16))) float s_dbl[];   // Lc * (R+2N) fp32
-  const int dir = blockIdx.z, b = blockIdx.y;
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  const int W = p.R + 2 * N;
-  const T* dbl = (const T*)p.xdbl + ((size_t)dir * p.B + b) * p.Lc * W;
-  for (int e = threadIdx.x; e < p.Lc * W; e += blockDim.x) s_dbl[e] = io<T>::ld(dbl + e);
-  __syncthreads();
-  if (d >= p.d_in) return;
-  float A[N], st[N], wdt[RMAX];
-#pragma unroll
-  for (int n = 0; n < N; ++n) {
-    A[n] = -__expf(p.Alog[dir][(size_t)d * N + n]) * FV_LOG2E;   // A = -exp(A_log) (mamba_simple_faster.py:197)
-    st[n] = 0.f;
-  }
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) wdt[r] = r < p.R ? p.Wdt[dir][(size_t)d * p.R + r] : 0.f;
-  const float bias = p.dtb[dir][d];
-  const T* u = (const T*)p.xc + ((size_t)dir * p.B + b) * p.Lc * p.d_in + d;
-  float* y = p.yc + ((size_t)dir * p.B + b) * p.Lc * p.d_in + d;
-  for (int step = 0; step < p.Lc; ++step) {
-    const int l = dir ? p.Lc - 1 - step : step;    // backward direction: descending rows
-    const float* row = s_dbl + l * W;
-    float dt = bias;
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < p.R) dt = fmaf(wdt[r], row[r], dt);
-    dt = fv_softplus(dt);
-    const float uv = io<T>::ld(u + (size_t)l * p.d_in);
-    const float du = dt * uv;
-    float acc = 0.f;
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      st[n] = fmaf(fv_exp2(dt * A[n]), st[n], du * row[p.R + n]);
-      acc = fmaf(row[p.R + N + n], st[n], acc);
-    }
-    y[(size_t)l * p.d_in] = acc;
-  }
-}
-
 template <typename T, int VEC>
 int launch_fwd_kernels(int which, const FwdParams& p, hipStream_t st) {
   const int nch = fv_cdiv(p.d_in, 64 * VEC);
@@ -329,38 +275,4 @@ extern "C" int fv_mixer_combine_fwd(const void* xz, const float* yc, const float
   p.B = batch; p.d_in = d_inner;
   return dtype == FV_F32 ? dispatch_vec<float>(1, p, (hipStream_t)stream)
                          : dispatch_vec<bf16_t>(1, p, (hipStream_t)stream);
-}
-
-extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
-                                 const float* A_log, const float* dt_w_b, const float* dt_bias_b,
-                                 const float* A_log_b, float* yc, int batch, int Lc, int d_inner, int dt_rank,
-                                 int d_state, int dtype, fv_stream_t stream) {
-  FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_fwd: empty dimension");
-  FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_fwd: dtype must be fp32 or bf16");
-  FV_CHECK(d_state == 16, "mixer_scan_fwd: only d_state == 16 is built (got %d)", d_state);
-  FV_CHECK(dt_rank <= 96, "mixer_scan_fwd: dt_rank %d > 96", dt_rank);
-  FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && yc,
-           "mixer_scan_fwd: null pointer");
-  ScanClParams p{};
-  p.xc = xc; p.xdbl = x_dbl; p.yc = yc;
-  p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
-  p.Alog[0] = A_log; p.Alog[1] = A_log_b;
-  p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
-  const int W = dt_rank + 2 * d_state;
-  size_t smem = (size_t)Lc * W * 4;
-  FV_CHECK(smem <= 64 * 1024, "mixer_scan_fwd: pooled length %d too long for the LDS stage", Lc);
-  const int bs = d_inner >= 256 ? 128 : 64;
-  dim3 grid(fv_cdiv(d_inner, bs), batch, 2), block(bs);
-  hipStream_t st = (hipStream_t)stream;
-#define FV_SCAN_LAUNCH(TT, RM) hipLaunchKernelGGL((scan_cl_fwd_kernel<TT, 16, RM>), grid, block, smem, st, p)
-  if (dtype == FV_F32) {
-    if (dt_rank <= 12) FV_SCAN_LAUNCH(float, 12); else if (dt_rank <= 24) FV_SCAN_LAUNCH(float, 24);
-    else if (dt_rank <= 48) FV_SCAN_LAUNCH(float, 48); else FV_SCAN_LAUNCH(float, 96);
-  } else {
-    if (dt_rank <= 12) FV_SCAN_LAUNCH(bf16_t, 12); else if (dt_rank <= 24) FV_SCAN_LAUNCH(bf16_t, 24);
-    else if (dt_rank <= 48) FV_SCAN_LAUNCH(bf16_t, 48); else FV_SCAN_LAUNCH(bf16_t, 96);
-  }
-#undef FV_SCAN_LAUNCH
-  FV_LAUNCH_CHECK();
-  return FV_OK;
 }

@@ -1,0 +1,375 @@
+// dt_proj + softplus + selective scan over the POOLED rows, channel-last, forward and backward,
+// both scan directions in one launch.  Replaces selective_scan_cuda.fwd/bwd as used by the FastVim
+// mixer (mamba_simple_faster.py:328-354, 390-410; selective_scan_interface.py:558-568, 679-696)
+// plus the dt_proj matmul and its adjoint einsums (selective_scan_interface.py:515-519, 721-723).
+//
+// Mapping: the pooled length Lc is short (14 at 224 px, <= 128 elsewhere), so the recurrence is
+// run serially in registers; parallelism comes from batch x d_inner x state-quads.  A lane owns
+// 4 of the 16 states of one channel (quad q = lane & 3 owns states 4q..4q+3); the 4 lanes of a
+// channel are adjacent, so the sums over states (y, du, d delta) are two DPP quad adds.  A wave
+// covers 16 channels, a 256-thread block 64 channels: loads/stores of u, y, du are contiguous
+// across the block.  B_t, C_t, dt_low_t are staged once per block in LDS (fp32) and read as
+// broadcasts.
+//
+// Backward: forward states of a segment of KS steps are recomputed into registers (KS x 4 per
+// lane); segments are walked high-to-low with the adjoint state carried in registers; states
+// entering later segments come from a forward sweep that checkpoints them (only when Lc > KS).
+// dB/dC/d dt_low need a sum over channels: a wave reduce-scatters its 16 channel lanes
+// (__shfl_xor butterfly on lane bits 2..5), waves are summed through LDS in fixed order, blocks
+// write per-chunk partials that fv_reduce_partials sums -- deterministic, no float atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int N = 16;        // d_state
+constexpr int CPB = 64;      // channels per block (256 threads)
+
+struct ScanClParams {
+  const void* xc;        // (2, B, Lc, d_in)   pooled conv output u
+  const void* xdbl;      // (2, B*Lc, R+2N)    [dt_low | B | C]
+  const float* Wdt[2];   // (d_in, R)
+  const float* dtb[2];   // (d_in)
+  const float* Alog[2];  // (d_in, N)
+  float* yc;             // (2, B, Lc, d_in)   fwd out
+  const float* dyc;      // (B, Lc, d_in)      bwd in (same for both directions)
+  float* dxc;            // (2, B, Lc, d_in)   bwd out: gradient wrt u
+  float* dxdbl;          // (nchunks, 2, B*Lc, R+2N) bwd out: per-chunk partial gradient wrt x_dbl
+  float* ckpt;           // (2, B, nseg, d_in, N)
+  float* pP;             // (B, 2, d_in, N+R+1) per-batch partials [dA_log | d dt_w | d dt_bias]
+  int B, Lc, d_in, R;
+};
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));  // [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));  // [2,3,0,1]
+  return v;
+}
+
+template <typename T, int RQ>
+struct Lane {
+  int d, q, dir, b;
+  bool act;
+  float A2[4], Araw[4], wdt[RQ], bias;
+  __device__ __forceinline__ void init(const ScanClParams& p) {
+    const int tid = threadIdx.x;
+    dir = blockIdx.z; b = blockIdx.y;
+    q = tid & 3;
+    d = blockIdx.x * CPB + (tid >> 2);
+    act = d < p.d_in;
+    const int dd = act ? d : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Araw[j] = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + j]);   // A = -exp(A_log) (mamba_simple_faster.py:197)
+      A2[j] = Araw[j] * FV_LOG2E;
+    }
+#pragma unroll
+    for (int i = 0; i < RQ; ++i) {
+      const int r = q + 4 * i;
+      wdt[i] = (r < p.R) ? p.Wdt[dir][(size_t)dd * p.R + r] : 0.f;
+    }
+    bias = p.dtb[dir][dd];
+  }
+  // softplus(dt_proj(dt_low) + bias) -- each quad lane sums its r = q, q+4, ... then quad add
+  __device__ __forceinline__ float delta(const float* row) const {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < RQ; ++i) acc = fmaf(wdt[i], row[q + 4 * i], acc);   // row padded with zeros to 4*RQ
+    return fv_softplus(quad_sum(acc) + bias);
+  }
+};
+
+// stage x_dbl rows of this (dir, b) into LDS as fp32, row stride WP (dt_low part padded to 4*RQ)
+template <typename T>
+__device__ __forceinline__ void stage_dbl(const ScanClParams& p, int dir, int b, float* s_dbl, int RP) {
+  const int W = p.R + 2 * N, WP = RP + 2 * N;
+  const T* dbl = (const T*)p.xdbl + ((size_t)dir * p.B + b) * p.Lc * W;
+  for (int e = threadIdx.x; e < p.Lc * WP; e += blockDim.x) {
+    const int l = e / WP, c = e - l * WP;
+    float v = 0.f;
+    if (c < p.R) v = io<T>::ld(dbl + (size_t)l * W + c);
+    else if (c >= RP) v = io<T>::ld(dbl + (size_t)l * W + p.R + (c - RP));
+    s_dbl[e] = v;
+  }
+}
+
+template <typename T, int RQ>
+__global__ __launch_bounds__(256) void scan_cl_fwd_kernel(ScanClParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int RP = 4 * RQ;
+  const int WP = RP + 2 * N;
+  Lane<T, RQ> ln;
+  ln.init(p);
+  stage_dbl<T>(p, ln.dir, ln.b, smem, RP);
+  __syncthreads();
+  const int dd = ln.act ? ln.d : 0;
+  const T* u = (const T*)p.xc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
+  float* y = p.yc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
+  float st[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int step = 0; step < p.Lc; ++step) {
+    const int l = ln.dir ? p.Lc - 1 - step : step;     // backward direction: descending rows
+    const float* row = smem + l * WP;
+    const float dt = ln.delta(row);
+    const float du = dt * io<T>::ld(u + (size_t)l * p.d_in);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st[j] = fmaf(fv_exp2(dt * ln.A2[j]), st[j], du * row[RP + ln.q * 4 + j]);
+      acc = fmaf(row[RP + N + ln.q * 4 + j], st[j], acc);
+    }
+    acc = quad_sum(acc);
+    if (ln.act && ln.q == 0) y[(size_t)l * p.d_in] = acc;
+  }
+}
+
+// butterfly over the 16 channel-lanes of a wave (lane bits 2..5); PV values per lane, PV in {16, 32}.
+// On return the lane whose channel index is c holds the totals of value indices [c*PV/16, (c+1)*PV/16).
+template <int PV>
+__device__ __forceinline__ void chan_reduce_scatter(float (&v)[PV], int lane) {
+#pragma unroll
+  for (int off = 32, h = PV / 2; off >= 4; off >>= 1, h >>= 1) {
+    const bool up = lane & off;
+#pragma unroll
+    for (int e = 0; e < h; ++e) {
+      float keep = up ? v[e + h] : v[e];
+      float send = up ? v[e] : v[e + h];
+      v[e] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+}
+
+template <typename T, int RQ, int KS, int PV>
+__global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int RP = 4 * RQ;
+  constexpr int Q = PV / 16;                // values a lane holds after the butterfly
+  constexpr int NWV = 4;                    // waves per block
+  const int WP = RP + 2 * N, W = p.R + 2 * N;
+  float* s_dbl = smem;                      // Lc * WP
+  float* s_part = smem + p.Lc * WP;         // KS * NWV * (4*PV)   [k][wave][q][value]
+  Lane<T, RQ> ln;
+  ln.init(p);
+  stage_dbl<T>(p, ln.dir, ln.b, s_dbl, RP);
+  __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dd = ln.act ? ln.d : 0;
+  const int nseg = (p.Lc + KS - 1) / KS;
+  const T* u = (const T*)p.xc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
+  float* ck = p.ckpt + (((size_t)ln.dir * p.B + ln.b) * nseg * p.d_in + dd) * N + ln.q * 4;
+  const size_t ck_seg = (size_t)p.d_in * N;
+
+  // ---- forward sweep: checkpoint the state entering every segment but the first
+  if (nseg > 1) {
+    float st[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int step = 0; step < (nseg - 1) * KS; ++step) {
+      const int l = ln.dir ? p.Lc - 1 - step : step;
+      const float* row = s_dbl + l * WP;
+      const float dt = ln.delta(row);
+      const float du = dt * io<T>::ld(u + (size_t)l * p.d_in);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * ln.A2[j]), st[j], du * row[RP + ln.q * 4 + j]);
+      if ((step + 1) % KS == 0 && ln.act) {
+        float* dst = ck + (size_t)((step + 1) / KS) * ck_seg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = st[j];
+      }
+    }
+  }
+
+  float dxa[4] = {0.f, 0.f, 0.f, 0.f}, dA[4] = {0.f, 0.f, 0.f, 0.f}, dW[RQ], dbias = 0.f;
+#pragma unroll
+  for (int i = 0; i < RQ; ++i) dW[i] = 0.f;
+
+  for (int seg = nseg - 1; seg >= 0; --seg) {
+    const int s0 = seg * KS;
+    const int ns = min(KS, p.Lc - s0);
+    float cur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (seg > 0 && ln.act) {
+      const float* src = ck + (size_t)seg * ck_seg;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cur[j] = src[j];
+    }
+    // recompute the segment's forward states
+    float xs[KS][4], dtv[KS], uv[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k < ns) {
+        const int l = ln.dir ? p.Lc - 1 - (s0 + k) : s0 + k;
+        const float* row = s_dbl + l * WP;
+        dtv[k] = ln.delta(row);
+        uv[k] = io<T>::ld(u + (size_t)l * p.d_in);
+        const float du = dtv[k] * uv[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cur[j] = fmaf(fv_exp2(dtv[k] * ln.A2[j]), cur[j], du * row[RP + ln.q * 4 + j]);
+          xs[k][j] = cur[j];
+        }
+      } else {
+        dtv[k] = uv[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[k][j] = 0.f;
+      }
+    }
+    // adjoint recurrence, high-to-low
+#pragma unroll
+    for (int k = KS - 1; k >= 0; --k) {
+      if (k < ns) {          // uniform across the block
+        const int l = ln.dir ? p.Lc - 1 - (s0 + k) : s0 + k;
+        const float* row = s_dbl + l * WP;
+        const float gq = ln.act ? p.dyc[((size_t)ln.b * p.Lc + l) * p.d_in + dd] : 0.f;
+        float vals[PV];
+#pragma unroll
+        for (int e = 0; e < PV; ++e) vals[e] = 0.f;
+        float du_acc = 0.f, ddt_acc = 0.f;
+        const float dtu = dtv[k] * uv[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float Bn = row[RP + ln.q * 4 + j], Cn = row[RP + N + ln.q * 4 + j];
+          const float a = fv_exp2(dtv[k] * ln.A2[j]);
+          const float dx = fmaf(gq, Cn, dxa[j]);
+          const float ax = xs[k][j] - dtu * Bn;               // a_t * x_{t-1}
+          du_acc = fmaf(dx, Bn, du_acc);
+          ddt_acc += dx * fmaf(ln.Araw[j], ax, Bn * uv[k]);
+          dA[j] = fmaf(dx * dtv[k], ax, dA[j]);
+          vals[j] = dx * dtu;                                  // dB[4q+j]
+          vals[4 + j] = gq * xs[k][j];                         // dC[4q+j]
+          dxa[j] = a * dx;
+        }
+        du_acc = quad_sum(du_acc);
+        ddt_acc = quad_sum(ddt_acc);
+        // d softplus: sigmoid(raw) = 1 - exp(-softplus(raw)); exact also above the threshold of 20
+        float ddraw = ln.act ? ddt_acc * (1.f - __expf(-dtv[k])) : 0.f;
+        dbias += ddraw;
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) {
+          dW[i] = fmaf(ddraw, row[ln.q + 4 * i], dW[i]);
+          vals[8 + i] = ddraw * ln.wdt[i];                     // d dt_low[q + 4i]
+        }
+        if (ln.act && ln.q == 0) p.dxc[(((size_t)ln.dir * p.B + ln.b) * p.Lc + l) * p.d_in + ln.d] = dtv[k] * du_acc;
+        chan_reduce_scatter<PV>(vals, lane);
+        const int c = lane >> 2;
+#pragma unroll
+        for (int e = 0; e < Q; ++e) s_part[((k * NWV + wv) * 4 + ln.q) * PV + c * Q + e] = vals[e];
+      }
+    }
+    __syncthreads();
+    // sum the 4 waves in fixed order and scatter to the x_dbl column layout [dt_low | B | C]
+    for (int e = tid; e < ns * 4 * PV; e += blockDim.x) {
+      const int k = e / (4 * PV), rem = e - k * 4 * PV;
+      const int qq = rem / PV, v = rem - qq * PV;
+      int col = -1;
+      if (v < 4) col = p.R + qq * 4 + v;
+      else if (v < 8) col = p.R + N + qq * 4 + (v - 4);
+      else if (v < 8 + RQ && qq + 4 * (v - 8) < p.R) col = qq + 4 * (v - 8);
+      if (col >= 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t += s_part[((k * NWV + w) * 4 + qq) * PV + v];
+        const int l = ln.dir ? p.Lc - 1 - (s0 + k) : s0 + k;
+        p.dxdbl[(((size_t)blockIdx.x * 2 + ln.dir) * p.B + ln.b) * p.Lc * W + (size_t)l * W + col] = t;
+      }
+    }
+    __syncthreads();
+  }
+  if (ln.act) {
+    const int PW = N + p.R + 1;
+    float* dst = p.pP + (((size_t)ln.b * 2 + ln.dir) * p.d_in + ln.d) * PW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[ln.q * 4 + j] = dA[j] * ln.Araw[j];     // dA_log = dA * A
+#pragma unroll
+    for (int i = 0; i < RQ; ++i)
+      if (ln.q + 4 * i < p.R) dst[N + ln.q + 4 * i] = dW[i];
+    dbias = quad_sum(dbias) * 0.25f;   // all four lanes accumulated the same value
+    if (ln.q == 0) dst[N + p.R] = dbias;
+  }
+}
+
+int rq_of(int R) { return (R + 3) / 4; }
+
+}  // namespace
+
+extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                 const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                 const float* A_log_b, float* yc, int batch, int Lc, int d_inner, int dt_rank,
+                                 int d_state, int dtype, fv_stream_t stream) {
+  FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_fwd: empty dimension");
+  FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_fwd: dtype must be fp32 or bf16");
+  FV_CHECK(d_state == N, "mixer_scan_fwd: only d_state == 16 is built (got %d)", d_state);
+  FV_CHECK(dt_rank <= 96, "mixer_scan_fwd: dt_rank %d > 96", dt_rank);
+  FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && yc,
+           "mixer_scan_fwd: null pointer");
+  ScanClParams p{};
+  p.xc = xc; p.xdbl = x_dbl; p.yc = yc;
+  p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
+  p.Alog[0] = A_log; p.Alog[1] = A_log_b;
+  p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
+  const int RQ = rq_of(dt_rank);
+  dim3 grid(fv_cdiv(d_inner, CPB), batch, 2), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define FV_F(TT, RQQ)                                                                        \
+  do {                                                                                       \
+    size_t smem = (size_t)Lc * (4 * RQQ + 2 * N) * 4;                                        \
+    FV_CHECK(smem <= 64 * 1024, "mixer_scan_fwd: pooled length %d too long for the LDS stage", Lc); \
+    hipLaunchKernelGGL((scan_cl_fwd_kernel<TT, RQQ>), grid, block, smem, st, p);             \
+  } while (0)
+#define FV_FD(TT)                                                                            \
+  do {                                                                                       \
+    if (RQ <= 3) FV_F(TT, 3); else if (RQ <= 6) FV_F(TT, 6); else if (RQ <= 12) FV_F(TT, 12); else FV_F(TT, 24); \
+  } while (0)
+  if (dtype == FV_F32) FV_FD(float); else FV_FD(bf16_t);
+#undef FV_FD
+#undef FV_F
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+extern "C" int fv_mixer_scan_bwd_chunks(int d_inner) { return fv_cdiv(d_inner, CPB); }
+
+static int ks_of(int Lc) { return Lc <= 16 ? 16 : 8; }
+
+extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state) {
+  const int ks = ks_of(Lc);
+  return (size_t)2 * batch * ((Lc + ks - 1) / ks) * d_inner * d_state;
+}
+
+extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                 const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                 const float* A_log_b, const float* dyc, float* dxc, float* dx_dbl, float* ckpt,
+                                 float* partials, int batch, int Lc, int d_inner, int dt_rank, int d_state,
+                                 int dtype, fv_stream_t stream) {
+  FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_bwd: empty dimension");
+  FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_bwd: dtype must be fp32 or bf16");
+  FV_CHECK(d_state == N, "mixer_scan_bwd: only d_state == 16 is built (got %d)", d_state);
+  FV_CHECK(dt_rank <= 96, "mixer_scan_bwd: dt_rank %d > 96", dt_rank);
+  FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && dyc && dxc && dx_dbl &&
+               ckpt && partials, "mixer_scan_bwd: null pointer");
+  ScanClParams p{};
+  p.xc = xc; p.xdbl = x_dbl; p.dyc = dyc; p.dxc = dxc; p.dxdbl = dx_dbl; p.ckpt = ckpt; p.pP = partials;
+  p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
+  p.Alog[0] = A_log; p.Alog[1] = A_log_b;
+  p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
+  const int RQ = rq_of(dt_rank);
+  const int KS = ks_of(Lc);
+  dim3 grid(fv_cdiv(d_inner, CPB), batch, 2), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define FV_B(TT, RQQ, KSS, PVV)                                                              \
+  do {                                                                                       \
+    size_t smem = ((size_t)Lc * (4 * RQQ + 2 * N) + (size_t)KSS * 4 * 4 * PVV) * 4;          \
+    FV_CHECK(smem <= 64 * 1024, "mixer_scan_bwd: pooled length %d too long for the LDS stage", Lc); \
+    hipLaunchKernelGGL((scan_cl_bwd_kernel<TT, RQQ, KSS, PVV>), grid, block, smem, st, p);   \
+  } while (0)
+#define FV_BK(TT, RQQ, PVV)                                                                  \
+  do {                                                                                       \
+    if (KS == 16) FV_B(TT, RQQ, 16, PVV); else FV_B(TT, RQQ, 8, PVV);                        \
+  } while (0)
+#define FV_BD(TT)                                                                            \
+  do {                                                                                       \
+    if (RQ <= 3) FV_BK(TT, 3, 16); else if (RQ <= 6) FV_BK(TT, 6, 16);                       \
+    else if (RQ <= 12) FV_BK(TT, 12, 32); else FV_BK(TT, 24, 32);                            \
+  } while (0)
+  if (dtype == FV_F32) FV_BD(float); else FV_BD(bf16_t);
+#undef FV_BD
+#undef FV_BK
+#undef FV_B
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}

@@ -21,6 +21,37 @@ from torch import Tensor
 
 from .layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
 from .mamba_simple_faster import Mamba, _compute_dtype
+from .mixer_ops import reduce_partials
+
+
+class _EmbedEpilogueFn(torch.autograd.Function):
+    """out (fp32) = lin (B, L, D; bf16/fp32) + bias (D) + pos (1, L, D): the tail of PatchEmbed plus the
+    ``x + pos_embed`` of models/fastvim.py:500.  Backward sums with the fixed-order HIP reduction
+    (d pos = sum over batch, d bias = sum over batch and tokens) instead of torch's multi-block sum."""
+
+    @staticmethod
+    def forward(ctx, lin, bias, pos):
+        ctx.lin_dtype = lin.dtype
+        ctx.has = (bias is not None, pos is not None)
+        out = lin.float()
+        if bias is not None:
+            out = out + bias.float()
+        if pos is not None:
+            out = out + pos.float()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, Ltok, D = g.shape
+        dpos = dbias = None
+        if ctx.has[1] or ctx.has[0]:
+            per_tok = reduce_partials(g.view(B, Ltok * D), B).view(1, Ltok, D)      # sum over batch
+            if ctx.has[1]:
+                dpos = per_tok
+            if ctx.has[0]:
+                dbias = reduce_partials(per_tok.view(Ltok, D), Ltok)                  # then over tokens
+        return g.to(ctx.lin_dtype), dbias, dpos
 
 
 def to_2tuple(v):
@@ -89,7 +120,9 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
 
-    def forward(self, x):
+    def forward(self, x, pos_embed=None):
+        """``pos_embed`` (1, L, D), optional: added in the same epilogue as the conv bias (only for the
+        row-major, flattened token order)."""
         B, C, H, W = x.shape
         if self.strict_img_size:
             assert H == self.img_size[0], f"Input height ({H}) doesn't match model ({self.img_size[0]})."
@@ -101,11 +134,24 @@ class PatchEmbed(nn.Module):
             pad_h = (self.patch_size[0] - H % self.patch_size[0]) % self.patch_size[0]
             pad_w = (self.patch_size[1] - W % self.patch_size[1]) % self.patch_size[1]
             x = F.pad(x, (0, pad_w, 0, pad_h))
-        x = self.proj(x)
+        # k == stride conv == one GEMM over non-overlapping patches: (B*gh*gw, C*ph*pw) x (C*ph*pw, D).
+        # (MIOpen resolves this bf16 conv to naive kernels on gfx950; the GEMM form is also what the
+        # patch-embed MFMA kernel consumes.)
+        ph, pw = self.patch_size
+        gh, gw = x.shape[2] // ph, x.shape[3] // pw
+        cdt = _compute_dtype(x)
+        patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
+        w = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
+        with torch.autocast("cuda", enabled=False):
+            x = F.linear(patches.to(cdt), w.to(cdt))
         if self.scanpath_type == "colwise":
-            x = x.transpose(2, 3)
-        if self.flatten:
-            x = x.flatten(2).transpose(1, 2)  # BCHW -> BNC
+            x = x.reshape(B, gh, gw, -1).transpose(1, 2).reshape(B, gh * gw, -1)
+        if pos_embed is not None or self.proj.bias is not None:
+            x = _EmbedEpilogueFn.apply(x, self.proj.bias, pos_embed)
+        if not self.flatten:
+            assert pos_embed is None
+            g0, g1 = (gh, gw) if self.scanpath_type != "colwise" else (gw, gh)
+            x = x.transpose(1, 2).reshape(B, -1, g0, g1)
         return self.norm(x)
 
 
@@ -260,16 +306,18 @@ class VisionMamba(nn.Module):
 
     def forward_features(self, x, inference_params=None, out_indices=None):
         B, _, H, W = x.shape
-        x = self.patch_embed(x)
         if self.if_abs_pos_embed:
             H, W = math.ceil(H / self.patch_size), math.ceil(W / self.patch_size)
-            if H != self.token_size[0] or W != self.token_size[1]:
+            hw = (H, W) if self.patch_embed.scanpath_type == "rowwise" else (W, H)
+            if hw[0] != self.token_size[0] or hw[1] != self.token_size[1]:
                 # the reference's resize call is broken for this case: construct
                 # the model with the target img_size instead
                 raise RuntimeError(f"input grid {H}x{W} differs from the model's {self.token_size}; "
                                    "build VisionMamba with the matching img_size")
-            x = x + self.pos_embed
+            x = self.patch_embed(x, pos_embed=self.pos_embed)     # x + pos_embed (:500) in the epilogue
             x = self.pos_drop(x)
+        else:
+            x = self.patch_embed(x)
         outs = []
         residual = None
         hidden_states = x

@@ -99,16 +99,15 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc):
     dxc = torch.empty(2, B, Lc, d_in, **f32o)
     dx_dbl = torch.empty(nchunks, 2, B * Lc, W, **f32o)
     ckpt = torch.empty(max(1, lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N))), **f32o)
-    pA = torch.empty(B, 2, d_in, N, **f32o)
-    pW = torch.empty(B, 2, d_in, R, **f32o)
-    pb = torch.empty(B, 2, d_in, **f32o)
+    part = torch.empty(B, 2, d_in, N + R + 1, **f32o)
     rc = lib.fv_mixer_scan_bwd(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
-        L.ptr(A_log_b), L.ptr(dyc), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(pA), L.ptr(pW), L.ptr(pb),
+        L.ptr(A_log_b), L.ptr(dyc), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(part),
         L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
     L.check(rc, "mixer_scan_bwd")
     dx_dbl = dx_dbl[0] if nchunks == 1 else reduce_partials(dx_dbl, nchunks)
-    return dxc, dx_dbl, reduce_partials(pA, B), reduce_partials(pW, B), reduce_partials(pb, B)
+    pr = reduce_partials(part, B)                    # (2, d_in, N+R+1)
+    return dxc, dx_dbl, pr[:, :, :N], pr[:, :, N:N + R], pr[:, :, N + R]
 
 
 def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed,

@@ -128,15 +128,14 @@ int fv_mixer_combine_bwd(const void* dg, const void* xz, const float* yc, const 
  *   dx_dbl (fv_mixer_scan_bwd_chunks, 2, batch*Lc, dt_rank+2*d_state) fp32 out: sum over chunks
  *          = gradient wrt x_dbl
  *   ckpt   fv_mixer_scan_bwd_ckpt_floats() fp32 scratch
- *   pA (batch, 2, d_inner, d_state), pW (batch, 2, d_inner, dt_rank), pb (batch, 2, d_inner):
- *          per-batch partials of dA_log, d dt_proj.weight, d dt_proj.bias (sum over batch). */
+ *   partials (batch, 2, d_inner, d_state + dt_rank + 1): per-batch partials of
+ *          [dA_log | d dt_proj.weight | d dt_proj.bias] (sum over batch with fv_reduce_partials). */
 int fv_mixer_scan_bwd_chunks(int d_inner);
 size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state);
 int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
                       const float* A_log, const float* dt_w_b, const float* dt_bias_b, const float* A_log_b,
-                      const float* dyc, float* dxc, float* dx_dbl, float* ckpt, float* pA, float* pW,
-                      float* pb, int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
-                      fv_stream_t stream);
+                      const float* dyc, float* dxc, float* dx_dbl, float* ckpt, float* partials, int batch,
+                      int Lc, int d_inner, int dt_rank, int d_state, int dtype, fv_stream_t stream);
 
 /* Adjoint of fv_mixer_conv_pool_fwd plus the D-skip path: consumes d_o and the total gradient
  * wrt the pooled conv output dxc (2, batch, rows, d_inner) fp32; writes dx into the x half of
