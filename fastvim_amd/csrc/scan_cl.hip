@@ -11,9 +11,9 @@
 // across the block.  B_t, C_t, dt_low_t are staged once per block in LDS (fp32) and read as
 // broadcasts.
 //
-// Backward: forward states of a segment of KS steps are recomputed into registers (KS x 4 per
-// lane); segments are walked high-to-low with the adjoint state carried in registers; states
-// entering later segments come from a forward sweep that checkpoints them (only when Lc > KS).
+// Backward: a forward sweep checkpoints the state entering every 4-step segment (LDS for short
+// pooled lengths, global scratch otherwise); segments are then walked high-to-low, recomputing the
+// segment's 4 states into registers and carrying the adjoint state in registers.
 // dB/dC/d dt_low need a sum over channels: a wave reduce-scatters its 16 channel lanes
 // (__shfl_xor butterfly on lane bits 2..5), waves are summed through LDS in fixed order, blocks
 // write per-chunk partials that fv_reduce_partials sums -- deterministic, no float atomics.
@@ -105,72 +105,106 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_kernel(ScanClParams p) {
   const T* u = (const T*)p.xc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
   float* y = p.yc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
   float st[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int step = 0; step < p.Lc; ++step) {
-    const int l = ln.dir ? p.Lc - 1 - step : step;     // backward direction: descending rows
-    const float* row = smem + l * WP;
-    const float dt = ln.delta(row);
-    const float du = dt * io<T>::ld(u + (size_t)l * p.d_in);
-    float acc = 0.f;
+  for (int s0 = 0; s0 < p.Lc; s0 += 4) {
+    // the 4 loads of the group are issued together, ahead of the arithmetic
+    float uv[4];
+    int lk[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      st[j] = fmaf(fv_exp2(dt * ln.A2[j]), st[j], du * row[RP + ln.q * 4 + j]);
-      acc = fmaf(row[RP + N + ln.q * 4 + j], st[j], acc);
+    for (int k = 0; k < 4; ++k) {
+      const int step = min(s0 + k, p.Lc - 1);
+      lk[k] = ln.dir ? p.Lc - 1 - step : step;       // backward direction: descending rows
+      uv[k] = io<T>::ld(u + (size_t)lk[k] * p.d_in);
     }
-    acc = quad_sum(acc);
-    if (ln.act && ln.q == 0) y[(size_t)l * p.d_in] = acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (s0 + k < p.Lc) {
+        const float* row = smem + lk[k] * WP;
+        const float dt = ln.delta(row);
+        const float du = dt * uv[k];
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st[j] = fmaf(fv_exp2(dt * ln.A2[j]), st[j], du * row[RP + ln.q * 4 + j]);
+          acc = fmaf(row[RP + N + ln.q * 4 + j], st[j], acc);
+        }
+        acc = quad_sum(acc);
+        if (ln.act && ln.q == 0) y[(size_t)lk[k] * p.d_in] = acc;
+      }
+    }
   }
 }
 
 // butterfly over the 16 channel-lanes of a wave (lane bits 2..5); PV values per lane, PV in {16, 32}.
 // On return the lane whose channel index is c holds the totals of value indices [c*PV/16, (c+1)*PV/16).
-template <int PV>
-__device__ __forceinline__ void chan_reduce_scatter(float (&v)[PV], int lane) {
+template <int H, int OFF, int PV>
+__device__ __forceinline__ void rs_step(float (&v)[PV], int lane) {
+  const bool up = lane & OFF;
 #pragma unroll
-  for (int off = 32, h = PV / 2; off >= 4; off >>= 1, h >>= 1) {
-    const bool up = lane & off;
-#pragma unroll
-    for (int e = 0; e < h; ++e) {
-      float keep = up ? v[e + h] : v[e];
-      float send = up ? v[e] : v[e + h];
-      v[e] = keep + __shfl_xor(send, off, 64);
-    }
+  for (int e = 0; e < H; ++e) {
+    const float keep = up ? v[e + H] : v[e];
+    const float send = up ? v[e] : v[e + H];
+    v[e] = keep + __shfl_xor(send, OFF, 64);
   }
 }
+template <int PV>
+__device__ __forceinline__ void chan_reduce_scatter(float (&v)[PV], int lane) {
+  rs_step<PV / 2, 32, PV>(v, lane);
+  rs_step<PV / 4, 16, PV>(v, lane);
+  rs_step<PV / 8, 8, PV>(v, lane);
+  rs_step<PV / 16, 4, PV>(v, lane);
+}
 
-template <typename T, int RQ, int KS, int PV>
+// Backward.  Segments of KS = 4 steps: the states entering every segment are checkpointed by a
+// forward sweep (in LDS when the pooled length is short, else in global scratch), then segments are
+// walked high-to-low: recompute the 4 states (registers), run the adjoint, reduce over channels.
+template <typename T, int RQ, int PV, bool CK_LDS>
 __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KS = 4;
   constexpr int RP = 4 * RQ;
   constexpr int Q = PV / 16;                // values a lane holds after the butterfly
   constexpr int NWV = 4;                    // waves per block
   const int WP = RP + 2 * N, W = p.R + 2 * N;
+  const int nseg = (p.Lc + KS - 1) / KS;
   float* s_dbl = smem;                      // Lc * WP
-  float* s_part = smem + p.Lc * WP;         // KS * NWV * (4*PV)   [k][wave][q][value]
+  float* s_part = s_dbl + p.Lc * WP;        // KS * NWV * 4 * PV   [k][wave][q][value]
+  float* s_ck = s_part + KS * NWV * 4 * PV; // nseg * 256 * 4 (CK_LDS only)
   Lane<T, RQ> ln;
   ln.init(p);
   stage_dbl<T>(p, ln.dir, ln.b, s_dbl, RP);
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int dd = ln.act ? ln.d : 0;
-  const int nseg = (p.Lc + KS - 1) / KS;
   const T* u = (const T*)p.xc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
-  float* ck = p.ckpt + (((size_t)ln.dir * p.B + ln.b) * nseg * p.d_in + dd) * N + ln.q * 4;
+  const float* gy = p.dyc + (size_t)ln.b * p.Lc * p.d_in + dd;
+  float* ckg = p.ckpt + (((size_t)ln.dir * p.B + ln.b) * nseg * p.d_in + dd) * N + ln.q * 4;
   const size_t ck_seg = (size_t)p.d_in * N;
 
   // ---- forward sweep: checkpoint the state entering every segment but the first
-  if (nseg > 1) {
+  {
     float st[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int step = 0; step < (nseg - 1) * KS; ++step) {
-      const int l = ln.dir ? p.Lc - 1 - step : step;
-      const float* row = s_dbl + l * WP;
-      const float dt = ln.delta(row);
-      const float du = dt * io<T>::ld(u + (size_t)l * p.d_in);
+    for (int seg = 0; seg + 1 < nseg; ++seg) {
+      float uv[KS];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * ln.A2[j]), st[j], du * row[RP + ln.q * 4 + j]);
-      if ((step + 1) % KS == 0 && ln.act) {
-        float* dst = ck + (size_t)((step + 1) / KS) * ck_seg;
+      for (int k = 0; k < KS; ++k) {
+        const int step = seg * KS + k;
+        const int l = ln.dir ? p.Lc - 1 - step : step;
+        uv[k] = io<T>::ld(u + (size_t)l * p.d_in);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = st[j];
+      for (int k = 0; k < KS; ++k) {
+        const int step = seg * KS + k;
+        const int l = ln.dir ? p.Lc - 1 - step : step;
+        const float* row = s_dbl + l * WP;
+        const float dt = ln.delta(row);
+        const float du = dt * uv[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * ln.A2[j]), st[j], du * row[RP + ln.q * 4 + j]);
+      }
+      if (CK_LDS) {
+        *reinterpret_cast<float4*>(s_ck + ((size_t)(seg + 1) * 256 + tid) * 4) = make_float4(st[0], st[1], st[2], st[3]);
+      } else if (ln.act) {
+        *reinterpret_cast<float4*>(ckg + (size_t)(seg + 1) * ck_seg) = make_float4(st[0], st[1], st[2], st[3]);
       }
     }
   }
@@ -182,40 +216,42 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
   for (int seg = nseg - 1; seg >= 0; --seg) {
     const int s0 = seg * KS;
     const int ns = min(KS, p.Lc - s0);
-    float cur[4] = {0.f, 0.f, 0.f, 0.f};
-    if (seg > 0 && ln.act) {
-      const float* src = ck + (size_t)seg * ck_seg;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cur[j] = src[j];
-    }
-    // recompute the segment's forward states
-    float xs[KS][4], dtv[KS], uv[KS];
+    // loads of the whole segment first (clamped rows; masked below), then the arithmetic
+    float uv[KS], gq[KS];
+    int lk[KS];
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      if (k < ns) {
-        const int l = ln.dir ? p.Lc - 1 - (s0 + k) : s0 + k;
-        const float* row = s_dbl + l * WP;
-        dtv[k] = ln.delta(row);
-        uv[k] = io<T>::ld(u + (size_t)l * p.d_in);
-        const float du = dtv[k] * uv[k];
+      const int step = min(s0 + k, p.Lc - 1);
+      lk[k] = ln.dir ? p.Lc - 1 - step : step;
+      uv[k] = io<T>::ld(u + (size_t)lk[k] * p.d_in);
+      gq[k] = gy[(size_t)lk[k] * p.d_in];
+    }
+    float cur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (seg > 0) {
+      float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (CK_LDS) c4 = *reinterpret_cast<const float4*>(s_ck + ((size_t)seg * 256 + tid) * 4);
+      else if (ln.act) c4 = *reinterpret_cast<const float4*>(ckg + (size_t)seg * ck_seg);
+      cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
+    }
+    float xs[KS][4], dtv[KS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          cur[j] = fmaf(fv_exp2(dtv[k] * ln.A2[j]), cur[j], du * row[RP + ln.q * 4 + j]);
-          xs[k][j] = cur[j];
-        }
-      } else {
-        dtv[k] = uv[k] = 0.f;
+    for (int k = 0; k < KS; ++k) {
+      const float* row = s_dbl + lk[k] * WP;
+      const bool on = k < ns && ln.act;
+      dtv[k] = on ? ln.delta(row) : 0.f;      // delta = 0: a = 1, b = 0 -> the step is an identity
+      if (!on) gq[k] = 0.f;
+      const float du = dtv[k] * uv[k];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xs[k][j] = 0.f;
+      for (int j = 0; j < 4; ++j) {
+        cur[j] = fmaf(fv_exp2(dtv[k] * ln.A2[j]), cur[j], du * row[RP + ln.q * 4 + j]);
+        xs[k][j] = cur[j];
       }
     }
     // adjoint recurrence, high-to-low
 #pragma unroll
     for (int k = KS - 1; k >= 0; --k) {
       if (k < ns) {          // uniform across the block
-        const int l = ln.dir ? p.Lc - 1 - (s0 + k) : s0 + k;
-        const float* row = s_dbl + l * WP;
-        const float gq = ln.act ? p.dyc[((size_t)ln.b * p.Lc + l) * p.d_in + dd] : 0.f;
+        const float* row = s_dbl + lk[k] * WP;
         float vals[PV];
 #pragma unroll
         for (int e = 0; e < PV; ++e) vals[e] = 0.f;
@@ -225,26 +261,27 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
         for (int j = 0; j < 4; ++j) {
           const float Bn = row[RP + ln.q * 4 + j], Cn = row[RP + N + ln.q * 4 + j];
           const float a = fv_exp2(dtv[k] * ln.A2[j]);
-          const float dx = fmaf(gq, Cn, dxa[j]);
+          const float dx = fmaf(gq[k], Cn, dxa[j]);
           const float ax = xs[k][j] - dtu * Bn;               // a_t * x_{t-1}
           du_acc = fmaf(dx, Bn, du_acc);
           ddt_acc += dx * fmaf(ln.Araw[j], ax, Bn * uv[k]);
           dA[j] = fmaf(dx * dtv[k], ax, dA[j]);
           vals[j] = dx * dtu;                                  // dB[4q+j]
-          vals[4 + j] = gq * xs[k][j];                         // dC[4q+j]
+          vals[4 + j] = gq[k] * xs[k][j];                      // dC[4q+j]
           dxa[j] = a * dx;
         }
         du_acc = quad_sum(du_acc);
         ddt_acc = quad_sum(ddt_acc);
-        // d softplus: sigmoid(raw) = 1 - exp(-softplus(raw)); exact also above the threshold of 20
-        float ddraw = ln.act ? ddt_acc * (1.f - __expf(-dtv[k])) : 0.f;
+        // d softplus: sigmoid(raw) = 1 - exp(-softplus(raw))
+        const float ddraw = ln.act ? ddt_acc * (1.f - __expf(-dtv[k])) : 0.f;
         dbias += ddraw;
 #pragma unroll
         for (int i = 0; i < RQ; ++i) {
           dW[i] = fmaf(ddraw, row[ln.q + 4 * i], dW[i]);
           vals[8 + i] = ddraw * ln.wdt[i];                     // d dt_low[q + 4i]
         }
-        if (ln.act && ln.q == 0) p.dxc[(((size_t)ln.dir * p.B + ln.b) * p.Lc + l) * p.d_in + ln.d] = dtv[k] * du_acc;
+        if (ln.act && ln.q == 0)
+          p.dxc[(((size_t)ln.dir * p.B + ln.b) * p.Lc + lk[k]) * p.d_in + ln.d] = dtv[k] * du_acc;
         chan_reduce_scatter<PV>(vals, lane);
         const int c = lane >> 2;
 #pragma unroll
@@ -264,7 +301,8 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) t += s_part[((k * NWV + w) * 4 + qq) * PV + v];
-        const int l = ln.dir ? p.Lc - 1 - (s0 + k) : s0 + k;
+        const int step = s0 + k;
+        const int l = ln.dir ? p.Lc - 1 - step : step;
         p.dxdbl[(((size_t)blockIdx.x * 2 + ln.dir) * p.B + ln.b) * p.Lc * W + (size_t)l * W + col] = t;
       }
     }
@@ -278,8 +316,7 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
 #pragma unroll
     for (int i = 0; i < RQ; ++i)
       if (ln.q + 4 * i < p.R) dst[N + ln.q + 4 * i] = dW[i];
-    dbias = quad_sum(dbias) * 0.25f;   // all four lanes accumulated the same value
-    if (ln.q == 0) dst[N + p.R] = dbias;
+    if (ln.q == 0) dst[N + p.R] = dbias;                                     // identical in all 4 lanes
   }
 }
 
@@ -324,11 +361,11 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
 
 extern "C" int fv_mixer_scan_bwd_chunks(int d_inner) { return fv_cdiv(d_inner, CPB); }
 
-static int ks_of(int Lc) { return Lc <= 16 ? 16 : 8; }
+static bool ck_in_lds(int Lc) { return ((Lc + 3) / 4) * 4096 <= 32 * 1024; }
 
 extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state) {
-  const int ks = ks_of(Lc);
-  return (size_t)2 * batch * ((Lc + ks - 1) / ks) * d_inner * d_state;
+  if (ck_in_lds(Lc)) return 0;
+  return (size_t)2 * batch * ((Lc + 3) / 4) * d_inner * d_state;
 }
 
 extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
@@ -341,25 +378,26 @@ extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float*
   FV_CHECK(d_state == N, "mixer_scan_bwd: only d_state == 16 is built (got %d)", d_state);
   FV_CHECK(dt_rank <= 96, "mixer_scan_bwd: dt_rank %d > 96", dt_rank);
   FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && dyc && dxc && dx_dbl &&
-               ckpt && partials, "mixer_scan_bwd: null pointer");
+               partials && (ckpt || ck_in_lds(Lc)), "mixer_scan_bwd: null pointer");
   ScanClParams p{};
   p.xc = xc; p.xdbl = x_dbl; p.dyc = dyc; p.dxc = dxc; p.dxdbl = dx_dbl; p.ckpt = ckpt; p.pP = partials;
   p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
   p.Alog[0] = A_log; p.Alog[1] = A_log_b;
   p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
   const int RQ = rq_of(dt_rank);
-  const int KS = ks_of(Lc);
+  const bool ckl = ck_in_lds(Lc);
   dim3 grid(fv_cdiv(d_inner, CPB), batch, 2), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define FV_B(TT, RQQ, KSS, PVV)                                                              \
+#define FV_B(TT, RQQ, PVV, CKK)                                                              \
   do {                                                                                       \
-    size_t smem = ((size_t)Lc * (4 * RQQ + 2 * N) + (size_t)KSS * 4 * 4 * PVV) * 4;          \
+    size_t smem = ((size_t)Lc * (4 * RQQ + 2 * N) + (size_t)4 * 4 * 4 * PVV +                \
+                   (CKK ? (size_t)((Lc + 3) / 4) * 1024 : 0)) * 4;                           \
     FV_CHECK(smem <= 64 * 1024, "mixer_scan_bwd: pooled length %d too long for the LDS stage", Lc); \
-    hipLaunchKernelGGL((scan_cl_bwd_kernel<TT, RQQ, KSS, PVV>), grid, block, smem, st, p);   \
+    hipLaunchKernelGGL((scan_cl_bwd_kernel<TT, RQQ, PVV, CKK>), grid, block, smem, st, p);   \
   } while (0)
 #define FV_BK(TT, RQQ, PVV)                                                                  \
   do {                                                                                       \
-    if (KS == 16) FV_B(TT, RQQ, 16, PVV); else FV_B(TT, RQQ, 8, PVV);                        \
+    if (ckl) FV_B(TT, RQQ, PVV, true); else FV_B(TT, RQQ, PVV, false);                       \
   } while (0)
 #define FV_BD(TT)                                                                            \
   do {                                                                                       \

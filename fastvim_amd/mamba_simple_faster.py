@@ -18,6 +18,20 @@ from . import _lib as L
 from . import mixer_ops as M
 
 
+def _wgrad(X, Y, splits=16):
+    """dW (I, J) fp32 = X^T Y for X (M, I), Y (M, J) with M >> I, J: the reduction dim is split into
+    `splits` batched GEMMs (enough workgroups to fill 256 CUs) whose fp32 partials are summed in a
+    fixed order by fv_reduce_partials -- a deterministic split-K."""
+    M_, I = X.shape
+    J = Y.shape[1]
+    while splits > 1 and M_ % splits:
+        splits //= 2
+    if splits == 1:
+        return (X.t() @ Y).float()
+    part = torch.bmm(X.view(splits, M_ // splits, I).transpose(1, 2), Y.view(splits, M_ // splits, J)).float()
+    return M.reduce_partials(part, splits)
+
+
 def _compute_dtype(t):
     """bf16/fp16 under torch.autocast (reference: mamba_simple_faster.py:312-318), else the input dtype."""
     if torch.is_autocast_enabled():
@@ -69,7 +83,7 @@ class FastVimMixerFn(torch.autograd.Function):
             dout = dout.to(cdt).contiguous()
             do2 = dout.view(B * Ltok, d)
             dg = do2 @ W_out.to(cdt)                                                     # (B*L, d_in)
-            dW_out = (do2.t() @ g.view(B * Ltok, d_in)).float()
+            dW_out = _wgrad(do2, g.view(B * Ltok, d_in))
             db_out = do2.float().sum(0) if ctx.has_bias[1] else None
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
@@ -84,7 +98,7 @@ class FastVimMixerFn(torch.autograd.Function):
                                  pool_max, scaling)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
             dhidden = (dxz2 @ W_in.to(cdt)).view(B, Ltok, d).to(ctx.in_dtype)
-            dW_in = (dxz2.t() @ h_c.view(B * Ltok, d)).float()
+            dW_in = _wgrad(dxz2, h_c.view(B * Ltok, d))
             db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
         has_ln = ln_w is not None
         return (dhidden, dW_in, db_in,
