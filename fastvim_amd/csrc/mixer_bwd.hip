@@ -3,19 +3,19 @@
 // hand-written backward of FastVim_MambaInnerFnNoOutProj_withoutZ
 // (mamba_ssm/ops/selective_scan_interface.py:607-776):
 //
-//   fv_mixer_combine_bwd   : d(gate), d(LayerNorm), d(average) -> dz, do, per-row pooled
-//                            dyc = 0.5*sum_j do, partials of dLN.weight/bias, dD, dD_b.
+//   fv_mixer_combine_bwd   : d(gate), d(LayerNorm) from the saved xhat -> dz, do, per-row pooled
+//                            dyc = 0.5*sum_j do, partials of dLN.weight/bias.
 //   (fv_mixer_scan_bwd, the adjoint of dt_proj + scan, lives in scan_cl.hip)
-//   fv_mixer_conv_pool_bwd : adjoint of mean-pool + SiLU + both depthwise convs -> dx, and
-//                            partials of the conv weight/bias gradients.
+//   fv_mixer_conv_pool_bwd : adjoint of the D-skip, mean-pool, SiLU and both depthwise convs -> dx,
+//                            and partials of the conv weight/bias and D, D_b gradients.
 //   fv_reduce_partials     : fixed-order sum of per-block partials (no float atomics anywhere).
 #include "mixer_common.h"
 
 namespace {
 
 struct BwdParams {
-  const void *xz, *dg, *dob_in;
-  const float *yc, *wf, *bf, *wb, *bb, *Df, *Db, *lnw, *lnb, *mean, *rstd, *dxc;
+  const void *xz, *dg, *xhat, *dob_in;
+  const float *wf, *bf, *wb, *bb, *Df, *Db, *lnw, *lnb, *rstd, *dxc;
   void *dxz, *dob;
   float *dyc, *part;
   Geo geo;
@@ -23,275 +23,294 @@ struct BwdParams {
   float pool_scale;
 };
 
-template <int VEC, int TJ>
-__device__ __forceinline__ void conv_pre(const ChanParams<VEC>& cp, const float (&x)[TJ + 6][VEC], int k,
-                                         float (&pf)[VEC], float (&pb)[VEC], bool want_f, bool want_b) {
-  // pre-activations at tile index k (token j0-3+k): forward needs x[k-3..k], backward x[k..k+3]
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    float f = cp.bf[v], bk = cp.bb[v];
-#pragma unroll
-    for (int kk = 0; kk < CW; ++kk) {
-      const int kf = k - 3 + kk < 0 ? 0 : k - 3 + kk;            // clamped: unused when !want_f
-      const int kb = k + 3 - kk > TJ + 5 ? TJ + 5 : k + 3 - kk;  // clamped: unused when !want_b
-      if (want_f) f = fmaf(cp.wf[v][kk], x[kf][v], f);
-      if (want_b) bk = fmaf(cp.wb[v][kk], x[kb][v], bk);
-    }
-    pf[v] = f;
-    pb[v] = bk;
-  }
-}
+constexpr int RGMAX = 4;   // a block walks up to RGMAX pooling rows concurrently (one per row group) and emits ONE partial
 
-// cross-wave sum of TJ wave-uniform values through LDS (block = nw waves of one row)
-template <int TJ>
-__device__ __forceinline__ void block_sum(float (&s)[TJ], float* s_red, int wv, int nw, int lane) {
-  if (nw == 1) return;
-  __syncthreads();
-  if (lane == 0)
-#pragma unroll
-    for (int jj = 0; jj < TJ; ++jj) s_red[wv * TJ + jj] = s[jj];
-  __syncthreads();
-#pragma unroll
-  for (int jj = 0; jj < TJ; ++jj) {
-    float t = 0.f;
-    for (int w = 0; w < nw; ++w) t += s_red[w * TJ + jj];
-    s[jj] = t;
-  }
-}
-
-// ------------------------------------------------------------------ combine backward
-template <typename T, int VEC, int TJ>
-__global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdParams p) {
-  __shared__ float s_red[16 * TJ];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int c0 = (wv * 64 + lane) * VEC;
+// ------------------------------------------------------------------ LayerNorm + gate backward
+// Reads dg, z, xhat once, writes dz and d_o once: 5 full-length tensors of traffic, no conv recompute
+// (the forward saved xhat).  Block = RG row groups x NCH waves; a row group walks one pooling row.
+template <typename T, int VEC, int TT>
+__global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdParams p, int nch, int RG) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rg = wv / nch, cw = wv - rg * nch;          // row group, channel-chunk wave
+  const int c0 = (cw * 64 + lane) * VEC;
   const bool act = c0 < p.d_in;
   const Geo g = p.geo;
-  ChanParams<VEC> cp;
-  cp.load(p.wf, p.bf, p.wb, p.bb, c0, act);
-  float Df[VEC], Db[VEC], lw[VEC], lb[VEC];
-  float a_lw[VEC], a_lb[VEC], a_Df[VEC], a_Db[VEC];
+  float* s_red = smem;                                   // RGMAX * 2 * TT * 16 (cross-wave LN sums)
+  float* s_acc = smem + RGMAX * 2 * TT * 16;             // 2 * d_in
+  float lw[VEC], lb[VEC], a_lw[VEC], a_lb[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
-    Df[v] = act ? p.Df[c0 + v] : 0.f;
-    Db[v] = act ? p.Db[c0 + v] : 0.f;
     lw[v] = act && p.use_norm ? p.lnw[c0 + v] : 1.f;
     lb[v] = act && p.use_norm ? p.lnb[c0 + v] : 0.f;
-    a_lw[v] = a_lb[v] = a_Df[v] = a_Db[v] = 0.f;
+    a_lw[v] = a_lb[v] = 0.f;
   }
   const float inv_d = 1.f / (float)p.d_in;
   const int nrows = p.B * g.rows;
-  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
-    const int b = row / g.rows, i = row - b * g.rows;
-    float ysum[VEC], dyc_acc[VEC];
-    {
-      size_t o = (size_t)row * p.d_in + c0;
-      size_t dstride = (size_t)p.B * g.rows * p.d_in;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        ysum[v] = act ? p.yc[o + v] + p.yc[dstride + o + v] : 0.f;
-        dyc_acc[v] = 0.f;
-      }
-    }
+  const int nit = (nrows + gridDim.x * RG - 1) / (gridDim.x * RG);
+  for (int it = 0; it < nit; ++it) {
+    const int row = (it * gridDim.x + blockIdx.x) * RG + rg;
+    const bool rv = row < nrows;                         // uniform per row group
+    const int b = rv ? row / g.rows : 0, i = rv ? row - b * g.rows : 0;
     const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
     const T* dg_b = (const T*)p.dg + (size_t)b * g.L * p.d_in;
+    const T* xh_b = (const T*)p.xhat + (size_t)b * g.L * p.d_in;
     T* dxz_b = (T*)p.dxz + (size_t)b * g.L * 2 * p.d_in;
     T* dob_b = (T*)p.dob + (size_t)b * g.L * p.d_in;
-    for (int j0 = 0; j0 < g.cols; j0 += TJ) {
-      float x[TJ + 6][VEC];
-      load_x_tile<T, VEC, TJ, 3>(xz_b, g, p.d_in, i, j0, c0, act, x);
-      float xf[TJ][VEC], xb[TJ][VEC], xh[TJ][VEC], dxh[TJ][VEC], c1[TJ], c2[TJ], rs[TJ];
-      int mtok[TJ];
+    float dyc_acc[VEC];
 #pragma unroll
-      for (int jj = 0; jj < TJ; ++jj) {
-        const bool valid = j0 + jj < g.cols;
-        float pf[VEC], pb[VEC];
-        conv_pre<VEC, TJ>(cp, x, jj + 3, pf, pb, true, true);
-        mtok[jj] = valid ? tok_mem(g, i * g.cols + j0 + jj) : 0;
-        float mu = 0.f;
-        rs[jj] = 1.f;
-        if (p.use_norm && valid) {
-          mu = p.mean[(size_t)b * g.L + mtok[jj]];
-          rs[jj] = p.rstd[(size_t)b * g.L + mtok[jj]];
-        }
+    for (int v = 0; v < VEC; ++v) dyc_acc[v] = 0.f;
+    for (int j0 = 0; j0 < g.cols; j0 += TT) {
+      float xh[TT][VEC], dxh[TT][VEC], c1[TT], c2[TT], rs[TT];
+      int mtok[TT];
+      bool tv[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        tv[t] = rv && (j0 + t < g.cols);
+        mtok[t] = tv[t] ? tok_mem(g, i * g.cols + j0 + t) : 0;
+        rs[t] = (tv[t] && p.use_norm) ? p.rstd[(size_t)b * g.L + mtok[t]] : 1.f;
         float dgv[VEC], zv[VEC], dzv[VEC];
-        if (valid && act) {
-          VecIO<T, VEC>::load(dg_b + (size_t)mtok[jj] * p.d_in + c0, dgv);
-          VecIO<T, VEC>::load(xz_b + (size_t)mtok[jj] * 2 * p.d_in + p.d_in + c0, zv);
+        if (tv[t] && act) {
+          VecIO<T, VEC>::load(dg_b + (size_t)mtok[t] * p.d_in + c0, dgv);
+          VecIO<T, VEC>::load(xz_b + (size_t)mtok[t] * 2 * p.d_in + p.d_in + c0, zv);
+          VecIO<T, VEC>::load(xh_b + (size_t)mtok[t] * p.d_in + c0, xh[t]);
         } else {
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) dgv[v] = zv[v] = 0.f;
+          for (int v = 0; v < VEC; ++v) dgv[v] = zv[v] = xh[t][v] = 0.f;
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          xf[jj][v] = fv_silu(pf[v]);
-          xb[jj][v] = fv_silu(pb[v]);
-          float o = 0.5f * (ysum[v] + Df[v] * xf[jj][v] + Db[v] * xb[jj][v]);
-          xh[jj][v] = (o - mu) * rs[jj];
-          float h = xh[jj][v] * lw[v] + lb[v];
-          float sg = fv_sigmoid(zv[v]);
-          float sz = zv[v] * sg;
-          float dh = dgv[v] * sz;
+          const float h = xh[t][v] * lw[v] + lb[v];
+          const float sg = fv_sigmoid(zv[v]);
+          const float dh = dgv[v] * (zv[v] * sg);
           dzv[v] = dgv[v] * h * (sg * (1.f + zv[v] * (1.f - sg)));
-          a_lw[v] += dh * xh[jj][v];
+          a_lw[v] = fmaf(dh, xh[t][v], a_lw[v]);
           a_lb[v] += dh;
-          dxh[jj][v] = dh * lw[v];
-          s1 += dxh[jj][v];
-          s2 += dxh[jj][v] * xh[jj][v];
+          dxh[t][v] = dh * lw[v];
+          s1 += dxh[t][v];
+          s2 = fmaf(dxh[t][v], xh[t][v], s2);
         }
-        c1[jj] = s1;
-        c2[jj] = s2;
-        if (valid && act) VecIO<T, VEC>::store(dxz_b + (size_t)mtok[jj] * 2 * p.d_in + p.d_in + c0, dzv);
+        c1[t] = s1;
+        c2[t] = s2;
+        if (tv[t] && act) VecIO<T, VEC>::store(dxz_b + (size_t)mtok[t] * 2 * p.d_in + p.d_in + c0, dzv);
       }
       if (p.use_norm) {
 #pragma unroll
-        for (int jj = 0; jj < TJ; ++jj) {
-          c1[jj] = wave_sum_uniform(c1[jj]);
-          c2[jj] = wave_sum_uniform(c2[jj]);
+        for (int t = 0; t < TT; ++t) {
+          c1[t] = wave_sum_uniform(c1[t]);
+          c2[t] = wave_sum_uniform(c2[t]);
         }
-        block_sum<TJ>(c1, s_red, wv, nw, lane);
-        block_sum<TJ>(c2, s_red, wv, nw, lane);
+        if (nch > 1) {      // sum over the row group's channel-chunk waves through LDS
+          __syncthreads();
+          if (lane == 0)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+              s_red[((rg * 2 + 0) * TT + t) * 16 + cw] = c1[t];
+              s_red[((rg * 2 + 1) * TT + t) * 16 + cw] = c2[t];
+            }
+          __syncthreads();
+#pragma unroll
+          for (int t = 0; t < TT; ++t) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int w = 0; w < nch; ++w) {
+              t1 += s_red[((rg * 2 + 0) * TT + t) * 16 + w];
+              t2 += s_red[((rg * 2 + 1) * TT + t) * 16 + w];
+            }
+            c1[t] = t1;
+            c2[t] = t2;
+          }
+        }
       }
 #pragma unroll
-      for (int jj = 0; jj < TJ; ++jj) {
-        const bool valid = j0 + jj < g.cols;
+      for (int t = 0; t < TT; ++t) {
         float dov[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          float d_o = p.use_norm ? rs[jj] * (dxh[jj][v] - inv_d * (c1[jj] + xh[jj][v] * c2[jj])) : dxh[jj][v];
-          if (!valid || !act) d_o = 0.f;
+          float d_o = p.use_norm ? rs[t] * (dxh[t][v] - inv_d * (c1[t] + xh[t][v] * c2[t])) : dxh[t][v];
           dov[v] = d_o;
-          a_Df[v] += 0.5f * d_o * xf[jj][v];
-          a_Db[v] += 0.5f * d_o * xb[jj][v];
           dyc_acc[v] += 0.5f * d_o;
         }
-        if (valid && act) VecIO<T, VEC>::store(dob_b + (size_t)mtok[jj] * p.d_in + c0, dov);
+        if (tv[t] && act) VecIO<T, VEC>::store(dob_b + (size_t)mtok[t] * p.d_in + c0, dov);
       }
     }
-    if (act) VecIO<float, VEC>::store(p.dyc + (size_t)row * p.d_in + c0, dyc_acc);
+    if (rv && act) VecIO<float, VEC>::store(p.dyc + (size_t)row * p.d_in + c0, dyc_acc);
   }
-  if (act) {
-    float* dst = p.part + ((size_t)blockIdx.x * p.d_in + c0) * 4;
+  // fixed-order accumulation of the RG row groups into one partial row [d ln_w | d ln_b]
+  for (int r = 0; r < RG; ++r) {
+    __syncthreads();
+    if (r == rg && act) {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      dst[v * 4 + 0] = a_lw[v];
-      dst[v * 4 + 1] = a_lb[v];
-      dst[v * 4 + 2] = a_Df[v];
-      dst[v * 4 + 3] = a_Db[v];
+      for (int v = 0; v < VEC; ++v) {
+        s_acc[c0 + v] = (r == 0 ? 0.f : s_acc[c0 + v]) + a_lw[v];
+        s_acc[p.d_in + c0 + v] = (r == 0 ? 0.f : s_acc[p.d_in + c0 + v]) + a_lb[v];
+      }
     }
   }
+  __syncthreads();
+  float* dst = p.part + (size_t)blockIdx.x * 2 * p.d_in;
+  for (int e = threadIdx.x; e < 2 * p.d_in; e += blockDim.x) dst[e] = s_acc[e];
 }
 
-// ------------------------------------------------------------------ conv + pool backward
-template <typename T, int VEC, int TJ>
-__global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_bwd_kernel(BwdParams p) {
+// ------------------------------------------------------------------ conv + pool backward (streaming)
+// Purely per-channel (no cross-lane traffic): a lane owns VEC channels and streams the row's tokens
+// through 4-deep register windows.  Step n consumes token n+3 and produces
+//   dpre_f[n+3] (needs x[n..n+3]),  dpre_b[n] (needs x[n..n+3]),  dx[n] (needs dpre_f[n..n+3], dpre_b[n-3..n]).
+template <typename T, int VEC>
+__global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(BwdParams p, int nch, int RG) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c0 = (wv * 64 + lane) * VEC;
+  const int rg = wv / nch, cw = wv - rg * nch;
+  const int c0 = (cw * 64 + lane) * VEC;
   const bool act = c0 < p.d_in;
   const Geo g = p.geo;
   ChanParams<VEC> cp;
   cp.load(p.wf, p.bf, p.wb, p.bb, c0, act);
   float Dfh[VEC], Dbh[VEC];
-  float a_wf[VEC][CW], a_wb[VEC][CW], a_bf[VEC], a_bb[VEC];
+  float a_wf[VEC][CW], a_wb[VEC][CW], a_bf[VEC], a_bb[VEC], a_Df[VEC], a_Db[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     Dfh[v] = act ? 0.5f * p.Df[c0 + v] : 0.f;
     Dbh[v] = act ? 0.5f * p.Db[c0 + v] : 0.f;
-    a_bf[v] = a_bb[v] = 0.f;
+    a_bf[v] = a_bb[v] = a_Df[v] = a_Db[v] = 0.f;
 #pragma unroll
     for (int k = 0; k < CW; ++k) a_wf[v][k] = a_wb[v][k] = 0.f;
   }
   const int nrows = p.B * g.rows;
   const size_t dstride = (size_t)p.B * g.rows * p.d_in;
-  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
-    const int b = row / g.rows, i = row - b * g.rows;
-    // pooled-gradient of rows i-1, i, i+1 (halo tokens belong to the neighbouring rows)
-    float dcf[3][VEC], dcb[3][VEC];
+  const int nit = (nrows + gridDim.x * RG - 1) / (gridDim.x * RG);
+  for (int it = 0; it < nit; ++it) {
+    const int row = (it * gridDim.x + blockIdx.x) * RG + rg;
+    if (row < nrows) {          // uniform per wave; no block-level sync inside
+      const int b = row / g.rows, i = row - b * g.rows;
+      float dcf[3][VEC], dcb[3][VEC];   // pooled gradients of rows i-1, i, i+1 (halo tokens)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      int ii = i - 1 + r;
-      bool ok = act && ii >= 0 && ii < g.rows;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        size_t o = ((size_t)b * g.rows + ii) * p.d_in + c0 + v;
-        dcf[r][v] = ok ? p.dxc[o] * p.pool_scale : 0.f;
-        dcb[r][v] = ok ? p.dxc[dstride + o] * p.pool_scale : 0.f;
-      }
-    }
-    const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
-    const T* dob_b = (const T*)p.dob_in + (size_t)b * g.L * p.d_in;
-    T* dxz_b = (T*)p.dxz + (size_t)b * g.L * 2 * p.d_in;
-    for (int j0 = 0; j0 < g.cols; j0 += TJ) {
-      float x[TJ + 6][VEC], dov[TJ + 6][VEC];
-      load_x_tile<T, VEC, TJ, 3>(xz_b, g, p.d_in, i, j0, c0, act, x);
-      bool tv[TJ + 6];
-      int rsel[TJ + 6];
-#pragma unroll
-      for (int k = 0; k < TJ + 6; ++k) {
-        int j = j0 - 3 + k;
-        int s = i * g.cols + j;
-        tv[k] = s >= 0 && s < g.L && j < g.cols + 3;
-        rsel[k] = j < 0 ? 0 : (j >= g.cols ? 2 : 1);
-        if (tv[k] && act) {
-          VecIO<T, VEC>::load(dob_b + (size_t)tok_mem(g, s) * p.d_in + c0, dov[k]);
-        } else {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) dov[k][v] = 0.f;
-        }
-      }
-      // d(pre-activation): forward dir for tile indices 3..TJ+5, backward dir for 0..TJ+2
-      float dpf[TJ + 6][VEC], dpb[TJ + 6][VEC];
-#pragma unroll
-      for (int k = 0; k < TJ + 6; ++k) {
-        const bool wf_ = k >= 3, wb_ = k <= TJ + 2;
-        float pf[VEC], pb[VEC];
-        conv_pre<VEC, TJ>(cp, x, k, pf, pb, wf_, wb_);
+      for (int r = 0; r < 3; ++r) {
+        const int ii = i - 1 + r;
+        const bool ok = act && ii >= 0 && ii < g.rows;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          float cf = rsel[k] == 0 ? dcf[0][v] : (rsel[k] == 1 ? dcf[1][v] : dcf[2][v]);
-          float cb = rsel[k] == 0 ? dcb[0][v] : (rsel[k] == 1 ? dcb[1][v] : dcb[2][v]);
-          dpf[k][v] = (wf_ && tv[k]) ? (Dfh[v] * dov[k][v] + cf) * fv_silu_grad(pf[v]) : 0.f;
-          dpb[k][v] = (wb_ && tv[k]) ? (Dbh[v] * dov[k][v] + cb) * fv_silu_grad(pb[v]) : 0.f;
+          const size_t o = ((size_t)b * g.rows + (ok ? ii : 0)) * p.d_in + (act ? c0 + v : 0);
+          dcf[r][v] = ok ? p.dxc[o] * p.pool_scale : 0.f;
+          dcb[r][v] = ok ? p.dxc[dstride + o] * p.pool_scale : 0.f;
         }
       }
+      const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
+      const T* dob_b = (const T*)p.dob_in + (size_t)b * g.L * p.d_in;
+      T* dxz_b = (T*)p.dxz + (size_t)b * g.L * 2 * p.d_in;
+      const int s_row = i * g.cols;
+      // windows: index 0 = token n, 3 = token n+3 (x, do, dpf); dpb: index 0 = token n-3, 3 = token n
+      float xw[4][VEC], dw[4][VEC], dpf[4][VEC], dpb[4][VEC];
 #pragma unroll
-      for (int jj = 0; jj < TJ; ++jj) {
-        const int k = jj + 3;
-        if (j0 + jj < g.cols) {
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xw[k][v] = dw[k][v] = dpf[k][v] = dpb[k][v] = 0.f;
+      // preload tokens -3, -2, -1 into slots 1..3 (they shift to 0..2 at the first step)
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const int s = s_row - 4 + k;
+        if (s >= 0 && act) {
+          const int m = tok_mem(g, s);
+          VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + c0, xw[k]);
+          VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dw[k]);
+        }
+      }
+#pragma unroll 4
+      for (int n = -3; n < g.cols; ++n) {
+        // shift the windows by one token and bring in token n+3
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            xw[k][v] = xw[k + 1][v];
+            dw[k][v] = dw[k + 1][v];
+            dpf[k][v] = dpf[k + 1][v];
+            dpb[k][v] = dpb[k + 1][v];
+          }
+        const int s3 = s_row + n + 3;
+        const bool v3 = s3 < g.L;                         // token n+3 exists (s3 >= 0 always here)
+        const bool v0 = s_row + n >= 0;                   // token n exists
+        if (v3 && act) {
+          const int m = tok_mem(g, s3);
+          VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + c0, xw[3]);
+          VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dw[3]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) xw[3][v] = dw[3][v] = 0.f;
+        }
+        const int r3 = (n + 3 >= g.cols) ? 2 : 1;         // row of token n+3 relative to i-1
+        const int r0 = (n < 0) ? 0 : 1;                   // row of token n
+        const bool own3 = n + 3 < g.cols;                 // token n+3 belongs to this row (n+3 >= 0 always)
+        const bool own0 = n >= 0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float pf = cp.bf[v], pb = cp.bb[v];
+#pragma unroll
+          for (int k = 0; k < CW; ++k) {
+            pf = fmaf(cp.wf[v][k], xw[k][v], pf);         // pre_f[n+3] = b + sum_k w[k] x[n+k]
+            pb = fmaf(cp.wb[v][k], xw[3 - k][v], pb);     // pre_b[n]   = b + sum_k w[k] x[n+3-k]
+          }
+          const float sgf = fv_sigmoid(pf), sgb = fv_sigmoid(pb);
+          const float dsf = sgf * (1.f + pf * (1.f - sgf)), dsb = sgb * (1.f + pb * (1.f - sgb));
+          const float cf = r3 == 2 ? dcf[2][v] : dcf[1][v];
+          const float cb = r0 == 0 ? dcb[0][v] : dcb[1][v];
+          const float nf = v3 ? (Dfh[v] * dw[3][v] + cf) * dsf : 0.f;
+          const float nb = v0 ? (Dbh[v] * dw[0][v] + cb) * dsb : 0.f;
+          dpf[3][v] = nf;
+          dpb[3][v] = nb;
+          if (own3) {
+#pragma unroll
+            for (int k = 0; k < CW; ++k) a_wf[v][k] = fmaf(nf, xw[k][v], a_wf[v][k]);
+            a_bf[v] += nf;
+            a_Df[v] = fmaf(0.5f * dw[3][v], pf * sgf, a_Df[v]);
+          }
+          if (own0) {
+#pragma unroll
+            for (int k = 0; k < CW; ++k) a_wb[v][k] = fmaf(nb, xw[3 - k][v], a_wb[v][k]);
+            a_bb[v] += nb;
+            a_Db[v] = fmaf(0.5f * dw[0][v], pb * sgb, a_Db[v]);
+          }
+        }
+        if (own0) {
           float dx[VEC];
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
             float acc = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < CW; ++kk) {
-              acc = fmaf(cp.wf[v][kk], dpf[k + 3 - kk][v], acc);
-              acc = fmaf(cp.wb[v][kk], dpb[k - 3 + kk][v], acc);
-              a_wf[v][kk] = fmaf(dpf[k][v], x[k - 3 + kk][v], a_wf[v][kk]);
-              a_wb[v][kk] = fmaf(dpb[k][v], x[k + 3 - kk][v], a_wb[v][kk]);
+            for (int k = 0; k < CW; ++k) {
+              acc = fmaf(cp.wf[v][k], dpf[3 - k][v], acc);   // dpre_f[n+3-k]
+              acc = fmaf(cp.wb[v][k], dpb[k][v], acc);       // dpre_b[n-3+k]
             }
-            a_bf[v] += dpf[k][v];
-            a_bb[v] += dpb[k][v];
             dx[v] = acc;
           }
-          if (act) VecIO<T, VEC>::store(dxz_b + (size_t)tok_mem(g, i * g.cols + j0 + jj) * 2 * p.d_in + c0, dx);
+          if (act) VecIO<T, VEC>::store(dxz_b + (size_t)tok_mem(g, s_row + n) * 2 * p.d_in + c0, dx);
         }
       }
     }
   }
-  if (act) {
-    float* dst = p.part + ((size_t)blockIdx.x * p.d_in + c0) * 10;
+  // one partial row per block: [d w (d_in*4) | d w_b (d_in*4) | d b | d b_b | dD | dD_b]
+  const int D = p.d_in;
+  for (int r = 0; r < RG; ++r) {
+    __syncthreads();
+    if (r == rg && act) {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
+      for (int v = 0; v < VEC; ++v) {
+        const int c = c0 + v;
 #pragma unroll
-      for (int k = 0; k < CW; ++k) {
-        dst[v * 10 + k] = a_wf[v][k];
-        dst[v * 10 + 4 + k] = a_wb[v][k];
+        for (int k = 0; k < CW; ++k) {
+          smem[c * 4 + k] = (r == 0 ? 0.f : smem[c * 4 + k]) + a_wf[v][k];
+          smem[4 * D + c * 4 + k] = (r == 0 ? 0.f : smem[4 * D + c * 4 + k]) + a_wb[v][k];
+        }
+        smem[8 * D + c] = (r == 0 ? 0.f : smem[8 * D + c]) + a_bf[v];
+        smem[9 * D + c] = (r == 0 ? 0.f : smem[9 * D + c]) + a_bb[v];
+        smem[10 * D + c] = (r == 0 ? 0.f : smem[10 * D + c]) + a_Df[v];
+        smem[11 * D + c] = (r == 0 ? 0.f : smem[11 * D + c]) + a_Db[v];
       }
-      dst[v * 10 + 8] = a_bf[v];
-      dst[v * 10 + 9] = a_bb[v];
     }
   }
+  __syncthreads();
+  float* dst = p.part + (size_t)blockIdx.x * 12 * D;
+  for (int e = threadIdx.x; e < 12 * D; e += blockDim.x) dst[e] = smem[e];
 }
 
 // out[i] = sum_s in[s*n + i] in a fixed order.  Block = 32 outputs x 8 row-slices: slice q sums rows
@@ -320,27 +339,56 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+int rg_combine(int d_in, int VEC) { int nch = fv_cdiv(d_in, 64 * VEC); int r = 8 / nch; return r < 1 ? 1 : (r > RGMAX ? RGMAX : r); }
+int rg_convpool(int d_in, int VEC) { int nch = fv_cdiv(d_in, 64 * VEC); int r = (VEC == 1 ? 16 : 12) / nch; return r < 1 ? 1 : (r > RGMAX ? RGMAX : r); }
+int vec_combine(int d_in) { return (d_in % 384 == 0 && d_in <= 8 * 384) ? 6 : (d_in % 256 == 0 && d_in <= 8 * 256) ? 4 : 1; }
+int vec_convpool(int d_in) { return (d_in % 128 == 0 && d_in <= 12 * 128) ? 2 : 1; }
+int persistent_blocks(long nrows, int rg) {
+  long groups = (nrows + rg - 1) / rg;
+  long per = (groups + 511) / 512;
+  return (int)((groups + per - 1) / per);
+}
+
 template <typename T, int VEC>
-int launch_bwd_kernels(int which, const BwdParams& p, int nblocks, hipStream_t st) {
+int launch_combine_bwd(const BwdParams& p, hipStream_t st) {
   const int nch = fv_cdiv(p.d_in, 64 * VEC);
-  FV_CHECK(nch <= (VEC == 1 ? 16 : 8), "mixer: d_inner %d too large for the VEC=%d row-walker", p.d_in, VEC);
-  dim3 grid(nblocks), block(64 * nch);
-  const bool t7 = p.geo.cols % 7 == 0;
-  if (which == 0) {
-    if (t7) hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 7>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 8>), grid, block, 0, st, p);
+  FV_CHECK(nch <= (VEC == 1 ? 16 : 8), "mixer_combine_bwd: d_inner %d too large for the VEC=%d row walker", p.d_in, VEC);
+  const int rg = rg_combine(p.d_in, VEC);
+  dim3 grid(persistent_blocks((long)p.B * p.geo.rows, rg)), block(64 * nch * rg);
+  if (p.geo.cols % 2 == 0) {
+    size_t smem = (size_t)(RGMAX * 2 * 2 * 16 + 2 * p.d_in) * 4;
+    hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 2>), grid, block, smem, st, p, nch, rg);
   } else {
-    if (t7) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 7>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8>), grid, block, 0, st, p);
+    size_t smem = (size_t)(RGMAX * 2 * 1 * 16 + 2 * p.d_in) * 4;
+    hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 1>), grid, block, smem, st, p, nch, rg);
   }
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
 
+template <typename T, int VEC>
+int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
+  const int nch = fv_cdiv(p.d_in, 64 * VEC);
+  FV_CHECK(nch <= (VEC == 1 ? 16 : 12), "mixer_conv_pool_bwd: d_inner %d too large for the VEC=%d row walker", p.d_in, VEC);
+  const int rg = rg_convpool(p.d_in, VEC);
+  dim3 grid(persistent_blocks((long)p.B * p.geo.rows, rg)), block(64 * nch * rg);
+  size_t smem = (size_t)12 * p.d_in * 4;
+  FV_CHECK(smem <= 64 * 1024, "mixer_conv_pool_bwd: d_inner %d too large", p.d_in);
+  hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC>), grid, block, smem, st, p, nch, rg);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
 template <typename T>
-int dispatch_bwd(int which, const BwdParams& p, int nblocks, hipStream_t st) {
-  if (p.d_in % 128 == 0) return launch_bwd_kernels<T, 2>(which, p, nblocks, st);
-  return launch_bwd_kernels<T, 1>(which, p, nblocks, st);
+int dispatch_bwd(int which, const BwdParams& p, hipStream_t st) {
+  if (which == 0) {
+    const int v = vec_combine(p.d_in);
+    if (v == 6) return launch_combine_bwd<T, 6>(p, st);
+    if (v == 4) return launch_combine_bwd<T, 4>(p, st);
+    return launch_combine_bwd<T, 1>(p, st);
+  }
+  if (vec_convpool(p.d_in) == 2) return launch_conv_pool_bwd<T, 2>(p, st);
+  return launch_conv_pool_bwd<T, 1>(p, st);
 }
 
 int check_geo_b(int B, int rows, int cols, int s_i, int s_j, int d_in, int dtype) {
@@ -353,35 +401,28 @@ int check_geo_b(int B, int rows, int cols, int s_i, int s_j, int d_in, int dtype
 
 }  // namespace
 
-extern "C" int fv_mixer_bwd_blocks(int batch, int rows) {
-  // balanced persistent grid: every block walks the same number of rows (+-1)
-  long n = (long)batch * rows;
-  long per = (n + 511) / 512;
-  return (int)((n + per - 1) / per);
+extern "C" int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int which) {
+  const long n = (long)batch * rows;
+  return which == 0 ? persistent_blocks(n, rg_combine(d_inner, vec_combine(d_inner)))
+                    : persistent_blocks(n, rg_convpool(d_inner, vec_convpool(d_inner)));
 }
 
-extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const float* yc, const float* conv_w,
-                                    const float* conv_b, const float* conv_w_b, const float* conv_b_b,
-                                    const float* D, const float* D_b, const float* ln_w, const float* ln_b,
-                                    const float* mean, const float* rstd, void* dxz, void* d_o, float* dyc,
+extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* xhat, const float* ln_w,
+                                    const float* ln_b, const float* rstd, void* dxz, void* d_o, float* dyc,
                                     float* partials, int batch, int rows, int cols, int tok_stride_row,
-                                    int tok_stride_col, int d_inner, int d_conv, int dtype, fv_stream_t stream) {
+                                    int tok_stride_col, int d_inner, int dtype, fv_stream_t stream) {
   int rc = check_geo_b(batch, rows, cols, tok_stride_row, tok_stride_col, d_inner, dtype);
   if (rc) return rc;
-  FV_CHECK(d_conv == CW, "mixer: only d_conv == %d is built (got %d)", CW, d_conv);
-  FV_CHECK(dg && xz && yc && conv_w && conv_w_b && D && D_b && dxz && d_o && dyc && partials,
-           "mixer_combine_bwd: null pointer");
-  FV_CHECK(!ln_w || (ln_b && mean && rstd), "mixer_combine_bwd: LayerNorm needs weight, bias, mean, rstd");
+  FV_CHECK(dg && xz && xhat && dxz && d_o && dyc && partials, "mixer_combine_bwd: null pointer");
+  FV_CHECK(!ln_w || (ln_b && rstd), "mixer_combine_bwd: LayerNorm needs weight, bias, rstd");
   BwdParams p{};
-  p.dg = dg; p.xz = xz; p.yc = yc; p.wf = conv_w; p.bf = conv_b; p.wb = conv_w_b; p.bb = conv_b_b;
-  p.Df = D; p.Db = D_b; p.lnw = ln_w; p.lnb = ln_b; p.mean = mean; p.rstd = rstd;
+  p.dg = dg; p.xz = xz; p.xhat = xhat; p.lnw = ln_w; p.lnb = ln_b; p.rstd = rstd;
   p.dxz = dxz; p.dob = d_o; p.dyc = dyc; p.part = partials;
   p.use_norm = ln_w != nullptr;
   p.geo = {rows, cols, rows * cols, tok_stride_row, tok_stride_col};
   p.B = batch; p.d_in = d_inner;
-  const int nb = fv_mixer_bwd_blocks(batch, rows);
-  return dtype == FV_F32 ? dispatch_bwd<float>(0, p, nb, (hipStream_t)stream)
-                         : dispatch_bwd<bf16_t>(0, p, nb, (hipStream_t)stream);
+  return dtype == FV_F32 ? dispatch_bwd<float>(0, p, (hipStream_t)stream)
+                         : dispatch_bwd<bf16_t>(0, p, (hipStream_t)stream);
 }
 
 extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, const float* conv_w,
@@ -405,9 +446,8 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
   p.geo = {rows, cols, rows * cols, tok_stride_row, tok_stride_col};
   p.B = batch; p.d_in = d_inner;
   p.pool_scale = scaling_factor / (float)cols;
-  const int nb = fv_mixer_bwd_blocks(batch, rows);
-  return dtype == FV_F32 ? dispatch_bwd<float>(1, p, nb, (hipStream_t)stream)
-                         : dispatch_bwd<bf16_t>(1, p, nb, (hipStream_t)stream);
+  return dtype == FV_F32 ? dispatch_bwd<float>(1, p, (hipStream_t)stream)
+                         : dispatch_bwd<bf16_t>(1, p, (hipStream_t)stream);
 }
 
 extern "C" int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n,

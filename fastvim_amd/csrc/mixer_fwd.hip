@@ -23,6 +23,7 @@ struct FwdParams {
   const float* yc;                      // (2, B, rows, d_in) scan output
   const float *Df, *Db, *lnw, *lnb;     // (d_in)
   void* g;                              // (B, L, d_in) gated LayerNorm output
+  void* xhat;                           // (B, L, d_in) normalised pre-gate value, saved for backward
   float *mean, *rstd;                   // (B*L) LayerNorm statistics (saved for backward)
   Geo geo;
   int B, d_in;
@@ -188,12 +189,15 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
       if (j0 + jj < g.cols) {
         int m = tok_mem(g, i * g.cols + j0 + jj);
         if (act) {
-          float z[VEC], out[VEC];
+          float z[VEC], out[VEC], xh[VEC];
           VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + p.d_in + c0, z);
 #pragma unroll
-          for (int v = 0; v < VEC; ++v)
-            out[v] = ((o[jj][v] - mean[jj]) * rstd[jj] * lw[v] + lb[v]) * fv_silu(z[v]);
+          for (int v = 0; v < VEC; ++v) {
+            xh[v] = (o[jj][v] - mean[jj]) * rstd[jj];
+            out[v] = (xh[v] * lw[v] + lb[v]) * fv_silu(z[v]);
+          }
           VecIO<T, VEC>::store(g_b + (size_t)m * p.d_in + c0, out);
+          if (p.xhat) VecIO<T, VEC>::store((T*)p.xhat + ((size_t)b * g.L + m) * p.d_in + c0, xh);
         }
         if (p.use_norm && threadIdx.x == 0) {
           p.mean[(size_t)b * g.L + m] = mean[jj];
@@ -259,9 +263,9 @@ extern "C" int fv_mixer_conv_pool_fwd(const void* xz, const float* conv_w, const
 extern "C" int fv_mixer_combine_fwd(const void* xz, const float* yc, const float* conv_w, const float* conv_b,
                                     const float* conv_w_b, const float* conv_b_b, const float* D,
                                     const float* D_b, const float* ln_w, const float* ln_b, float ln_eps,
-                                    void* g, float* mean, float* rstd, int batch, int rows, int cols,
-                                    int tok_stride_row, int tok_stride_col, int d_inner, int d_conv, int dtype,
-                                    fv_stream_t stream) {
+                                    void* g, void* xhat, float* mean, float* rstd, int batch, int rows,
+                                    int cols, int tok_stride_row, int tok_stride_col, int d_inner, int d_conv,
+                                    int dtype, fv_stream_t stream) {
   int rc = check_geo(batch, rows, cols, tok_stride_row, tok_stride_col, d_inner, dtype);
   if (rc) return rc;
   FV_CHECK(d_conv == CW, "mixer: only d_conv == %d is built (got %d)", CW, d_conv);
@@ -269,7 +273,7 @@ extern "C" int fv_mixer_combine_fwd(const void* xz, const float* yc, const float
   FV_CHECK(!ln_w || (ln_b && mean && rstd), "mixer_combine_fwd: LayerNorm needs weight, bias, mean, rstd");
   FwdParams p{};
   p.xz = xz; p.yc = yc; p.wf = conv_w; p.bf = conv_b; p.wb = conv_w_b; p.bb = conv_b_b;
-  p.Df = D; p.Db = D_b; p.lnw = ln_w; p.lnb = ln_b; p.eps = ln_eps; p.g = g; p.mean = mean; p.rstd = rstd;
+  p.Df = D; p.Db = D_b; p.lnw = ln_w; p.lnb = ln_b; p.eps = ln_eps; p.g = g; p.xhat = xhat; p.mean = mean; p.rstd = rstd;
   p.use_norm = ln_w != nullptr;
   p.geo = {rows, cols, rows * cols, tok_stride_row, tok_stride_col};
   p.B = batch; p.d_in = d_inner;

@@ -60,11 +60,11 @@ class FastVimMixerFn(torch.autograd.Function):
             Wx2 = torch.stack([Wx, Wx_b])                                               # (2, R+2N, d_in) fp32
             x_dbl = torch.bmm(xc.view(2, B * rows, d_in), Wx2.to(cdt).transpose(1, 2))  # (2, B*Lc, R+2N)
             yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
-            g, mean, rstd = M.combine_fwd(xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, ln_eps,
-                                          rows, cols, transposed)
+            g, xhat, mean, rstd = M.combine_fwd(xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, ln_eps,
+                                                rows, cols, transposed)
             out = F.linear(g, W_out_c, None if b_out is None else b_out.to(cdt))
         ctx.save_for_backward(h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b,
-                              ln_w, ln_b, W_out, xz, xc, x_dbl, yc, g, mean, rstd)
+                              ln_w, ln_b, W_out, xz, xc, x_dbl, g, xhat, rstd)
         ctx.geo = (rows, cols, transposed, pool_max, scaling)
         ctx.has_bias = (b_in is not None, b_out is not None)
         ctx.cdt = cdt
@@ -74,7 +74,7 @@ class FastVimMixerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b, ln_w, ln_b, W_out,
-         xz, xc, x_dbl, yc, g, mean, rstd) = ctx.saved_tensors
+         xz, xc, x_dbl, g, xhat, rstd) = ctx.saved_tensors
         rows, cols, transposed, pool_max, scaling = ctx.geo
         cdt = ctx.cdt
         B, Ltok, d = h_c.shape
@@ -87,8 +87,7 @@ class FastVimMixerFn(torch.autograd.Function):
             db_out = do2.float().sum(0) if ctx.has_bias[1] else None
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
-            d_o, dyc, p1 = M.combine_bwd(dg, xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, mean, rstd, dxz,
-                                         rows, cols, transposed)
+            d_o, dyc, p1 = M.combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed)
             dxc, dx_dbl, dA2, dWdt2, dbdt2 = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc)
             # x_proj adjoint (selective_scan_interface.py:726-734), both directions batched, fp32
             xc2 = xc.view(2, B * rows, d_in)
@@ -101,11 +100,13 @@ class FastVimMixerFn(torch.autograd.Function):
             dW_in = _wgrad(dxz2, h_c.view(B * Ltok, d))
             db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
         has_ln = ln_w is not None
+        n4 = 4 * d_in
         return (dhidden, dW_in, db_in,
-                p2[:, 0:4].reshape(cw.shape), p2[:, 8] if cb is not None else None,
-                p2[:, 4:8].reshape(cw_b.shape), p2[:, 9] if cb_b is not None else None,
+                p2[0:n4].view(cw.shape), p2[2 * n4:2 * n4 + d_in] if cb is not None else None,
+                p2[n4:2 * n4].view(cw_b.shape), p2[2 * n4 + d_in:2 * n4 + 2 * d_in] if cb_b is not None else None,
                 dWx2[0], dWx2[1], dWdt2[0], dbdt2[0], dWdt2[1], dbdt2[1], dA2[0], dA2[1],
-                p1[:, 2], p1[:, 3], p1[:, 0] if has_ln else None, p1[:, 1] if has_ln else None,
+                p2[2 * n4 + 2 * d_in:2 * n4 + 3 * d_in], p2[2 * n4 + 3 * d_in:2 * n4 + 4 * d_in],
+                p1[0] if has_ln else None, p1[1] if has_ln else None,
                 dW_out, db_out, None, None, None, None, None, None, None)
 
 

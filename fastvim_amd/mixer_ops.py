@@ -40,11 +40,13 @@ def scan_fwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
     return yc
 
 
-def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, eps, rows, cols, transposed):
+def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, eps, rows, cols, transposed,
+                save_xhat=True):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     g = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype)
+    xhat = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype) if save_xhat else None
     if ln_w is not None:
         mean = torch.empty(B * Ltok, device=xz.device, dtype=torch.float32)
         rstd = torch.empty(B * Ltok, device=xz.device, dtype=torch.float32)
@@ -52,11 +54,11 @@ def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, 
         mean = rstd = None
     rc = L.lib().fv_mixer_combine_fwd(
         L.ptr(xz), L.ptr(yc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(D),
-        L.ptr(D_b), L.ptr(ln_w), L.ptr(ln_b), f32(eps), L.ptr(g), L.ptr(mean), L.ptr(rstd), L.i32(B),
+        L.ptr(D_b), L.ptr(ln_w), L.ptr(ln_b), f32(eps), L.ptr(g), L.ptr(xhat), L.ptr(mean), L.ptr(rstd), L.i32(B),
         L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in), L.i32(conv_w.shape[-1]),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_combine_fwd")
-    return g, mean, rstd
+    return g, xhat, mean, rstd
 
 
 def reduce_partials(part, n_partials):
@@ -69,23 +71,21 @@ def reduce_partials(part, n_partials):
     return out
 
 
-def combine_bwd(dg, xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, mean, rstd, dxz,
-                rows, cols, transposed):
+def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     lib = L.lib()
-    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows))
+    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows), L.i32(d_in), L.i32(0))
     d_o = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype)
     dyc = torch.empty(B, rows, d_in, device=xz.device, dtype=torch.float32)
-    part = torch.empty(nb, d_in, 4, device=xz.device, dtype=torch.float32)
+    part = torch.empty(nb, 2, d_in, device=xz.device, dtype=torch.float32)
     rc = lib.fv_mixer_combine_bwd(
-        L.ptr(dg), L.ptr(xz), L.ptr(yc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
-        L.ptr(D), L.ptr(D_b), L.ptr(ln_w), L.ptr(ln_b), L.ptr(mean), L.ptr(rstd), L.ptr(dxz), L.ptr(d_o),
+        L.ptr(dg), L.ptr(xz), L.ptr(xhat), L.ptr(ln_w), L.ptr(ln_b), L.ptr(rstd), L.ptr(dxz), L.ptr(d_o),
         L.ptr(dyc), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in),
-        L.i32(conv_w.shape[-1]), L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
+        L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_combine_bwd")
-    return d_o, dyc, reduce_partials(part, nb)      # (d_in, 4): [dln_w, dln_b, dD, dD_b]
+    return d_o, dyc, reduce_partials(part, nb)      # (2, d_in): [dln_w, dln_b]
 
 
 def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc):
@@ -116,12 +116,13 @@ def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz,
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     lib = L.lib()
-    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows))
-    part = torch.empty(nb, d_in, 10, device=xz.device, dtype=torch.float32)
+    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows), L.i32(d_in), L.i32(1))
+    part = torch.empty(nb, 12 * d_in, device=xz.device, dtype=torch.float32)
     rc = lib.fv_mixer_conv_pool_bwd(
         L.ptr(xz), L.ptr(d_o), L.ptr(dxc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
         L.ptr(D), L.ptr(D_b), L.ptr(dxz), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i),
         L.i32(s_j), L.i32(d_in), L.i32(conv_w.shape[-1]), L.i32(pool_max), f32(scaling),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_conv_pool_bwd")
-    return reduce_partials(part, nb)                # (d_in, 10): [dw(4), dw_b(4), db, db_b]
+    # segments: [dw (d_in*4) | dw_b (d_in*4) | db | db_b | dD | dD_b]
+    return reduce_partials(part, nb)

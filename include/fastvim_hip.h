@@ -98,28 +98,27 @@ int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, cons
                       int d_state, int dtype, fv_stream_t stream);
 
 /* g = LayerNorm(((yc_f + D*conv_f(x)) + (yc_b + D_b*conv_b(x))) / 2) * silu(z); ln_w == NULL
- * skips the norm (use_norm_after_ssm=False).  mean/rstd (batch*L) fp32 are saved for backward. */
+ * skips the norm (use_norm_after_ssm=False).  Saved for backward: xhat (batch, L, d_inner), the
+ * normalised pre-gate value (nullable when no backward is needed), and mean/rstd (batch*L) fp32. */
 int fv_mixer_combine_fwd(const void* xz, const float* yc, const float* conv_w, const float* conv_b,
                          const float* conv_w_b, const float* conv_b_b, const float* D, const float* D_b,
-                         const float* ln_w, const float* ln_b, float ln_eps, void* g, float* mean,
-                         float* rstd, int batch, int rows, int cols, int tok_stride_row,
+                         const float* ln_w, const float* ln_b, float ln_eps, void* g, void* xhat,
+                         float* mean, float* rstd, int batch, int rows, int cols, int tok_stride_row,
                          int tok_stride_col, int d_inner, int d_conv, int dtype, fv_stream_t stream);
 
 /* ---- backward of the fused mixer middle --------------------------------------------
- * Number of persistent blocks the two row-walking backward kernels launch; their `partials`
- * buffers are (fv_mixer_bwd_blocks, d_inner, 4) and (fv_mixer_bwd_blocks, d_inner, 10) fp32. */
-int fv_mixer_bwd_blocks(int batch, int rows);
+ * Number of persistent blocks a row-walking backward kernel launches (which = 0: combine_bwd,
+ * 1: conv_pool_bwd); their `partials` buffers are (blocks, 2*d_inner) and (blocks, 12*d_inner) fp32. */
+int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int which);
 
-/* Adjoint of fv_mixer_combine_fwd.  dg: gradient wrt g.  Writes dz into the z half of dxz
- * (batch, L, 2*d_inner), d_o (batch, L, d_inner) = gradient wrt the averaged pre-norm value,
- * dyc (batch, rows, d_inner) fp32 = 0.5 * sum_j d_o (gradient wrt BOTH directions' scan
- * outputs), and per-block partials [d ln_w | d ln_b | dD | dD_b] per channel. */
-int fv_mixer_combine_bwd(const void* dg, const void* xz, const float* yc, const float* conv_w,
-                         const float* conv_b, const float* conv_w_b, const float* conv_b_b, const float* D,
-                         const float* D_b, const float* ln_w, const float* ln_b, const float* mean,
-                         const float* rstd, void* dxz, void* d_o, float* dyc, float* partials, int batch,
-                         int rows, int cols, int tok_stride_row, int tok_stride_col, int d_inner, int d_conv,
-                         int dtype, fv_stream_t stream);
+/* Adjoint of the LayerNorm + gate of fv_mixer_combine_fwd, from the saved xhat.  dg: gradient wrt g.
+ * Writes dz into the z half of dxz (batch, L, 2*d_inner), d_o (batch, L, d_inner) = gradient wrt the
+ * averaged pre-norm value, dyc (batch, rows, d_inner) fp32 = 0.5 * sum_j d_o (gradient wrt BOTH
+ * directions' scan outputs), and per-block partials [d ln_w (d_inner) | d ln_b (d_inner)]. */
+int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* xhat, const float* ln_w,
+                         const float* ln_b, const float* rstd, void* dxz, void* d_o, float* dyc,
+                         float* partials, int batch, int rows, int cols, int tok_stride_row,
+                         int tok_stride_col, int d_inner, int dtype, fv_stream_t stream);
 
 /* Adjoint of fv_mixer_scan_fwd with the dt_proj adjoint fused in (replaces
  * selective_scan_cuda.bwd + the einsums of selective_scan_interface.py:698-723).
@@ -139,7 +138,8 @@ int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, cons
 
 /* Adjoint of fv_mixer_conv_pool_fwd plus the D-skip path: consumes d_o and the total gradient
  * wrt the pooled conv output dxc (2, batch, rows, d_inner) fp32; writes dx into the x half of
- * dxz and per-block partials [d conv_w (4) | d conv_w_b (4) | d conv_b | d conv_b_b] per channel. */
+ * dxz and per-block partials [d conv_w (d_inner*4) | d conv_w_b (d_inner*4) | d conv_b | d conv_b_b |
+ * dD | dD_b] (12*d_inner floats). */
 int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, const float* conv_w,
                            const float* conv_b, const float* conv_w_b, const float* conv_b_b, const float* D,
                            const float* D_b, void* dxz, float* partials, int batch, int rows, int cols,

@@ -31,7 +31,7 @@ def run(case, transposed=False, dtype=torch.float32):
     Wx = torch.stack([p["x_proj.weight"], p["x_proj_b.weight"]]).to(dtype)
     x_dbl = torch.bmm(xc.reshape(2, Bsz * rows, d_in), Wx.transpose(1, 2)).contiguous()
     yc = M.scan_fwd(xc, x_dbl, p["dt_proj.weight"], p["dt_proj.bias"], p["A_log"], p["dt_proj_b.weight"], p["dt_proj_b.bias"], p["A_b_log"])
-    g, mean, rstd = M.combine_fwd(xz, yc, cw, p["conv1d.bias"], cwb, p["conv1d_b.bias"], p["D"], p["D_b"],
+    g, _xh, mean, rstd = M.combine_fwd(xz, yc, cw, p["conv1d.bias"], cwb, p["conv1d_b.bias"], p["D"], p["D_b"],
                                   p["layernorm.weight"], p["layernorm.bias"], 1e-5, rows, cols, transposed)
     y = g @ p["out_proj.weight"].to(dtype).t()
     err = (y.float().cpu() - ref).abs().max().item()
