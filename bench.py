@@ -221,7 +221,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
-    from fastvim_amd.ddp import FlatGradAllReduce
+    from fastvim_amd.flat import FlatTrainingState
 
     torch.manual_seed(1234)                    # identical init on every rank (DDP broadcast equivalent)
     drop_path = {"T": 0.05, "S": 0.15, "B": 0.4}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
@@ -229,13 +229,13 @@ def main():
     gen = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(args.batch, 3, args.img, args.img, generator=gen).to(dev)
     tgt = soft_targets(args.batch, 1000, gen, dev)
-    flat = FlatGradAllReduce(model.parameters())
+    flat = FlatTrainingState(model)      # flat fp32 params / grads + bf16 shadow weights
     opt = torch.optim.AdamW(param_groups(model, 0.05), lr=1e-3, betas=(0.9, 0.999), fused=True, capturable=True)
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(5678 + rank)             # per-rank DropPath streams
 
     def fwd_bwd():
-        flat.zero_()
+        flat.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
             logits = model(x)
         loss = torch.sum(-tgt * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()   # SoftTargetCrossEntropy
@@ -251,6 +251,7 @@ def main():
                 fwd_bwd()
                 if world == 1:
                     opt.step()
+                    flat.refresh_shadow()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -258,18 +259,21 @@ def main():
             loss_buf = fwd_bwd()
             if world == 1:
                 opt.step()
+                flat.refresh_shadow()
 
         def step():
             graph.replay()
             if world > 1:
                 flat.allreduce_mean_()
                 opt.step()
+                flat.refresh_shadow()
             return loss_buf
     else:
         def step():
             l = fwd_bwd()
             flat.allreduce_mean_()
             opt.step()
+            flat.refresh_shadow()
             return l
 
     for _ in range(args.warmup):

@@ -450,12 +450,12 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
                          : dispatch_bwd<bf16_t>(1, p, (hipStream_t)stream);
 }
 
-extern "C" int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n,
+extern "C" int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n, int accumulate,
                                   fv_stream_t stream) {
   FV_CHECK(partials && out && n_partials > 0, "reduce_partials: bad arguments");
   if (n == 0) return FV_OK;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(fv_cdiv((long)n, 32)), dim3(256), 0, (hipStream_t)stream,
-                     partials, out, n_partials, n, 0);
+                     partials, out, n_partials, n, accumulate);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

@@ -35,7 +35,7 @@ struct ScanClParams {
   float* dxc;            // (2, B, Lc, d_in)   bwd out: gradient wrt u
   float* dxdbl;          // (nchunks, 2, B*Lc, R+2N) bwd out: per-chunk partial gradient wrt x_dbl
   float* ckpt;           // (2, B, nseg, d_in, N)
-  float* pP;             // (B, 2, d_in, N+R+1) per-batch partials [dA_log | d dt_w | d dt_bias]
+  float* pP;             // (B, 2, d_in*(N+R+1)) per-batch partials, per direction [dA_log | d dt_w | d dt_bias]
   int B, Lc, d_in, R;
 };
 
@@ -309,14 +309,15 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
     __syncthreads();
   }
   if (ln.act) {
-    const int PW = N + p.R + 1;
-    float* dst = p.pP + (((size_t)ln.b * 2 + ln.dir) * p.d_in + ln.d) * PW;
+    // per-batch partial row, segment layout per direction: [dA_log (d_in*N) | d dt_w (d_in*R) | d dt_bias (d_in)]
+    const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
+    float* base = p.pP + ((size_t)ln.b * 2 + ln.dir) * per_dir;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dst[ln.q * 4 + j] = dA[j] * ln.Araw[j];     // dA_log = dA * A
+    for (int j = 0; j < 4; ++j) base[(size_t)ln.d * N + ln.q * 4 + j] = dA[j] * ln.Araw[j];   // dA_log = dA * A
 #pragma unroll
     for (int i = 0; i < RQ; ++i)
-      if (ln.q + 4 * i < p.R) dst[N + ln.q + 4 * i] = dW[i];
-    if (ln.q == 0) dst[N + p.R] = dbias;                                     // identical in all 4 lanes
+      if (ln.q + 4 * i < p.R) base[(size_t)p.d_in * N + (size_t)ln.d * p.R + ln.q + 4 * i] = dW[i];
+    if (ln.q == 0) base[(size_t)p.d_in * (N + p.R) + ln.d] = dbias;                           // identical in all 4 lanes
   }
 }
 

@@ -29,6 +29,7 @@ class LayerNormFn(torch.autograd.Function):
             if residual.shape != x_shape_og:
                 raise RuntimeError("layer_norm_fn: residual must have x's shape")
             res2 = residual.reshape(-1, N).contiguous()
+        w_param = weight
         weight = weight.float().contiguous()
         bias = bias.float().contiguous() if bias is not None else None
         res_dtype = residual.dtype if residual is not None else (torch.float32 if residual_in_fp32 else x.dtype)
@@ -59,6 +60,8 @@ class LayerNormFn(torch.autograd.Function):
         ctx.res_in_dtype = residual.dtype if residual is not None else None
         ctx.rows_per_scale = rows_per_scale
         ctx.x_needs_grad = x.requires_grad
+        ctx.w_direct = (w_param.grad if (getattr(w_param, "_fv_direct", False) and w_param.grad is not None
+                                         and w_param.grad.is_contiguous() and w_param.dtype == torch.float32) else None)
         y = y.reshape(x_shape_og)
         return y if not prenorm else (y, res_out.reshape(x_shape_og))
 
@@ -84,7 +87,11 @@ class LayerNormFn(torch.autograd.Function):
             L.i32(L.dtype_code(dx.dtype)), L.ptr(dres_in), L.i32(L.dtype_code(dres_in.dtype) if dres_in is not None else 0),
             L.ptr(pw), L.ptr(pb), L.i32(M), L.i32(N), L.i32(ctx.is_rms_norm), L.stream_of(r))
         L.check(rc, "add_norm_bwd")
-        dw = reduce_partials(pw, nb)
+        if ctx.w_direct is not None:
+            reduce_partials(pw, nb, out=ctx.w_direct.view(-1), accumulate=True)
+            dw = None
+        else:
+            dw = reduce_partials(pw, nb)
         db = reduce_partials(pb, nb) if pb is not None else None
         return (dx.reshape(ctx.x_shape_og), dw, db,
                 dres_in.reshape(ctx.x_shape_og) if ctx.has_residual else None,

@@ -18,17 +18,38 @@ from . import _lib as L
 from . import mixer_ops as M
 
 
-def _wgrad(X, Y, splits=16):
+def _shadow(w, cdt):
+    """bf16 shadow copy kept by FlatTrainingState, else a cast."""
+    sh = getattr(w, "_fv_shadow", None)
+    if sh is not None and sh.dtype == cdt:
+        return sh
+    return w.to(cdt)
+
+
+def _direct_grad(w):
+    """The preallocated .grad view my kernels may accumulate into (flat training state), or None."""
+    g = w.grad
+    if getattr(w, "_fv_direct", False) and g is not None and g.is_contiguous() and g.dtype == torch.float32:
+        return g
+    return None
+
+
+def _wgrad(X, Y, W=None, splits=16):
     """dW (I, J) fp32 = X^T Y for X (M, I), Y (M, J) with M >> I, J: the reduction dim is split into
     `splits` batched GEMMs (enough workgroups to fill 256 CUs) whose fp32 partials are summed in a
-    fixed order by fv_reduce_partials -- a deterministic split-K."""
+    fixed order by fv_reduce_partials -- a deterministic split-K.  If the weight ``W`` owns a
+    preallocated flat gradient, the sum is accumulated straight into it and None is returned."""
     M_, I = X.shape
     J = Y.shape[1]
     while splits > 1 and M_ % splits:
         splits //= 2
-    if splits == 1:
-        return (X.t() @ Y).float()
-    part = torch.bmm(X.view(splits, M_ // splits, I).transpose(1, 2), Y.view(splits, M_ // splits, J)).float()
+    part = torch.bmm(X.view(splits, M_ // splits, I).transpose(1, 2), Y.view(splits, M_ // splits, J),
+                     out_dtype=torch.float32) if X.dtype != torch.float32 else \
+        torch.bmm(X.view(splits, M_ // splits, I).transpose(1, 2), Y.view(splits, M_ // splits, J))
+    g = _direct_grad(W) if W is not None else None
+    if g is not None:
+        M.reduce_partials(part, splits, out=g.view(-1), accumulate=True)
+        return None
     return M.reduce_partials(part, splits)
 
 
@@ -45,7 +66,7 @@ class FastVimMixerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden, W_in, b_in, cw, cb, cw_b, cb_b, Wx, Wx_b, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log,
-                D, D_b, ln_w, ln_b, W_out, b_out, rows, cols, transposed, pool_max, scaling, ln_eps, cdt):
+                D, D_b, ln_w, ln_b, W_out, b_out, rows, cols, transposed, pool_max, scaling, ln_eps, cdt, fv):
         L.require_gpu(hidden)
         B, Ltok, d = hidden.shape
         if Ltok != rows * cols:
@@ -53,12 +74,17 @@ class FastVimMixerFn(torch.autograd.Function):
         d_in = W_in.shape[0] // 2
         with torch.autocast("cuda", enabled=False):
             h_c = hidden.to(cdt).contiguous()
-            W_in_c, W_out_c = W_in.to(cdt), W_out.to(cdt)
+            W_in_c, W_out_c = _shadow(W_in, cdt), _shadow(W_out, cdt)
             xz = F.linear(h_c, W_in_c, None if b_in is None else b_in.to(cdt))          # (B, L, 2 d_in)
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             xc = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling)
-            Wx2 = torch.stack([Wx, Wx_b])                                               # (2, R+2N, d_in) fp32
-            x_dbl = torch.bmm(xc.view(2, B * rows, d_in), Wx2.to(cdt).transpose(1, 2))  # (2, B*Lc, R+2N)
+            if fv is not None and "Wx2" in fv:          # x_proj / x_proj_b adjacent in the flat buffers
+                Wx2 = fv["Wx2"]
+                Wx2_c = fv["Wx2_shadow"] if fv["Wx2_shadow"].dtype == cdt else Wx2.to(cdt)
+            else:
+                Wx2 = torch.stack([Wx, Wx_b])                                           # (2, R+2N, d_in) fp32
+                Wx2_c = Wx2.to(cdt)
+            x_dbl = torch.bmm(xc.view(2, B * rows, d_in), Wx2_c.transpose(1, 2))        # (2, B*Lc, R+2N)
             yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
             g, xhat, mean, rstd = M.combine_fwd(xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, ln_eps,
                                                 rows, cols, transposed)
@@ -69,6 +95,7 @@ class FastVimMixerFn(torch.autograd.Function):
         ctx.has_bias = (b_in is not None, b_out is not None)
         ctx.cdt = cdt
         ctx.in_dtype = hidden.dtype
+        ctx.fv = fv
         return out
 
     @staticmethod
@@ -79,35 +106,54 @@ class FastVimMixerFn(torch.autograd.Function):
         cdt = ctx.cdt
         B, Ltok, d = h_c.shape
         d_in = W_in.shape[0] // 2
+        fv = ctx.fv or {}
         with torch.autocast("cuda", enabled=False):
             dout = dout.to(cdt).contiguous()
             do2 = dout.view(B * Ltok, d)
-            dg = do2 @ W_out.to(cdt)                                                     # (B*L, d_in)
-            dW_out = _wgrad(do2, g.view(B * Ltok, d_in))
+            dg = do2 @ _shadow(W_out, cdt)                                               # (B*L, d_in)
+            dW_out = _wgrad(do2, g.view(B * Ltok, d_in), W_out)
             db_out = do2.float().sum(0) if ctx.has_bias[1] else None
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
-            d_o, dyc, p1 = M.combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed)
-            dxc, dx_dbl, dA2, dWdt2, dbdt2 = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc)
+            d_o, dyc, p1 = M.combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed,
+                                         grad_out=fv.get("ln_grad") if ln_w is not None else None)
+            dxc, dx_dbl, ps = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
+                                         grad_out=fv.get("scan_grad"))
             # x_proj adjoint (selective_scan_interface.py:726-734), both directions batched, fp32
             xc2 = xc.view(2, B * rows, d_in)
-            dWx2 = torch.bmm(dx_dbl.transpose(1, 2), xc2.float())                        # (2, R+2N, d_in)
+            if "Wx2_grad" in fv:
+                fv["Wx2_grad"].baddbmm_(dx_dbl.transpose(1, 2), xc2.float())
+                dWx2 = (None, None)
+            else:
+                dWx2 = torch.bmm(dx_dbl.transpose(1, 2), xc2.float())                    # (2, R+2N, d_in)
             dxc = torch.baddbmm(dxc.view(2, B * rows, d_in), dx_dbl, Wx2)                # + dx_dbl @ Wx
             p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
-                                 pool_max, scaling)
+                                 pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
-            dhidden = (dxz2 @ W_in.to(cdt)).view(B, Ltok, d).to(ctx.in_dtype)
-            dW_in = _wgrad(dxz2, h_c.view(B * Ltok, d))
+            dhidden = (dxz2 @ _shadow(W_in, cdt)).view(B, Ltok, d).to(ctx.in_dtype)
+            dW_in = _wgrad(dxz2, h_c.view(B * Ltok, d), W_in)
             db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
         has_ln = ln_w is not None
         n4 = 4 * d_in
-        return (dhidden, dW_in, db_in,
-                p2[0:n4].view(cw.shape), p2[2 * n4:2 * n4 + d_in] if cb is not None else None,
-                p2[n4:2 * n4].view(cw_b.shape), p2[2 * n4 + d_in:2 * n4 + 2 * d_in] if cb_b is not None else None,
-                dWx2[0], dWx2[1], dWdt2[0], dbdt2[0], dWdt2[1], dbdt2[1], dA2[0], dA2[1],
-                p2[2 * n4 + 2 * d_in:2 * n4 + 3 * d_in], p2[2 * n4 + 3 * d_in:2 * n4 + 4 * d_in],
-                p1[0] if has_ln else None, p1[1] if has_ln else None,
-                dW_out, db_out, None, None, None, None, None, None, None)
+        N_, R_ = A_log.shape[1], Wdt.shape[1]
+        if p2 is None:
+            g_cw = g_cb = g_cwb = g_cbb = g_D = g_Db = None
+        else:
+            g_cw, g_cwb = p2[0:n4].view(cw.shape), p2[n4:2 * n4].view(cw_b.shape)
+            g_cb = p2[2 * n4:2 * n4 + d_in] if cb is not None else None
+            g_cbb = p2[2 * n4 + d_in:2 * n4 + 2 * d_in] if cb_b is not None else None
+            g_D, g_Db = p2[2 * n4 + 2 * d_in:2 * n4 + 3 * d_in], p2[2 * n4 + 3 * d_in:2 * n4 + 4 * d_in]
+        if ps is None:
+            g_A = g_Wdt = g_bdt = (None, None)
+        else:
+            g_A = [ps[k, :d_in * N_].view(d_in, N_) for k in range(2)]
+            g_Wdt = [ps[k, d_in * N_:d_in * (N_ + R_)].view(d_in, R_) for k in range(2)]
+            g_bdt = [ps[k, d_in * (N_ + R_):] for k in range(2)]
+        g_lw = p1[0] if (has_ln and p1 is not None) else None
+        g_lb = p1[1] if (has_ln and p1 is not None) else None
+        return (dhidden, dW_in, db_in, g_cw, g_cb, g_cwb, g_cbb,
+                dWx2[0], dWx2[1], g_Wdt[0], g_bdt[0], g_Wdt[1], g_bdt[1], g_A[0], g_A[1],
+                g_D, g_Db, g_lw, g_lb, dW_out, db_out, None, None, None, None, None, None, None, None)
 
 
 class Mamba(nn.Module):
@@ -209,7 +255,7 @@ class Mamba(nn.Module):
             self.A_log, self.A_b_log, self.D, self.D_b, ln_w, ln_b,
             self.out_proj.weight, self.out_proj.bias,
             self.num_of_rows, self.num_of_col, bool(transposed_grid), self.collapse_method == "max",
-            float(self.scaling_factor), float(ln_eps), cdt)
+            float(self.scaling_factor), float(ln_eps), cdt, self.__dict__.get("_fv"))
         if self.init_layer_scale is not None:
             out = out * self.gamma
         return out

@@ -61,17 +61,20 @@ def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, 
     return g, xhat, mean, rstd
 
 
-def reduce_partials(part, n_partials):
-    """Fixed-order sum over the leading dim of a (n_partials, ...) fp32 buffer."""
-    out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
-    n = out.numel()
+def reduce_partials(part, n_partials, out=None, accumulate=False):
+    """Fixed-order sum over the leading dim of a (n_partials, ...) fp32 buffer.  ``out`` (contiguous
+    fp32, same element count) receives the result; ``accumulate`` adds into it instead."""
+    if out is None:
+        out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
+    n = part.numel() // n_partials
+    assert out.numel() == n and out.is_contiguous() and out.dtype == torch.float32
     rc = L.lib().fv_reduce_partials(L.ptr(part), L.ptr(out), L.i32(n_partials), ctypes.c_size_t(n),
-                                    L.stream_of(part))
+                                    L.i32(accumulate), L.stream_of(part))
     L.check(rc, "reduce_partials")
     return out
 
 
-def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed):
+def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed, grad_out=None):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
@@ -85,10 +88,16 @@ def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed):
         L.ptr(dyc), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_combine_bwd")
+    if grad_out is not None:
+        reduce_partials(part, nb, out=grad_out, accumulate=True)
+        return d_o, dyc, None
     return d_o, dyc, reduce_partials(part, nb)      # (2, d_in): [dln_w, dln_b]
 
 
-def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc):
+def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_out=None):
+    """Returns (dxc, dx_dbl, pr) with pr (2, d_in*(N+R+1)) = per direction [dA_log | d dt_w | d dt_bias];
+    when ``grad_out`` (flat fp32 view of exactly that layout) is given, the sums are accumulated into
+    it instead and pr is None."""
     _, B, Lc, d_in = xc.shape
     R, N = dt_w.shape[1], A_log.shape[1]
     W = R + 2 * N
@@ -98,20 +107,23 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc):
     f32o = dict(device=dev, dtype=torch.float32)
     dxc = torch.empty(2, B, Lc, d_in, **f32o)
     dx_dbl = torch.empty(nchunks, 2, B * Lc, W, **f32o)
-    ckpt = torch.empty(max(1, lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N))), **f32o)
-    part = torch.empty(B, 2, d_in, N + R + 1, **f32o)
+    nck = lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N))
+    ckpt = torch.empty(nck, **f32o) if nck else None
+    part = torch.empty(B, 2 * d_in * (N + R + 1), **f32o)
     rc = lib.fv_mixer_scan_bwd(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
         L.ptr(A_log_b), L.ptr(dyc), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(part),
         L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
     L.check(rc, "mixer_scan_bwd")
     dx_dbl = dx_dbl[0] if nchunks == 1 else reduce_partials(dx_dbl, nchunks)
-    pr = reduce_partials(part, B)                    # (2, d_in, N+R+1)
-    return dxc, dx_dbl, pr[:, :, :N], pr[:, :, N:N + R], pr[:, :, N + R]
+    if grad_out is not None:
+        reduce_partials(part, B, out=grad_out, accumulate=True)
+        return dxc, dx_dbl, None
+    return dxc, dx_dbl, reduce_partials(part, B).view(2, d_in * (N + R + 1))
 
 
 def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed,
-                  pool_max, scaling):
+                  pool_max, scaling, grad_out=None):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
@@ -125,4 +137,7 @@ def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz,
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_conv_pool_bwd")
     # segments: [dw (d_in*4) | dw_b (d_in*4) | db | db_b | dD | dD_b]
+    if grad_out is not None:
+        reduce_partials(part, nb, out=grad_out, accumulate=True)
+        return None
     return reduce_partials(part, nb)

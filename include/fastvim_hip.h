@@ -127,8 +127,9 @@ int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* xhat, const
  *   dx_dbl (fv_mixer_scan_bwd_chunks, 2, batch*Lc, dt_rank+2*d_state) fp32 out: sum over chunks
  *          = gradient wrt x_dbl
  *   ckpt   fv_mixer_scan_bwd_ckpt_floats() fp32 scratch
- *   partials (batch, 2, d_inner, d_state + dt_rank + 1): per-batch partials of
- *          [dA_log | d dt_proj.weight | d dt_proj.bias] (sum over batch with fv_reduce_partials). */
+ *   partials (batch, 2, d_inner*(d_state + dt_rank + 1)): per-batch partials, per direction the
+ *          segments [dA_log (d_inner*d_state) | d dt_proj.weight (d_inner*dt_rank) | d dt_proj.bias (d_inner)]
+ *          (sum over batch with fv_reduce_partials). */
 int fv_mixer_scan_bwd_chunks(int d_inner);
 size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state);
 int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
@@ -146,8 +147,10 @@ int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, co
                            int tok_stride_row, int tok_stride_col, int d_inner, int d_conv, int pool_max,
                            float scaling_factor, int dtype, fv_stream_t stream);
 
-/* out[i] = sum_{s < n_partials} partials[s*n + i], fixed order (deterministic). */
-int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n, fv_stream_t stream);
+/* out[i] (+)= sum_{s < n_partials} partials[s*n + i], fixed order (deterministic); accumulate != 0
+ * adds into `out` (gradient accumulation straight into a parameter's .grad). */
+int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n, int accumulate,
+                       fv_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused (per-sample scale) + residual add + RMSNorm / LayerNorm over the last dim.

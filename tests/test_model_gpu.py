@@ -114,3 +114,45 @@ def test_full_size_step_finite_and_deterministic():
         res.append((loss.detach().clone(), m.layers[3].mixer.A_log.grad.clone(), m.pos_embed.grad.clone()))
     assert all(torch.isfinite(t).all() for t in res[0])
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_flat_training_state_matches_autograd(amp):
+    """FlatTrainingState (flat params/grads, bf16 shadows, kernels accumulating straight into .grad)
+    must produce the same gradients as plain autograd accumulation, twice in a row (zero + accumulate)."""
+    import copy
+    from fastvim_amd.flat import FlatTrainingState
+    torch.manual_seed(0)
+    m1 = _tiny((64, 64), drop_path_rate=0.0).cuda().train()
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.endswith(("D", "D_b", "layernorm.bias", "conv1d.bias")):
+                p.add_(0.1 * torch.randn_like(p))
+    m2 = copy.deepcopy(m1)
+    flat = FlatTrainingState(m2)
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    g = torch.randn(4, 10, device="cuda")
+
+    def run(m):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y = m(x)
+        (y.float() * g).sum().backward()
+        return y
+
+    for it in range(2):
+        m1.zero_grad(set_to_none=True)
+        flat.zero_grad()
+        y1, y2 = run(m1), run(m2)
+        assert torch.equal(y1, y2)
+        p2 = dict(m2.named_parameters())
+        for n, p in m1.named_parameters():
+            a, b = p.grad, p2[n].grad
+            assert b.data_ptr() >= flat.grad_flat.data_ptr() and b.data_ptr() < flat.grad_flat.data_ptr() + flat.grad_flat.numel() * 4
+            tol = 1e-6 * max(1.0, a.abs().max().item())
+            assert (a - b).abs().max().item() <= tol, (n, it, (a - b).abs().max().item())
+    # an optimizer step through the flat views + shadow refresh keeps the two models in lock-step
+    o1 = torch.optim.AdamW(m1.parameters(), lr=1e-2, fused=True)
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1e-2, fused=True)
+    o1.step(); o2.step(); flat.refresh_shadow()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        assert torch.equal(m1(x), m2(x))
