@@ -1,0 +1,250 @@
+// bf16 MFMA GEMM for the projections of the FastVim block (in_proj, out_proj, patch-embed, and their
+// data- and weight-gradient forms).  Replaces the cuBLAS calls behind F.linear / matmul in
+// mamba_simple_faster.py:189-193, 435-444 and models/fastvim.py:95 (Conv2d k=s=16 == a GEMM).
+//
+//   C[M][N] = sum_k A(m,k) * B(k,n),   bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)
+//
+// Operand storage (per operand, template parameter):
+//   KC (K-contiguous): A(m,k) = A[m*lda + k];  B(k,n) = B[n*ldb + k]   ("NT": activations x weight^T)
+//   KS (K-slow)      : A(m,k) = A[k*lda + m];  B(k,n) = B[k*ldb + n]
+// so forward / data-gradient GEMMs are <KC,KC> or <KC,KS> and weight gradients X^T Y are <KS,KS> with
+// the reduction over tokens split across grid.z (fp32 partials, summed by fv_reduce_partials).
+//
+// gfx950 structure: 256 threads = 4 wave64, each wave owns a 64x64 accumulator (4x4 MFMA tiles);
+// K tiles of 64 are staged global -> registers -> LDS (double buffered: the loads of tile t+1 are in
+// flight while tile t is multiplied).  KC tiles are stored [row][k] with a 16-byte XOR swizzle and read
+// with ds_read_b128; KS tiles are stored as loaded, [k][col], and read with the CDNA4 transposing
+// LDS read ds_read_b64_tr_b16, so no operand is ever transposed in HBM.  The MFMA is issued with the
+// roles swapped (weight-side operand in the A slot), which leaves each lane with 4 consecutive output
+// columns of one row: the epilogue stores 8-byte (bf16) / 16-byte (fp32) vectors.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;
+enum { KC = 0, KS = 1 };
+
+struct GemmParams {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;     // (N) fp32, nullable, added in the epilogue
+  int M, N, K;
+  long lda, ldb, ldc;
+  int k_per_split;       // K range of one grid.z slice (multiple of BK)
+  int c_fp32;            // 1: C is fp32, else bf16
+  long c_split_stride;   // elements between split-K partials
+};
+
+// ---- staging: 256 threads move a (ROWS x 64) KC tile or a (64 x COLS) KS tile, 16 B per access ----
+template <int MODE, int EXT>   // EXT = tile extent along the non-K dim (128 or 256 or 64)
+struct Stage {
+  static constexpr int NV = EXT * BK / 8 / 256;   // 16-byte vectors per thread
+  u32x4 v[NV];
+  // global -> registers.  r0 = first row/col of the tile in the non-K dim, k0 = first k.
+  __device__ __forceinline__ void load(const bf16_t* base, long ld, int r0, int k0, int rmax, int kmax, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * 256;
+      int r, k;
+      if (MODE == KC) { r = e >> 3; k = (e & 7) * 8; }                 // 8 vectors per 64-k row
+      else { k = e / (EXT / 8); r = (e % (EXT / 8)) * 8; }             // EXT/8 vectors per k row
+      const int gr = r0 + r, gk = k0 + k;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      if (MODE == KC) {
+        v[i] = (gr < rmax && gk < kmax) ? *reinterpret_cast<const u32x4*>(base + (long)gr * ld + gk) : z;
+      } else {
+        v[i] = (gk < kmax && gr < rmax) ? *reinterpret_cast<const u32x4*>(base + (long)gk * ld + gr) : z;
+      }
+    }
+  }
+  // registers -> LDS.  KC: [row][64] with chunk ^= row & 7;  KS: [k][EXT] as is.
+  __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * 256;
+      int off;
+      if (MODE == KC) {
+        const int r = e >> 3, c = e & 7;
+        off = r * 128 + ((c ^ (r & 7)) << 4);
+      } else {
+        off = e * 16;
+      }
+      *reinterpret_cast<u32x4*>(lds + off) = v[i];
+    }
+  }
+};
+
+// fragment of a 16-wide block `blk` (rows for KC, cols for KS) at k-step ks (32 k) of the staged tile
+template <int MODE, int EXT>
+__device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lane) {
+  if (MODE == KC) {
+    const int r = blk * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((c ^ (r & 7)) << 4));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int k0 = ks * 32 + g * 8;
+    const int col = blk * 16 + pp * 4;
+    typedef s4v __attribute__((address_space(3))) * lptr;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + ((k0 + q) * EXT + col) * 2));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + ((k0 + 4 + q) * EXT + col) * 2));
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    s8v t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, t);
+  }
+}
+
+// WM x WN waves, each 64x64: tile BM = 64*WM rows (m), BN = 64*WN cols (n)
+template <int AMODE, int BMODE, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto sA = [&](int i) { return smem + i * (A_BYTES + B_BYTES); };             // [A0 | B0 | A1 | B1]
+  auto sB = [&](int i) { return smem + i * (A_BYTES + B_BYTES) + A_BYTES; };
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WN, wn = wv % WN;
+  // XCD-aware tile order: the N tiles that share an A row panel are consecutive on one XCD
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q8 = nblk / 8, r8 = nblk % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;   // bijective remap
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  f32x4 acc[4][4];   // [n tile][m tile]: rows = n (MFMA A slot = B operand), cols = m
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  Stage<AMODE, BM> ra;
+  Stage<BMODE, BN> rb;
+  ra.load(p.A, p.lda, m0, kbeg, p.M, kend, tid);
+  rb.load(p.B, p.ldb, n0, kbeg, p.N, kend, tid);
+  ra.store(sA(0), tid);
+  rb.store(sB(0), tid);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      ra.load(p.A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, tid);
+      rb.load(p.B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = frag<AMODE, BM>(sA(cur), wm * 4 + i, ks, lane);
+        fb[i] = frag<BMODE, BN>(sB(cur), wn * 4 + i, ks, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[a], fa[b], acc[a][b], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      ra.store(sA(cur ^ 1), tid);
+      rb.store(sB(cur ^ 1), tid);
+    }
+    __syncthreads();
+  }
+  // epilogue: acc[a][b][j] = C[m = m0 + wm*64 + b*16 + (lane&15)][n = n0 + wn*64 + a*16 + (lane>>4)*4 + j]
+  const long zoff = (long)blockIdx.z * p.c_split_stride;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int m = m0 + wm * 64 + b * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[a][b];
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < p.N) v[j] += p.bias[n + j];
+      }
+      if (p.c_fp32) {
+        float* dst = (float*)p.C + zoff + (long)m * p.ldc + n;
+        if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
+        else
+          for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = v[j];
+      } else {
+        bf16_t* dst = (bf16_t*)p.C + zoff + (long)m * p.ldc + n;
+        if (n + 3 < p.N) {
+          uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<uint2*>(dst) = pk;
+        } else {
+          for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = __float2bfloat16(v[j]);
+        }
+      }
+    }
+  }
+}
+
+template <int AMODE, int BMODE, int WM, int WN>
+int launch(const GemmParams& p, int splits, hipStream_t st) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  const int tiles = fv_cdiv(p.M, BM) * fv_cdiv(p.N, BN);
+  const size_t smem = (size_t)2 * (BM + BN) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, BMODE, WM, WN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, BMODE, WM, WN>), dim3(tiles, 1, splits), dim3(256), smem, st, p);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+template <int AMODE, int BMODE>
+int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
+  // 128x128 tiles unless N (<= 64 mod 128) wastes half a tile: then 256x64
+  const int rem = p.N % 128;
+  if (rem != 0 && rem <= 64 && p.M >= 256) return launch<AMODE, BMODE, 4, 1>(p, splits, st);
+  return launch<AMODE, BMODE, 2, 2>(p, splits, st);
+}
+
+}  // namespace
+
+extern "C" int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K,
+                            long lda, long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits,
+                            fv_stream_t stream) {
+  FV_CHECK(A && B && C, "gemm_bf16: null pointer");
+  FV_CHECK(M > 0 && N > 0 && K > 0 && splits >= 1, "gemm_bf16: empty problem");
+  FV_CHECK(lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16: leading dimensions must be multiples of 8 (16-byte rows)");
+  FV_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_bf16: operands must be 16-byte aligned");
+  FV_CHECK(ldc % 4 == 0 && ((uintptr_t)C & 15) == 0, "gemm_bf16: C must be 16-byte aligned with ldc %% 4 == 0");
+  FV_CHECK(splits == 1 || c_fp32, "gemm_bf16: split-K partials must be fp32");
+  FV_CHECK(a_k_slow ? M % 8 == 0 : K % 8 == 0, "gemm_bf16: A's contiguous extent must be a multiple of 8");
+  FV_CHECK(b_k_slow ? N % 8 == 0 : K % 8 == 0, "gemm_bf16: B's contiguous extent must be a multiple of 8");
+  GemmParams p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.c_fp32 = c_fp32;
+  int kps = fv_cdiv(fv_cdiv(K, splits), BK) * BK;
+  p.k_per_split = kps;
+  p.c_split_stride = (long)M * ldc;
+  const int zs = fv_cdiv(K, kps);
+  FV_CHECK(zs == splits, "gemm_bf16: K=%d cannot be cut into %d slices of whole 64-deep tiles (got %d)", K, splits, zs);
+  hipStream_t st = (hipStream_t)stream;
+  if (!a_k_slow && !b_k_slow) return launch_shape<KC, KC>(p, splits, st);
+  if (!a_k_slow && b_k_slow) return launch_shape<KC, KS>(p, splits, st);
+  if (a_k_slow && b_k_slow) return launch_shape<KS, KS>(p, splits, st);
+  fv_set_error("gemm_bf16: A K-slow with B K-contiguous is not built");
+  return FV_ERR_UNSUPPORTED;
+}

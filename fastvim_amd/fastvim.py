@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
-from .mamba_simple_faster import Mamba, _compute_dtype
+from .mamba_simple_faster import LinearFn, Mamba, _compute_dtype
 from .mixer_ops import reduce_partials
 
 
@@ -141,9 +141,7 @@ class PatchEmbed(nn.Module):
         gh, gw = x.shape[2] // ph, x.shape[3] // pw
         cdt = _compute_dtype(x)
         patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
-        w = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
-        with torch.autocast("cuda", enabled=False):
-            x = F.linear(patches.to(cdt), w.to(cdt))
+        x = LinearFn.apply(patches, self.proj.weight, cdt)          # (B, gh*gw, D), weight viewed (D, C*ph*pw)
         if self.scanpath_type == "colwise":
             x = x.reshape(B, gh, gw, -1).transpose(1, 2).reshape(B, gh * gw, -1)
         if pos_embed is not None or self.proj.bias is not None:

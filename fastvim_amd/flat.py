@@ -52,11 +52,11 @@ class FlatTrainingState:
         self.names = order
         params = [named[n] for n in order]
         dev = params[0].device
-        # 16-byte aligned offsets so every view can be read with wide loads
+        # offsets in multiples of 8 elements: every fp32 AND bf16 view is 16-byte aligned (MFMA GEMM loads)
         offs, off = [], 0
         for p in params:
             offs.append(off)
-            off += (p.numel() + 3) // 4 * 4
+            off += (p.numel() + 7) // 8 * 8
         self.param_flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self.grad_flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self.shadow_flat = torch.zeros(off, device=dev, dtype=shadow_dtype)

@@ -1,0 +1,47 @@
+"""Host wrappers of the bf16 MFMA GEMM (csrc/gemm_mfma.hip, C ABI fv_gemm_bf16)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .mixer_ops import reduce_partials
+
+
+def _call(A, B, C, bias, M, N, K, lda, ldb, ldc, a_ks, b_ks, splits):
+    rc = L.lib().fv_gemm_bf16(L.ptr(A), L.ptr(B), L.ptr(C), L.ptr(bias), L.i32(M), L.i32(N), L.i32(K),
+                              ctypes.c_long(lda), ctypes.c_long(ldb), ctypes.c_long(ldc), L.i32(a_ks), L.i32(b_ks),
+                              L.i32(C.dtype == torch.float32), L.i32(splits), L.stream_of(A))
+    L.check(rc, "gemm_bf16")
+
+
+def gemm_nt(a, w, bias=None, out_dtype=torch.bfloat16):
+    """a (M, K) @ w (N, K)^T -> (M, N): F.linear(a, w, bias) with bf16 operands."""
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty(M, N, device=a.device, dtype=out_dtype)
+    _call(a, w, c, bias, M, N, K, a.stride(0), w.stride(0), N, 0, 0, 1)
+    return c
+
+
+def gemm_nn(a, b, out_dtype=torch.bfloat16):
+    """a (M, K) @ b (K, N) -> (M, N), b row-major as stored (data gradient g @ W)."""
+    M, K = a.shape
+    N = b.shape[1]
+    c = torch.empty(M, N, device=a.device, dtype=out_dtype)
+    _call(a, b, c, None, M, N, K, a.stride(0), b.stride(0), N, 0, 1, 1)
+    return c
+
+
+def gemm_tn(x, y, splits=1, out=None, accumulate=False):
+    """x (Kd, M)^T @ y (Kd, N) -> (M, N) fp32: weight gradient, reduction over the leading (token) dim
+    cut into `splits` slices whose fp32 partials are summed in fixed order (deterministic split-K)."""
+    Kd, M = x.shape
+    N = y.shape[1]
+    while splits > 1 and (Kd % (splits * 64)):
+        splits //= 2
+    part = torch.empty(splits, M, N, device=x.device, dtype=torch.float32)
+    _call(x, y, part, None, M, N, Kd, x.stride(0), y.stride(0), N, 1, 1, splits)
+    if out is not None:
+        reduce_partials(part, splits, out=out, accumulate=accumulate)
+        return None
+    return part[0] if splits == 1 else reduce_partials(part, splits)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import mixer_ops as M
+from .gemm import gemm_nn, gemm_nt, gemm_tn
 
 
 def _shadow(w, cdt):
@@ -53,6 +54,64 @@ def _wgrad(X, Y, W=None, splits=16):
     return M.reduce_partials(part, splits)
 
 
+def _mfma_ok(*ts):
+    return all(t.dtype == torch.bfloat16 and t.stride(-1) == 1 and t.data_ptr() % 16 == 0 for t in ts)
+
+
+def linear_fwd(a2, w_c, bias=None):
+    """a2 (M, K) x w_c (N, K)^T (+ bias) in the compute dtype: hand-written MFMA GEMM for bf16, rocBLAS for fp32."""
+    if _mfma_ok(a2, w_c) and a2.shape[1] % 8 == 0:
+        return gemm_nt(a2, w_c, bias=None if bias is None else bias.float())
+    return F.linear(a2, w_c, None if bias is None else bias.to(a2.dtype))
+
+
+def linear_dgrad(g2, w_c):
+    """g2 (M, N) x w_c (N, K) -> (M, K): data gradient with the weight as stored."""
+    if _mfma_ok(g2, w_c) and w_c.shape[1] % 8 == 0 and g2.shape[1] % 8 == 0:
+        return gemm_nn(g2, w_c)
+    return g2 @ w_c
+
+
+def linear_wgrad(g2, a2, W=None, splits=28):
+    """dW (N, K) fp32 = g2 (M, N)^T a2 (M, K), deterministic split-K; accumulates into W's flat .grad if present."""
+    if _mfma_ok(g2, a2) and g2.shape[1] % 8 == 0 and a2.shape[1] % 8 == 0 and g2.shape[0] % 64 == 0:
+        gdir = _direct_grad(W) if W is not None else None
+        if gdir is not None:
+            gemm_tn(g2, a2, splits=splits, out=gdir.view(-1), accumulate=True)
+            return None
+        return gemm_tn(g2, a2, splits=splits)
+    return _wgrad(g2, a2, W)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = a @ W^T (no bias) through the MFMA GEMMs, with the deterministic split-K weight gradient
+    (and direct accumulation into a flat .grad).  Used for the patch-embed projection."""
+
+    @staticmethod
+    def forward(ctx, a, W, cdt):
+        with torch.autocast("cuda", enabled=False):
+            a2 = a.reshape(-1, a.shape[-1]).to(cdt).contiguous()
+            W2 = W.reshape(W.shape[0], -1)
+            y = linear_fwd(a2, _shadow(W, cdt).reshape(W2.shape))
+        ctx.save_for_backward(a2, W)
+        ctx.a_shape, ctx.a_dtype, ctx.cdt = a.shape, a.dtype, cdt
+        ctx.need_da = a.requires_grad
+        return y.view(*a.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, W = ctx.saved_tensors
+        cdt = ctx.cdt
+        with torch.autocast("cuda", enabled=False):
+            g2 = g.reshape(-1, g.shape[-1]).to(cdt).contiguous()
+            W2s = _shadow(W, cdt).reshape(W.shape[0], -1)
+            da = linear_dgrad(g2, W2s).view(ctx.a_shape).to(ctx.a_dtype) if ctx.need_da else None
+            dW = linear_wgrad(g2, a2, W)
+            if dW is not None:
+                dW = dW.view(W.shape)
+        return da, dW, None
+
+
 def _compute_dtype(t):
     """bf16/fp16 under torch.autocast (reference: mamba_simple_faster.py:312-318), else the input dtype."""
     if torch.is_autocast_enabled():
@@ -75,7 +134,7 @@ class FastVimMixerFn(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             h_c = hidden.to(cdt).contiguous()
             W_in_c, W_out_c = _shadow(W_in, cdt), _shadow(W_out, cdt)
-            xz = F.linear(h_c, W_in_c, None if b_in is None else b_in.to(cdt))          # (B, L, 2 d_in)
+            xz = linear_fwd(h_c.view(B * Ltok, d), W_in_c, b_in).view(B, Ltok, 2 * d_in)  # (B, L, 2 d_in)
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             xc = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling)
             if fv is not None and "Wx2" in fv:          # x_proj / x_proj_b adjacent in the flat buffers
@@ -88,7 +147,7 @@ class FastVimMixerFn(torch.autograd.Function):
             yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
             g, xhat, mean, rstd = M.combine_fwd(xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, ln_eps,
                                                 rows, cols, transposed)
-            out = F.linear(g, W_out_c, None if b_out is None else b_out.to(cdt))
+            out = linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
         ctx.save_for_backward(h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b,
                               ln_w, ln_b, W_out, xz, xc, x_dbl, g, xhat, rstd)
         ctx.geo = (rows, cols, transposed, pool_max, scaling)
@@ -110,8 +169,8 @@ class FastVimMixerFn(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             dout = dout.to(cdt).contiguous()
             do2 = dout.view(B * Ltok, d)
-            dg = do2 @ _shadow(W_out, cdt)                                               # (B*L, d_in)
-            dW_out = _wgrad(do2, g.view(B * Ltok, d_in), W_out)
+            dg = linear_dgrad(do2, _shadow(W_out, cdt))                                  # (B*L, d_in)
+            dW_out = linear_wgrad(do2, g.view(B * Ltok, d_in), W_out)
             db_out = do2.float().sum(0) if ctx.has_bias[1] else None
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
@@ -130,8 +189,8 @@ class FastVimMixerFn(torch.autograd.Function):
             p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
                                  pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
-            dhidden = (dxz2 @ _shadow(W_in, cdt)).view(B, Ltok, d).to(ctx.in_dtype)
-            dW_in = _wgrad(dxz2, h_c.view(B * Ltok, d), W_in)
+            dhidden = linear_dgrad(dxz2, _shadow(W_in, cdt)).view(B, Ltok, d).to(ctx.in_dtype)
+            dW_in = linear_wgrad(dxz2, h_c.view(B * Ltok, d), W_in)
             db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
         has_ln = ln_w is not None
         n4 = 4 * d_in

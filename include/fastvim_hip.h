@@ -174,6 +174,19 @@ int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidual_out, int
                     int dresidual_in_dtype, float* partial_dw, float* partial_db, int M, int N,
                     int is_rms_norm, fv_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * bf16 MFMA GEMM  C[M][N] = sum_k A(m,k) B(k,n) (+ bias[n]), fp32 accumulate.
+ * Replaces the cuBLAS GEMMs behind in_proj / out_proj (mamba_simple_faster.py:189-193, 435-444),
+ * the patch-embed Conv2d (models/fastvim.py:95, k == stride) and their autograd adjoints.
+ *   a_k_slow = 0: A(m,k) = A[m*lda + k]      a_k_slow = 1: A(m,k) = A[k*lda + m]
+ *   b_k_slow = 0: B(k,n) = B[n*ldb + k]      b_k_slow = 1: B(k,n) = B[k*ldb + n]
+ *   (0,0) activations x weight^T;  (0,1) data gradient with the weight as stored;  (1,1) weight
+ *   gradient X^T Y.  splits > 1 cuts K across grid.z and writes `splits` fp32 partials (stride
+ *   M*ldc) for fv_reduce_partials.  C is bf16 (c_fp32 = 0) or fp32; bias (N) fp32 nullable.
+ * ---------------------------------------------------------------------- */
+int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
+                 long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits, fv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
