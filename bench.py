@@ -240,6 +240,7 @@ def main():
             logits = model(x)
         loss = torch.sum(-tgt * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()   # SoftTargetCrossEntropy
         loss.backward()
+        flat.finish_backward()
         return loss.detach()
 
     use_graph = not args.no_graph

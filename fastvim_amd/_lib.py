@@ -21,7 +21,7 @@ C_ABI_SYMBOLS = (
     "fv_selective_scan_fwd", "fv_selective_scan_bwd_workspace", "fv_selective_scan_bwd",
     "fv_mixer_conv_pool_fwd", "fv_mixer_scan_fwd", "fv_mixer_combine_fwd",
     "fv_mixer_bwd_blocks", "fv_mixer_combine_bwd", "fv_mixer_scan_bwd_chunks",
-    "fv_mixer_scan_bwd_ckpt_floats", "fv_mixer_scan_bwd", "fv_mixer_conv_pool_bwd", "fv_reduce_partials",
+    "fv_mixer_scan_bwd_ckpt_floats", "fv_mixer_scan_bwd", "fv_mixer_conv_pool_bwd", "fv_reduce_partials", "fv_reduce_partials_multi",
     "fv_add_norm_blocks", "fv_add_norm_fwd", "fv_add_norm_bwd", "fv_gemm_bf16",
 )
 

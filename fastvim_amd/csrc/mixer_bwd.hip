@@ -215,8 +215,26 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
           VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dw[k]);
         }
       }
-#pragma unroll 4
-      for (int n = -3; n < g.cols; ++n) {
+      // tokens are fetched CH at a time, ahead of the arithmetic that consumes them
+      constexpr int CH = 8;
+      for (int n0 = -3; n0 < g.cols; n0 += CH) {
+        float xp[CH][VEC], dp[CH][VEC];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {                    // token n0 + c + 3
+          const int j3 = n0 + c + 3, sp = s_row + j3;
+          if (act && sp < g.L && j3 < g.cols + 3) {
+            const int m = tok_mem(g, sp);
+            VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + c0, xp[c]);
+            VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dp[c]);
+          } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xp[c][v] = dp[c][v] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+        const int n = n0 + c;
+        if (n >= g.cols) break;
         // shift the windows by one token and bring in token n+3
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -230,13 +248,10 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
         const int s3 = s_row + n + 3;
         const bool v3 = s3 < g.L;                         // token n+3 exists (s3 >= 0 always here)
         const bool v0 = s_row + n >= 0;                   // token n exists
-        if (v3 && act) {
-          const int m = tok_mem(g, s3);
-          VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + c0, xw[3]);
-          VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dw[3]);
-        } else {
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) xw[3][v] = dw[3][v] = 0.f;
+        for (int v = 0; v < VEC; ++v) {
+          xw[3][v] = xp[c][v];
+          dw[3][v] = dp[c][v];
         }
         const int r3 = (n + 3 >= g.cols) ? 2 : 1;         // row of token n+3 relative to i-1
         const int r0 = (n < 0) ? 0 : 1;                   // row of token n
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
             dx[v] = acc;
           }
           if (act) VecIO<T, VEC>::store(dxz_b + (size_t)tok_mem(g, s_row + n) * 2 * p.d_in + c0, dx);
+        }
         }
       }
     }
@@ -448,6 +464,67 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
   p.pool_scale = scaling_factor / (float)cols;
   return dtype == FV_F32 ? dispatch_bwd<float>(1, p, (hipStream_t)stream)
                          : dispatch_bwd<bf16_t>(1, p, (hipStream_t)stream);
+}
+
+// Several independent fixed-order reductions in ONE launch (gradient partials of different kernels /
+// layers whose sums are only needed before the optimizer step).
+constexpr int MAXJOBS = 16;
+struct ReduceJobs {
+  const float* in[MAXJOBS];
+  float* out[MAXJOBS];
+  int S[MAXJOBS];
+  long n[MAXJOBS];
+  int blk_end[MAXJOBS];   // exclusive prefix of blocks per job
+  int njobs, accumulate;
+};
+
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J) {
+  __shared__ float s_acc[8][33];
+  int job = 0;
+  while (job + 1 < J.njobs && (int)blockIdx.x >= J.blk_end[job]) ++job;
+  const int blk = blockIdx.x - (job ? J.blk_end[job - 1] : 0);
+  const float* __restrict__ in = J.in[job];
+  const int S = J.S[job];
+  const size_t n = (size_t)J.n[job];
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const size_t i = (size_t)blk * 32 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < n) {
+    int s = q;
+    for (; s + 8 < S; s += 16) {
+      a0 += in[(size_t)s * n + i];
+      a1 += in[(size_t)(s + 8) * n + i];
+    }
+    if (s < S) a0 += in[(size_t)s * n + i];
+  }
+  s_acc[q][c] = a0 + a1;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += s_acc[k][c];
+    float* out = J.out[job];
+    out[i] = J.accumulate ? out[i] + t : t;
+  }
+}
+
+extern "C" int fv_reduce_partials_multi(const float* const* partials, float* const* outs, const int* n_partials,
+                                        const size_t* ns, int njobs, int accumulate, fv_stream_t stream) {
+  FV_CHECK(partials && outs && n_partials && ns && njobs > 0 && njobs <= MAXJOBS,
+           "reduce_partials_multi: 1..%d jobs", MAXJOBS);
+  ReduceJobs J{};
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    FV_CHECK(partials[j] && outs[j] && n_partials[j] > 0, "reduce_partials_multi: bad job %d", j);
+    J.in[j] = partials[j]; J.out[j] = outs[j]; J.S[j] = n_partials[j]; J.n[j] = (long)ns[j];
+    blocks += fv_cdiv((long)ns[j], 32);
+    J.blk_end[j] = blocks;
+  }
+  J.njobs = njobs; J.accumulate = accumulate;
+  if (blocks == 0) return FV_OK;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
 }
 
 extern "C" int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n, int accumulate,

@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int MAXK = 8;   // up to 8 * 256 = 2048 channels per row
+constexpr int MAXK_LIMIT = 8;   // up to 8 * 256 = 2048 channels per row (MAXK = ceil(N / 256) is a template parameter)
 
 struct NormParams {
   const void *x, *res, *dy, *dres_out, *r;
@@ -33,6 +33,7 @@ __device__ __forceinline__ void st4(void* p, int dt, size_t idx, const float (&v
   else VecIO<bf16_t, 4>::store((bf16_t*)p + idx, v);
 }
 
+template <int MAXK>
 __global__ __launch_bounds__(256) void add_norm_fwd_kernel(NormParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(NormParams p) {
 
 // backward: dr = rstd * (dxhat - mean(dxhat)[LN only] - xhat * mean(dxhat * xhat)) + dres_out
 //           dx = dr * row_scale, dres_in = dr;  per-wave-group partials of dw (and db)
+template <int MAXK>
 __global__ __launch_bounds__(256) void add_norm_bwd_kernel(NormParams p) {
   __shared__ float s_acc[4][MAXK * 256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -203,7 +205,7 @@ extern "C" int fv_add_norm_fwd(const void* x, int x_dtype, const void* residual,
                                int residual_out_dtype, float* mean, float* rstd, int M, int N, float eps,
                                int is_rms_norm, fv_stream_t stream) {
   FV_CHECK(M > 0 && N > 0, "add_norm_fwd: empty input");
-  FV_CHECK(N % 4 == 0 && N <= MAXK * 256, "add_norm_fwd: hidden size %d must be a multiple of 4 and <= %d", N, MAXK * 256);
+  FV_CHECK(N % 4 == 0 && N <= MAXK_LIMIT * 256, "add_norm_fwd: hidden size %d must be a multiple of 4 and <= %d", N, MAXK_LIMIT * 256);
   FV_CHECK(x && weight && y && rstd, "add_norm_fwd: null pointer");
   FV_CHECK(dt_ok(x_dtype) && dt_ok(y_dtype) && (!residual || dt_ok(residual_dtype)) &&
                (!residual_out || dt_ok(residual_out_dtype)), "add_norm_fwd: dtypes must be fp32 or bf16");
@@ -214,7 +216,12 @@ extern "C" int fv_add_norm_fwd(const void* x, int x_dtype, const void* residual,
   p.mean = mean; p.rstd = rstd;
   p.x_dt = x_dtype; p.res_dt = residual_dtype; p.y_dt = y_dtype; p.ro_dt = residual_out_dtype;
   p.M = M; p.N = N; p.rows_per_scale = rows_per_scale; p.is_rms = is_rms_norm; p.eps = eps;
-  hipLaunchKernelGGL(add_norm_fwd_kernel, dim3(fv_add_norm_blocks(M)), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid(fv_add_norm_blocks(M)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 256) hipLaunchKernelGGL(add_norm_fwd_kernel<1>, grid, block, 0, st, p);
+  else if (N <= 512) hipLaunchKernelGGL(add_norm_fwd_kernel<2>, grid, block, 0, st, p);
+  else if (N <= 1024) hipLaunchKernelGGL(add_norm_fwd_kernel<4>, grid, block, 0, st, p);
+  else hipLaunchKernelGGL(add_norm_fwd_kernel<8>, grid, block, 0, st, p);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
@@ -225,7 +232,7 @@ extern "C" int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidu
                                int dx_dtype, void* dresidual_in, int dresidual_in_dtype, float* partial_dw,
                                float* partial_db, int M, int N, int is_rms_norm, fv_stream_t stream) {
   FV_CHECK(M > 0 && N > 0, "add_norm_bwd: empty input");
-  FV_CHECK(N % 4 == 0 && N <= MAXK * 256, "add_norm_bwd: hidden size %d must be a multiple of 4 and <= %d", N, MAXK * 256);
+  FV_CHECK(N % 4 == 0 && N <= MAXK_LIMIT * 256, "add_norm_bwd: hidden size %d must be a multiple of 4 and <= %d", N, MAXK_LIMIT * 256);
   FV_CHECK(dy && r && weight && rstd && partial_dw, "add_norm_bwd: null pointer");
   FV_CHECK(is_rms_norm || mean, "add_norm_bwd: LayerNorm needs the saved mean");
   FV_CHECK(dt_ok(dy_dtype) && dt_ok(r_dtype) && (!dresidual_out || dt_ok(dresidual_out_dtype)) &&
@@ -236,7 +243,12 @@ extern "C" int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidu
   p.row_scale = row_scale; p.dx = dx; p.dres_in = dresidual_in; p.pw = partial_dw; p.pb = partial_db;
   p.dy_dt = dy_dtype; p.dro_dt = dresidual_out_dtype; p.r_dt = r_dtype; p.dx_dt = dx_dtype; p.dri_dt = dresidual_in_dtype;
   p.M = M; p.N = N; p.rows_per_scale = rows_per_scale; p.is_rms = is_rms_norm;
-  hipLaunchKernelGGL(add_norm_bwd_kernel, dim3(fv_add_norm_blocks(M)), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid(fv_add_norm_blocks(M)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 256) hipLaunchKernelGGL(add_norm_bwd_kernel<1>, grid, block, 0, st, p);
+  else if (N <= 512) hipLaunchKernelGGL(add_norm_bwd_kernel<2>, grid, block, 0, st, p);
+  else if (N <= 1024) hipLaunchKernelGGL(add_norm_bwd_kernel<4>, grid, block, 0, st, p);
+  else hipLaunchKernelGGL(add_norm_bwd_kernel<8>, grid, block, 0, st, p);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

@@ -17,6 +17,7 @@ import torch.distributed as dist
 
 from .layernorm import RMSNorm
 from .mamba_simple_faster import Mamba
+from .mixer_ops import defer_reductions, flush_reductions
 
 # per-mixer parameter order; each group is one contiguous region matching a kernel's partial layout
 _MIXER_GROUPS = (
@@ -88,10 +89,16 @@ class FlatTrainingState:
                 if mod.weight.requires_grad:
                     mod.weight._fv_direct = True     # my backward kernels may accumulate into .grad directly
         self.refresh_shadow()
+        defer_reductions(True)
 
     # ------------------------------------------------------------------ per-step operations
     def zero_grad(self):
+        flush_reductions()
         self.grad_flat.zero_()
+
+    def finish_backward(self):
+        """Issue the queued gradient reductions; call after loss.backward(), before reading any .grad."""
+        flush_reductions()
 
     def refresh_shadow(self):
         self.shadow_flat.copy_(self.param_flat)
@@ -102,6 +109,7 @@ class FlatTrainingState:
 
     def allreduce_mean_(self):
         """Sum the flat gradient across ranks (RCCL) and divide by the world size (torch DDP semantics)."""
+        flush_reductions()
         ws = self.world_size
         if ws == 1:
             return

@@ -61,9 +61,49 @@ def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, 
     return g, xhat, mean, rstd
 
 
+class _Deferred:
+    """Gradient-partial reductions whose results are only needed before the optimizer step are queued
+    (flat training state only) and issued 16 at a time by ONE launch (fv_reduce_partials_multi)."""
+    enabled = False
+    jobs = []
+
+    @classmethod
+    def add(cls, part, out, n_partials):
+        cls.jobs.append((part, out, n_partials))
+        if len(cls.jobs) >= 16:
+            cls.flush()
+
+    @classmethod
+    def flush(cls):
+        if not cls.jobs:
+            return
+        jobs, cls.jobs = cls.jobs, []
+        k = len(jobs)
+        ins = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in jobs])
+        outs = (ctypes.c_void_p * k)(*[j[1].data_ptr() for j in jobs])
+        Ss = (ctypes.c_int * k)(*[j[2] for j in jobs])
+        ns = (ctypes.c_size_t * k)(*[j[0].numel() // j[2] for j in jobs])
+        rc = L.lib().fv_reduce_partials_multi(ins, outs, Ss, ns, L.i32(k), L.i32(1), L.stream_of(jobs[0][0]))
+        L.check(rc, "reduce_partials_multi")
+
+
+def defer_reductions(on):
+    _Deferred.flush()
+    _Deferred.enabled = bool(on)
+
+
+def flush_reductions():
+    _Deferred.flush()
+
+
 def reduce_partials(part, n_partials, out=None, accumulate=False):
     """Fixed-order sum over the leading dim of a (n_partials, ...) fp32 buffer.  ``out`` (contiguous
-    fp32, same element count) receives the result; ``accumulate`` adds into it instead."""
+    fp32, same element count) receives the result; ``accumulate`` adds into it instead (and may be
+    deferred, see _Deferred)."""
+    if out is not None and accumulate and _Deferred.enabled:
+        assert out.numel() == part.numel() // n_partials and out.is_contiguous() and out.dtype == torch.float32
+        _Deferred.add(part, out, n_partials)
+        return out
     if out is None:
         out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
     n = part.numel() // n_partials
