@@ -31,7 +31,8 @@ constexpr int RGMAX = 4;   // a block walks up to RGMAX pooling rows concurrentl
 template <typename T, int VEC, int TT>
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: row/token index math stays on the scalar unit
   const int rg = wv / nch, cw = wv - rg * nch;          // row group, channel-chunk wave
   const int c0 = (cw * 64 + lane) * VEC;
   const bool act = c0 < p.d_in;
@@ -60,24 +61,42 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
     float dyc_acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) dyc_acc[v] = 0.f;
+    // software pipeline: the (packed) loads of token group j0+TT are in flight while group j0 is processed
+    RawVec<T, VEC> n_dg[TT], n_z[TT], n_xh[TT];
+    auto fetch = [&](int j0) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (rv && act && j0 + t < g.cols) {
+          const int m = tok_mem(g, i * g.cols + j0 + t);
+          n_dg[t].load(dg_b + (size_t)m * p.d_in + c0);
+          n_z[t].load(xz_b + (size_t)m * 2 * p.d_in + p.d_in + c0);
+          n_xh[t].load(xh_b + (size_t)m * p.d_in + c0);
+        } else {
+          n_dg[t].zero(); n_z[t].zero(); n_xh[t].zero();
+        }
+      }
+    };
+    fetch(0);
     for (int j0 = 0; j0 < g.cols; j0 += TT) {
       float xh[TT][VEC], dxh[TT][VEC], c1[TT], c2[TT], rs[TT];
+      float dgq[TT][VEC], zq[TT][VEC];
       int mtok[TT];
       bool tv[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        n_dg[t].get(dgq[t]);
+        n_z[t].get(zq[t]);
+        n_xh[t].get(xh[t]);
+      }
+      if (j0 + TT < g.cols) fetch(j0 + TT);
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         tv[t] = rv && (j0 + t < g.cols);
         mtok[t] = tv[t] ? tok_mem(g, i * g.cols + j0 + t) : 0;
         rs[t] = (tv[t] && p.use_norm) ? p.rstd[(size_t)b * g.L + mtok[t]] : 1.f;
-        float dgv[VEC], zv[VEC], dzv[VEC];
-        if (tv[t] && act) {
-          VecIO<T, VEC>::load(dg_b + (size_t)mtok[t] * p.d_in + c0, dgv);
-          VecIO<T, VEC>::load(xz_b + (size_t)mtok[t] * 2 * p.d_in + p.d_in + c0, zv);
-          VecIO<T, VEC>::load(xh_b + (size_t)mtok[t] * p.d_in + c0, xh[t]);
-        } else {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) dgv[v] = zv[v] = xh[t][v] = 0.f;
-        }
+        float dzv[VEC];
+        const float (&dgv)[VEC] = dgq[t];
+        const float (&zv)[VEC] = zq[t];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -156,10 +175,11 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
 // Purely per-channel (no cross-lane traffic): a lane owns VEC channels and streams the row's tokens
 // through 4-deep register windows.  Step n consumes token n+3 and produces
 //   dpre_f[n+3] (needs x[n..n+3]),  dpre_b[n] (needs x[n..n+3]),  dx[n] (needs dpre_f[n..n+3], dpre_b[n-3..n]).
-template <typename T, int VEC>
+template <typename T, int VEC, int CH>   // CH tokens are fetched (packed, as loaded) ahead of the arithmetic that consumes them
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform (scalar index math)
   const int rg = wv / nch, cw = wv - rg * nch;
   const int c0 = (cw * 64 + lane) * VEC;
   const bool act = c0 < p.d_in;
@@ -215,20 +235,18 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
           VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dw[k]);
         }
       }
-      // tokens are fetched CH at a time, ahead of the arithmetic that consumes them
-      constexpr int CH = 8;
       for (int n0 = -3; n0 < g.cols; n0 += CH) {
-        float xp[CH][VEC], dp[CH][VEC];
+        RawVec<T, VEC> xp[CH], dp[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {                    // token n0 + c + 3
           const int j3 = n0 + c + 3, sp = s_row + j3;
           if (act && sp < g.L && j3 < g.cols + 3) {
             const int m = tok_mem(g, sp);
-            VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + c0, xp[c]);
-            VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dp[c]);
+            xp[c].load(xz_b + (size_t)m * 2 * p.d_in + c0);
+            dp[c].load(dob_b + (size_t)m * p.d_in + c0);
           } else {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) xp[c][v] = dp[c][v] = 0.f;
+            xp[c].zero();
+            dp[c].zero();
           }
         }
 #pragma unroll
@@ -248,11 +266,8 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
         const int s3 = s_row + n + 3;
         const bool v3 = s3 < g.L;                         // token n+3 exists (s3 >= 0 always here)
         const bool v0 = s_row + n >= 0;                   // token n exists
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          xw[3][v] = xp[c][v];
-          dw[3][v] = dp[c][v];
-        }
+        xp[c].get(xw[3]);
+        dp[c].get(dw[3]);
         const int r3 = (n + 3 >= g.cols) ? 2 : 1;         // row of token n+3 relative to i-1
         const int r0 = (n < 0) ? 0 : 1;                   // row of token n
         const bool own3 = n + 3 < g.cols;                 // token n+3 belongs to this row (n+3 >= 0 always)
@@ -390,7 +405,8 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
   dim3 grid(persistent_blocks((long)p.B * p.geo.rows, rg)), block(64 * nch * rg);
   size_t smem = (size_t)12 * p.d_in * 4;
   FV_CHECK(smem <= 64 * 1024, "mixer_conv_pool_bwd: d_inner %d too large", p.d_in);
-  hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC>), grid, block, smem, st, p, nch, rg);
+  if (p.geo.cols + 3 <= 17) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 17>), grid, block, smem, st, p, nch, rg);   // whole row in flight
+  else hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8>), grid, block, smem, st, p, nch, rg);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

@@ -53,7 +53,7 @@ __device__ __forceinline__ void conv_both(const ChanParams<VEC>& cp, const float
 // ------------------------------------------------------------------ conv + pool
 template <typename T, int VEC, int TJ>
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(FwdParams p) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.x, b = blockIdx.y;
   const int c0 = (wv * 64 + lane) * VEC;
   const bool act = c0 < p.d_in;
@@ -67,6 +67,14 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
   for (int j0 = 0; j0 < g.cols; j0 += TJ) {
     float x[TJ + 6][VEC];
     load_x_tile<T, VEC, TJ, 3>(xz_b, g, p.d_in, i, j0, c0, act, x);
+    RawVec<T, VEC> zr[TJ];           // gate inputs fetched with the tile, not at their use
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) {
+      if (act && j0 + jj < g.cols)
+        zr[jj].load(xz_b + (size_t)tok_mem(g, i * g.cols + j0 + jj) * 2 * p.d_in + p.d_in + c0);
+      else
+        zr[jj].zero();
+    }
 #pragma unroll
     for (int jj = 0; jj < TJ; ++jj) {
       if (j0 + jj < g.cols) {
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
 template <typename T, int VEC, int TJ>
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdParams p) {
   __shared__ float s_red[16 * TJ];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const int i = blockIdx.x, b = blockIdx.y;
   const int c0 = (wv * 64 + lane) * VEC;
   const bool act = c0 < p.d_in;
@@ -123,6 +131,14 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
   for (int j0 = 0; j0 < g.cols; j0 += TJ) {
     float x[TJ + 6][VEC];
     load_x_tile<T, VEC, TJ, 3>(xz_b, g, p.d_in, i, j0, c0, act, x);
+    RawVec<T, VEC> zr[TJ];           // gate inputs fetched with the tile, not at their use
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) {
+      if (act && j0 + jj < g.cols)
+        zr[jj].load(xz_b + (size_t)tok_mem(g, i * g.cols + j0 + jj) * 2 * p.d_in + p.d_in + c0);
+      else
+        zr[jj].zero();
+    }
     float o[TJ][VEC], s1[TJ];
 #pragma unroll
     for (int jj = 0; jj < TJ; ++jj) {
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
         int m = tok_mem(g, i * g.cols + j0 + jj);
         if (act) {
           float z[VEC], out[VEC], xh[VEC];
-          VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + p.d_in + c0, z);
+          zr[jj].get(z);
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
             xh[v] = (o[jj][v] - mean[jj]) * rstd[jj];

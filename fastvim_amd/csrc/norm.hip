@@ -35,71 +35,87 @@ __device__ __forceinline__ void st4(void* p, int dt, size_t idx, const float (&v
 
 template <int MAXK>
 __global__ __launch_bounds__(256) void add_norm_fwd_kernel(NormParams p) {
+  constexpr int RU = MAXK == 1 ? 4 : (MAXK == 2 ? 2 : 1);   // rows in flight per wave: all their loads are issued before any wait
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // scalar
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const float inv_n = 1.f / (float)p.N;
-  for (int row = wave; row < p.M; row += nwaves) {
-    const size_t base = (size_t)row * p.N;
-    const float sc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.f;
-    float v[MAXK][4];
-    float s = 0.f;
+  for (int row0 = wave * RU; row0 < p.M; row0 += nwaves * RU) {
+    float v[RU][MAXK][4], r[RU][MAXK][4];
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < p.N) {
-        ld4(p.x, p.x_dt, base + c, v[k]);
-        if (p.res) {
-          float r[4];
-          ld4(p.res, p.res_dt, base + c, r);
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u;
+      const size_t base = (size_t)row * p.N;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[k][e] = fmaf(v[k][e], sc, r[e]);
-        } else if (p.row_scale) {
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (row < p.M && c < p.N) {
+          ld4(p.x, p.x_dt, base + c, v[u][k]);
+          if (p.res) ld4(p.res, p.res_dt, base + c, r[u][k]);
+        } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[k][e] *= sc;
-        }
-        if (p.res_out) st4(p.res_out, p.ro_dt, base + c, v[k]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s += v[k][e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[k][e] = 0.f;
-      }
-    }
-    float mu = 0.f;
-    if (!p.is_rms) mu = wave_sum_uniform(s) * inv_n;
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < p.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float d = v[k][e] - mu;
-          q = fmaf(d, d, q);
+          for (int e = 0; e < 4; ++e) v[u][k][e] = 0.f;
         }
       }
     }
-    const float rstd = rsqrtf(wave_sum_uniform(q) * inv_n + p.eps);
-    if (lane == 0) {
-      p.rstd[row] = rstd;
-      if (!p.is_rms && p.mean) p.mean[row] = mu;
-    }
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < p.N) {
-        float w[4], o[4];
-        VecIO<float, 4>::load(p.w + c, w);
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u;
+      if (row >= p.M) break;
+      const size_t base = (size_t)row * p.N;
+      const float sc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.f;
+      float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu) * rstd * w[e];
-        if (p.b) {
-          float bb[4];
-          VecIO<float, 4>::load(p.b + c, bb);
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < p.N) {
+          if (p.res) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += bb[e];
+            for (int e = 0; e < 4; ++e) v[u][k][e] = fmaf(v[u][k][e], sc, r[u][k][e]);
+          } else if (p.row_scale) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][k][e] *= sc;
+          }
+          if (p.res_out) st4(p.res_out, p.ro_dt, base + c, v[u][k]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s += v[u][k][e];
         }
-        st4(p.y, p.y_dt, base + c, o);
+      }
+      float mu = 0.f;
+      if (!p.is_rms) mu = wave_sum_uniform(s) * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < p.N) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float d = v[u][k][e] - mu;
+            q = fmaf(d, d, q);
+          }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum_uniform(q) * inv_n + p.eps);
+      if (lane == 0) {
+        p.rstd[row] = rstd;
+        if (!p.is_rms && p.mean) p.mean[row] = mu;
+      }
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < p.N) {
+          float w[4], o[4];
+          VecIO<float, 4>::load(p.w + c, w);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (v[u][k][e] - mu) * rstd * w[e];
+          if (p.b) {
+            float bb[4];
+            VecIO<float, 4>::load(p.b + c, bb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += bb[e];
+          }
+          st4(p.y, p.y_dt, base + c, o);
+        }
       }
     }
   }
@@ -110,8 +126,8 @@ __global__ __launch_bounds__(256) void add_norm_fwd_kernel(NormParams p) {
 template <int MAXK>
 __global__ __launch_bounds__(256) void add_norm_bwd_kernel(NormParams p) {
   __shared__ float s_acc[4][MAXK * 256];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);   // scalar
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const float inv_n = 1.f / (float)p.N;
   float aw[MAXK][4], ab[MAXK][4];
@@ -119,56 +135,76 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(NormParams p) {
   for (int k = 0; k < MAXK; ++k)
 #pragma unroll
     for (int e = 0; e < 4; ++e) aw[k][e] = ab[k][e] = 0.f;
-  for (int row = wave; row < p.M; row += nwaves) {
-    const size_t base = (size_t)row * p.N;
-    const float rstd = p.rstd_in[row];
-    const float mu = p.is_rms ? 0.f : p.mean_in[row];
-    float xh[MAXK][4], dxh[MAXK][4];
-    float c1 = 0.f, c2 = 0.f;
+  constexpr int RU = MAXK == 1 ? 4 : (MAXK == 2 ? 2 : 1);   // rows in flight per wave
+  for (int row0 = wave * RU; row0 < p.M; row0 += nwaves * RU) {
+    float rr[RU][MAXK][4], dyv[RU][MAXK][4], gg[RU][MAXK][4];
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < p.N) {
-        float r[4], dy[4], w[4];
-        ld4(p.r, p.r_dt, base + c, r);
-        ld4(p.dy, p.dy_dt, base + c, dy);
-        VecIO<float, 4>::load(p.w + c, w);
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u;
+      const size_t base = (size_t)row * p.N;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[k][e] = (r[e] - mu) * rstd;
-          dxh[k][e] = dy[e] * w[e];
-          aw[k][e] = fmaf(dy[e], xh[k][e], aw[k][e]);
-          ab[k][e] += dy[e];
-          c1 += dxh[k][e];
-          c2 = fmaf(dxh[k][e], xh[k][e], c2);
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (row < p.M && c < p.N) {
+          ld4(p.r, p.r_dt, base + c, rr[u][k]);
+          ld4(p.dy, p.dy_dt, base + c, dyv[u][k]);
+          if (p.dres_out) ld4(p.dres_out, p.dro_dt, base + c, gg[u][k]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rr[u][k][e] = dyv[u][k][e] = 0.f;
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xh[k][e] = dxh[k][e] = 0.f;
       }
     }
-    c2 = wave_sum_uniform(c2) * inv_n;
-    c1 = p.is_rms ? 0.f : wave_sum_uniform(c1) * inv_n;
-    const float sc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.f;
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < p.N) {
-        float dr[4];
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u;
+      if (row >= p.M) break;
+      const size_t base = (size_t)row * p.N;
+      const float rstd = p.rstd_in[row];
+      const float mu = p.is_rms ? 0.f : p.mean_in[row];
+      float xh[MAXK][4], dxh[MAXK][4];
+      float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dr[e] = rstd * (dxh[k][e] - c1 - xh[k][e] * c2);
-        if (p.dres_out) {
-          float g[4];
-          ld4(p.dres_out, p.dro_dt, base + c, g);
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < p.N) {
+          float w[4];
+          VecIO<float, 4>::load(p.w + c, w);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dr[e] += g[e];
+          for (int e = 0; e < 4; ++e) {
+            xh[k][e] = (rr[u][k][e] - mu) * rstd;
+            dxh[k][e] = dyv[u][k][e] * w[e];
+            aw[k][e] = fmaf(dyv[u][k][e], xh[k][e], aw[k][e]);
+            ab[k][e] += dyv[u][k][e];
+            c1 += dxh[k][e];
+            c2 = fmaf(dxh[k][e], xh[k][e], c2);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xh[k][e] = dxh[k][e] = 0.f;
         }
-        if (p.dres_in) st4(p.dres_in, p.dri_dt, base + c, dr);
-        if (p.dx) {
-          if (p.row_scale)
+      }
+      c2 = wave_sum_uniform(c2) * inv_n;
+      c1 = p.is_rms ? 0.f : wave_sum_uniform(c1) * inv_n;
+      const float sc = p.row_scale ? p.row_scale[row / p.rows_per_scale] : 1.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dr[e] *= sc;
-          st4(p.dx, p.dx_dt, base + c, dr);
+      for (int k = 0; k < MAXK; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < p.N) {
+          float dr[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dr[e] = rstd * (dxh[k][e] - c1 - xh[k][e] * c2);
+          if (p.dres_out) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dr[e] += gg[u][k][e];
+          }
+          if (p.dres_in) st4(p.dres_in, p.dri_dt, base + c, dr);
+          if (p.dx) {
+            if (p.row_scale)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dr[e] *= sc;
+            st4(p.dx, p.dx_dt, base + c, dr);
+          }
         }
       }
     }

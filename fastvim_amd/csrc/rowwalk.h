@@ -18,6 +18,7 @@ struct Geo {
 };
 
 __device__ __forceinline__ int tok_mem(const Geo& g, int s) {
+  if (g.s_j == 1) return s;          // natural order: sequence position == memory token
   int i = s / g.cols;
   int j = s - i * g.cols;
   return i * g.s_i + j * g.s_j;
@@ -103,6 +104,51 @@ template <int VEC> struct VecIO<bf16_t, VEC> {
         if constexpr (W == 1) w = x; else w[k] = x;
       }
       *reinterpret_cast<typename raw_words<W>::type*>(p) = w;
+    }
+  }
+};
+
+// VEC channels held exactly as loaded (bf16 stays packed: half the registers while a load is in flight)
+template <typename T, int VEC> struct RawVec;
+template <int VEC> struct RawVec<float, VEC> {
+  float v[VEC];
+  __device__ __forceinline__ void load(const float* p) { VecIO<float, VEC>::load(p, v); }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+  }
+  __device__ __forceinline__ void get(float (&o)[VEC]) const {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = v[k];
+  }
+};
+template <int VEC> struct RawVec<bf16_t, VEC> {
+  static constexpr int W = (VEC + 1) / 2;
+  uint32_t w[W];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    if constexpr (VEC == 1) {
+      w[0] = *reinterpret_cast<const uint16_t*>(p);
+    } else {
+      auto r = *reinterpret_cast<const typename raw_words<W>::type*>(p);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if constexpr (W == 1) w[k] = r; else w[k] = r[k];
+      }
+    }
+  }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int k = 0; k < W; ++k) w[k] = 0u;
+  }
+  __device__ __forceinline__ void get(float (&o)[VEC]) const {
+    if constexpr (VEC == 1) {
+      o[0] = __uint_as_float(w[0] << 16);
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        o[2 * k] = __uint_as_float(w[k] << 16);
+        o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+      }
     }
   }
 };

@@ -1,0 +1,37 @@
+"""Launch each fused-mixer kernel a few times at the benchmark shape (for rocprofv3 --pmc runs)."""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import torch
+from fastvim_amd import mixer_ops as M
+from fastvim_amd.layernorm import layer_norm_fn
+B, rows, cols, d = 128, 14, 14, 192
+dtype = torch.bfloat16
+dev = "cuda"
+d_in, L, R_, N = 2 * d, rows * cols, 12, 16
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s, dt=dtype: torch.randn(*s, device=dev, generator=g).to(dt)
+xz = rn(B, L, 2 * d_in)
+cw, cwb = rn(d_in, 4, dt=torch.float32) * 0.5, rn(d_in, 4, dt=torch.float32) * 0.5
+cb, cbb = rn(d_in, dt=torch.float32) * 0.1, rn(d_in, dt=torch.float32) * 0.1
+D, Db = torch.ones(d_in, device=dev), torch.ones(d_in, device=dev)
+lnw, lnb = torch.ones(d_in, device=dev), torch.zeros(d_in, device=dev)
+Wdt = rn(d_in, R_, dt=torch.float32) * R_ ** -0.5
+bdt = torch.full((d_in,), -4.0, device=dev)
+A_log = torch.log(torch.arange(1, N + 1, device=dev, dtype=torch.float32)).repeat(d_in, 1).contiguous()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+for _ in range(n):
+    xc = M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0)
+    x_dbl = rn(2, B * rows, R_ + 2 * N)
+    yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log)
+    gout, xhat, mean, rstd = M.combine_fwd(xz, yc, cw, cb, cwb, cbb, D, Db, lnw, lnb, 1e-5, rows, cols, False)
+    dg = rn(B, L, d_in)
+    dxz = torch.empty_like(xz)
+    d_o, dyc, _ = M.combine_bwd(dg, xz, xhat, lnw, lnb, rstd, dxz, rows, cols, False)
+    dxc, dxd, _ = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc)
+    M.conv_pool_bwd(xz, d_o, dxc, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 0, 1.0)
+    hid, res = rn(B, L, d), torch.randn(B, L, d, device=dev, generator=g)
+    nw = torch.ones(d, device=dev, requires_grad=True)
+    hid.requires_grad_(); res.requires_grad_()
+    y, ro = layer_norm_fn(hid, nw, None, residual=res, eps=1e-5, prenorm=True, residual_in_fp32=True, is_rms_norm=True)
+    torch.autograd.backward((y, ro), (torch.randn_like(y), torch.randn_like(ro)))
+torch.cuda.synchronize()
