@@ -12,11 +12,13 @@ buckets + autocast casts + AccumulateGrad nodes, imagenet_classification/train.p
   each: the reduction kernel accumulates straight into ``grad_flat`` and autograd never sees those
   gradients (no AccumulateGrad launches, no strided adds).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from .layernorm import RMSNorm
-from .mamba_simple_faster import Mamba
+from .mamba_simple_faster import Mamba, _SideStream
 from .mixer_ops import defer_reductions, flush_reductions
 
 # per-mixer parameter order; each group is one contiguous region matching a kernel's partial layout
@@ -90,14 +92,20 @@ class FlatTrainingState:
                     mod.weight._fv_direct = True     # my backward kernels may accumulate into .grad directly
         self.refresh_shadow()
         defer_reductions(True)
+        # weight-gradient GEMMs on a second stream (joined in finish_backward): measured neutral-to-slower
+        # on MI355X under graph replay (12.35 vs 12.04 ms/step), so opt-in only
+        _SideStream.enabled = os.environ.get("FASTVIM_WGRAD_STREAM", "0") == "1"
 
     # ------------------------------------------------------------------ per-step operations
     def zero_grad(self):
+        _SideStream.join()
         flush_reductions()
         self.grad_flat.zero_()
 
     def finish_backward(self):
-        """Issue the queued gradient reductions; call after loss.backward(), before reading any .grad."""
+        """Join the weight-gradient stream and issue the queued gradient reductions; call after
+        loss.backward(), before reading any .grad."""
+        _SideStream.join()
         flush_reductions()
 
     def refresh_shadow(self):
@@ -109,6 +117,7 @@ class FlatTrainingState:
 
     def allreduce_mean_(self):
         """Sum the flat gradient across ranks (RCCL) and divide by the world size (torch DDP semantics)."""
+        _SideStream.join()
         flush_reductions()
         ws = self.world_size
         if ws == 1:

@@ -32,7 +32,7 @@ def gemm_nn(a, b, out_dtype=torch.bfloat16):
     return c
 
 
-def gemm_tn(x, y, splits=1, out=None, accumulate=False):
+def gemm_tn(x, y, splits=1, out=None, accumulate=False, defer=True):
     """x (Kd, M)^T @ y (Kd, N) -> (M, N) fp32: weight gradient, reduction over the leading (token) dim
     cut into `splits` slices whose fp32 partials are summed in fixed order (deterministic split-K)."""
     Kd, M = x.shape
@@ -42,6 +42,7 @@ def gemm_tn(x, y, splits=1, out=None, accumulate=False):
     part = torch.empty(splits, M, N, device=x.device, dtype=torch.float32)
     _call(x, y, part, None, M, N, Kd, x.stride(0), y.stride(0), N, 1, 1, splits)
     if out is not None:
-        reduce_partials(part, splits, out=out, accumulate=accumulate)
+        # defer=False keeps the reduction on the stream the GEMM ran on (weight-gradient side stream)
+        reduce_partials(part, splits, out=out, accumulate=accumulate, defer=defer)
         return None
     return part[0] if splits == 1 else reduce_partials(part, splits)

@@ -72,12 +72,41 @@ def linear_dgrad(g2, w_c):
     return g2 @ w_c
 
 
+class _SideStream:
+    """Weight-gradient GEMMs are off the critical path of backward: in flat-training mode they are
+    enqueued on a second HIP stream (fork after the producer, join in finish_backward) so they overlap
+    the latency-bound row-walker / scan kernels of the main chain.  Operands are kept referenced
+    until the join, so the caching allocator cannot hand their memory to main-stream kernels."""
+    enabled = False
+    stream = None
+    pending = []
+
+    @classmethod
+    def run(cls, fn, *keep):
+        if not cls.enabled:
+            return fn()
+        cur = torch.cuda.current_stream()
+        if cls.stream is None:
+            cls.stream = torch.cuda.Stream()
+        cls.stream.wait_stream(cur)
+        with torch.cuda.stream(cls.stream):
+            out = fn()
+        cls.pending.append(keep)
+        return out
+
+    @classmethod
+    def join(cls):
+        if cls.stream is not None and cls.pending:
+            torch.cuda.current_stream().wait_stream(cls.stream)
+        cls.pending = []
+
+
 def linear_wgrad(g2, a2, W=None, splits=28):
     """dW (N, K) fp32 = g2 (M, N)^T a2 (M, K), deterministic split-K; accumulates into W's flat .grad if present."""
     if _mfma_ok(g2, a2) and g2.shape[1] % 8 == 0 and a2.shape[1] % 8 == 0 and g2.shape[0] % 64 == 0:
         gdir = _direct_grad(W) if W is not None else None
         if gdir is not None:
-            gemm_tn(g2, a2, splits=splits, out=gdir.view(-1), accumulate=True)
+            gemm_tn(g2, a2, splits=splits, out=gdir.view(-1), accumulate=True, defer=not _SideStream.enabled)
             return None
         return gemm_tn(g2, a2, splits=splits)
     return _wgrad(g2, a2, W)
@@ -170,7 +199,7 @@ class FastVimMixerFn(torch.autograd.Function):
             dout = dout.to(cdt).contiguous()
             do2 = dout.view(B * Ltok, d)
             dg = linear_dgrad(do2, _shadow(W_out, cdt))                                  # (B*L, d_in)
-            dW_out = linear_wgrad(do2, g.view(B * Ltok, d_in), W_out)
+            dW_out = _SideStream.run(lambda: linear_wgrad(do2, g.view(B * Ltok, d_in), W_out), do2, g)
             db_out = do2.float().sum(0) if ctx.has_bias[1] else None
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
@@ -190,7 +219,7 @@ class FastVimMixerFn(torch.autograd.Function):
                                  pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
             dhidden = linear_dgrad(dxz2, _shadow(W_in, cdt)).view(B, Ltok, d).to(ctx.in_dtype)
-            dW_in = linear_wgrad(dxz2, h_c.view(B * Ltok, d), W_in)
+            dW_in = _SideStream.run(lambda: linear_wgrad(dxz2, h_c.view(B * Ltok, d), W_in), dxz2, h_c)
             db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
         has_ln = ln_w is not None
         n4 = 4 * d_in

@@ -96,11 +96,11 @@ def flush_reductions():
     _Deferred.flush()
 
 
-def reduce_partials(part, n_partials, out=None, accumulate=False):
+def reduce_partials(part, n_partials, out=None, accumulate=False, defer=True):
     """Fixed-order sum over the leading dim of a (n_partials, ...) fp32 buffer.  ``out`` (contiguous
     fp32, same element count) receives the result; ``accumulate`` adds into it instead (and may be
     deferred, see _Deferred)."""
-    if out is not None and accumulate and _Deferred.enabled:
+    if out is not None and accumulate and defer and _Deferred.enabled:
         assert out.numel() == part.numel() // n_partials and out.is_contiguous() and out.dtype == torch.float32
         _Deferred.add(part, out, n_partials)
         return out

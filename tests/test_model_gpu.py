@@ -156,6 +156,8 @@ def test_flat_training_state_matches_autograd(amp):
     o2 = torch.optim.AdamW(m2.parameters(), lr=1e-2, fused=True)
     o1.step(); o2.step(); flat.refresh_shadow()
     from fastvim_amd.mixer_ops import defer_reductions
+    from fastvim_amd.mamba_simple_faster import _SideStream
     defer_reductions(False)
+    _SideStream.enabled = False
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
         assert torch.equal(m1(x), m2(x))
