@@ -311,7 +311,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "images_per_sec_per_gpu": round(value / world, 1),
             "config": {"workload": f"FastVim-{args.model} {args.img}x{args.img} bs={args.batch}/GPU {args.dtype} "
-                                   f"training step, synthetic ImageNet tensors (BASELINE configs[1])",
+                                   f"training step, synthetic ImageNet tensors"
+                                   + (" (BASELINE configs[1])" if (args.model, args.img, args.batch) == ("T", 224, 128) else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "hip_graph": use_graph, "optimizer_in_step": True, "final_loss": round(loss_val, 4)},
         }

@@ -404,7 +404,12 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
   const int rg = rg_convpool(p.d_in, VEC);
   dim3 grid(persistent_blocks((long)p.B * p.geo.rows, rg)), block(64 * nch * rg);
   size_t smem = (size_t)12 * p.d_in * 4;
-  FV_CHECK(smem <= 64 * 1024, "mixer_conv_pool_bwd: d_inner %d too large", p.d_in);
+  FV_CHECK(smem <= 160 * 1024, "mixer_conv_pool_bwd: d_inner %d too large", p.d_in);
+  if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
+    static bool done17 = false, done8 = false;
+    if (!done17) { (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done17 = true; }
+    if (!done8) { (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done8 = true; }
+  }
   if (p.geo.cols + 3 <= 17) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 17>), grid, block, smem, st, p, nch, rg);   // whole row in flight
   else hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8>), grid, block, smem, st, p, nch, rg);
   FV_LAUNCH_CHECK();

@@ -147,3 +147,37 @@ def test_mixer_full_size_deterministic_and_linear_in_out_proj():
         m.out_proj.weight.mul_(2.0)
         y2 = m(h)
     assert _err(y2, 2 * y1) <= 1e-5 * max(1.0, y2.abs().max().item())
+
+
+@pytest.mark.parametrize("d_model,grid", [(384, (6, 7)), (768, (4, 14)), (96, (5, 3)), (512, (3, 16))])
+def test_mixer_wide_models_vs_oracle(d_model, grid):
+    """FastVim-S / -B widths (2 and 4 waves per pooling row, cross-wave LayerNorm statistics) and
+    widths that take the generic lane mapping, fp32, forward + all gradients against the fp64 oracle."""
+    from fastvim_amd.mamba_simple_faster import Mamba
+    from oracle import fastvim_mixer_oracle
+    torch.manual_seed(d_model)
+    m = Mamba(d_model, token_size=list(grid)).cuda()
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if n in ("D", "D_b", "layernorm.weight") or n.endswith("bias"):
+                p_.add_(0.1 * torch.randn_like(p_))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    Ltok = grid[0] * grid[1]
+    h = torch.randn(2, Ltok, d_model)
+    for transposed in (False, True):
+        m.zero_grad(set_to_none=True)
+        rows, cols = grid
+        perm = (lambda t: t.reshape(2, rows, cols, -1).transpose(1, 2).reshape(2, Ltok, -1)) if transposed else (lambda t: t)
+        hg = perm(h).contiguous().cuda().requires_grad_()
+        y = m(hg, transposed_grid=transposed)
+        p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+        hc = h.clone().requires_grad_()
+        yref = fastvim_mixer_oracle(p, hc, grid, compute_dtype=F64, out_dtype=F64)
+        assert _err(y, perm(yref)) <= 2e-5 * max(1.0, yref.abs().max().item()), _err(y, perm(yref))
+        g = torch.randn(2, Ltok, d_model)
+        y.backward(perm(g).contiguous().cuda())
+        yref.backward(g.double())
+        assert _err(hg.grad, perm(hc.grad)) <= 5e-5 * max(1.0, hc.grad.abs().max().item())
+        for n, q in m.named_parameters():
+            e = _err(q.grad, p[n].grad)
+            assert e <= 2e-4 * max(1.0, p[n].grad.abs().max().item()), (d_model, transposed, n, e, p[n].grad.abs().max().item())
