@@ -146,7 +146,7 @@ def kernel_table(B, rows, cols, d, depth, dtype):
 
 
 # --------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=15.0):
     """The CPU oracle (port of the reference's pure-PyTorch FastVim path incl. selective_scan_ref)
     running the SAME workload -- FastVim-T 224x224 fwd+bwd, fp32 -- on a bounded sample."""
     from oracle import fastvim_forward_oracle, make_state_dict, selective_scan_ref_port
@@ -172,7 +172,7 @@ def cpu_baseline(seconds_budget=25.0):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el + el / n > seconds_budget - warm_s or n >= 4:
+        if el + el / n > seconds_budget - warm_s or n >= 24:
             break
     ips = n * bs / el
     # the scan op alone at the benchmark shape (B, d_in, Lc, N) = (128, 384, 14, 16)
@@ -320,9 +320,16 @@ def main():
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
             dom = max((k for k in kt if k not in ("scan_fwd", "scan_bwd")), key=lambda k: kt[k]["us_per_step"])
             out["kernels"] = kt
+            traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                if (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16") and dom in pm:
+                    traffic = pm[dom]["traffic_bytes"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kt[dom]["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
-                               "traffic": None, "avg_us": kt[dom]["us"],
+                               "traffic": traffic, "avg_us": kt[dom]["us"],
                                "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
