@@ -41,6 +41,15 @@ struct GemmParams {
   long c_split_stride;   // elements between split-K partials
 };
 
+// KS tiles: rows (k) are EXT*2 bytes = a multiple of the 256-byte bank row, and a transposing read
+// touches 8 different k rows at one column per 32-lane half -> 8-way conflict.  XOR the 32-byte
+// column chunk with a per-row code so those 8 rows land on 8 different chunks.
+template <int EXT>
+__device__ __forceinline__ int ks_swz(int k) {
+  const int code = (k & 3) | (((k >> 3) & 1) << 2);
+  return EXT >= 128 ? code : (code & (EXT / 16 - 1));
+}
+
 // ---- staging: 256 threads move a (ROWS x 64) KC tile or a (64 x COLS) KS tile, 16 B per access ----
 template <int MODE, int EXT>   // EXT = tile extent along the non-K dim (128 or 256 or 64)
 struct Stage {
@@ -73,7 +82,8 @@ struct Stage {
         const int r = e >> 3, c = e & 7;
         off = r * 128 + ((c ^ (r & 7)) << 4);
       } else {
-        off = e * 16;
+        const int k = e / (EXT / 8), cb = (e % (EXT / 8)) * 16;          // byte column of this 16-B vector
+        off = k * (EXT * 2) + ((((cb >> 5) ^ ks_swz<EXT>(k)) << 5) | (cb & 16));
       }
       *reinterpret_cast<u32x4*>(lds + off) = v[i];
     }
@@ -91,8 +101,10 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lan
     const int k0 = ks * 32 + g * 8;
     const int col = blk * 16 + pp * 4;
     typedef s4v __attribute__((address_space(3))) * lptr;
-    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + ((k0 + q) * EXT + col) * 2));
-    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + ((k0 + 4 + q) * EXT + col) * 2));
+    (void)col;
+    const int kl = k0 + q, kh = k0 + 4 + q;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + kl * (EXT * 2) + ((blk ^ ks_swz<EXT>(kl)) << 5) + pp * 8));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + kh * (EXT * 2) + ((blk ^ ks_swz<EXT>(kh)) << 5) + pp * 8));
     typedef short s8v __attribute__((ext_vector_type(8)));
     s8v t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, t);
@@ -164,6 +176,57 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   }
   // epilogue: acc[a][b][j] = C[m = m0 + wm*64 + b*16 + (lane&15)][n = n0 + wn*64 + a*16 + (lane>>4)*4 + j]
   const long zoff = (long)blockIdx.z * p.c_split_stride;
+  if (p.bias) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bj = (n + j < p.N) ? p.bias[n + j] : 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b][j] += bj;
+      }
+    }
+  }
+  if (!p.c_fp32) {
+    // bf16 C: the wave's 64x64 tile goes through LDS (two 32-row halves, 144-byte padded rows) so that
+    // every global store is 16 B per lane and a wave instruction writes 8 whole 128-byte row segments
+    constexpr int RS = 144;
+    __syncthreads();                                  // all waves are done reading the operand tiles
+    char* my = smem + wv * (32 * RS);
+    bf16_t* Cb = (bf16_t*)p.C + zoff;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int b = 2 * h + bb;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const f32x4 v = acc[a][b];
+          uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<uint2*>(my + (bb * 16 + (lane & 15)) * RS + (a * 16 + (lane >> 4) * 4) * 2) = pk;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = i * 64 + lane, r = idx >> 3, ch = idx & 7;
+        const int m = m0 + wm * 64 + h * 32 + r, n = n0 + wn * 64 + ch * 8;
+        if (m < p.M && n < p.N) {
+          const u32x4 q = *reinterpret_cast<const u32x4*>(my + r * RS + ch * 16);
+          bf16_t* dst = Cb + (long)m * p.ldc + n;
+          if (n + 8 <= p.N && (((uintptr_t)dst) & 15) == 0) {
+            *reinterpret_cast<u32x4*>(dst) = q;
+          } else {
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&q);
+            for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = e[j];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const int m = m0 + wm * 64 + b * 16 + (lane & 15);
@@ -172,26 +235,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     for (int a = 0; a < 4; ++a) {
       const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
-      f32x4 v = acc[a][b];
-      if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < p.N) v[j] += p.bias[n + j];
-      }
-      if (p.c_fp32) {
-        float* dst = (float*)p.C + zoff + (long)m * p.ldc + n;
-        if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
-        else
-          for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = v[j];
-      } else {
-        bf16_t* dst = (bf16_t*)p.C + zoff + (long)m * p.ldc + n;
-        if (n + 3 < p.N) {
-          uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<uint2*>(dst) = pk;
-        } else {
-          for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = __float2bfloat16(v[j]);
-        }
-      }
+      const f32x4 v = acc[a][b];
+      float* dst = (float*)p.C + zoff + (long)m * p.ldc + n;
+      if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
+      else
+        for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = v[j];
     }
   }
 }

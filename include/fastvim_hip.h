@@ -189,6 +189,8 @@ int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidual_out, int
  * ---------------------------------------------------------------------- */
 int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                  long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits, fv_stream_t stream);
+/* tuning/test hook: -1 = heuristic, 0 = single LDS buffer, 1 = double buffer */
+void fv_gemm_force_dbuf(int mode);
 
 #ifdef __cplusplus
 }
