@@ -12,6 +12,8 @@
 //
 // The flip()s of the reference never happen: the backward direction is the anti-causal
 // conv on the original order and a scan over pooled rows in descending order.
+#include <stdlib.h>
+
 #include "mixer_common.h"
 
 namespace {
@@ -243,6 +245,8 @@ int launch_fwd_kernels(int which, const FwdParams& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_vec(int which, const FwdParams& p, hipStream_t st) {
+  static const int force = getenv("FASTVIM_FWD_VEC") ? atoi(getenv("FASTVIM_FWD_VEC")) : 0;   // tuning hook
+  if (force == 2 && p.d_in % 128 == 0 && p.d_in <= 8 * 128) return launch_fwd_kernels<T, 2>(which, p, st);
   if (p.d_in % 384 == 0) return launch_fwd_kernels<T, 6>(which, p, st);
   if (p.d_in % 256 == 0) return launch_fwd_kernels<T, 4>(which, p, st);
   return launch_fwd_kernels<T, 1>(which, p, st);

@@ -1,0 +1,114 @@
+// Adjoint of the x_proj linear layer of both scan directions, fused with the sum over the scan
+// backward's channel-chunk partials.  Replaces, per block and per step, the einsum / addmm chain of
+// selective_scan_interface.py:698-734:
+//     dx_dbl = sum_chunks dx_dbl_partial                              (was fv_reduce_partials)
+//     d x_proj.weight[dir] += dx_dbl[dir]^T @ xc[dir]                 (was a cast + baddbmm_)
+//     dxc[dir] = dxc_scan[dir] + dx_dbl[dir] @ x_proj.weight[dir]     (was a copy + baddbmm)
+// One lane per channel d: it keeps column d of the weight (W values) and W accumulators of the
+// weight gradient in registers; the dx_dbl rows of the block's row slice are LDS broadcasts.  Blocks
+// emit per-slice partials of the weight gradient for the fixed-order reduction (no atomics).
+#include "common.h"
+
+namespace {
+
+struct XprojParams {
+  const float* dxdbl_part;   // (nchunks, 2, M, W) fp32
+  const void* xc;            // (2, M, d_in)
+  const float* Wx[2];        // (W, d_in) fp32
+  float* dxc;                // (2, M, d_in) fp32: in = through-the-scan part, out = total
+  float* dW_part;            // (nslices, 2, W, d_in) fp32
+  int nchunks, M, d_in, rows_per_block;
+};
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
+  extern __shared__ __attribute__((aligned(16))) float s_dx[];     // rows_per_block * W
+  const int dir = blockIdx.z, slice = blockIdx.y;
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = d < p.d_in;
+  const int dd = act ? d : 0;
+  const int m0 = slice * p.rows_per_block;
+  const int nr = min(p.rows_per_block, p.M - m0);
+  // stage the slice's dx_dbl rows, summing the channel-chunk partials in fixed order
+  for (int e = threadIdx.x; e < nr * W; e += blockDim.x) {
+    float t = 0.f;
+    for (int c = 0; c < p.nchunks; ++c)
+      t += p.dxdbl_part[(((size_t)c * 2 + dir) * p.M + m0) * W + e];
+    s_dx[e] = t;
+  }
+  __syncthreads();
+  float wcol[W], acc[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    wcol[c] = p.Wx[dir][(size_t)c * p.d_in + dd];
+    acc[c] = 0.f;
+  }
+  const T* xc = (const T*)p.xc + ((size_t)dir * p.M + m0) * p.d_in + dd;
+  float* dxc = p.dxc + ((size_t)dir * p.M + m0) * p.d_in + dd;
+  for (int r0 = 0; r0 < nr; r0 += 4) {
+    float xv[4], base[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = min(r0 + k, nr - 1);
+      xv[k] = io<T>::ld(xc + (size_t)r * p.d_in);
+      base[k] = dxc[(size_t)r * p.d_in];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (r0 + k < nr) {
+        const float* row = s_dx + (r0 + k) * W;
+        float o = base[k];
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const float g = row[c];
+          o = fmaf(g, wcol[c], o);
+          acc[c] = fmaf(g, xv[k], acc[c]);
+        }
+        if (act) dxc[(size_t)(r0 + k) * p.d_in] = o;
+      }
+    }
+  }
+  if (act) {
+    float* dst = p.dW_part + (((size_t)slice * 2 + dir) * W) * p.d_in + d;
+#pragma unroll
+    for (int c = 0; c < W; ++c) dst[(size_t)c * p.d_in] = acc[c];
+  }
+}
+
+}  // namespace
+
+extern "C" int fv_mixer_xproj_bwd_slices(int M) { return fv_cdiv(M, 16); }
+
+extern "C" int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
+                                  const float* x_proj_w_b, float* dxc, float* dW_partials, int M, int d_inner,
+                                  int width, int dtype, fv_stream_t stream) {
+  FV_CHECK(dx_dbl_partials && xc && x_proj_w && x_proj_w_b && dxc && dW_partials, "mixer_xproj_bwd: null pointer");
+  FV_CHECK(M > 0 && d_inner > 0 && nchunks > 0, "mixer_xproj_bwd: empty dimension");
+  FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_xproj_bwd: dtype must be fp32 or bf16");
+  XprojParams p{};
+  p.dxdbl_part = dx_dbl_partials; p.xc = xc; p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.dxc = dxc;
+  p.dW_part = dW_partials; p.nchunks = nchunks; p.M = M; p.d_in = d_inner; p.rows_per_block = 16;
+  const int bs = d_inner >= 256 ? 128 : 64;
+  dim3 grid(fv_cdiv(d_inner, bs), fv_mixer_xproj_bwd_slices(M), 2), block(bs);
+  hipStream_t st = (hipStream_t)stream;
+#define FV_XP(TT, WW) hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW>), grid, block, (size_t)16 * WW * 4, st, p)
+#define FV_XPD(WW) do { if (dtype == FV_F32) FV_XP(float, WW); else FV_XP(bf16_t, WW); } while (0)
+  switch (width) {   // dt_rank + 2 * d_state for d_model = 192 / 384 / 768 / 1024 / 1280 (d_state 16) and small test models
+    case 44: FV_XPD(44); break;
+    case 56: FV_XPD(56); break;
+    case 80: FV_XPD(80); break;
+    case 96: FV_XPD(96); break;
+    case 112: FV_XPD(112); break;
+    case 34: FV_XPD(34); break;
+    case 36: FV_XPD(36); break;
+    case 38: FV_XPD(38); break;
+    case 64: FV_XPD(64); break;
+    default:
+      fv_set_error("mixer_xproj_bwd: x_dbl width %d is not built", width);
+      return FV_ERR_UNSUPPORTED;
+  }
+#undef FV_XPD
+#undef FV_XP
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}

@@ -205,16 +205,23 @@ class FastVimMixerFn(torch.autograd.Function):
             dxz = torch.empty_like(xz)
             d_o, dyc, p1 = M.combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed,
                                          grad_out=fv.get("ln_grad") if ln_w is not None else None)
+            W_ = x_dbl.shape[-1]
+            fused_xproj = W_ in M.XPROJ_WIDTHS
             dxc, dx_dbl, ps = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
-                                         grad_out=fv.get("scan_grad"))
-            # x_proj adjoint (selective_scan_interface.py:726-734), both directions batched, fp32
-            xc2 = xc.view(2, B * rows, d_in)
-            if "Wx2_grad" in fv:
-                fv["Wx2_grad"].baddbmm_(dx_dbl.transpose(1, 2), xc2.float())
-                dWx2 = (None, None)
+                                         grad_out=fv.get("scan_grad"), keep_chunks=fused_xproj)
+            # x_proj adjoint (selective_scan_interface.py:726-734), both directions
+            if fused_xproj:
+                dWx2 = M.xproj_bwd(dx_dbl, xc, Wx2[0], Wx2[1], dxc, grad_out=fv.get("Wx2_grad"))
+                if dWx2 is None:
+                    dWx2 = (None, None)
             else:
-                dWx2 = torch.bmm(dx_dbl.transpose(1, 2), xc2.float())                    # (2, R+2N, d_in)
-            dxc = torch.baddbmm(dxc.view(2, B * rows, d_in), dx_dbl, Wx2)                # + dx_dbl @ Wx
+                xc2 = xc.view(2, B * rows, d_in)
+                if "Wx2_grad" in fv:
+                    fv["Wx2_grad"].baddbmm_(dx_dbl.transpose(1, 2), xc2.float())
+                    dWx2 = (None, None)
+                else:
+                    dWx2 = torch.bmm(dx_dbl.transpose(1, 2), xc2.float())                # (2, R+2N, d_in)
+                dxc = torch.baddbmm(dxc.view(2, B * rows, d_in), dx_dbl, Wx2)            # + dx_dbl @ Wx
             p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
                                  pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)

@@ -134,7 +134,7 @@ def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed, gra
     return d_o, dyc, reduce_partials(part, nb)      # (2, d_in): [dln_w, dln_b]
 
 
-def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_out=None):
+def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_out=None, keep_chunks=False):
     """Returns (dxc, dx_dbl, pr) with pr (2, d_in*(N+R+1)) = per direction [dA_log | d dt_w | d dt_bias];
     when ``grad_out`` (flat fp32 view of exactly that layout) is given, the sums are accumulated into
     it instead and pr is None."""
@@ -155,7 +155,8 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
         L.ptr(A_log_b), L.ptr(dyc), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(part),
         L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
     L.check(rc, "mixer_scan_bwd")
-    dx_dbl = dx_dbl[0] if nchunks == 1 else reduce_partials(dx_dbl, nchunks)
+    if not keep_chunks:       # keep_chunks: the x_proj adjoint kernel sums the chunk partials itself
+        dx_dbl = dx_dbl[0] if nchunks == 1 else reduce_partials(dx_dbl, nchunks)
     if grad_out is not None:
         reduce_partials(part, B, out=grad_out, accumulate=True)
         return dxc, dx_dbl, None
@@ -181,3 +182,24 @@ def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz,
         reduce_partials(part, nb, out=grad_out, accumulate=True)
         return None
     return reduce_partials(part, nb)
+
+
+XPROJ_WIDTHS = (44, 56, 80, 96, 112, 34, 36, 38, 64)
+
+
+def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None):
+    """dxc (2, B, Lc, d_in) fp32 += dx_dbl @ Wx (in place); returns d x_proj weights (2, W, d_in) fp32, or
+    accumulates them into ``grad_out`` (flat view of that shape) and returns None."""
+    nchunks, _, Mrows, W = dx_dbl_chunks.shape
+    d_in = xc.shape[-1]
+    lib = L.lib()
+    ns = lib.fv_mixer_xproj_bwd_slices(L.i32(Mrows))
+    part = torch.empty(ns, 2, W, d_in, device=xc.device, dtype=torch.float32)
+    rc = lib.fv_mixer_xproj_bwd(L.ptr(dx_dbl_chunks), L.i32(nchunks), L.ptr(xc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(dxc),
+                                L.ptr(part), L.i32(Mrows), L.i32(d_in), L.i32(W), L.i32(L.dtype_code(xc.dtype)),
+                                L.stream_of(xc))
+    L.check(rc, "mixer_xproj_bwd")
+    if grad_out is not None:
+        reduce_partials(part, ns, out=grad_out.view(-1), accumulate=True)
+        return None
+    return reduce_partials(part, ns)

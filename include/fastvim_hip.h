@@ -189,8 +189,17 @@ int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidual_out, int
  * ---------------------------------------------------------------------- */
 int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                  long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits, fv_stream_t stream);
-/* tuning/test hook: -1 = heuristic, 0 = single LDS buffer, 1 = double buffer */
-void fv_gemm_force_dbuf(int mode);
+
+/* Adjoint of x_proj for both directions, fused with the sum of the scan backward's chunk partials
+ * (replaces the einsum/addmm chain of selective_scan_interface.py:698-734):
+ *   dx_dbl = sum_c dx_dbl_partials[c];  dxc += dx_dbl @ W;  dW_partials[slice] = dx_dbl[slice]^T @ xc[slice].
+ * dx_dbl_partials (nchunks, 2, M, width) fp32; xc (2, M, d_inner) storage dtype; W (width, d_inner) fp32;
+ * dxc (2, M, d_inner) fp32 in/out; dW_partials (fv_mixer_xproj_bwd_slices(M), 2, width, d_inner) fp32.
+ * Returns FV_ERR_UNSUPPORTED for a width that is not built (the host then uses library GEMMs). */
+int fv_mixer_xproj_bwd_slices(int M);
+int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
+                       const float* x_proj_w_b, float* dxc, float* dW_partials, int M, int d_inner, int width,
+                       int dtype, fv_stream_t stream);
 
 #ifdef __cplusplus
 }
