@@ -221,7 +221,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
-    from fastvim_amd.flat import FlatTrainingState
+    from fastvim_amd.flat import FlatAdamW, FlatTrainingState
 
     torch.manual_seed(1234)                    # identical init on every rank (DDP broadcast equivalent)
     drop_path = {"T": 0.05, "S": 0.15, "B": 0.4}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
@@ -230,7 +230,10 @@ def main():
     x = torch.randn(args.batch, 3, args.img, args.img, generator=gen).to(dev)
     tgt = soft_targets(args.batch, 1000, gen, dev)
     flat = FlatTrainingState(model)      # flat fp32 params / grads + bf16 shadow weights
-    opt = torch.optim.AdamW(param_groups(model, 0.05), lr=1e-3, betas=(0.9, 0.999), fused=True, capturable=True)
+    no_decay = {n for n, p in model.named_parameters()
+                if p.ndim <= 1 or n.endswith(".bias") or n in model.no_weight_decay() or getattr(p, "_no_weight_decay", False)}
+    # one fused kernel: AdamW (the reference recipe's two param groups) + ModelEmaV2 lerp + bf16 shadow refresh
+    opt = FlatAdamW(flat, model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05, no_decay=no_decay, ema_decay=0.9999)
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(5678 + rank)             # per-rank DropPath streams
 
@@ -252,7 +255,6 @@ def main():
                 fwd_bwd()
                 if world == 1:
                     opt.step()
-                    flat.refresh_shadow()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -260,21 +262,18 @@ def main():
             loss_buf = fwd_bwd()
             if world == 1:
                 opt.step()
-                flat.refresh_shadow()
 
         def step():
             graph.replay()
             if world > 1:
                 flat.allreduce_mean_()
                 opt.step()
-                flat.refresh_shadow()
             return loss_buf
     else:
         def step():
             l = fwd_bwd()
             flat.allreduce_mean_()
             opt.step()
-            flat.refresh_shadow()
             return l
 
     for _ in range(args.warmup):
@@ -305,7 +304,7 @@ def main():
         gs = args.img // 16
         d = {"T": 192, "S": 384, "B": 768}[args.model]
         out = {
-            "metric": "images/sec FastVim-%s %dpx bs=%d/GPU fwd+bwd (+all-reduce +AdamW), whole job" % (args.model, args.img, args.batch),
+            "metric": "images/sec FastVim-%s %dpx bs=%d/GPU fwd+bwd (+all-reduce +AdamW +EMA), whole job" % (args.model, args.img, args.batch),
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -12,11 +12,13 @@ buckets + autocast casts + AccumulateGrad nodes, imagenet_classification/train.p
   each: the reduction kernel accumulates straight into ``grad_flat`` and autograd never sees those
   gradients (no AccumulateGrad launches, no strided adds).
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
+from . import _lib as L
 from .layernorm import RMSNorm
 from .mamba_simple_faster import Mamba, _SideStream
 from .mixer_ops import defer_reductions, flush_reductions
@@ -132,3 +134,45 @@ class FlatTrainingState:
             else:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         self.grad_flat.div_(ws)
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics as ONE HIP kernel over a FlatTrainingState (csrc/optim.hip): AdamW
+    update, optional EMA of the weights (timm ModelEmaV2) and the bf16 shadow refresh in a single pass.
+    ``no_decay`` is a set of parameter names excluded from weight decay (reference recipe:
+    imagenet_classification/utils.py:52-69).  ``lr`` may be changed between steps with ``set_lr`` --
+    it lives in device memory, so a captured HIP graph replays with the new value."""
+
+    def __init__(self, flat, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, no_decay=(),
+                 ema_decay=None):
+        self.flat = flat
+        dev = flat.param_flat.device
+        n = flat.param_flat.numel()
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.ema = flat.param_flat.clone() if ema_decay is not None else None
+        self.ema_decay = float(ema_decay or 0.0)
+        mask = torch.zeros(n, dtype=torch.uint8)
+        named = dict(model.named_parameters())
+        no_decay = set(no_decay)
+        for name, off in flat.offsets.items():
+            p = named[name]
+            if name not in no_decay:
+                mask[off:off + p.numel()] = 1
+        self.decay_mask = mask.to(dev)
+        self.lr = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
+        self.step_t = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(lr))
+
+    def step(self):
+        f = self.flat
+        rc = L.lib().fv_adamw_flat(
+            L.ptr(f.param_flat), L.ptr(f.grad_flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(self.ema),
+            L.ptr(f.shadow_flat), L.ptr(self.decay_mask), L.ptr(self.lr), L.ptr(self.step_t),
+            ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
+            ctypes.c_float(self.weight_decay), ctypes.c_float(self.ema_decay), ctypes.c_size_t(f.param_flat.numel()),
+            L.stream_of(f.param_flat))
+        L.check(rc, "adamw_flat")

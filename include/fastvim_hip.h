@@ -201,6 +201,18 @@ int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, const void* xc
                        const float* x_proj_w_b, float* dxc, float* dW_partials, int M, int d_inner, int width,
                        int dtype, fv_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Fused AdamW (decoupled weight decay, bias correction; torch.optim.AdamW semantics) over a flat fp32
+ * parameter buffer, optionally updating an EMA copy (timm ModelEmaV2: ema = d*ema + (1-d)*p) and the
+ * bf16 shadow weights in the same pass.  Replaces the optimizer + EMA + autocast casts of the
+ * reference step (imagenet_classification/supervised_imagenet.py:134-147, 270-276).
+ * decay_mask: one byte per element (1 = weight decay applies).  lr, step: device scalars (fp32);
+ * step is incremented by the call.  n % 4 == 0.
+ * ---------------------------------------------------------------------- */
+int fv_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema,
+                  void* shadow_bf16, const uint8_t* decay_mask, const float* lr, float* step, float beta1,
+                  float beta2, float eps, float weight_decay, float ema_decay, size_t n, fv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,3 +161,42 @@ def test_flat_training_state_matches_autograd(amp):
     _SideStream.enabled = False
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
         assert torch.equal(m1(x), m2(x))
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """fv_adamw_flat == torch.optim.AdamW (two param groups) for several steps, + EMA + bf16 shadow."""
+    import copy
+    from fastvim_amd.flat import FlatAdamW, FlatTrainingState
+    torch.manual_seed(0)
+    m1 = _tiny((64, 64), drop_path_rate=0.0).cuda().train()
+    m2 = copy.deepcopy(m1)
+    flat = FlatTrainingState(m2)
+    no_decay = {n for n, p in m2.named_parameters() if p.ndim <= 1 or n.endswith(".bias") or n == "pos_embed"
+                or getattr(p, "_no_weight_decay", False)}
+    dec = [p for n, p in m1.named_parameters() if n not in no_decay]
+    nod = [p for n, p in m1.named_parameters() if n in no_decay]
+    o1 = torch.optim.AdamW([{"params": dec, "weight_decay": 0.05}, {"params": nod, "weight_decay": 0.0}], lr=3e-3)
+    o2 = FlatAdamW(flat, m2, lr=3e-3, weight_decay=0.05, no_decay=no_decay, ema_decay=0.9)
+    ema_ref = {n: p.detach().clone() for n, p in m1.named_parameters()}
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    for it in range(4):
+        for m, zero in ((m1, lambda: m1.zero_grad(set_to_none=True)), (m2, flat.zero_grad)):
+            zero()
+            m(x).float().square().mean().backward()
+        flat.finish_backward()
+        if it == 2:
+            for g in o1.param_groups:
+                g["lr"] = 1e-3
+            o2.set_lr(1e-3)
+        o1.step(); o2.step()
+        for n, p in m1.named_parameters():
+            ema_ref[n].mul_(0.9).add_(p.detach(), alpha=0.1)
+    p2 = dict(m2.named_parameters())
+    for n, p in m1.named_parameters():
+        assert (p - p2[n]).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item()), n
+        assert (p2[n]._fv_shadow.float() - p2[n]).abs().max().item() <= 2.0 ** -8 * max(1e-3, p2[n].abs().max().item()), n
+        off = flat.offsets[n]
+        e = o2.ema[off:off + p.numel()].view_as(p)
+        assert (e - ema_ref[n]).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item()), n
+    from fastvim_amd.mixer_ops import defer_reductions
+    defer_reductions(False)
