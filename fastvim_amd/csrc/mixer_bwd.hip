@@ -39,6 +39,8 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
   const Geo g = p.geo;
   float* s_red = smem;                                   // RGMAX * 2 * TT * 16 (cross-wave LN sums)
   float* s_acc = smem + RGMAX * 2 * TT * 16;             // 2 * d_in
+  float* s_dyc = s_acc + 2 * p.d_in;                     // tpp > 1: thread-private [slot][thread][VEC] pooled sums
+  const int tpp = g.tpp, nthr = blockDim.x;
   float lw[VEC], lb[VEC], a_lw[VEC], a_lb[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -61,6 +63,10 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
     float dyc_acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) dyc_acc[v] = 0.f;
+    if (tpp > 1)
+      for (int c = 0; c < tpp; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s_dyc[(c * nthr + threadIdx.x) * VEC + v] = 0.f;
     // software pipeline: the (packed) loads of token group j0+TT are in flight while group j0 is processed
     RawVec<T, VEC> n_dg[TT], n_z[TT], n_xh[TT];
     auto fetch = [&](int j0) {
@@ -150,10 +156,25 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
           dov[v] = d_o;
           dyc_acc[v] += 0.5f * d_o;
         }
+        if (tpp > 1) {
+          float* sl = s_dyc + (((j0 + t) % tpp) * nthr + threadIdx.x) * VEC;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) sl[v] += 0.5f * dov[v];
+        }
         if (tv[t] && act) VecIO<T, VEC>::store(dob_b + (size_t)mtok[t] * p.d_in + c0, dov);
       }
     }
-    if (rv && act) VecIO<float, VEC>::store(p.dyc + (size_t)row * p.d_in + c0, dyc_acc);
+    if (rv && act) {
+      if (tpp == 1) {
+        VecIO<float, VEC>::store(p.dyc + (size_t)row * p.d_in + c0, dyc_acc);
+      } else {
+        for (int c = 0; c < tpp; ++c) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) dyc_acc[v] = s_dyc[(c * nthr + threadIdx.x) * VEC + v];
+          VecIO<float, VEC>::store(p.dyc + ((size_t)row * tpp + c) * p.d_in + c0, dyc_acc);
+        }
+      }
+    }
   }
   // fixed-order accumulation of the RG row groups into one partial row [d ln_w | d ln_b]
   for (int r = 0; r < RG; ++r) {
@@ -197,7 +218,8 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
     for (int k = 0; k < CW; ++k) a_wf[v][k] = a_wb[v][k] = 0.f;
   }
   const int nrows = p.B * g.rows;
-  const size_t dstride = (size_t)p.B * g.rows * p.d_in;
+  const int tpp = g.tpp;
+  const size_t dstride = (size_t)p.B * g.rows * tpp * p.d_in;
   const int nit = (nrows + gridDim.x * RG - 1) / (gridDim.x * RG);
   for (int it = 0; it < nit; ++it) {
     const int row = (it * gridDim.x + blockIdx.x) * RG + rg;
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int ii = i - 1 + r;
-        const bool ok = act && ii >= 0 && ii < g.rows;
+        const bool ok = act && tpp == 1 && ii >= 0 && ii < g.rows;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const size_t o = ((size_t)b * g.rows + (ok ? ii : 0)) * p.d_in + (act ? c0 + v : 0);
@@ -272,6 +294,23 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
         const int r0 = (n < 0) ? 0 : 1;                   // row of token n
         const bool own3 = n + 3 < g.cols;                 // token n+3 belongs to this row (n+3 >= 0 always)
         const bool own0 = n >= 0;
+        float cf_t[VEC], cb_t[VEC];                       // channel-wise tokenization: pooled gradient of (row, channel slot)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) cf_t[v] = cb_t[v] = 0.f;
+        if (tpp > 1 && act) {
+          const int i3 = i - 1 + r3, i0 = i - 1 + r0;
+          const int sl3 = (n + 3 + tpp * 4) % tpp, sl0 = (n + tpp * 4) % tpp;     // n >= -3 > -4*tpp
+          if (i3 >= 0 && i3 < g.rows) {
+            const size_t o = (((size_t)b * g.rows + i3) * tpp + sl3) * p.d_in + c0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) cf_t[v] = p.dxc[o + v] * p.pool_scale;
+          }
+          if (i0 >= 0 && i0 < g.rows) {
+            const size_t o = (((size_t)b * g.rows + i0) * tpp + sl0) * p.d_in + c0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) cb_t[v] = p.dxc[dstride + o + v] * p.pool_scale;
+          }
+        }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           float pf = cp.bf[v], pb = cp.bb[v];
@@ -282,8 +321,8 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
           }
           const float sgf = fv_sigmoid(pf), sgb = fv_sigmoid(pb);
           const float dsf = sgf * (1.f + pf * (1.f - sgf)), dsb = sgb * (1.f + pb * (1.f - sgb));
-          const float cf = r3 == 2 ? dcf[2][v] : dcf[1][v];
-          const float cb = r0 == 0 ? dcb[0][v] : dcb[1][v];
+          const float cf = tpp > 1 ? cf_t[v] : (r3 == 2 ? dcf[2][v] : dcf[1][v]);
+          const float cb = tpp > 1 ? cb_t[v] : (r0 == 0 ? dcb[0][v] : dcb[1][v]);
           const float nf = v3 ? (Dfh[v] * dw[3][v] + cf) * dsf : 0.f;
           const float nb = v0 ? (Dbh[v] * dw[0][v] + cb) * dsb : 0.f;
           dpf[3][v] = nf;
@@ -372,7 +411,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 int rg_combine(int d_in, int VEC) { int nch = fv_cdiv(d_in, 64 * VEC); int r = 8 / nch; return r < 1 ? 1 : (r > RGMAX ? RGMAX : r); }
 int rg_convpool(int d_in, int VEC) { int nch = fv_cdiv(d_in, 64 * VEC); int r = (VEC == 1 ? 16 : 12) / nch; return r < 1 ? 1 : (r > RGMAX ? RGMAX : r); }
-int vec_combine(int d_in) { return (d_in % 384 == 0 && d_in <= 8 * 384) ? 6 : (d_in % 256 == 0 && d_in <= 8 * 256) ? 4 : 1; }
+int vec_combine(int d_in, int tpp) {
+  if (tpp > 1)      // LDS slot accumulators: keep the per-lane state small
+    return (d_in % 128 == 0 && d_in <= 8 * 128) ? 2 : (d_in % 256 == 0 && d_in <= 8 * 256) ? 4 : 1;
+  return (d_in % 384 == 0 && d_in <= 8 * 384) ? 6 : (d_in % 256 == 0 && d_in <= 8 * 256) ? 4 : 1;
+}
 int vec_convpool(int d_in) { return (d_in % 128 == 0 && d_in <= 12 * 128) ? 2 : 1; }
 int persistent_blocks(long nrows, int rg) {
   long groups = (nrows + rg - 1) / rg;
@@ -386,11 +429,13 @@ int launch_combine_bwd(const BwdParams& p, hipStream_t st) {
   FV_CHECK(nch <= (VEC == 1 ? 16 : 8), "mixer_combine_bwd: d_inner %d too large for the VEC=%d row walker", p.d_in, VEC);
   const int rg = rg_combine(p.d_in, VEC);
   dim3 grid(persistent_blocks((long)p.B * p.geo.rows, rg)), block(64 * nch * rg);
+  const size_t extra = p.geo.tpp > 1 ? (size_t)p.geo.tpp * 64 * nch * rg * VEC : 0;
+  FV_CHECK((RGMAX * 64 + 2 * p.d_in + extra) * 4 <= 64 * 1024, "mixer_combine_bwd: tokens_per_patch %d too large", p.geo.tpp);
   if (p.geo.cols % 2 == 0) {
-    size_t smem = (size_t)(RGMAX * 2 * 2 * 16 + 2 * p.d_in) * 4;
+    size_t smem = (size_t)(RGMAX * 2 * 2 * 16 + 2 * p.d_in + extra) * 4;
     hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 2>), grid, block, smem, st, p, nch, rg);
   } else {
-    size_t smem = (size_t)(RGMAX * 2 * 1 * 16 + 2 * p.d_in) * 4;
+    size_t smem = (size_t)(RGMAX * 2 * 1 * 16 + 2 * p.d_in + extra) * 4;
     hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 1>), grid, block, smem, st, p, nch, rg);
   }
   FV_LAUNCH_CHECK();
@@ -419,9 +464,10 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
 template <typename T>
 int dispatch_bwd(int which, const BwdParams& p, hipStream_t st) {
   if (which == 0) {
-    const int v = vec_combine(p.d_in);
+    const int v = vec_combine(p.d_in, p.geo.tpp);
     if (v == 6) return launch_combine_bwd<T, 6>(p, st);
     if (v == 4) return launch_combine_bwd<T, 4>(p, st);
+    if (v == 2) return launch_combine_bwd<T, 2>(p, st);
     return launch_combine_bwd<T, 1>(p, st);
   }
   if (vec_convpool(p.d_in) == 2) return launch_conv_pool_bwd<T, 2>(p, st);
@@ -438,17 +484,19 @@ int check_geo_b(int B, int rows, int cols, int s_i, int s_j, int d_in, int dtype
 
 }  // namespace
 
-extern "C" int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int which) {
+extern "C" int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int tokens_per_patch, int which) {
   const long n = (long)batch * rows;
-  return which == 0 ? persistent_blocks(n, rg_combine(d_inner, vec_combine(d_inner)))
+  return which == 0 ? persistent_blocks(n, rg_combine(d_inner, vec_combine(d_inner, tokens_per_patch)))
                     : persistent_blocks(n, rg_convpool(d_inner, vec_convpool(d_inner)));
 }
 
 extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* xhat, const float* ln_w,
                                     const float* ln_b, const float* rstd, void* dxz, void* d_o, float* dyc,
                                     float* partials, int batch, int rows, int cols, int tok_stride_row,
-                                    int tok_stride_col, int d_inner, int dtype, fv_stream_t stream) {
+                                    int tok_stride_col, int tokens_per_patch, int d_inner, int dtype,
+                                    fv_stream_t stream) {
   int rc = check_geo_b(batch, rows, cols, tok_stride_row, tok_stride_col, d_inner, dtype);
+  FV_CHECK(tokens_per_patch > 0, "mixer_combine_bwd: tokens_per_patch must be positive");
   if (rc) return rc;
   FV_CHECK(dg && xz && xhat && dxz && d_o && dyc && partials, "mixer_combine_bwd: null pointer");
   FV_CHECK(!ln_w || (ln_b && rstd), "mixer_combine_bwd: LayerNorm needs weight, bias, rstd");
@@ -456,7 +504,7 @@ extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* 
   p.dg = dg; p.xz = xz; p.xhat = xhat; p.lnw = ln_w; p.lnb = ln_b; p.rstd = rstd;
   p.dxz = dxz; p.dob = d_o; p.dyc = dyc; p.part = partials;
   p.use_norm = ln_w != nullptr;
-  p.geo = {rows, cols, rows * cols, tok_stride_row, tok_stride_col};
+  p.geo = make_geo(rows, cols, tok_stride_row, tok_stride_col, tokens_per_patch);
   p.B = batch; p.d_in = d_inner;
   return dtype == FV_F32 ? dispatch_bwd<float>(0, p, (hipStream_t)stream)
                          : dispatch_bwd<bf16_t>(0, p, (hipStream_t)stream);
@@ -465,22 +513,23 @@ extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* 
 extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, const float* conv_w,
                                       const float* conv_b, const float* conv_w_b, const float* conv_b_b,
                                       const float* D, const float* D_b, void* dxz, float* partials, int batch,
-                                      int rows, int cols, int tok_stride_row, int tok_stride_col, int d_inner,
-                                      int d_conv, int pool_max, float scaling_factor, int dtype,
-                                      fv_stream_t stream) {
+                                      int rows, int cols, int tok_stride_row, int tok_stride_col,
+                                      int tokens_per_patch, int d_inner, int d_conv, int pool_max,
+                                      float scaling_factor, int dtype, fv_stream_t stream) {
   int rc = check_geo_b(batch, rows, cols, tok_stride_row, tok_stride_col, d_inner, dtype);
+  FV_CHECK(tokens_per_patch > 0, "mixer_conv_pool_bwd: tokens_per_patch must be positive");
   if (rc) return rc;
   FV_CHECK(d_conv == CW, "mixer: only d_conv == %d is built (got %d)", CW, d_conv);
   if (pool_max) {
     fv_set_error("mixer_conv_pool_bwd: collapse_method='max' has no backward kernel yet");
     return FV_ERR_UNSUPPORTED;
   }
-  FV_CHECK(cols >= 3, "mixer_conv_pool_bwd: needs cols >= 3 (got %d)", cols);
+  FV_CHECK(cols * tokens_per_patch >= 3, "mixer_conv_pool_bwd: needs at least 3 tokens per pooling row (got %d)", cols * tokens_per_patch);
   FV_CHECK(xz && d_o && dxc && conv_w && conv_w_b && D && D_b && dxz && partials, "mixer_conv_pool_bwd: null pointer");
   BwdParams p{};
   p.xz = xz; p.dob_in = d_o; p.dxc = dxc; p.wf = conv_w; p.bf = conv_b; p.wb = conv_w_b; p.bb = conv_b_b;
   p.Df = D; p.Db = D_b; p.dxz = dxz; p.part = partials;
-  p.geo = {rows, cols, rows * cols, tok_stride_row, tok_stride_col};
+  p.geo = make_geo(rows, cols, tok_stride_row, tok_stride_col, tokens_per_patch);
   p.B = batch; p.d_in = d_inner;
   p.pool_scale = scaling_factor / (float)cols;
   return dtype == FV_F32 ? dispatch_bwd<float>(1, p, (hipStream_t)stream)

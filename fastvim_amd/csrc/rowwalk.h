@@ -13,15 +13,24 @@
 #include "common.h"
 
 struct Geo {
-  int rows, cols, L;   // pooling grid of this mixer (L = rows*cols)
-  int s_i, s_j;        // memory-token strides of (row, col) of the sequence grid
+  int rows, cols, L;   // pooling rows; FLAT positions per row (= patch columns * tokens_per_patch); L = rows*cols
+  int s_i, s_j;        // memory strides, in patches, of (row, patch column) of the sequence grid
+  int tpp, pcols;      // tokens per patch (channel-wise tokenization, Channel-First order), patch columns
 };
+// Sequence position s = (i*pcols + j)*tpp + c (row i, patch column j, channel token c); the pooling
+// group of a token is (i, c) = pooled index i*tpp + c  (mamba_simple_channel_faster.py:242-256).
+
+static inline Geo make_geo(int rows, int pcols, int s_i, int s_j, int tpp) {
+  return Geo{rows, pcols * tpp, rows * pcols * tpp, s_i, s_j, tpp, pcols};
+}
 
 __device__ __forceinline__ int tok_mem(const Geo& g, int s) {
   if (g.s_j == 1) return s;          // natural order: sequence position == memory token
-  int i = s / g.cols;
-  int j = s - i * g.cols;
-  return i * g.s_i + j * g.s_j;
+  const int i = s / g.cols;
+  const int jf = s - i * g.cols;
+  const int j = jf / g.tpp;
+  const int c = jf - j * g.tpp;
+  return (i * g.s_i + j * g.s_j) * g.tpp + c;
 }
 
 // ---------------------------------------------------------------- vector I/O of VEC channels

@@ -154,32 +154,32 @@ class FastVimMixerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden, W_in, b_in, cw, cb, cw_b, cb_b, Wx, Wx_b, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log,
-                D, D_b, ln_w, ln_b, W_out, b_out, rows, cols, transposed, pool_max, scaling, ln_eps, cdt, fv):
+                D, D_b, ln_w, ln_b, W_out, b_out, rows, cols, transposed, pool_max, scaling, ln_eps, cdt, fv, tpp=1):
         L.require_gpu(hidden)
         B, Ltok, d = hidden.shape
-        if Ltok != rows * cols:
-            raise RuntimeError(f"Mamba: sequence length {Ltok} != token grid {rows}x{cols}")
+        if Ltok != rows * cols * tpp:
+            raise RuntimeError(f"Mamba: sequence length {Ltok} != token grid {rows}x{cols}x{tpp}")
         d_in = W_in.shape[0] // 2
         with torch.autocast("cuda", enabled=False):
             h_c = hidden.to(cdt).contiguous()
             W_in_c, W_out_c = _shadow(W_in, cdt), _shadow(W_out, cdt)
             xz = linear_fwd(h_c.view(B * Ltok, d), W_in_c, b_in).view(B, Ltok, 2 * d_in)  # (B, L, 2 d_in)
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
-            xc = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling)
+            xc = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp)
             if fv is not None and "Wx2" in fv:          # x_proj / x_proj_b adjacent in the flat buffers
                 Wx2 = fv["Wx2"]
                 Wx2_c = fv["Wx2_shadow"] if fv["Wx2_shadow"].dtype == cdt else Wx2.to(cdt)
             else:
                 Wx2 = torch.stack([Wx, Wx_b])                                           # (2, R+2N, d_in) fp32
                 Wx2_c = Wx2.to(cdt)
-            x_dbl = torch.bmm(xc.view(2, B * rows, d_in), Wx2_c.transpose(1, 2))        # (2, B*Lc, R+2N)
+            x_dbl = torch.bmm(xc.view(2, B * rows * tpp, d_in), Wx2_c.transpose(1, 2))        # (2, B*Lc, R+2N)
             yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
             g, xhat, mean, rstd = M.combine_fwd(xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, ln_eps,
-                                                rows, cols, transposed)
+                                                rows, cols, transposed, tpp=tpp)
             out = linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
         ctx.save_for_backward(h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b,
                               ln_w, ln_b, W_out, xz, xc, x_dbl, g, xhat, rstd)
-        ctx.geo = (rows, cols, transposed, pool_max, scaling)
+        ctx.geo = (rows, cols, transposed, pool_max, scaling, tpp)
         ctx.has_bias = (b_in is not None, b_out is not None)
         ctx.cdt = cdt
         ctx.in_dtype = hidden.dtype
@@ -190,7 +190,7 @@ class FastVimMixerFn(torch.autograd.Function):
     def backward(ctx, dout):
         (h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b, ln_w, ln_b, W_out,
          xz, xc, x_dbl, g, xhat, rstd) = ctx.saved_tensors
-        rows, cols, transposed, pool_max, scaling = ctx.geo
+        rows, cols, transposed, pool_max, scaling, tpp = ctx.geo
         cdt = ctx.cdt
         B, Ltok, d = h_c.shape
         d_in = W_in.shape[0] // 2
@@ -204,7 +204,7 @@ class FastVimMixerFn(torch.autograd.Function):
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
             d_o, dyc, p1 = M.combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed,
-                                         grad_out=fv.get("ln_grad") if ln_w is not None else None)
+                                         grad_out=fv.get("ln_grad") if ln_w is not None else None, tpp=tpp)
             W_ = x_dbl.shape[-1]
             fused_xproj = W_ in M.XPROJ_WIDTHS
             dxc, dx_dbl, ps = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
@@ -215,15 +215,16 @@ class FastVimMixerFn(torch.autograd.Function):
                 if dWx2 is None:
                     dWx2 = (None, None)
             else:
-                xc2 = xc.view(2, B * rows, d_in)
+                xc2 = xc.view(2, B * rows * tpp, d_in)
                 if "Wx2_grad" in fv:
                     fv["Wx2_grad"].baddbmm_(dx_dbl.transpose(1, 2), xc2.float())
                     dWx2 = (None, None)
                 else:
                     dWx2 = torch.bmm(dx_dbl.transpose(1, 2), xc2.float())                # (2, R+2N, d_in)
-                dxc = torch.baddbmm(dxc.view(2, B * rows, d_in), dx_dbl, Wx2)            # + dx_dbl @ Wx
+                dxc = torch.baddbmm(dxc.view(2, B * rows * tpp, d_in), dx_dbl, Wx2)            # + dx_dbl @ Wx
             p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
-                                 pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None)
+                                 pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None,
+                                 tpp=tpp)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
             dhidden = linear_dgrad(dxz2, _shadow(W_in, cdt)).view(B, Ltok, d).to(ctx.in_dtype)
             dW_in = _SideStream.run(lambda: linear_wgrad(dxz2, h_c.view(B * Ltok, d), W_in), dxz2, h_c)
@@ -248,7 +249,7 @@ class FastVimMixerFn(torch.autograd.Function):
         g_lb = p1[1] if (has_ln and p1 is not None) else None
         return (dhidden, dW_in, db_in, g_cw, g_cb, g_cwb, g_cbb,
                 dWx2[0], dWx2[1], g_Wdt[0], g_bdt[0], g_Wdt[1], g_bdt[1], g_A[0], g_A[1],
-                g_D, g_Db, g_lw, g_lb, dW_out, db_out, None, None, None, None, None, None, None, None)
+                g_D, g_Db, g_lw, g_lb, dW_out, db_out, None, None, None, None, None, None, None, None, None)
 
 
 class Mamba(nn.Module):

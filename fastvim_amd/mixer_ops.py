@@ -14,14 +14,14 @@ def _geo(rows, cols, transposed):
     return (1, rows) if transposed else (cols, 1)
 
 
-def conv_pool_fwd(xz, conv_w, conv_b, conv_w_b, conv_b_b, rows, cols, transposed, pool_max, scaling):
+def conv_pool_fwd(xz, conv_w, conv_b, conv_w_b, conv_b_b, rows, cols, transposed, pool_max, scaling, tpp=1):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
-    xc = torch.empty(2, B, rows, d_in, device=xz.device, dtype=xz.dtype)
+    xc = torch.empty(2, B, rows * tpp, d_in, device=xz.device, dtype=xz.dtype)
     rc = L.lib().fv_mixer_conv_pool_fwd(
         L.ptr(xz), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(xc),
-        L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in), L.i32(conv_w.shape[-1]),
+        L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in), L.i32(conv_w.shape[-1]),
         L.i32(pool_max), f32(scaling), L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_conv_pool_fwd")
     return xc
@@ -41,7 +41,7 @@ def scan_fwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
 
 
 def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, eps, rows, cols, transposed,
-                save_xhat=True):
+                save_xhat=True, tpp=1):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
@@ -55,7 +55,7 @@ def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, 
     rc = L.lib().fv_mixer_combine_fwd(
         L.ptr(xz), L.ptr(yc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(D),
         L.ptr(D_b), L.ptr(ln_w), L.ptr(ln_b), f32(eps), L.ptr(g), L.ptr(xhat), L.ptr(mean), L.ptr(rstd), L.i32(B),
-        L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in), L.i32(conv_w.shape[-1]),
+        L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in), L.i32(conv_w.shape[-1]),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_combine_fwd")
     return g, xhat, mean, rstd
@@ -114,18 +114,18 @@ def reduce_partials(part, n_partials, out=None, accumulate=False, defer=True):
     return out
 
 
-def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed, grad_out=None):
+def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed, grad_out=None, tpp=1):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     lib = L.lib()
-    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows), L.i32(d_in), L.i32(0))
+    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows), L.i32(d_in), L.i32(tpp), L.i32(0))
     d_o = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype)
-    dyc = torch.empty(B, rows, d_in, device=xz.device, dtype=torch.float32)
+    dyc = torch.empty(B, rows * tpp, d_in, device=xz.device, dtype=torch.float32)
     part = torch.empty(nb, 2, d_in, device=xz.device, dtype=torch.float32)
     rc = lib.fv_mixer_combine_bwd(
         L.ptr(dg), L.ptr(xz), L.ptr(xhat), L.ptr(ln_w), L.ptr(ln_b), L.ptr(rstd), L.ptr(dxz), L.ptr(d_o),
-        L.ptr(dyc), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in),
+        L.ptr(dyc), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_combine_bwd")
     if grad_out is not None:
@@ -164,17 +164,17 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
 
 
 def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed,
-                  pool_max, scaling, grad_out=None):
+                  pool_max, scaling, grad_out=None, tpp=1):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     lib = L.lib()
-    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows), L.i32(d_in), L.i32(1))
+    nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows), L.i32(d_in), L.i32(tpp), L.i32(1))
     part = torch.empty(nb, 12 * d_in, device=xz.device, dtype=torch.float32)
     rc = lib.fv_mixer_conv_pool_bwd(
         L.ptr(xz), L.ptr(d_o), L.ptr(dxc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
         L.ptr(D), L.ptr(D_b), L.ptr(dxz), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i),
-        L.i32(s_j), L.i32(d_in), L.i32(conv_w.shape[-1]), L.i32(pool_max), f32(scaling),
+        L.i32(s_j), L.i32(tpp), L.i32(d_in), L.i32(conv_w.shape[-1]), L.i32(pool_max), f32(scaling),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_conv_pool_bwd")
     # segments: [dw (d_in*4) | dw_b (d_in*4) | db | db_b | dD | dD_b]

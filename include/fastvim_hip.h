@@ -84,12 +84,16 @@ int fv_selective_scan_bwd(const void* u, const void* delta, const float* A, cons
  * Token grid: the mixer's sequence position (i, j), i < rows, j < cols, is memory token
  *           i*tok_stride_row + j*tok_stride_col.  (cols, 1) = natural order; (1, rows) = the
  *           transposed grid odd layers see (models/fastvim.py:192-210) -- no copy is made.
+ *           tokens_per_patch = t > 1 (channel-wise tokenization, Channel-First order,
+ *           mamba_simple_channel_faster.py:242-256, 333-340): every grid cell holds t consecutive
+ *           tokens, sequence position ((i*cols + j)*t + c), pooling groups (i, c), pooled tensors
+ *           (2, batch, rows*t, d_inner), pooled index i*t + c; strides are in cells.
  * Conv weights are (d_inner, d_conv) fp32 (= conv1d.weight viewed "d 1 w -> d w").
  * ---------------------------------------------------------------------- */
 int fv_mixer_conv_pool_fwd(const void* xz, const float* conv_w, const float* conv_b,
                            const float* conv_w_b, const float* conv_b_b, void* xc, int batch, int rows,
-                           int cols, int tok_stride_row, int tok_stride_col, int d_inner, int d_conv,
-                           int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
+                           int cols, int tok_stride_row, int tok_stride_col, int tokens_per_patch, int d_inner,
+                           int d_conv, int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
 
 /* dt_proj + softplus + selective scan (A = -exp(A_log)) for both directions.  yc is fp32. */
 int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
@@ -104,12 +108,13 @@ int fv_mixer_combine_fwd(const void* xz, const float* yc, const float* conv_w, c
                          const float* conv_w_b, const float* conv_b_b, const float* D, const float* D_b,
                          const float* ln_w, const float* ln_b, float ln_eps, void* g, void* xhat,
                          float* mean, float* rstd, int batch, int rows, int cols, int tok_stride_row,
-                         int tok_stride_col, int d_inner, int d_conv, int dtype, fv_stream_t stream);
+                         int tok_stride_col, int tokens_per_patch, int d_inner, int d_conv, int dtype,
+                         fv_stream_t stream);
 
 /* ---- backward of the fused mixer middle --------------------------------------------
  * Number of persistent blocks a row-walking backward kernel launches (which = 0: combine_bwd,
  * 1: conv_pool_bwd); their `partials` buffers are (blocks, 2*d_inner) and (blocks, 12*d_inner) fp32. */
-int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int which);
+int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int tokens_per_patch, int which);
 
 /* Adjoint of the LayerNorm + gate of fv_mixer_combine_fwd, from the saved xhat.  dg: gradient wrt g.
  * Writes dz into the z half of dxz (batch, L, 2*d_inner), d_o (batch, L, d_inner) = gradient wrt the
@@ -118,7 +123,7 @@ int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int which);
 int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* xhat, const float* ln_w,
                          const float* ln_b, const float* rstd, void* dxz, void* d_o, float* dyc,
                          float* partials, int batch, int rows, int cols, int tok_stride_row,
-                         int tok_stride_col, int d_inner, int dtype, fv_stream_t stream);
+                         int tok_stride_col, int tokens_per_patch, int d_inner, int dtype, fv_stream_t stream);
 
 /* Adjoint of fv_mixer_scan_fwd with the dt_proj adjoint fused in (replaces
  * selective_scan_cuda.bwd + the einsums of selective_scan_interface.py:698-723).
@@ -144,8 +149,8 @@ int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, cons
 int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, const float* conv_w,
                            const float* conv_b, const float* conv_w_b, const float* conv_b_b, const float* D,
                            const float* D_b, void* dxz, float* partials, int batch, int rows, int cols,
-                           int tok_stride_row, int tok_stride_col, int d_inner, int d_conv, int pool_max,
-                           float scaling_factor, int dtype, fv_stream_t stream);
+                           int tok_stride_row, int tok_stride_col, int tokens_per_patch, int d_inner, int d_conv,
+                           int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
 
 /* out[i] (+)= sum_{s < n_partials} partials[s*n + i], fixed order (deterministic); accumulate != 0
  * adds into `out` (gradient accumulation straight into a parameter's .grad). */

@@ -57,13 +57,13 @@ def state_dict_shapes(embed_dim=192, depth=24, img_size=224, patch_size=16, chan
     return shapes
 
 
-def make_state_dict(seed=0, **cfg):
+def make_state_dict(seed=0, shapes=None, **cfg):
     """Deterministic synthetic parameters, re-derivable anywhere from (seed, key):
     each tensor is drawn from ``Generator().manual_seed(crc32(key) ^ seed)`` with a
     per-kind scale that keeps activations O(1) through 24 blocks.  Lets the 28 MB
     FastVim-T state be rebuilt on the GPU box instead of committed."""
     sd = {}
-    for key, shape in state_dict_shapes(**cfg).items():
+    for key, shape in (shapes if shapes is not None else state_dict_shapes(**cfg)).items():
         g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
         r = torch.randn(shape, generator=g, dtype=torch.float32)
         leaf = key.split("mixer.")[-1] if "mixer." in key else key
@@ -174,3 +174,96 @@ def fastvim_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, rot
     if final_pool_type == "max":
         logits = logits.max(1)[0]
     return (logits, hiddens) if return_hidden else logits
+
+
+# ------------------------------------------------------------------------------------------------
+# FastChannelVim (channel-wise tokenization, Channel-First scan order)
+# ------------------------------------------------------------------------------------------------
+def channel_state_dict_shapes(embed_dim=384, depth=24, img_size=224, patch_size=16, channels=8, **kw):
+    """Reference ``state_dict`` of models_channel_mamba_faster.VisionMamba (:458-589): the FastVim table
+    with a Conv3d(1, d, (1, p, p)) patch projection and a ``channel_embed`` lookup table."""
+    shapes = state_dict_shapes(embed_dim=embed_dim, depth=depth, img_size=img_size, patch_size=patch_size,
+                               channels=1, **kw)
+    shapes["patch_embed.proj.weight"] = (embed_dim, 1, 1, patch_size, patch_size)
+    shapes["patch_embed.channel_embed.weight"] = (channels, embed_dim)
+    return shapes
+
+
+def make_channel_state_dict(seed=0, **cfg):
+    """``make_state_dict`` for the channel model (same per-key generators and scales)."""
+    return make_state_dict(seed, shapes=channel_state_dict_shapes(**cfg))
+
+
+def channel_patch_embed_oracle(sd, x, patch_size, cd, channels=None):
+    """PatchEmbedPerChannel.forward (models_channel_mamba_faster.py:130-203), rowwise scan path,
+    Channel-First order: the shared Conv3d(1, d, (1, p, p)) restated as per-channel patch-unfold +
+    matmul, plus the channel embedding; tokens come out ordered (row, col, channel).
+    ``channels``: the HCS subset (sorted list) or None for all."""
+    Bsz, C, H, W = x.shape
+    ps = patch_size
+    idx = list(range(C)) if channels is None else list(channels)
+    xf = x[:, idx].to(cd)
+    gh, gw = H // ps, W // ps
+    k = len(idx)
+    patches = xf.reshape(Bsz, k, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(Bsz, gh * gw * k, ps * ps)
+    Wp = sd["patch_embed.proj.weight"].to(cd).reshape(-1, ps * ps)
+    tok = patches @ Wp.t() + sd["patch_embed.proj.bias"].to(cd)                       # :188
+    ce = sd["patch_embed.channel_embed.weight"].to(cd)[idx]                            # :159-181
+    tok = tok.reshape(Bsz, gh * gw, k, -1) + ce[None, None]                            # :191
+    return tok.reshape(Bsz, gh * gw * k, -1), (gh, gw), k
+
+
+def channel_block_oracle(sd_layer, hidden, residual, layer_idx, token_size, tokens_per_patch, *,
+                         norm_eps=1e-5, rotate_every_block=True, row_scale=None,
+                         compute_dtype=torch.float64, mixer_kwargs=None):
+    """Block.forward of the channel model (models_channel_mamba_faster.py:249-331), Channel-First."""
+    cd = compute_dtype
+    h, res = fused_add_norm_oracle(hidden, sd_layer["norm.weight"], None, residual, norm_eps,
+                                   prenorm=True, residual_in_fp32=True, is_rms_norm=True,
+                                   row_scale=row_scale if residual is not None else None,
+                                   compute_dtype=cd)
+    T0, T1 = token_size
+    Bsz, M, d = h.shape
+    t = tokens_per_patch
+    rot = rotate_every_block and layer_idx % 2 != 0
+    ts = token_size
+    if rot:                                                               # :307-311
+        h = h.reshape(Bsz, T0, T1, t, d).transpose(1, 2).reshape(Bsz, M, d)
+        ts = (T1, T0)                                                     # create_block :363-374
+    h = fastvim_mixer_oracle(_sub(sd_layer, "mixer."), h, ts, tokens_per_patch=t, compute_dtype=cd,
+                             **(mixer_kwargs or {}))
+    if rot:                                                               # :325-329
+        h = h.reshape(Bsz, T1, T0, t, d).transpose(1, 2).reshape(Bsz, M, d)
+    return h, res
+
+
+def channel_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, rotate_every_block=True,
+                           final_pool_type="mean", channels=None, row_scales=None,
+                           compute_dtype=torch.float64, return_features=False, mixer_kwargs=None):
+    """VisionMamba.forward_features / forward of the channel model
+    (models_channel_mamba_faster.py:614-682), Channel-First, fused_add_norm + rms_norm + fp32 residual."""
+    cd = compute_dtype
+    h, token_size, t = channel_patch_embed_oracle(sd, x, patch_size, cd, channels)
+    h = h + torch.repeat_interleave(sd["pos_embed"].to(cd), t, 1)          # :626-627
+    h = h.to(cd if cd == torch.float64 else torch.float32)
+    residual = None
+    for i in range(depth):
+        rs = row_scales[i] if row_scales is not None else None
+        h, residual = channel_block_oracle(_sub(sd, f"layers.{i}."), h, residual, i, token_size, t,
+                                           norm_eps=norm_eps, rotate_every_block=rotate_every_block,
+                                           row_scale=rs, compute_dtype=cd, mixer_kwargs=mixer_kwargs)
+    rs = row_scales[depth] if row_scales is not None else None
+    h = fused_add_norm_oracle(h, sd["norm_f.weight"], None, residual, norm_eps, prenorm=False,
+                              residual_in_fp32=True, is_rms_norm=True, row_scale=rs, compute_dtype=cd)
+    if final_pool_type == "mean":
+        feat = h.to(cd).mean(1)
+    elif final_pool_type == "none":
+        feat = h[:, -1, :].to(cd)
+    else:
+        feat = h.to(cd)
+    if return_features:
+        return feat
+    logits = feat @ sd["head.weight"].to(cd).t() + sd["head.bias"].to(cd)
+    if final_pool_type == "max":
+        logits = logits.max(1)[0]
+    return logits

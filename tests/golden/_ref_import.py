@@ -162,13 +162,17 @@ def load_reference():
     from mamba_ssm.modules import mamba_simple_faster as msf
     import models.fastvim as fastvim
 
-    for m in (fastvim, msf):
+    from mamba_ssm.modules import mamba_simple_channel_faster as mscf
+    import importlib
+    chan = importlib.import_module("models.channel_wise_tokenization.models_channel_mamba_faster")
+
+    for m in (fastvim, msf, chan, mscf):
         m.rms_norm_fn = rms_norm_fn
         m.layer_norm_fn = layer_norm_fn
         m.RMSNorm = RMSNorm
 
     ns = types.SimpleNamespace(
-        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, rms_norm_fn=rms_norm_fn,
+        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, rms_norm_fn=rms_norm_fn,
         layer_norm_fn=layer_norm_fn, RMSNorm=RMSNorm, causal_conv1d_fn=causal_conv1d_fn,
     )
     _loaded = ns

@@ -243,7 +243,70 @@ def gen_model():
                                      logits=logits.detach(), grads=grads))
 
 
+def gen_channel():
+    """FastChannelVim (BASELINE config 5 family): channel mixer + tiny channel backbone, Channel-First."""
+    import random
+    cases = {}
+    # ---- mixer: mamba_simple_channel_faster.Mamba.forward(hidden, tokens_per_patch)
+    for name, d_model, ts, tpp, Bsz, seed in (("d32_4x4_t3", 32, (4, 4), 3, 2, 21), ("d32_2x6_t5", 32, (2, 6), 5, 2, 22),
+                                              ("d64_4x2_t8", 64, (4, 2), 8, 1, 23)):
+        torch.manual_seed(seed)
+        m = ref.mscf.Mamba(d_model, token_size=list(ts))
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n in ("D", "D_b", "layernorm.weight"):
+                    p.add_(0.2 * torch.randn_like(p))
+                elif n in ("layernorm.bias", "conv1d.bias", "conv1d_b.bias"):
+                    p.add_(0.1 * torch.randn_like(p))
+                elif n in ("A_log", "A_b_log"):
+                    p.add_(0.1 * torch.randn_like(p))
+        h = torch.randn(Bsz, ts[0] * ts[1] * tpp, d_model, requires_grad=True)
+        y = m(h, tpp)
+        g = torch.randn_like(y)
+        y.backward(g)
+        cases["mixer_" + name] = dict(
+            hidden=h.detach(), out=y.detach(), g=g, dhidden=h.grad.clone(), token_size=ts, tokens_per_patch=tpp,
+            grads={n: p.grad.clone() for n, p in m.named_parameters()},
+            state_dict={k: v.clone() for k, v in m.state_dict().items()})
+    # ---- backbone, eval mode (HCS off) and one training-mode HCS draw
+    for name, img, chans, train in (("tiny_64x64_c3", (64, 64), 3, False), ("tiny_64x96_c5_hcs", (64, 96), 5, True)):
+        torch.manual_seed(31)
+        model = ref.chan.VisionMamba(img_size=img, patch_size=16, depth=4, embed_dim=32, channels=chans,
+                                     num_classes=10, rms_norm=True, residual_in_fp32=True, fused_add_norm=True,
+                                     final_pool_type="mean", if_abs_pos_embed=True, drop_path_rate=0.0)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith(("D", "D_b", "norm.weight", "layernorm.weight", "norm_f.weight")):
+                    p.add_(0.2 * torch.randn_like(p))
+                elif n.endswith(("layernorm.bias", "head.bias", "patch_embed.proj.bias")):
+                    p.add_(0.1 * torch.randn_like(p))
+        model.train(train)
+        x = torch.randn(2, chans, *img)
+        random.seed(1234)
+        # record the HCS subset the reference draws (PatchEmbedPerChannel.forward :167-185)
+        st = random.getstate()
+        if train:
+            k = random.randint(1, chans)
+            subset = sorted(random.sample(range(chans), k=k))
+        else:
+            subset = list(range(chans))
+        random.setstate(st)
+        logits = model(x)
+        g = torch.randn_like(logits)
+        logits.backward(g)
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()
+                 if n in ("pos_embed", "head.weight", "layers.0.mixer.in_proj.weight", "layers.1.mixer.A_b_log",
+                          "layers.3.mixer.x_proj_b.weight", "layers.2.norm.weight", "patch_embed.proj.bias",
+                          "patch_embed.proj.weight", "patch_embed.channel_embed.weight", "norm_f.weight",
+                          "layers.1.mixer.conv1d.weight", "layers.2.mixer.dt_proj.bias")}
+        cases[name] = dict(img=img, channels=chans, train=train, py_seed=1234, subset=subset,
+                           state_dict={k: v.clone() for k, v in model.state_dict().items()},
+                           x=x, logits=logits.detach(), g=g, grads=grads,
+                           cfg=dict(patch_size=16, depth=4, embed_dim=32, num_classes=10))
+    save("channel.pt", cases)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model"]
+    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel"]
     for w in which:
         globals()["gen_" + w]()

@@ -133,3 +133,30 @@ def test_model_oracle_fastvim_t_logits():
     with torch.no_grad():
         logits = fastvim_forward_oracle(sd, x, compute_dtype=torch.float32)
     close(logits, c["logits"], 0, 2e-3 * max(1.0, c["logits"].abs().max().item()))
+
+
+# ---- FastChannelVim (channel-wise tokenization, Channel-First): oracle vs the imported reference
+@pytest.mark.parametrize("case", ["mixer_d32_4x4_t3", "mixer_d32_2x6_t5", "mixer_d64_4x2_t8"])
+def test_channel_mixer_oracle(case):
+    c = load_golden("channel.pt")[case]
+    p = {k: v.clone().requires_grad_() for k, v in c["state_dict"].items()}
+    h = c["hidden"].clone().requires_grad_()
+    y = fastvim_mixer_oracle(p, h, c["token_size"], tokens_per_patch=c["tokens_per_patch"],
+                             compute_dtype=F64, out_dtype=F64)
+    close(y, c["out"], 0, 2e-5 * max(1.0, c["out"].abs().max().item()))
+    y.backward(c["g"].double())
+    close(h.grad, c["dhidden"], 0, 1e-4 * max(1.0, c["dhidden"].abs().max().item()))
+    for k, gref in c["grads"].items():
+        close(p[k].grad, gref, 0, 2e-4 * max(1.0, gref.abs().max().item()))
+
+
+@pytest.mark.parametrize("case", ["tiny_64x64_c3", "tiny_64x96_c5_hcs"])
+def test_channel_model_oracle(case):
+    from oracle import channel_forward_oracle
+    c = load_golden("channel.pt")[case]
+    sd = {k: v.clone().requires_grad_() for k, v in c["state_dict"].items()}
+    logits = channel_forward_oracle(sd, c["x"], patch_size=16, depth=4, channels=c["subset"], compute_dtype=F64)
+    close(logits, c["logits"], 0, 5e-5 * max(1.0, c["logits"].abs().max().item()))
+    logits.backward(c["g"].double())
+    for k, gref in c["grads"].items():
+        close(sd[k].grad, gref, 0, 5e-4 * max(1.0, gref.abs().max().item()))
