@@ -30,7 +30,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
-def build_model(name, img_size, drop_path):
+def build_model(name, img_size, drop_path, channels=8):
+    if name == "C":      # FastChannelVim-S/16 (BASELINE configs[4]); HCS off so the token count is the config's L = 196*channels
+        from fastvim_amd.models_channel_mamba_faster import (
+            channelvim_small_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2 as chan_s)
+        return chan_s(img_size=img_size, channels=channels, hcs=False, drop_path_rate=drop_path)
     from fastvim_amd import fastvim as fv
     factory = {"T": fv.FastVimT, "S": fv.FastVimS, "B": fv.FastVimB}[name]
     return factory(img_size=img_size, drop_path_rate=drop_path)
@@ -199,7 +203,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="T", choices=["T", "S", "B"])
+    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C"],
+                    help="FastVim-T/S/B, or C = FastChannelVim-S/16 (use --batch 64 for BASELINE configs[4])")
+    ap.add_argument("--channels", type=int, default=8, help="input channels of the channel model (--model C)")
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -224,10 +230,11 @@ def main():
     from fastvim_amd.flat import FlatAdamW, FlatTrainingState
 
     torch.manual_seed(1234)                    # identical init on every rank (DDP broadcast equivalent)
-    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
-    model = build_model(args.model, args.img, drop_path).to(dev).train()
+    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
+    model = build_model(args.model, args.img, drop_path, args.channels).to(dev).train()
     gen = torch.Generator().manual_seed(100 + rank)
-    x = torch.randn(args.batch, 3, args.img, args.img, generator=gen).to(dev)
+    in_ch = args.channels if args.model == "C" else 3
+    x = torch.randn(args.batch, in_ch, args.img, args.img, generator=gen).to(dev)
     tgt = soft_targets(args.batch, 1000, gen, dev)
     flat = FlatTrainingState(model)      # flat fp32 params / grads + bf16 shadow weights
     no_decay = {n for n, p in model.named_parameters()
@@ -302,20 +309,22 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         gs = args.img // 16
-        d = {"T": 192, "S": 384, "B": 768}[args.model]
+        d = {"T": 192, "S": 384, "B": 768, "C": 384}[args.model]
+        mname = f"FastChannelVim-S/16 {args.channels}ch" if args.model == "C" else f"FastVim-{args.model}"
         out = {
-            "metric": "images/sec FastVim-%s %dpx bs=%d/GPU fwd+bwd (+all-reduce +AdamW +EMA), whole job" % (args.model, args.img, args.batch),
+            "metric": "images/sec %s %dpx bs=%d/GPU fwd+bwd (+all-reduce +AdamW +EMA), whole job" % (mname, args.img, args.batch),
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "images_per_sec_per_gpu": round(value / world, 1),
-            "config": {"workload": f"FastVim-{args.model} {args.img}x{args.img} bs={args.batch}/GPU {args.dtype} "
+            "config": {"workload": f"{mname} {args.img}x{args.img} bs={args.batch}/GPU {args.dtype} "
                                    f"training step, synthetic ImageNet tensors"
-                                   + (" (BASELINE configs[1])" if (args.model, args.img, args.batch) == ("T", 224, 128) else ""),
+                                   + (" (BASELINE configs[1])" if (args.model, args.img, args.batch) == ("T", 224, 128) else "")
+                                   + (" (BASELINE configs[4], HCS off)" if (args.model, args.img, args.batch, args.channels) == ("C", 224, 64, 8) else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "hip_graph": use_graph, "optimizer_in_step": True, "final_loss": round(loss_val, 4)},
         }
-        if not args.no_kernels:
+        if not args.no_kernels and args.model != "C":
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
             dom = max((k for k in kt if k not in ("scan_fwd", "scan_bwd")), key=lambda k: kt[k]["us_per_step"])
             out["kernels"] = kt
@@ -330,7 +339,7 @@ def main():
                                "unit": "GB/s", "frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "avg_us": kt[dom]["us"],
                                "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.model != "C":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

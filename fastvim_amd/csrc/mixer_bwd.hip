@@ -28,7 +28,7 @@ constexpr int RGMAX = 4;   // a block walks up to RGMAX pooling rows concurrentl
 // ------------------------------------------------------------------ LayerNorm + gate backward
 // Reads dg, z, xhat once, writes dz and d_o once: 5 full-length tensors of traffic, no conv recompute
 // (the forward saved xhat).  Block = RG row groups x NCH waves; a row group walks one pooling row.
-template <typename T, int VEC, int TT>
+template <typename T, int VEC, int TT, bool TP>
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
   float* s_red = smem;                                   // RGMAX * 2 * TT * 16 (cross-wave LN sums)
   float* s_acc = smem + RGMAX * 2 * TT * 16;             // 2 * d_in
   float* s_dyc = s_acc + 2 * p.d_in;                     // tpp > 1: thread-private [slot][thread][VEC] pooled sums
-  const int tpp = g.tpp, nthr = blockDim.x;
+  const int tpp = TP ? g.tpp : 1, nthr = blockDim.x;
   float lw[VEC], lb[VEC], a_lw[VEC], a_lb[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
     float dyc_acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) dyc_acc[v] = 0.f;
-    if (tpp > 1)
+    if constexpr (TP)
       for (int c = 0; c < tpp; ++c)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) s_dyc[(c * nthr + threadIdx.x) * VEC + v] = 0.f;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         if (rv && act && j0 + t < g.cols) {
-          const int m = tok_mem(g, i * g.cols + j0 + t);
+          const int m = tok_mem<TP>(g, i * g.cols + j0 + t);
           n_dg[t].load(dg_b + (size_t)m * p.d_in + c0);
           n_z[t].load(xz_b + (size_t)m * 2 * p.d_in + p.d_in + c0);
           n_xh[t].load(xh_b + (size_t)m * p.d_in + c0);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         tv[t] = rv && (j0 + t < g.cols);
-        mtok[t] = tv[t] ? tok_mem(g, i * g.cols + j0 + t) : 0;
+        mtok[t] = tv[t] ? tok_mem<TP>(g, i * g.cols + j0 + t) : 0;
         rs[t] = (tv[t] && p.use_norm) ? p.rstd[(size_t)b * g.L + mtok[t]] : 1.f;
         float dzv[VEC];
         const float (&dgv)[VEC] = dgq[t];
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
           dov[v] = d_o;
           dyc_acc[v] += 0.5f * d_o;
         }
-        if (tpp > 1) {
+        if constexpr (TP) {
           float* sl = s_dyc + (((j0 + t) % tpp) * nthr + threadIdx.x) * VEC;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) sl[v] += 0.5f * dov[v];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
       }
     }
     if (rv && act) {
-      if (tpp == 1) {
+      if constexpr (!TP) {
         VecIO<float, VEC>::store(p.dyc + (size_t)row * p.d_in + c0, dyc_acc);
       } else {
         for (int c = 0; c < tpp; ++c) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
 // Purely per-channel (no cross-lane traffic): a lane owns VEC channels and streams the row's tokens
 // through 4-deep register windows.  Step n consumes token n+3 and produces
 //   dpre_f[n+3] (needs x[n..n+3]),  dpre_b[n] (needs x[n..n+3]),  dx[n] (needs dpre_f[n..n+3], dpre_b[n-3..n]).
-template <typename T, int VEC, int CH>   // CH tokens are fetched (packed, as loaded) ahead of the arithmetic that consumes them
+template <typename T, int VEC, int CH, bool TP>   // CH tokens are fetched (packed, as loaded) ahead of the arithmetic that consumes them
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
   const int lane = threadIdx.x & 63;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
     for (int k = 0; k < CW; ++k) a_wf[v][k] = a_wb[v][k] = 0.f;
   }
   const int nrows = p.B * g.rows;
-  const int tpp = g.tpp;
+  const int tpp = TP ? g.tpp : 1;
   const size_t dstride = (size_t)p.B * g.rows * tpp * p.d_in;
   const int nit = (nrows + gridDim.x * RG - 1) / (gridDim.x * RG);
   for (int it = 0; it < nit; ++it) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int ii = i - 1 + r;
-        const bool ok = act && tpp == 1 && ii >= 0 && ii < g.rows;
+        const bool ok = act && !TP && ii >= 0 && ii < g.rows;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const size_t o = ((size_t)b * g.rows + (ok ? ii : 0)) * p.d_in + (act ? c0 + v : 0);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
       for (int k = 1; k < 4; ++k) {
         const int s = s_row - 4 + k;
         if (s >= 0 && act) {
-          const int m = tok_mem(g, s);
+          const int m = tok_mem<TP>(g, s);
           VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * p.d_in + c0, xw[k]);
           VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dw[k]);
         }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
         for (int c = 0; c < CH; ++c) {                    // token n0 + c + 3
           const int j3 = n0 + c + 3, sp = s_row + j3;
           if (act && sp < g.L && j3 < g.cols + 3) {
-            const int m = tok_mem(g, sp);
+            const int m = tok_mem<TP>(g, sp);
             xp[c].load(xz_b + (size_t)m * 2 * p.d_in + c0);
             dp[c].load(dob_b + (size_t)m * p.d_in + c0);
           } else {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
         float cf_t[VEC], cb_t[VEC];                       // channel-wise tokenization: pooled gradient of (row, channel slot)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) cf_t[v] = cb_t[v] = 0.f;
-        if (tpp > 1 && act) {
+        if (TP && act) {
           const int i3 = i - 1 + r3, i0 = i - 1 + r0;
           const int sl3 = (n + 3 + tpp * 4) % tpp, sl0 = (n + tpp * 4) % tpp;     // n >= -3 > -4*tpp
           if (i3 >= 0 && i3 < g.rows) {
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
           }
           const float sgf = fv_sigmoid(pf), sgb = fv_sigmoid(pb);
           const float dsf = sgf * (1.f + pf * (1.f - sgf)), dsb = sgb * (1.f + pb * (1.f - sgb));
-          const float cf = tpp > 1 ? cf_t[v] : (r3 == 2 ? dcf[2][v] : dcf[1][v]);
-          const float cb = tpp > 1 ? cb_t[v] : (r0 == 0 ? dcb[0][v] : dcb[1][v]);
+          const float cf = TP ? cf_t[v] : (r3 == 2 ? dcf[2][v] : dcf[1][v]);
+          const float cb = TP ? cb_t[v] : (r0 == 0 ? dcb[0][v] : dcb[1][v]);
           const float nf = v3 ? (Dfh[v] * dw[3][v] + cf) * dsf : 0.f;
           const float nb = v0 ? (Dbh[v] * dw[0][v] + cb) * dsb : 0.f;
           dpf[3][v] = nf;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
             }
             dx[v] = acc;
           }
-          if (act) VecIO<T, VEC>::store(dxz_b + (size_t)tok_mem(g, s_row + n) * 2 * p.d_in + c0, dx);
+          if (act) VecIO<T, VEC>::store(dxz_b + (size_t)tok_mem<TP>(g, s_row + n) * 2 * p.d_in + c0, dx);
         }
         }
       }
@@ -431,12 +431,15 @@ int launch_combine_bwd(const BwdParams& p, hipStream_t st) {
   dim3 grid(persistent_blocks((long)p.B * p.geo.rows, rg)), block(64 * nch * rg);
   const size_t extra = p.geo.tpp > 1 ? (size_t)p.geo.tpp * 64 * nch * rg * VEC : 0;
   FV_CHECK((RGMAX * 64 + 2 * p.d_in + extra) * 4 <= 64 * 1024, "mixer_combine_bwd: tokens_per_patch %d too large", p.geo.tpp);
+  const bool tp = p.geo.tpp > 1;
   if (p.geo.cols % 2 == 0) {
     size_t smem = (size_t)(RGMAX * 2 * 2 * 16 + 2 * p.d_in + extra) * 4;
-    hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 2>), grid, block, smem, st, p, nch, rg);
+    if (tp) hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 2, true>), grid, block, smem, st, p, nch, rg);
+    else hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 2, false>), grid, block, smem, st, p, nch, rg);
   } else {
     size_t smem = (size_t)(RGMAX * 2 * 1 * 16 + 2 * p.d_in + extra) * 4;
-    hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 1>), grid, block, smem, st, p, nch, rg);
+    if (tp) hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 1, true>), grid, block, smem, st, p, nch, rg);
+    else hipLaunchKernelGGL((combine_bwd_kernel<T, VEC, 1, false>), grid, block, smem, st, p, nch, rg);
   }
   FV_LAUNCH_CHECK();
   return FV_OK;
@@ -451,12 +454,17 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
   size_t smem = (size_t)12 * p.d_in * 4;
   FV_CHECK(smem <= 160 * 1024, "mixer_conv_pool_bwd: d_inner %d too large", p.d_in);
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
-    static bool done17 = false, done8 = false;
-    if (!done17) { (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done17 = true; }
-    if (!done8) { (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done8 = true; }
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 17, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
   }
-  if (p.geo.cols + 3 <= 17) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 17>), grid, block, smem, st, p, nch, rg);   // whole row in flight
-  else hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8>), grid, block, smem, st, p, nch, rg);
+  if (p.geo.tpp > 1) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, true>), grid, block, smem, st, p, nch, rg);
+  else if (p.geo.cols + 3 <= 17) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 17, false>), grid, block, smem, st, p, nch, rg);   // whole row in flight
+  else hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, false>), grid, block, smem, st, p, nch, rg);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

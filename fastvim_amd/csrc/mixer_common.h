@@ -24,7 +24,7 @@ struct ChanParams {   // per-lane conv parameters of its VEC channels
 };
 
 // loads the x half of TJ+2*H tokens around tile [j0, j0+TJ) of row i (zero outside [0,L))
-template <typename T, int VEC, int TJ, int H>
+template <typename T, int VEC, int TJ, int H, bool TP = true>
 __device__ __forceinline__ void load_x_tile(const T* xz_b, const Geo& g, int d_in, int i, int j0, int c0,
                                             bool act, float (&x)[TJ + 2 * H][VEC]) {
 #pragma unroll
@@ -32,7 +32,7 @@ __device__ __forceinline__ void load_x_tile(const T* xz_b, const Geo& g, int d_i
     int s = i * g.cols + j0 - H + k;
     bool ok = act && s >= 0 && s < g.L && (j0 - H + k) < g.cols + H;
     if (ok) {
-      int m = tok_mem(g, s);
+      int m = tok_mem<TP>(g, s);
       VecIO<T, VEC>::load(xz_b + (size_t)m * 2 * d_in + c0, x[k]);
     } else {
 #pragma unroll

@@ -53,7 +53,7 @@ __device__ __forceinline__ void conv_both(const ChanParams<VEC>& cp, const float
 }
 
 // ------------------------------------------------------------------ conv + pool
-template <typename T, int VEC, int TJ>
+template <typename T, int VEC, int TJ, bool TP>
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(FwdParams p) {
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.x, b = blockIdx.y;
@@ -65,24 +65,24 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
   const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
   // pooled accumulators: registers for tpp == 1; thread-private LDS slots [dir][slot][thread][VEC] otherwise
   extern __shared__ __attribute__((aligned(16))) float s_pool[];
-  const int tpp = g.tpp, nthr = blockDim.x;
+  const int tpp = TP ? g.tpp : 1, nthr = blockDim.x;
   float accf[VEC], accb[VEC];
   const float init = p.pool_max ? -INFINITY : 0.f;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) accf[v] = accb[v] = init;
-  if (tpp > 1)
+  if constexpr (TP)
     for (int c = 0; c < 2 * tpp; ++c)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) s_pool[(c * nthr + threadIdx.x) * VEC + v] = init;
   for (int j0 = 0; j0 < g.cols; j0 += TJ) {
     float x[TJ + 6][VEC];
-    load_x_tile<T, VEC, TJ, 3>(xz_b, g, p.d_in, i, j0, c0, act, x);
+    load_x_tile<T, VEC, TJ, 3, TP>(xz_b, g, p.d_in, i, j0, c0, act, x);
 #pragma unroll
     for (int jj = 0; jj < TJ; ++jj) {
       if (j0 + jj < g.cols) {
         float xf[VEC], xb[VEC];
         conv_both<VEC, TJ>(cp, x, jj, xf, xb);
-        if (tpp == 1) {
+        if constexpr (!TP) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
             accf[v] = p.pool_max ? fmaxf(accf[v], xf[v]) : accf[v] + xf[v];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
     T* xc = (T*)p.xc;
     const size_t dstride = (size_t)p.B * g.rows * tpp * p.d_in;
     for (int c = 0; c < tpp; ++c) {
-      if (tpp > 1) {
+      if constexpr (TP) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           accf[v] = s_pool[(c * nthr + threadIdx.x) * VEC + v];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
 }
 
 // ------------------------------------------------------------------ combine
-template <typename T, int VEC, int TJ>
+template <typename T, int VEC, int TJ, bool TP>
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdParams p) {
   __shared__ float s_red[16 * TJ];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
   ChanParams<VEC> cp;
   cp.load(p.wf, p.bf, p.wb, p.bb, c0, act);
   float Df[VEC], Db[VEC], lw[VEC], lb[VEC], ysum[VEC];
-  const int tpp = g.tpp;
+  const int tpp = TP ? g.tpp : 1;
   const size_t yrow = ((size_t)b * g.rows + i) * tpp;              // first pooled index of this row
   const size_t ydir = (size_t)p.B * g.rows * tpp * p.d_in;
   {
@@ -154,12 +154,12 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
   const float inv_d = 1.f / (float)p.d_in;
   for (int j0 = 0; j0 < g.cols; j0 += TJ) {
     float x[TJ + 6][VEC];
-    load_x_tile<T, VEC, TJ, 3>(xz_b, g, p.d_in, i, j0, c0, act, x);
+    load_x_tile<T, VEC, TJ, 3, TP>(xz_b, g, p.d_in, i, j0, c0, act, x);
     RawVec<T, VEC> zr[TJ];           // gate inputs fetched with the tile, not at their use
 #pragma unroll
     for (int jj = 0; jj < TJ; ++jj) {
       if (act && j0 + jj < g.cols)
-        zr[jj].load(xz_b + (size_t)tok_mem(g, i * g.cols + j0 + jj) * 2 * p.d_in + p.d_in + c0);
+        zr[jj].load(xz_b + (size_t)tok_mem<TP>(g, i * g.cols + j0 + jj) * 2 * p.d_in + p.d_in + c0);
       else
         zr[jj].zero();
     }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
       float xf[VEC], xb[VEC];
       conv_both<VEC, TJ>(cp, x, jj, xf, xb);
       float acc = 0.f;
-      if (tpp > 1 && act) {       // channel-wise tokenization: the scan output of this token's channel slot
+      if (TP && act) {       // channel-wise tokenization: the scan output of this token's channel slot
         const size_t yo = (yrow + (j0 + jj) % tpp) * p.d_in + c0;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) ysum[v] = p.yc[yo + v] + p.yc[ydir + yo + v];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_fwd_kernel(FwdP
 #pragma unroll
     for (int jj = 0; jj < TJ; ++jj) {
       if (j0 + jj < g.cols) {
-        int m = tok_mem(g, i * g.cols + j0 + jj);
+        int m = tok_mem<TP>(g, i * g.cols + j0 + jj);
         if (act) {
           float z[VEC], out[VEC], xh[VEC];
           zr[jj].get(z);
@@ -265,16 +265,17 @@ int launch_fwd_kernels(int which, const FwdParams& p, hipStream_t st) {
     if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
       static bool done = false;
       if (!done) {
-        (void)hipFuncSetAttribute((const void*)conv_pool_fwd_kernel<T, VEC, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_pool_fwd_kernel<T, VEC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_pool_fwd_kernel<T, VEC, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         done = true;
       }
     }
-    if (t14) hipLaunchKernelGGL((conv_pool_fwd_kernel<T, VEC, 7>), grid, block, smem, st, p);
-    else hipLaunchKernelGGL((conv_pool_fwd_kernel<T, VEC, 8>), grid, block, smem, st, p);
+    if (p.geo.tpp > 1) hipLaunchKernelGGL((conv_pool_fwd_kernel<T, VEC, 8, true>), grid, block, smem, st, p);
+    else if (t14) hipLaunchKernelGGL((conv_pool_fwd_kernel<T, VEC, 7, false>), grid, block, smem, st, p);
+    else hipLaunchKernelGGL((conv_pool_fwd_kernel<T, VEC, 8, false>), grid, block, smem, st, p);
   } else {
-    if (t14) hipLaunchKernelGGL((combine_fwd_kernel<T, VEC, 7>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((combine_fwd_kernel<T, VEC, 8>), grid, block, 0, st, p);
+    if (p.geo.tpp > 1) hipLaunchKernelGGL((combine_fwd_kernel<T, VEC, 8, true>), grid, block, 0, st, p);
+    else if (t14) hipLaunchKernelGGL((combine_fwd_kernel<T, VEC, 7, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((combine_fwd_kernel<T, VEC, 8, false>), grid, block, 0, st, p);
   }
   FV_LAUNCH_CHECK();
   return FV_OK;

@@ -24,13 +24,19 @@ static inline Geo make_geo(int rows, int pcols, int s_i, int s_j, int tpp) {
   return Geo{rows, pcols * tpp, rows * pcols * tpp, s_i, s_j, tpp, pcols};
 }
 
+// TP = false: compiled for tokens_per_patch == 1 (the FastVim models) without the channel-slot decode
+template <bool TP = true>
 __device__ __forceinline__ int tok_mem(const Geo& g, int s) {
   if (g.s_j == 1) return s;          // natural order: sequence position == memory token
   const int i = s / g.cols;
   const int jf = s - i * g.cols;
-  const int j = jf / g.tpp;
-  const int c = jf - j * g.tpp;
-  return (i * g.s_i + j * g.s_j) * g.tpp + c;
+  if constexpr (!TP) {
+    return i * g.s_i + jf * g.s_j;
+  } else {
+    const int j = jf / g.tpp;
+    const int c = jf - j * g.tpp;
+    return (i * g.s_i + j * g.s_j) * g.tpp + c;
+  }
 }
 
 // ---------------------------------------------------------------- vector I/O of VEC channels
