@@ -19,6 +19,7 @@ _lib = None
 C_ABI_SYMBOLS = (
     "fv_last_error", "fv_version",
     "fv_selective_scan_fwd", "fv_selective_scan_bwd_workspace", "fv_selective_scan_bwd",
+    "fv_causal_conv1d_fwd", "fv_causal_conv1d_bwd", "fv_scan_expand_skip_fwd",
     "fv_mixer_conv_pool_fwd", "fv_mixer_scan_fwd", "fv_mixer_combine_fwd",
     "fv_mixer_bwd_blocks", "fv_mixer_combine_bwd", "fv_mixer_scan_bwd_chunks",
     "fv_mixer_scan_bwd_ckpt_floats", "fv_mixer_scan_bwd", "fv_mixer_conv_pool_bwd", "fv_reduce_partials", "fv_reduce_partials_multi",

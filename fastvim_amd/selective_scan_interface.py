@@ -140,3 +140,131 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     """if return_last_state is True, returns (out, last_state); last_state is (batch, dim, dstate)
     fp32 and carries no gradient (selective_scan_interface.py:105-123)."""
     return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+# ------------------------------------------------------------------------------------------------
+# Fused op surface of the reference (optional path of the mixer, use_fast_path=True)
+# ------------------------------------------------------------------------------------------------
+def FastVim_mamba_inner_fn_no_out_proj_withoutZ(
+        x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None, D=None, delta_bias=None,
+        B_proj_bias=None, C_proj_bias=None, delta_softplus=True, num_of_col=14, collapse_method="mean",
+        scaling_factor=1, pre_x_shape=None):
+    """One direction of the FastVim mixer in the reference op layout: x (batch, dim, seqlen) ->
+    conv1d+SiLU -> mean over the grid columns -> x_proj / dt_proj -> selective scan over the pooled
+    rows -> repeat over columns + D * conv_out; returns (batch, dim, seqlen)
+    (selective_scan_interface.py:452-606 forward, 1716-1753 wrapper; same argument list).
+
+    The training hot path does not go through here (fastvim_amd.mamba_simple_faster drives the fused
+    channel-last kernels for both directions at once); this keeps the op importable for code written
+    against the reference, built from the HIP ops above -- causal_conv1d_fn and selective_scan_fn --
+    with autograd composing their hand-written backwards."""
+    import torch.nn.functional as F
+    from .causal_conv1d import causal_conv1d_fn
+    if collapse_method != "mean":
+        raise NotImplementedError("FastVim_mamba_inner_fn_no_out_proj_withoutZ: collapse_method='mean' only "
+                                  "(the reference leaves other methods undefined here)")
+    if A.is_complex():
+        raise NotImplementedError("complex A is not supported")
+    delta_rank = delta_proj_weight.shape[1]
+    d_state = A.shape[-1]
+    if torch.is_autocast_enabled():
+        adt = torch.get_autocast_dtype("cuda")
+        x_proj_weight, delta_proj_weight = x_proj_weight.to(adt), delta_proj_weight.to(adt)
+        x = x.to(adt)
+    with torch.autocast("cuda", enabled=False):
+        conv_out = causal_conv1d_fn(x, conv1d_weight.reshape(conv1d_weight.shape[0], -1), conv1d_bias,
+                                    activation="silu")
+        pooled = conv_out.reshape(pre_x_shape).mean(dim=3)                          # (B, d, Lc)
+        if scaling_factor != 1:
+            pooled = pooled * scaling_factor
+        Bsz, dim, Lc = pooled.shape
+        x_dbl = F.linear(pooled.transpose(1, 2).reshape(Bsz * Lc, dim), x_proj_weight.to(pooled.dtype))
+        delta = (delta_proj_weight.to(pooled.dtype) @ x_dbl[:, :delta_rank].t()).view(dim, Bsz, Lc).transpose(0, 1)
+        if B is None:
+            B = x_dbl[:, delta_rank:delta_rank + d_state]
+            if B_proj_bias is not None:
+                B = B + B_proj_bias.to(B.dtype)
+            B = B.view(Bsz, Lc, d_state).transpose(1, 2).unsqueeze(1)
+        if C is None:
+            C = x_dbl[:, -d_state:]
+            if C_proj_bias is not None:
+                C = C + C_proj_bias.to(C.dtype)
+            C = C.view(Bsz, Lc, d_state).transpose(1, 2).unsqueeze(1)
+        out = selective_scan_fn(pooled, delta, A, B, C, None, None, delta_bias, delta_softplus)
+        out = out.repeat_interleave(num_of_col, dim=2)
+        if D is not None:
+            out = out + D.to(out.dtype).unsqueeze(-1) * conv_out
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# "Compressed scan" of the FastVim kernel fork (experimental in the reference; forward only there)
+# ------------------------------------------------------------------------------------------------
+class CompressedSelectiveScanFn(torch.autograd.Function):
+    """out (B, D, L) = repeat_interleave(scan(u_compressed (B, D, Lc), delta, A, B, C), L / Lc) + D * u
+    (fastvim_kernel/mamba-1p1p1/faster_mamba_ssm/ops/selective_scan_interface.py:9-116, native
+    `faster_selective_scan_cuda.fwd`).  The reference's backward for this op is broken (SURVEY.md
+    section 9); here it is the exact adjoint: the scan backward kernel on the cf-summed output gradient."""
+
+    @staticmethod
+    def forward(ctx, u, u_compressed, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                return_last_state=False):
+        if z is not None:
+            raise ValueError("compressed selective scan: z is not supported (reference: same)")
+        L.require_gpu(u)
+        u, u_c, delta = u.contiguous(), u_compressed.contiguous(), delta.contiguous()
+        A, B, C = A.contiguous(), B.contiguous(), C.contiguous()
+        ctx.squeeze_B, ctx.squeeze_C = B.dim() == 3, C.dim() == 3
+        if B.dim() == 3:
+            B = B.unsqueeze(1)
+        if C.dim() == 3:
+            C = C.unsqueeze(1)
+        D = D.contiguous() if D is not None else None
+        delta_bias = delta_bias.contiguous() if delta_bias is not None else None
+        _validate(u_c, delta, A, B, C, D, None, delta_bias)
+        if u.shape[:2] != u_c.shape[:2] or u.shape[2] % u_c.shape[2] or u.dtype != u_c.dtype:
+            raise RuntimeError("compressed selective scan: u (B, D, L) must be a whole multiple of u_compressed (B, D, Lc)")
+        yc, last = _scan_fwd(u_c, delta, A, B, C, None, None, delta_bias, delta_softplus, return_last_state)
+        out = torch.empty_like(u)
+        rc = L.lib().fv_scan_expand_skip_fwd(L.ptr(yc), L.ptr(u), L.ptr(D), L.ptr(out), L.i32(u.shape[0]),
+                                             L.i32(u.shape[1]), L.i32(u.shape[2]), L.i32(u_c.shape[2]),
+                                             L.i32(L.dtype_code(u.dtype)), L.stream_of(u))
+        L.check(rc, "scan_expand_skip_fwd")
+        ctx.delta_softplus = delta_softplus
+        ctx.has_D, ctx.has_bias = D is not None, delta_bias is not None
+        ctx.save_for_backward(u, u_c, delta, A, B, C, D, delta_bias)
+        if return_last_state:
+            ctx.mark_non_differentiable(last)
+            return out, last
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        u, u_c, delta, A, B, C, D, delta_bias = ctx.saved_tensors
+        Bsz, dim, Lf = u.shape
+        Lc = u_c.shape[2]
+        dyc = dout.reshape(Bsz, dim, Lc, Lf // Lc).float().sum(-1).to(u_c.dtype)
+        with torch.enable_grad():
+            leaves = [t.detach().requires_grad_() for t in (u_c, delta, A, B, C)]
+            db = delta_bias.detach().requires_grad_() if ctx.has_bias else None
+            y = SelectiveScanFn.apply(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], None, None, db,
+                                      ctx.delta_softplus, False)
+        grads = torch.autograd.grad(y, leaves + ([db] if db is not None else []), dyc)
+        du_c, ddelta, dA, dB, dC = grads[:5]
+        dbias = grads[5] if db is not None else None
+        du = dD = None
+        if ctx.has_D:
+            du = (dout.float() * D[None, :, None]).to(u.dtype)
+            dD = (dout.float() * u.float()).sum((0, 2))
+        if ctx.squeeze_B:
+            dB = dB.squeeze(1)
+        if ctx.squeeze_C:
+            dC = dC.squeeze(1)
+        return du, du_c, ddelta, dA, dB, dC, dD, None, dbias, None, None
+
+
+def compressed_selective_scan_fn(u, u_compressed, delta, A, B, C, D=None, z=None, delta_bias=None,
+                                 delta_softplus=False, return_last_state=False):
+    """``faster_mamba_ssm.ops.selective_scan_interface.selective_scan_fn`` of the FastVim kernel fork."""
+    return CompressedSelectiveScanFn.apply(u, u_compressed, delta, A, B, C, D, z, delta_bias, delta_softplus,
+                                           return_last_state)

@@ -69,6 +69,34 @@ int fv_selective_scan_bwd(const void* u, const void* delta, const float* A, cons
                           int delta_softplus, int dtype, fv_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Causal depthwise conv1d (+ SiLU), reference op layout (batch, dim, seqlen), seqlen contiguous.
+ * Replaces `causal_conv1d_cuda.causal_conv1d_fwd(x, weight, bias, seq_idx=None, silu)` and
+ * `causal_conv1d_cuda.causal_conv1d_bwd(x, weight, bias, dout, seq_idx=None, dx, silu) -> (dx, dw, dbias)`
+ * of PyPI causal-conv1d 1.1.3.post1 (third-party, not vendored; pinned by the reference README.md:43 and
+ * called at mamba_ssm/modules/mamba_simple_faster.py:274-285 and
+ * mamba_ssm/ops/selective_scan_interface.py:496-498, 640-642, 751-753).
+ *
+ *   x, y, dy, dx : (batch, dim, seqlen) storage `dtype`;  weight (dim, width) fp32, width in 2..4;
+ *   bias (dim) fp32, nullable;  silu != 0 applies SiLU to the output.
+ *   y[b,d,l] = act(bias[d] + sum_k weight[d,k] * x[b,d,l-(width-1)+k])
+ * Backward writes dx and per-(batch, dim) partials (batch, dim, 5) = [dw front-padded to 4 taps | dbias];
+ * the caller sums them over batch with fv_reduce_partials (fixed order, deterministic).
+ * ---------------------------------------------------------------------- */
+int fv_causal_conv1d_fwd(const void* x, const float* weight, const float* bias, void* y, int batch, int dim,
+                         int seqlen, int width, int silu, int dtype, fv_stream_t stream);
+int fv_causal_conv1d_bwd(const void* x, const float* weight, const float* bias, const void* dy, void* dx,
+                         float* partials, int batch, int dim, int seqlen, int width, int silu, int dtype,
+                         fv_stream_t stream);
+
+/* Expand + skip epilogue of the "compressed scan" fork: out[b,d,l] = yc[b,d,l/cf] + D[d]*u_full[b,d,l],
+ * cf = seqlen / seqlen_compressed.  With fv_selective_scan_fwd on (u_compressed, delta, ...) this replaces
+ * `faster_selective_scan_cuda.fwd(u, u_compressed, delta, A, B, C, D, z=None, delta_bias, softplus)`
+ * (fastvim_kernel/mamba-1p1p1/csrc/selective_scan/selective_scan.cpp:216-360,
+ *  selective_scan_fwd_kernel.cuh:68-299).  D nullable (then u_full may be null). */
+int fv_scan_expand_skip_fwd(const void* yc, const void* u_full, const float* D, void* out, int batch, int dim,
+                            int seqlen, int seqlen_compressed, int dtype, fv_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Fused FastVim mixer "middle", channel-last (token-major) activations.
  * Together these replace the body of `Mamba.forward` between in_proj and out_proj
  *   (mamba-1p1p1/mamba_ssm/modules/mamba_simple_faster.py:270-444) and the fused autograd
