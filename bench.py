@@ -111,27 +111,27 @@ def kernel_table(B, rows, cols, d, depth, dtype):
     Wdt = rn(d_in, R, dt=torch.float32) * R ** -0.5
     bdt = torch.full((d_in,), -4.0, device=dev)
     A_log = torch.log(torch.arange(1, N + 1, device=dev, dtype=torch.float32)).repeat(d_in, 1).contiguous()
-    xc = M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0)
+    xc, skip = M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0, D=D, D_b=Db)
     x_dbl = rn(2, B * rows, R + 2 * N)
     yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log)
-    gout, xhat, mean, rstd = M.combine_fwd(xz, yc, cw, cb, cwb, cbb, D, Db, lnw, lnb, 1e-5, rows, cols, False)
+    gout, mean, rstd = M.combine_fwd(xz, skip, yc, lnw, lnb, 1e-5, rows, cols, False)
     dg = rn(B, L, d_in)
     dxz = torch.empty_like(xz)
-    d_o, dyc, _ = M.combine_bwd(dg, xz, xhat, lnw, lnb, rstd, dxz, rows, cols, False)
+    d_o, dyc, _ = M.combine_bwd(dg, xz, skip, yc, lnw, lnb, mean, rstd, dxz, rows, cols, False)
     dxc = torch.randn(2, B, rows, d_in, device=dev, generator=g)
     hid, res = rn(B, L, d), torch.randn(B, L, d, device=dev, generator=g)
     nw = torch.ones(d, device=dev)
     U = B * L * d_in * e                      # one full-length (B, L, d_in) tensor
     small = B * rows * d_in
     table = {
-        "conv_pool_fwd": (lambda: M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0),
-                          U + 2 * small * e, 1),
+        "conv_pool_fwd": (lambda: M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0, D=D, D_b=Db),
+                          2 * U + 2 * small * e, 1),            # x read, skip written, xc written
         "scan_fwd": (lambda: M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log),
                      2 * (small * e + B * rows * (R + 2 * N) * e + small * 4), 1),
-        "combine_fwd": (lambda: M.combine_fwd(xz, yc, cw, cb, cwb, cbb, D, Db, lnw, lnb, 1e-5, rows, cols, False),
-                        4 * U + 2 * small * 4 + 2 * B * L * 4, 1),
-        "combine_bwd": (lambda: M.combine_bwd(dg, xz, xhat, lnw, lnb, rstd, dxz, rows, cols, False),
-                        5 * U + small * 4 + B * L * 4, 1),
+        "combine_fwd": (lambda: M.combine_fwd(xz, skip, yc, lnw, lnb, 1e-5, rows, cols, False),
+                        3 * U + 2 * small * 4 + 2 * B * L * 4, 1),    # skip, z read; g written
+        "combine_bwd": (lambda: M.combine_bwd(dg, xz, skip, yc, lnw, lnb, mean, rstd, dxz, rows, cols, False),
+                        5 * U + 3 * small * 4 + 2 * B * L * 4, 1),   # dg, z, skip read; dz, do written
         "scan_bwd": (lambda: M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc),
                      2 * (small * e + B * rows * (R + 2 * N) * (e + 4) + small * 4) + small * 4, 1),
         "conv_pool_bwd": (lambda: M.conv_pool_bwd(xz, d_o, dxc, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 0, 1.0),

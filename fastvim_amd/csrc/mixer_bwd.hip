@@ -3,7 +3,7 @@
 // hand-written backward of FastVim_MambaInnerFnNoOutProj_withoutZ
 // (mamba_ssm/ops/selective_scan_interface.py:607-776):
 //
-//   fv_mixer_combine_bwd   : d(gate), d(LayerNorm) from the saved xhat -> dz, do, per-row pooled
+//   fv_mixer_combine_bwd   : d(gate), d(LayerNorm) with xhat rebuilt from the saved skip/yc/mean/rstd -> dz, do, per-row pooled
 //                            dyc = 0.5*sum_j do, partials of dLN.weight/bias.
 //   (fv_mixer_scan_bwd, the adjoint of dt_proj + scan, lives in scan_cl.hip)
 //   fv_mixer_conv_pool_bwd : adjoint of the D-skip, mean-pool, SiLU and both depthwise convs -> dx,
@@ -14,8 +14,8 @@
 namespace {
 
 struct BwdParams {
-  const void *xz, *dg, *xhat, *dob_in;
-  const float *wf, *bf, *wb, *bb, *Df, *Db, *lnw, *lnb, *rstd, *dxc;
+  const void *xz, *dg, *skip, *dob_in;
+  const float *wf, *bf, *wb, *bb, *Df, *Db, *lnw, *lnb, *mean, *rstd, *dxc, *yc;
   void *dxz, *dob;
   float *dyc, *part;
   Geo geo;
@@ -26,8 +26,8 @@ struct BwdParams {
 constexpr int RGMAX = 4;   // a block walks up to RGMAX pooling rows concurrently (one per row group) and emits ONE partial
 
 // ------------------------------------------------------------------ LayerNorm + gate backward
-// Reads dg, z, xhat once, writes dz and d_o once: 5 full-length tensors of traffic, no conv recompute
-// (the forward saved xhat).  Block = RG row groups x NCH waves; a row group walks one pooling row.
+// Reads dg, z, skip once, writes dz and d_o once: 5 full-length tensors of traffic, no conv recompute
+// (xhat = ((yc_f + yc_b + skip)/2 - mean) * rstd is two FMAs from what the forward saved).  Block = RG row groups x NCH waves; a row group walks one pooling row.
 template <typename T, int VEC, int TT, bool TP>
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -57,7 +57,12 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
     const int b = rv ? row / g.rows : 0, i = rv ? row - b * g.rows : 0;
     const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
     const T* dg_b = (const T*)p.dg + (size_t)b * g.L * p.d_in;
-    const T* xh_b = (const T*)p.xhat + (size_t)b * g.L * p.d_in;
+    const T* xh_b = (const T*)p.skip + (size_t)b * g.L * p.d_in;
+    const size_t ydir = (size_t)p.B * g.rows * tpp * p.d_in;
+    const float* yc_r = p.yc + (size_t)(rv ? row : 0) * tpp * p.d_in + (act ? c0 : 0);
+    float ysum[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ysum[v] = (!TP && rv && act) ? yc_r[v] + yc_r[ydir + v] : 0.f;
     T* dxz_b = (T*)p.dxz + (size_t)b * g.L * 2 * p.d_in;
     T* dob_b = (T*)p.dob + (size_t)b * g.L * p.d_in;
     float dyc_acc[VEC];
@@ -100,6 +105,16 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
         tv[t] = rv && (j0 + t < g.cols);
         mtok[t] = tv[t] ? tok_mem<TP>(g, i * g.cols + j0 + t) : 0;
         rs[t] = (tv[t] && p.use_norm) ? p.rstd[(size_t)b * g.L + mtok[t]] : 1.f;
+        const float mu = (tv[t] && p.use_norm) ? p.mean[(size_t)b * g.L + mtok[t]] : 0.f;
+        if constexpr (TP) {
+          if (tv[t] && act) {
+            const float* y = yc_r + (size_t)((j0 + t) % tpp) * p.d_in;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) ysum[v] = y[v] + y[ydir + v];
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xh[t][v] = (tv[t] && act) ? (0.5f * (ysum[v] + xh[t][v]) - mu) * rs[t] : 0.f;   // skip -> xhat
         float dzv[VEC];
         const float (&dgv)[VEC] = dgq[t];
         const float (&zv)[VEC] = zq[t];
@@ -498,18 +513,19 @@ extern "C" int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int tokens_
                     : persistent_blocks(n, rg_convpool(d_inner, vec_convpool(d_inner)));
 }
 
-extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* xhat, const float* ln_w,
-                                    const float* ln_b, const float* rstd, void* dxz, void* d_o, float* dyc,
+extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* skip, const float* yc,
+                                    const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                                    void* dxz, void* d_o, float* dyc,
                                     float* partials, int batch, int rows, int cols, int tok_stride_row,
                                     int tok_stride_col, int tokens_per_patch, int d_inner, int dtype,
                                     fv_stream_t stream) {
   int rc = check_geo_b(batch, rows, cols, tok_stride_row, tok_stride_col, d_inner, dtype);
   FV_CHECK(tokens_per_patch > 0, "mixer_combine_bwd: tokens_per_patch must be positive");
   if (rc) return rc;
-  FV_CHECK(dg && xz && xhat && dxz && d_o && dyc && partials, "mixer_combine_bwd: null pointer");
-  FV_CHECK(!ln_w || (ln_b && rstd), "mixer_combine_bwd: LayerNorm needs weight, bias, rstd");
+  FV_CHECK(dg && xz && skip && yc && dxz && d_o && dyc && partials, "mixer_combine_bwd: null pointer");
+  FV_CHECK(!ln_w || (ln_b && mean && rstd), "mixer_combine_bwd: LayerNorm needs weight, bias, mean, rstd");
   BwdParams p{};
-  p.dg = dg; p.xz = xz; p.xhat = xhat; p.lnw = ln_w; p.lnb = ln_b; p.rstd = rstd;
+  p.dg = dg; p.xz = xz; p.skip = skip; p.yc = yc; p.lnw = ln_w; p.lnb = ln_b; p.mean = mean; p.rstd = rstd;
   p.dxz = dxz; p.dob = d_o; p.dyc = dyc; p.part = partials;
   p.use_norm = ln_w != nullptr;
   p.geo = make_geo(rows, cols, tok_stride_row, tok_stride_col, tokens_per_patch);

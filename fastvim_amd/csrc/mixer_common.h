@@ -12,11 +12,14 @@ struct ChanParams {   // per-lane conv parameters of its VEC channels
   __device__ __forceinline__ void load(const float* wf_, const float* bf_, const float* wb_, const float* bb_, int c0, bool act) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-#pragma unroll
-      for (int k = 0; k < CW; ++k) {
-        wf[v][k] = act ? wf_[(c0 + v) * CW + k] : 0.f;
-        wb[v][k] = act ? wb_[(c0 + v) * CW + k] : 0.f;
+      // one 16-byte load per channel and direction (rows of the (d_in, 4) weight are 16-byte aligned)
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+      if (act) {
+        a = *reinterpret_cast<const float4*>(wf_ + (size_t)(c0 + v) * CW);
+        c = *reinterpret_cast<const float4*>(wb_ + (size_t)(c0 + v) * CW);
       }
+      wf[v][0] = a.x; wf[v][1] = a.y; wf[v][2] = a.z; wf[v][3] = a.w;
+      wb[v][0] = c.x; wb[v][1] = c.y; wb[v][2] = c.z; wb[v][3] = c.w;
       bf[v] = act && bf_ ? bf_[c0 + v] : 0.f;
       bb[v] = act && bb_ ? bb_[c0 + v] : 0.f;
     }

@@ -78,9 +78,34 @@ class DropPath(nn.Module):
         self.drop_prob = drop_prob
         self.scale_by_keep = scale_by_keep
 
+    @staticmethod
+    def predraw(mods, batch, device):
+        """Draw the per-sample keep masks of several DropPath modules in one shot (4 small launches per
+        step instead of 2 per layer): Bernoulli(keep) == floor(keep + U[0,1)).  Each module's next
+        ``row_scale`` call consumes its row."""
+        mods = [m for m in mods if isinstance(m, DropPath) and m.drop_prob > 0.0 and m.training]
+        if not mods:
+            return
+        key = (tuple(m.drop_prob for m in mods), str(device))
+        cache = DropPath._keep_cache
+        if key not in cache:
+            keep = torch.tensor([1.0 - m.drop_prob for m in mods], dtype=torch.float32, device=device)[:, None]
+            inv = torch.tensor([1.0 / (1.0 - m.drop_prob) if (m.scale_by_keep and m.drop_prob < 1.0) else 1.0
+                                for m in mods], dtype=torch.float32, device=device)[:, None]
+            cache[key] = (keep, inv)
+        keep, inv = cache[key]
+        table = torch.rand(len(mods), batch, device=device, dtype=torch.float32).add_(keep).floor_().mul_(inv)
+        for i, m in enumerate(mods):
+            m.__dict__["_pre"] = table[i]
+
+    _keep_cache = {}
+
     def row_scale(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return None
+        pre = self.__dict__.pop("_pre", None)
+        if pre is not None and pre.shape[0] == x.shape[0] and pre.device == x.device:
+            return pre
         keep = 1.0 - self.drop_prob
         mask = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
@@ -319,6 +344,8 @@ class VisionMamba(nn.Module):
         outs = []
         residual = None
         hidden_states = x
+        if self.training:
+            DropPath.predraw([l.drop_path for l in self.layers] + [self.drop_path], x.shape[0], x.device)
         for layer_idx, layer in enumerate(self.layers):
             hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
             if out_indices is not None and layer_idx in out_indices:

@@ -165,7 +165,8 @@ class FastVimMixerFn(torch.autograd.Function):
             W_in_c, W_out_c = _shadow(W_in, cdt), _shadow(W_out, cdt)
             xz = linear_fwd(h_c.view(B * Ltok, d), W_in_c, b_in).view(B, Ltok, 2 * d_in)  # (B, L, 2 d_in)
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
-            xc = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp)
+            xc, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
+                                       D=D, D_b=D_b)
             if fv is not None and "Wx2" in fv:          # x_proj / x_proj_b adjacent in the flat buffers
                 Wx2 = fv["Wx2"]
                 Wx2_c = fv["Wx2_shadow"] if fv["Wx2_shadow"].dtype == cdt else Wx2.to(cdt)
@@ -174,11 +175,10 @@ class FastVimMixerFn(torch.autograd.Function):
                 Wx2_c = Wx2.to(cdt)
             x_dbl = torch.bmm(xc.view(2, B * rows * tpp, d_in), Wx2_c.transpose(1, 2))        # (2, B*Lc, R+2N)
             yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
-            g, xhat, mean, rstd = M.combine_fwd(xz, yc, cw2, cb, cwb2, cb_b, D, D_b, ln_w, ln_b, ln_eps,
-                                                rows, cols, transposed, tpp=tpp)
+            g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
             out = linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
         ctx.save_for_backward(h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b,
-                              ln_w, ln_b, W_out, xz, xc, x_dbl, g, xhat, rstd)
+                              ln_w, ln_b, W_out, xz, xc, x_dbl, g, skip, yc, mean, rstd)
         ctx.geo = (rows, cols, transposed, pool_max, scaling, tpp)
         ctx.has_bias = (b_in is not None, b_out is not None)
         ctx.cdt = cdt
@@ -189,7 +189,7 @@ class FastVimMixerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b, ln_w, ln_b, W_out,
-         xz, xc, x_dbl, g, xhat, rstd) = ctx.saved_tensors
+         xz, xc, x_dbl, g, skip, yc, mean, rstd) = ctx.saved_tensors
         rows, cols, transposed, pool_max, scaling, tpp = ctx.geo
         cdt = ctx.cdt
         B, Ltok, d = h_c.shape
@@ -203,7 +203,7 @@ class FastVimMixerFn(torch.autograd.Function):
             db_out = do2.float().sum(0) if ctx.has_bias[1] else None
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
-            d_o, dyc, p1 = M.combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed,
+            d_o, dyc, p1 = M.combine_bwd(dg, xz, skip, yc, ln_w, ln_b, mean, rstd, dxz, rows, cols, transposed,
                                          grad_out=fv.get("ln_grad") if ln_w is not None else None, tpp=tpp)
             W_ = x_dbl.shape[-1]
             fused_xproj = W_ in M.XPROJ_WIDTHS

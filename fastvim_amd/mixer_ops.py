@@ -14,17 +14,20 @@ def _geo(rows, cols, transposed):
     return (1, rows) if transposed else (cols, 1)
 
 
-def conv_pool_fwd(xz, conv_w, conv_b, conv_w_b, conv_b_b, rows, cols, transposed, pool_max, scaling, tpp=1):
+def conv_pool_fwd(xz, conv_w, conv_b, conv_w_b, conv_b_b, rows, cols, transposed, pool_max, scaling, tpp=1,
+                  D=None, D_b=None):
+    """Returns xc (2, B, rows*tpp, d_in); with D / D_b also skip (B, L, d_in) = D*conv_f + D_b*conv_b."""
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     xc = torch.empty(2, B, rows * tpp, d_in, device=xz.device, dtype=xz.dtype)
+    skip = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype) if D is not None else None
     rc = L.lib().fv_mixer_conv_pool_fwd(
-        L.ptr(xz), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(xc),
-        L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in), L.i32(conv_w.shape[-1]),
-        L.i32(pool_max), f32(scaling), L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
+        L.ptr(xz), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(D), L.ptr(D_b), L.ptr(xc),
+        L.ptr(skip), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in),
+        L.i32(conv_w.shape[-1]), L.i32(pool_max), f32(scaling), L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_conv_pool_fwd")
-    return xc
+    return xc if D is None else (xc, skip)
 
 
 def scan_fwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
@@ -40,25 +43,23 @@ def scan_fwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
     return yc
 
 
-def combine_fwd(xz, yc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, ln_w, ln_b, eps, rows, cols, transposed,
-                save_xhat=True, tpp=1):
+def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1):
+    """g (B, L, d_in) = LayerNorm((yc_f + yc_b + skip) / 2) * silu(z); also returns mean, rstd (B*L) fp32."""
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     g = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype)
-    xhat = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype) if save_xhat else None
     if ln_w is not None:
         mean = torch.empty(B * Ltok, device=xz.device, dtype=torch.float32)
         rstd = torch.empty(B * Ltok, device=xz.device, dtype=torch.float32)
     else:
         mean = rstd = None
     rc = L.lib().fv_mixer_combine_fwd(
-        L.ptr(xz), L.ptr(yc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(D),
-        L.ptr(D_b), L.ptr(ln_w), L.ptr(ln_b), f32(eps), L.ptr(g), L.ptr(xhat), L.ptr(mean), L.ptr(rstd), L.i32(B),
-        L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in), L.i32(conv_w.shape[-1]),
+        L.ptr(xz), L.ptr(skip), L.ptr(yc), L.ptr(ln_w), L.ptr(ln_b), f32(eps), L.ptr(g), L.ptr(mean), L.ptr(rstd),
+        L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_combine_fwd")
-    return g, xhat, mean, rstd
+    return g, mean, rstd
 
 
 class _Deferred:
@@ -114,7 +115,7 @@ def reduce_partials(part, n_partials, out=None, accumulate=False, defer=True):
     return out
 
 
-def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed, grad_out=None, tpp=1):
+def combine_bwd(dg, xz, skip, yc, ln_w, ln_b, mean, rstd, dxz, rows, cols, transposed, grad_out=None, tpp=1):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
@@ -124,7 +125,7 @@ def combine_bwd(dg, xz, xhat, ln_w, ln_b, rstd, dxz, rows, cols, transposed, gra
     dyc = torch.empty(B, rows * tpp, d_in, device=xz.device, dtype=torch.float32)
     part = torch.empty(nb, 2, d_in, device=xz.device, dtype=torch.float32)
     rc = lib.fv_mixer_combine_bwd(
-        L.ptr(dg), L.ptr(xz), L.ptr(xhat), L.ptr(ln_w), L.ptr(ln_b), L.ptr(rstd), L.ptr(dxz), L.ptr(d_o),
+        L.ptr(dg), L.ptr(xz), L.ptr(skip), L.ptr(yc), L.ptr(ln_w), L.ptr(ln_b), L.ptr(mean), L.ptr(rstd), L.ptr(dxz), L.ptr(d_o),
         L.ptr(dyc), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_combine_bwd")

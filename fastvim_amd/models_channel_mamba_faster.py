@@ -269,6 +269,8 @@ class VisionMamba(nn.Module):
             x, tokens_per_patch, h, w, _ = self.patch_embed(x)
         residual = None
         hidden_states = x
+        if self.training:
+            DropPath.predraw([l.drop_path for l in self.layers] + [self.drop_path], x.shape[0], x.device)
         for layer in self.layers:
             hidden_states, residual = layer(hidden_states, tokens_per_patch, residual,
                                             inference_params=inference_params)

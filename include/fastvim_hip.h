@@ -118,10 +118,14 @@ int fv_scan_expand_skip_fwd(const void* yc, const void* u_full, const float* D, 
  *           (2, batch, rows*t, d_inner), pooled index i*t + c; strides are in cells.
  * Conv weights are (d_inner, d_conv) fp32 (= conv1d.weight viewed "d 1 w -> d w").
  * ---------------------------------------------------------------------- */
+/* Both depthwise convs + SiLU, the pooling over `cols` -> xc, and (skip != NULL) the D-weighted skip term
+ * skip[b, token, :] = D*conv_f(x) + D_b*conv_b(x)  (batch, L, d_inner), memory token order, storage `dtype`
+ * (mamba_simple_faster.py:356-358, 412-416): each conv+SiLU is evaluated once per forward pass. */
 int fv_mixer_conv_pool_fwd(const void* xz, const float* conv_w, const float* conv_b,
-                           const float* conv_w_b, const float* conv_b_b, void* xc, int batch, int rows,
-                           int cols, int tok_stride_row, int tok_stride_col, int tokens_per_patch, int d_inner,
-                           int d_conv, int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
+                           const float* conv_w_b, const float* conv_b_b, const float* D, const float* D_b,
+                           void* xc, void* skip, int batch, int rows, int cols, int tok_stride_row,
+                           int tok_stride_col, int tokens_per_patch, int d_inner, int d_conv, int pool_max,
+                           float scaling_factor, int dtype, fv_stream_t stream);
 
 /* dt_proj + softplus + selective scan (A = -exp(A_log)) for both directions.  yc is fp32. */
 int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
@@ -129,28 +133,27 @@ int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, cons
                       const float* A_log_b, float* yc, int batch, int Lc, int d_inner, int dt_rank,
                       int d_state, int dtype, fv_stream_t stream);
 
-/* g = LayerNorm(((yc_f + D*conv_f(x)) + (yc_b + D_b*conv_b(x))) / 2) * silu(z); ln_w == NULL
- * skips the norm (use_norm_after_ssm=False).  Saved for backward: xhat (batch, L, d_inner), the
- * normalised pre-gate value (nullable when no backward is needed), and mean/rstd (batch*L) fp32. */
-int fv_mixer_combine_fwd(const void* xz, const float* yc, const float* conv_w, const float* conv_b,
-                         const float* conv_w_b, const float* conv_b_b, const float* D, const float* D_b,
-                         const float* ln_w, const float* ln_b, float ln_eps, void* g, void* xhat,
-                         float* mean, float* rstd, int batch, int rows, int cols, int tok_stride_row,
-                         int tok_stride_col, int tokens_per_patch, int d_inner, int d_conv, int dtype,
-                         fv_stream_t stream);
+/* g = LayerNorm((yc_f + yc_b + skip) / 2) * silu(z), the scan outputs expanded over `cols`; ln_w == NULL
+ * skips the norm (use_norm_after_ssm=False).  mean/rstd (batch*L) fp32 are saved for backward, which
+ * rebuilds the normalised value from skip, yc, mean, rstd. */
+int fv_mixer_combine_fwd(const void* xz, const void* skip, const float* yc, const float* ln_w,
+                         const float* ln_b, float ln_eps, void* g, float* mean, float* rstd, int batch,
+                         int rows, int cols, int tok_stride_row, int tok_stride_col, int tokens_per_patch,
+                         int d_inner, int dtype, fv_stream_t stream);
 
 /* ---- backward of the fused mixer middle --------------------------------------------
  * Number of persistent blocks a row-walking backward kernel launches (which = 0: combine_bwd,
  * 1: conv_pool_bwd); their `partials` buffers are (blocks, 2*d_inner) and (blocks, 12*d_inner) fp32. */
 int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int tokens_per_patch, int which);
 
-/* Adjoint of the LayerNorm + gate of fv_mixer_combine_fwd, from the saved xhat.  dg: gradient wrt g.
+/* Adjoint of the LayerNorm + gate of fv_mixer_combine_fwd; the normalised value is rebuilt from the saved
+ * skip, yc, mean, rstd.  dg: gradient wrt g.
  * Writes dz into the z half of dxz (batch, L, 2*d_inner), d_o (batch, L, d_inner) = gradient wrt the
  * averaged pre-norm value, dyc (batch, rows, d_inner) fp32 = 0.5 * sum_j d_o (gradient wrt BOTH
  * directions' scan outputs), and per-block partials [d ln_w (d_inner) | d ln_b (d_inner)]. */
-int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* xhat, const float* ln_w,
-                         const float* ln_b, const float* rstd, void* dxz, void* d_o, float* dyc,
-                         float* partials, int batch, int rows, int cols, int tok_stride_row,
+int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* skip, const float* yc,
+                         const float* ln_w, const float* ln_b, const float* mean, const float* rstd,
+                         void* dxz, void* d_o, float* dyc, float* partials, int batch, int rows, int cols, int tok_stride_row,
                          int tok_stride_col, int tokens_per_patch, int d_inner, int dtype, fv_stream_t stream);
 
 /* Adjoint of fv_mixer_scan_fwd with the dt_proj adjoint fused in (replaces

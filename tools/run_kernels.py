@@ -20,13 +20,13 @@ bdt = torch.full((d_in,), -4.0, device=dev)
 A_log = torch.log(torch.arange(1, N + 1, device=dev, dtype=torch.float32)).repeat(d_in, 1).contiguous()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for _ in range(n):
-    xc = M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0)
+    xc, skip = M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0, D=D, D_b=Db)
     x_dbl = rn(2, B * rows, R_ + 2 * N)
     yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log)
-    gout, xhat, mean, rstd = M.combine_fwd(xz, yc, cw, cb, cwb, cbb, D, Db, lnw, lnb, 1e-5, rows, cols, False)
+    gout, mean, rstd = M.combine_fwd(xz, skip, yc, lnw, lnb, 1e-5, rows, cols, False)
     dg = rn(B, L, d_in)
     dxz = torch.empty_like(xz)
-    d_o, dyc, _ = M.combine_bwd(dg, xz, xhat, lnw, lnb, rstd, dxz, rows, cols, False)
+    d_o, dyc, _ = M.combine_bwd(dg, xz, skip, yc, lnw, lnb, mean, rstd, dxz, rows, cols, False)
     dxc, dxd, _ = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc)
     M.conv_pool_bwd(xz, d_o, dxc, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 0, 1.0)
     hid, res = rn(B, L, d), torch.randn(B, L, d, device=dev, generator=g)
