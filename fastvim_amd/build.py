@@ -26,8 +26,15 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
+def _file_flags(src):
+    """Extra flags a source asks for on its first line: ``// hipcc-flags: -fno-slp-vectorize``."""
+    with open(src) as f:
+        first = f.readline()
+    return first.split("hipcc-flags:", 1)[1].split() if "hipcc-flags:" in first else []
+
+
 def _compile(src, obj, verbose):
-    cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *_file_flags(src), "-x", "hip", "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

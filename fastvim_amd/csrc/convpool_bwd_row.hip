@@ -1,0 +1,239 @@
+// hipcc-flags: -fno-slp-vectorize
+// Whole-row conv + pool backward for short pooling rows (cols == 14 or 16, tokens_per_patch == 1,
+// d_inner a multiple of 128): the adjoint of the D-skip, mean-pool, SiLU and both depthwise convs
+// (mamba_simple_faster.py:270-305, 356-358, 412-416; FastVim_MambaInnerFnNoOutProj_withoutZ.backward,
+// selective_scan_interface.py:607-776).  Same persistent grid and per-block partial layout as the generic
+// kernel in mixer_bwd.hip.
+//
+// These launches are instruction-issue bound (two sigmoids = four quarter-rate transcendentals per element
+// and ~50 FMAs), so the kernel is written for instruction count:
+//   * a lane owns a channel PAIR and all per-channel arithmetic is on 2-wide vectors -> v_pk_fma/mul/add_f32
+//     (the SLP vectoriser is off for this file: left to itself it pairs values across the unrolled token
+//     steps instead and drowns in splat copies);
+//   * all positions are compile-time: token offsets are affine (no integer division), the 4-deep windows are
+//     register renaming;
+//   * token accesses are buffer instructions: descriptor + uniform byte offset in SGPRs and one shared
+//     32-bit lane offset, instead of a 64-bit VGPR address pair per access;
+//   * every load of the row (2 x (cols + 6) tokens, packed) is issued before the first sigmoid; halo
+//     positions of a missing neighbour row read this row (always mapped) and are zeroed by scalar selects.
+#include "mixer_common.h"
+
+namespace {
+
+using fvi::BwdParams;
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Pair;
+template <> struct Pair<bf16_t> {     // one dword = two bf16 channels
+  typedef uint32_t raw;
+  static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+  }
+  static __device__ __forceinline__ f2 unpack(raw w) {
+    f2 o;
+    o.x = __uint_as_float(w << 16);
+    o.y = __uint_as_float(w & 0xffff0000u);
+    return o;
+  }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, f2 v) {
+    __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(v.x, v.y), r, voff, soff, 0);
+  }
+};
+template <> struct Pair<float> {
+  typedef fv_u32x2 raw;
+  static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  }
+  static __device__ __forceinline__ f2 unpack(raw w) {
+    f2 o;
+    o.x = __uint_as_float(w.x);
+    o.y = __uint_as_float(w.y);
+    return o;
+  }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, f2 v) {
+    fv_u32x2 w;
+    w.x = __float_as_uint(v.x);
+    w.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
+  }
+};
+
+__device__ __forceinline__ f2 splat(float a) { f2 o; o.x = a; o.y = a; return o; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 sigmoid2(f2 a) {
+  f2 e;
+  e.x = __builtin_amdgcn_exp2f(a.x * -FV_LOG2E);
+  e.y = __builtin_amdgcn_exp2f(a.y * -FV_LOG2E);
+  f2 d = e + 1.f, o;
+  o.x = __builtin_amdgcn_rcpf(d.x);
+  o.y = __builtin_amdgcn_rcpf(d.y);
+  return o;
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int nch, int RG) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
+  typedef Pair<T> P;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rg = wv / nch, cw = wv - rg * nch;
+  const int c0 = (cw * 64 + lane) * 2;                 // first channel of this lane's pair
+  const Geo g = p.geo;
+  f2 wf[CW], wb[CW], bf, bb, Dfh, Dbh;
+  {
+    const float4 a0 = *reinterpret_cast<const float4*>(p.wf + (size_t)c0 * CW);
+    const float4 a1 = *reinterpret_cast<const float4*>(p.wf + (size_t)(c0 + 1) * CW);
+    const float4 b0 = *reinterpret_cast<const float4*>(p.wb + (size_t)c0 * CW);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.wb + (size_t)(c0 + 1) * CW);
+    wf[0].x = a0.x; wf[1].x = a0.y; wf[2].x = a0.z; wf[3].x = a0.w;
+    wf[0].y = a1.x; wf[1].y = a1.y; wf[2].y = a1.z; wf[3].y = a1.w;
+    wb[0].x = b0.x; wb[1].x = b0.y; wb[2].x = b0.z; wb[3].x = b0.w;
+    wb[0].y = b1.x; wb[1].y = b1.y; wb[2].y = b1.z; wb[3].y = b1.w;
+    bf = p.bf ? *reinterpret_cast<const f2*>(p.bf + c0) : splat(0.f);
+    bb = p.bb ? *reinterpret_cast<const f2*>(p.bb + c0) : splat(0.f);
+    Dfh = *reinterpret_cast<const f2*>(p.Df + c0) * 0.5f;
+    Dbh = *reinterpret_cast<const f2*>(p.Db + c0) * 0.5f;
+  }
+  f2 a_wf[CW], a_wb[CW], a_bf = splat(0.f), a_bb = splat(0.f), a_Df = splat(0.f), a_Db = splat(0.f);
+#pragma unroll
+  for (int k = 0; k < CW; ++k) a_wf[k] = a_wb[k] = splat(0.f);
+  const int nrows = p.B * g.rows;
+  const size_t dstride = (size_t)p.B * g.rows * p.d_in;
+  const int nit = (nrows + gridDim.x * RG - 1) / (gridDim.x * RG);
+  const int tok_x = 2 * p.d_in * (int)sizeof(T), tok_d = p.d_in * (int)sizeof(T);   // bytes per token
+  const int voff = c0 * (int)sizeof(T);
+  for (int it = 0; it < nit; ++it) {
+    const int row = (it * gridDim.x + blockIdx.x) * RG + rg;
+    if (row < nrows) {          // uniform per wave; no block-level sync inside
+      const int b = row / g.rows, i = row - b * g.rows;
+      const __amdgpu_buffer_rsrc_t bx = fv_make_buf((const T*)p.xz + (size_t)b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
+      const __amdgpu_buffer_rsrc_t bd = fv_make_buf((const T*)p.dob_in + (size_t)b * g.L * p.d_in, (size_t)g.L * tok_d);
+      const __amdgpu_buffer_rsrc_t bo = fv_make_buf((T*)p.dxz + (size_t)b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
+      const int m_row = i * g.s_i;
+      const bool up = i > 0, down = i + 1 < g.rows;
+      const int s_up = up ? -g.s_i : 0, s_dn = down ? g.s_i : 0;
+      // positions q = -3 .. NT+2 of row i  (index q + 3)
+      typename P::raw xr[NT + 6], dr[NT + 6];
+#pragma unroll
+      for (int k = 0; k < NT + 6; ++k) {
+        const int di = k < 3 ? -1 : (k >= NT + 3 ? 1 : 0);
+        const int j = k - 3 - di * NT;
+        const int m = m_row + (di < 0 ? s_up : di > 0 ? s_dn : 0) + j * g.s_j;
+        xr[k] = P::load(bx, voff, m * tok_x);
+        dr[k] = P::load(bd, voff, m * tok_d);
+      }
+      f2 dcf[3], dcb[3];   // pooled gradients of rows i-1, i, i+1 (x pool_scale; 0 for a missing row)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const bool ok = r == 1 || (r == 0 ? up : down);
+        const float* dxc_r = p.dxc + ((size_t)b * g.rows + (ok ? i - 1 + r : i)) * p.d_in;
+        const float sc = ok ? p.pool_scale : 0.f;
+        dcf[r] = *reinterpret_cast<const f2*>(dxc_r + c0) * sc;
+        dcb[r] = *reinterpret_cast<const f2*>(dxc_r + dstride + c0) * sc;
+      }
+      f2 x[NT + 6], dov[NT + 6], dpf[NT + 6], dpb[NT + 6];   // index q + 3; live ranges are 4 steps (full unroll)
+      const float m_up = up ? 1.f : 0.f, m_dn = down ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        x[k] = P::unpack(xr[k]) * m_up;
+        dov[k] = P::unpack(dr[k]);
+        dpf[k] = dpb[k] = splat(0.f);
+      }
+#pragma unroll
+      for (int n = -3; n < NT; ++n) {
+        // step n: pre_f of position n+3 and pre_b of position n, both from x[n .. n+3]
+        const int q3 = n + 3, k0 = n + 3, k3 = n + 6;             // array indices of positions n and n+3
+        x[k3] = P::unpack(xr[k3]);
+        if (q3 >= NT) x[k3] *= m_dn;
+        dov[k3] = P::unpack(dr[k3]);
+        f2 pf = bf, pb = bb;
+#pragma unroll
+        for (int k = 0; k < CW; ++k) {
+          pf = fma2(wf[k], x[k0 + k], pf);             // pre_f[n+3] = b + sum_k w[k] x[n+k]
+          pb = fma2(wb[k], x[k3 - k], pb);             // pre_b[n]   = b + sum_k w[k] x[n+3-k]
+        }
+        const f2 sgf = sigmoid2(pf), sgb = sigmoid2(pb);
+        const f2 dsf = sgf * fma2(pf, 1.f - sgf, splat(1.f)), dsb = sgb * fma2(pb, 1.f - sgb, splat(1.f));
+        // position n+3 / n missing (outside the sequence): its gradient is zero
+        const float e3 = q3 < NT ? 1.f : m_dn, e0 = n >= 0 ? 1.f : m_up;
+        const f2 nf = fma2(Dfh, dov[k3], dcf[q3 >= NT ? 2 : 1]) * dsf * e3;
+        const f2 nb = fma2(Dbh, dov[k0], dcb[n < 0 ? 0 : 1]) * dsb * e0;
+        dpf[k3] = nf;
+        dpb[k0] = nb;
+        if (q3 < NT) {        // position n+3 belongs to this row: its parameter gradients are accumulated here
+#pragma unroll
+          for (int k = 0; k < CW; ++k) a_wf[k] = fma2(nf, x[k0 + k], a_wf[k]);
+          a_bf += nf;
+          a_Df = fma2(dov[k3] * 0.5f, pf * sgf, a_Df);
+        }
+        if (n >= 0) {
+#pragma unroll
+          for (int k = 0; k < CW; ++k) a_wb[k] = fma2(nb, x[k3 - k], a_wb[k]);
+          a_bb += nb;
+          a_Db = fma2(dov[k0] * 0.5f, pb * sgb, a_Db);
+          // dx[n] = sum_k wf[k] dpre_f[n+3-k] + wb[k] dpre_b[n-3+k]
+          f2 dx = splat(0.f);
+#pragma unroll
+          for (int k = 0; k < CW; ++k) {
+            dx = fma2(wf[k], dpf[k3 - k], dx);
+            dx = fma2(wb[k], dpb[k0 - 3 + k], dx);
+          }
+          P::store(bo, voff, (m_row + n * g.s_j) * tok_x, dx);
+        }
+      }
+    }
+  }
+  // one partial row per block: [d w (d_in*4) | d w_b (d_in*4) | d b | d b_b | dD | dD_b]
+  const int D = p.d_in;
+  for (int r = 0; r < RG; ++r) {
+    __syncthreads();
+    if (r == rg) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int c = c0 + v;
+#pragma unroll
+        for (int k = 0; k < CW; ++k) {
+          smem[c * 4 + k] = (r == 0 ? 0.f : smem[c * 4 + k]) + a_wf[k][v];
+          smem[4 * D + c * 4 + k] = (r == 0 ? 0.f : smem[4 * D + c * 4 + k]) + a_wb[k][v];
+        }
+        smem[8 * D + c] = (r == 0 ? 0.f : smem[8 * D + c]) + a_bf[v];
+        smem[9 * D + c] = (r == 0 ? 0.f : smem[9 * D + c]) + a_bb[v];
+        smem[10 * D + c] = (r == 0 ? 0.f : smem[10 * D + c]) + a_Df[v];
+        smem[11 * D + c] = (r == 0 ? 0.f : smem[11 * D + c]) + a_Db[v];
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = p.part + (size_t)blockIdx.x * 12 * D;
+  for (int e = threadIdx.x; e < 12 * D; e += blockDim.x) dst[e] = smem[e];
+}
+
+template <typename T, int NT>
+int launch_row(const BwdParams& p, int nch, int rgr, int grid, size_t smem, hipStream_t st) {
+  if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_row_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL((conv_pool_bwd_row_kernel<T, NT>), dim3(grid), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+}  // namespace
+
+int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t smem, int dtype, hipStream_t st) {
+  // nch counts 128-channel waves (a lane owns a channel pair)
+  if (p.geo.tpp != 1 || p.d_in != nch * 128 || nch > 8 || (p.geo.cols != 14 && p.geo.cols != 16))
+    return FV_ERR_UNSUPPORTED;
+  if ((size_t)p.geo.L * 2 * p.d_in * 4 > 0xfffff000ull) return FV_ERR_UNSUPPORTED;   // one batch element per descriptor
+  // a whole row lives in registers: blocks of <= 512 threads (256 VGPRs per wave), i.e. fewer row groups per
+  // block than the generic kernel, over the same persistent grid
+  const int cap = 8 / nch < 1 ? 1 : 8 / nch;
+  const int rgr = rg < cap ? rg : cap;
+  if (dtype == FV_F32)
+    return p.geo.cols == 14 ? launch_row<float, 14>(p, nch, rgr, grid, smem, st) : launch_row<float, 16>(p, nch, rgr, grid, smem, st);
+  return p.geo.cols == 14 ? launch_row<bf16_t, 14>(p, nch, rgr, grid, smem, st) : launch_row<bf16_t, 16>(p, nch, rgr, grid, smem, st);
+}

@@ -9,19 +9,13 @@
 //   fv_mixer_conv_pool_bwd : adjoint of the D-skip, mean-pool, SiLU and both depthwise convs -> dx,
 //                            and partials of the conv weight/bias and D, D_b gradients.
 //   fv_reduce_partials     : fixed-order sum of per-block partials (no float atomics anywhere).
+#include <stdlib.h>
+
 #include "mixer_common.h"
 
 namespace {
 
-struct BwdParams {
-  const void *xz, *dg, *skip, *dob_in;
-  const float *wf, *bf, *wb, *bb, *Df, *Db, *lnw, *lnb, *mean, *rstd, *dxc, *yc;
-  void *dxz, *dob;
-  float *dyc, *part;
-  Geo geo;
-  int B, d_in, use_norm;
-  float pool_scale;
-};
+using fvi::BwdParams;
 
 constexpr int RGMAX = 4;   // a block walks up to RGMAX pooling rows concurrently (one per row group) and emits ONE partial
 
@@ -476,6 +470,12 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       done = true;
     }
+  }
+  // short rows: the whole-row kernel (convpool_bwd_row.hip) over the same persistent grid / partial layout
+  static const bool rowk = !(getenv("FASTVIM_BWD_ROWK") && atoi(getenv("FASTVIM_BWD_ROWK")) == 0);   // tuning hook
+  if (rowk && VEC == 2) {
+    int rc = fvi::conv_pool_bwd_row(p, nch, rg, (int)grid.x, smem, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
+    if (rc != FV_ERR_UNSUPPORTED) return rc;
   }
   if (p.geo.tpp > 1) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, true>), grid, block, smem, st, p, nch, rg);
   else if (p.geo.cols + 3 <= 17) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 17, false>), grid, block, smem, st, p, nch, rg);   // whole row in flight

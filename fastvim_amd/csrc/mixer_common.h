@@ -2,6 +2,26 @@
 #pragma once
 #include "rowwalk.h"
 
+namespace fvi {   // shared between the mixer translation units
+
+struct BwdParams {
+  const void *xz, *dg, *skip, *dob_in;
+  const float *wf, *bf, *wb, *bb, *Df, *Db, *lnw, *lnb, *mean, *rstd, *dxc, *yc;
+  void *dxz, *dob;
+  float *dyc, *part;
+  Geo geo;
+  int B, d_in, use_norm;
+  float pool_scale;
+};
+
+constexpr int RGMAX = 4;   // a block walks up to RGMAX pooling rows concurrently (one per row group) and emits ONE partial
+
+// Whole-row conv+pool backward (convpool_bwd_row.hip).  Same grid / partial layout as the generic kernel;
+// returns FV_ERR_UNSUPPORTED when the shape is not one it is built for (the caller then runs the generic one).
+int conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t smem, int dtype, hipStream_t st);
+
+}  // namespace fvi
+
 namespace {
 
 constexpr int CW = 4;  // conv width (d_conv); the FastVim configs never change it

@@ -168,6 +168,100 @@ template <int VEC> struct RawVec<bf16_t, VEC> {
   }
 };
 
+// ---------------------------------------------------------------- buffer addressing
+// A token's address is (wave-uniform token offset) + (lane channel offset).  Expressed as a flat pointer
+// the compiler materialises one 64-bit VGPR pair per access; the row kernels that keep a whole row of
+// loads in flight use buffer instructions instead: descriptor + uniform byte offset in SGPRs, ONE 32-bit
+// lane offset VGPR shared by every access.
+typedef unsigned fv_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned fv_u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned fv_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fv_make_buf(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes > 0xfffff000ull ? (int)0xfffff000u : (int)bytes,
+                                           0x00020000);
+}
+
+template <int W>
+__device__ __forceinline__ void fv_buf_load_words(__amdgpu_buffer_rsrc_t r, int voff, int soff, uint32_t (&w)[W]) {
+  if constexpr (W == 1) {
+    w[0] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+  } else if constexpr (W == 2) {
+    fv_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    w[0] = t.x; w[1] = t.y;
+  } else if constexpr (W == 3) {
+    fv_u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0);
+    w[0] = t.x; w[1] = t.y; w[2] = t.z;
+  } else if constexpr (W == 4) {
+    fv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+  } else {
+    static_assert(W % 2 == 0 && W <= 8, "unsupported vector width");
+    uint32_t a[W / 2], b[W / 2];
+    fv_buf_load_words<W / 2>(r, voff, soff, a);
+    fv_buf_load_words<W / 2>(r, voff + 2 * W, soff, b);
+#pragma unroll
+    for (int k = 0; k < W / 2; ++k) { w[k] = a[k]; w[W / 2 + k] = b[k]; }
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void fv_buf_store_words(__amdgpu_buffer_rsrc_t r, int voff, int soff, const uint32_t (&w)[W]) {
+  if constexpr (W == 1) {
+    __builtin_amdgcn_raw_buffer_store_b32(w[0], r, voff, soff, 0);
+  } else if constexpr (W == 2) {
+    fv_u32x2 t; t.x = w[0]; t.y = w[1];
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+  } else if constexpr (W == 3) {
+    fv_u32x3 t; t.x = w[0]; t.y = w[1]; t.z = w[2];
+    __builtin_amdgcn_raw_buffer_store_b96(t, r, voff, soff, 0);
+  } else if constexpr (W == 4) {
+    fv_u32x4 t; t.x = w[0]; t.y = w[1]; t.z = w[2]; t.w = w[3];
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+  } else {
+    static_assert(W % 2 == 0 && W <= 8, "unsupported vector width");
+    uint32_t a[W / 2], b[W / 2];
+#pragma unroll
+    for (int k = 0; k < W / 2; ++k) { a[k] = w[k]; b[k] = w[W / 2 + k]; }
+    fv_buf_store_words<W / 2>(r, voff, soff, a);
+    fv_buf_store_words<W / 2>(r, voff + 2 * W, soff, b);
+  }
+}
+
+// VEC channels of storage type T through a buffer descriptor (VEC even for bf16)
+template <typename T, int VEC> struct BufIO;
+template <int VEC> struct BufIO<float, VEC> {
+  static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voff, int soff, RawVec<float, VEC>& o) {
+    uint32_t w[VEC];
+    fv_buf_load_words<VEC>(r, voff, soff, w);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o.v[k] = __uint_as_float(w[k]);
+  }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&v)[VEC]) {
+    uint32_t w[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) w[k] = __float_as_uint(v[k]);
+    fv_buf_store_words<VEC>(r, voff, soff, w);
+  }
+};
+template <int VEC> struct BufIO<bf16_t, VEC> {
+  static_assert(VEC == 1 || VEC % 2 == 0, "bf16 buffer access moves single channels or channel pairs");
+  static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voff, int soff, RawVec<bf16_t, VEC>& o) {
+    if constexpr (VEC == 1) o.w[0] = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    else fv_buf_load_words<VEC / 2>(r, voff, soff, o.w);
+  }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&v)[VEC]) {
+    if constexpr (VEC == 1) {
+      __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16_bits(v[0]), r, voff, soff, 0);
+    } else {
+      uint32_t w[VEC / 2];
+#pragma unroll
+      for (int k = 0; k < VEC / 2; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+      fv_buf_store_words<VEC / 2>(r, voff, soff, w);
+    }
+  }
+};
+
 template <int VEC>
 __device__ __forceinline__ void load_f32(const float* p, float (&v)[VEC]) {
   VecIO<float, VEC>::load(p, v);
