@@ -17,83 +17,27 @@
 //   * every load of the row (2 x (cols + 6) tokens, packed) is issued before the first sigmoid; halo
 //     positions of a missing neighbour row read this row (always mapped) and are zeroed by scalar selects.
 #include "mixer_common.h"
+#include "packed.h"
 
 namespace {
 
 using fvi::BwdParams;
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-template <typename T> struct Pair;
-template <> struct Pair<bf16_t> {     // one dword = two bf16 channels
-  typedef uint32_t raw;
-  static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
-  }
-  static __device__ __forceinline__ f2 unpack(raw w) {
-    f2 o;
-    o.x = __uint_as_float(w << 16);
-    o.y = __uint_as_float(w & 0xffff0000u);
-    return o;
-  }
-  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, f2 v) {
-    __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(v.x, v.y), r, voff, soff, 0);
-  }
-};
-template <> struct Pair<float> {
-  typedef fv_u32x2 raw;
-  static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  }
-  static __device__ __forceinline__ f2 unpack(raw w) {
-    f2 o;
-    o.x = __uint_as_float(w.x);
-    o.y = __uint_as_float(w.y);
-    return o;
-  }
-  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, f2 v) {
-    fv_u32x2 w;
-    w.x = __float_as_uint(v.x);
-    w.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
-  }
-};
-
-__device__ __forceinline__ f2 splat(float a) { f2 o; o.x = a; o.y = a; return o; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 sigmoid2(f2 a) {
-  f2 e;
-  e.x = __builtin_amdgcn_exp2f(a.x * -FV_LOG2E);
-  e.y = __builtin_amdgcn_exp2f(a.y * -FV_LOG2E);
-  f2 d = e + 1.f, o;
-  o.x = __builtin_amdgcn_rcpf(d.x);
-  o.y = __builtin_amdgcn_rcpf(d.y);
-  return o;
-}
-
 template <typename T, int NT>
 __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
-  typedef Pair<T> P;
+  typedef PairVec<T, 1> P;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rg = wv / nch, cw = wv - rg * nch;
   const int c0 = (cw * 64 + lane) * 2;                 // first channel of this lane's pair
   const Geo g = p.geo;
   f2 wf[CW], wb[CW], bf, bb, Dfh, Dbh;
-  {
-    const float4 a0 = *reinterpret_cast<const float4*>(p.wf + (size_t)c0 * CW);
-    const float4 a1 = *reinterpret_cast<const float4*>(p.wf + (size_t)(c0 + 1) * CW);
-    const float4 b0 = *reinterpret_cast<const float4*>(p.wb + (size_t)c0 * CW);
-    const float4 b1 = *reinterpret_cast<const float4*>(p.wb + (size_t)(c0 + 1) * CW);
-    wf[0].x = a0.x; wf[1].x = a0.y; wf[2].x = a0.z; wf[3].x = a0.w;
-    wf[0].y = a1.x; wf[1].y = a1.y; wf[2].y = a1.z; wf[3].y = a1.w;
-    wb[0].x = b0.x; wb[1].x = b0.y; wb[2].x = b0.z; wb[3].x = b0.w;
-    wb[0].y = b1.x; wb[1].y = b1.y; wb[2].y = b1.z; wb[3].y = b1.w;
-    bf = p.bf ? *reinterpret_cast<const f2*>(p.bf + c0) : splat(0.f);
-    bb = p.bb ? *reinterpret_cast<const f2*>(p.bb + c0) : splat(0.f);
-    Dfh = *reinterpret_cast<const f2*>(p.Df + c0) * 0.5f;
-    Dbh = *reinterpret_cast<const f2*>(p.Db + c0) * 0.5f;
-  }
+  load_taps2(p.wf, c0, wf);
+  load_taps2(p.wb, c0, wb);
+  bf = load_f2(p.bf, c0);
+  bb = load_f2(p.bb, c0);
+  Dfh = load_f2(p.Df, c0) * 0.5f;
+  Dbh = load_f2(p.Db, c0) * 0.5f;
   f2 a_wf[CW], a_wb[CW], a_bf = splat(0.f), a_bb = splat(0.f), a_Df = splat(0.f), a_Db = splat(0.f);
 #pragma unroll
   for (int k = 0; k < CW; ++k) a_wf[k] = a_wb[k] = splat(0.f);
@@ -113,14 +57,14 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
       const bool up = i > 0, down = i + 1 < g.rows;
       const int s_up = up ? -g.s_i : 0, s_dn = down ? g.s_i : 0;
       // positions q = -3 .. NT+2 of row i  (index q + 3)
-      typename P::raw xr[NT + 6], dr[NT + 6];
+      P xr[NT + 6], dr[NT + 6];
 #pragma unroll
       for (int k = 0; k < NT + 6; ++k) {
         const int di = k < 3 ? -1 : (k >= NT + 3 ? 1 : 0);
         const int j = k - 3 - di * NT;
         const int m = m_row + (di < 0 ? s_up : di > 0 ? s_dn : 0) + j * g.s_j;
-        xr[k] = P::load(bx, voff, m * tok_x);
-        dr[k] = P::load(bd, voff, m * tok_d);
+        xr[k].load(bx, voff, m * tok_x);
+        dr[k].load(bd, voff, m * tok_d);
       }
       f2 dcf[3], dcb[3];   // pooled gradients of rows i-1, i, i+1 (x pool_scale; 0 for a missing row)
 #pragma unroll
@@ -135,17 +79,17 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
       const float m_up = up ? 1.f : 0.f, m_dn = down ? 1.f : 0.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        x[k] = P::unpack(xr[k]) * m_up;
-        dov[k] = P::unpack(dr[k]);
+        x[k] = xr[k].get(0) * m_up;
+        dov[k] = dr[k].get(0);
         dpf[k] = dpb[k] = splat(0.f);
       }
 #pragma unroll
       for (int n = -3; n < NT; ++n) {
         // step n: pre_f of position n+3 and pre_b of position n, both from x[n .. n+3]
         const int q3 = n + 3, k0 = n + 3, k3 = n + 6;             // array indices of positions n and n+3
-        x[k3] = P::unpack(xr[k3]);
+        x[k3] = xr[k3].get(0);
         if (q3 >= NT) x[k3] *= m_dn;
-        dov[k3] = P::unpack(dr[k3]);
+        dov[k3] = dr[k3].get(0);
         f2 pf = bf, pb = bb;
 #pragma unroll
         for (int k = 0; k < CW; ++k) {
@@ -178,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
             dx = fma2(wf[k], dpf[k3 - k], dx);
             dx = fma2(wb[k], dpb[k0 - 3 + k], dx);
           }
-          P::store(bo, voff, (m_row + n * g.s_j) * tok_x, dx);
+          { const f2 dxa[1] = {dx}; P::store(bo, voff, (m_row + n * g.s_j) * tok_x, dxa); }
         }
       }
     }

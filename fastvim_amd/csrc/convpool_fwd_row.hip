@@ -1,0 +1,120 @@
+// hipcc-flags: -fno-slp-vectorize
+// Whole-row conv + pool (+ skip) forward for short pooling rows (cols == 14 or 16, tokens_per_patch == 1):
+// both depthwise convs + SiLU, the pooling over the row and skip = D*conv_f + D_b*conv_b
+// (mamba_simple_faster.py:272-305, 356-358, 412-416).  Written for instruction count like
+// convpool_bwd_row.hip: explicit 2-wide packed math, compile-time token positions, buffer addressing,
+// every load of the row (cols + 6 packed tokens) in flight before the first SiLU.
+#include <stdlib.h>
+
+#include "mixer_common.h"
+#include "packed.h"
+
+namespace {
+
+using fvi::FwdParams;
+
+template <typename T, int NT, int NP, bool PMAX>
+__global__ __launch_bounds__(NP == 1 ? 1024 : 512) void conv_pool_fwd_row_kernel(FwdParams p) {
+  typedef PairVec<T, NP> P;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int c0 = (wv * 64 + lane) * 2 * NP;           // first channel of this lane
+  const Geo g = p.geo;
+  const int tok_x = 2 * p.d_in * (int)sizeof(T), tok_s = p.d_in * (int)sizeof(T);
+  const int voff = c0 * (int)sizeof(T);
+  const __amdgpu_buffer_rsrc_t bx = fv_make_buf((const T*)p.xz + (size_t)b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
+  const __amdgpu_buffer_rsrc_t bs = fv_make_buf((T*)p.skip + (size_t)b * g.L * p.d_in, p.skip ? (size_t)g.L * tok_s : 0);
+  const int m_row = i * g.s_i;
+  const bool up = i > 0, down = i + 1 < g.rows;
+  const int s_up = up ? -g.s_i : 0, s_dn = down ? g.s_i : 0;
+  P xr[NT + 6];
+#pragma unroll
+  for (int k = 0; k < NT + 6; ++k) {
+    const int di = k < 3 ? -1 : (k >= NT + 3 ? 1 : 0);
+    const int j = k - 3 - di * NT;
+    xr[k].load(bx, voff, (m_row + (di < 0 ? s_up : di > 0 ? s_dn : 0) + j * g.s_j) * tok_x);
+  }
+  f2 wf[NP][CW], wb[NP][CW], bf[NP], bb[NP], Df[NP], Db[NP], accf[NP], accb[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    load_taps2(p.wf, c0 + 2 * q, wf[q]);
+    load_taps2(p.wb, c0 + 2 * q, wb[q]);
+    bf[q] = load_f2(p.bf, c0 + 2 * q);
+    bb[q] = load_f2(p.bb, c0 + 2 * q);
+    Df[q] = load_f2(p.skip ? p.Df : nullptr, c0 + 2 * q);
+    Db[q] = load_f2(p.skip ? p.Db : nullptr, c0 + 2 * q);
+    accf[q] = accb[q] = splat(PMAX ? -INFINITY : 0.f);
+  }
+  const float m_up = up ? 1.f : 0.f, m_dn = down ? 1.f : 0.f;
+  f2 x[NT + 6][NP];                      // index q + 3; live ranges are 7 steps (full unroll)
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int q = 0; q < NP; ++q) x[k][q] = k < 3 ? xr[k].get(q) * m_up : xr[k].get(q);
+#pragma unroll
+  for (int jj = 0; jj < NT; ++jj) {
+    f2 sk[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      x[jj + 6][q] = xr[jj + 6].get(q);
+      if (jj + 3 >= NT) x[jj + 6][q] *= m_dn;
+      f2 pf = bf[q], pb = bb[q];
+#pragma unroll
+      for (int k = 0; k < CW; ++k) {
+        pf = fma2(wf[q][k], x[jj + k][q], pf);            // x[s-3+k]
+        pb = fma2(wb[q][k], x[jj + 6 - k][q], pb);        // x[s+3-k]
+      }
+      const f2 xf = silu2(pf), xb = silu2(pb);
+      sk[q] = fma2(Df[q], xf, Db[q] * xb);
+      if (PMAX) {
+        accf[q] = __builtin_elementwise_max(accf[q], xf);
+        accb[q] = __builtin_elementwise_max(accb[q], xb);
+      } else {
+        accf[q] += xf;
+        accb[q] += xb;
+      }
+    }
+    if (p.skip) P::store(bs, voff, (m_row + jj * g.s_j) * tok_s, sk);
+  }
+  T* xc = (T*)p.xc;
+  const size_t dstride = (size_t)p.B * g.rows * p.d_in;
+  const size_t o = ((size_t)b * g.rows + i) * p.d_in + c0;
+  float of[2 * NP], ob[2 * NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const f2 a = accf[q] * p.pool_scale, c = accb[q] * p.pool_scale;
+    of[2 * q] = a.x; of[2 * q + 1] = a.y;
+    ob[2 * q] = c.x; ob[2 * q + 1] = c.y;
+  }
+  VecIO<T, 2 * NP>::store(xc + o, of);
+  VecIO<T, 2 * NP>::store(xc + dstride + o, ob);
+}
+
+template <typename T, int NT, int NP>
+int launch_row(const FwdParams& p, int pool_max, hipStream_t st) {
+  const int nch = p.d_in / (128 * NP);
+  dim3 grid(p.geo.rows, p.B), block(64 * nch);
+  if (pool_max) hipLaunchKernelGGL((conv_pool_fwd_row_kernel<T, NT, NP, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((conv_pool_fwd_row_kernel<T, NT, NP, false>), grid, block, 0, st, p);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+template <typename T, int NT>
+int pick_np(const FwdParams& p, int pool_max, hipStream_t st) {
+  static const int force = getenv("FASTVIM_FWD_NP") ? atoi(getenv("FASTVIM_FWD_NP")) : 0;   // tuning hook
+  // one channel pair per lane measured fastest (12.8 vs 16.5 us with three pairs on FastVim-T): more, shorter waves
+  if ((force == 0 || force == 1) && p.d_in % 128 == 0 && p.d_in <= 16 * 128) return launch_row<T, NT, 1>(p, pool_max, st);
+  if ((force == 0 || force == 3) && p.d_in % 384 == 0 && p.d_in <= 8 * 384) return launch_row<T, NT, 3>(p, pool_max, st);
+  if ((force == 0 || force == 2) && p.d_in % 256 == 0 && p.d_in <= 8 * 256) return launch_row<T, NT, 2>(p, pool_max, st);
+  return FV_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+int fvi::conv_pool_fwd_row(const FwdParams& p, int pool_max, int dtype, hipStream_t st) {
+  if (p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16)) return FV_ERR_UNSUPPORTED;
+  if ((size_t)p.geo.L * 2 * p.d_in * 4 > 0xfffff000ull) return FV_ERR_UNSUPPORTED;   // one batch element per descriptor
+  if (dtype == FV_F32) return p.geo.cols == 14 ? pick_np<float, 14>(p, pool_max, st) : pick_np<float, 16>(p, pool_max, st);
+  return p.geo.cols == 14 ? pick_np<bf16_t, 14>(p, pool_max, st) : pick_np<bf16_t, 16>(p, pool_max, st);
+}

@@ -14,6 +14,25 @@ struct BwdParams {
   float pool_scale;
 };
 
+struct FwdParams {
+  const void* xz;                       // (B, L, 2*d_in)
+  const float *wf, *bf, *wb, *bb;       // conv1d / conv1d_b: (d_in, CW), (d_in)
+  void* xc;                             // (2, B, rows*tpp, d_in) pooled conv output [dir 0 = fwd]
+  void* skip;                           // (B, L, d_in) D*conv_f + D_b*conv_b, memory token order (nullable in conv_pool)
+  const float* yc;                      // (2, B, rows*tpp, d_in) scan output
+  const float *Df, *Db, *lnw, *lnb;     // (d_in)
+  void* g;                              // (B, L, d_in) gated LayerNorm output
+  float *mean, *rstd;                   // (B*L) LayerNorm statistics (saved for backward)
+  Geo geo;
+  int B, d_in;
+  float pool_scale;                     // scaling_factor / cols (mean) or 1 (max)
+  float eps;
+  int use_norm;
+};
+
+// Whole-row conv+pool(+skip) forward (convpool_fwd_row.hip); FV_ERR_UNSUPPORTED -> caller runs the generic kernel.
+int conv_pool_fwd_row(const FwdParams& p, int pool_max, int dtype, hipStream_t st);
+
 constexpr int RGMAX = 4;   // a block walks up to RGMAX pooling rows concurrently (one per row group) and emits ONE partial
 
 // Whole-row conv+pool backward (convpool_bwd_row.hip).  Same grid / partial layout as the generic kernel;

@@ -22,21 +22,7 @@
 
 namespace {
 
-struct FwdParams {
-  const void* xz;                       // (B, L, 2*d_in)
-  const float *wf, *bf, *wb, *bb;       // conv1d / conv1d_b: (d_in, CW), (d_in)
-  void* xc;                             // (2, B, rows*tpp, d_in) pooled conv output [dir 0 = fwd]
-  void* skip;                           // (B, L, d_in) D*conv_f + D_b*conv_b, memory token order (nullable in conv_pool)
-  const float* yc;                      // (2, B, rows*tpp, d_in) scan output
-  const float *Df, *Db, *lnw, *lnb;     // (d_in)
-  void* g;                              // (B, L, d_in) gated LayerNorm output
-  float *mean, *rstd;                   // (B*L) LayerNorm statistics (saved for backward)
-  Geo geo;
-  int B, d_in;
-  float pool_scale;                     // scaling_factor / cols (mean) or 1 (max)
-  float eps;
-  int use_norm;
-};
+using fvi::FwdParams;
 
 template <int VEC>
 __device__ __forceinline__ void conv_silu_both(const ChanParams<VEC>& cp, const float (&xw)[7][VEC],
@@ -140,79 +126,6 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
       VecIO<T, VEC>::store(xc + o, accf);
       VecIO<T, VEC>::store(xc + dstride + o, accb);
     }
-  }
-}
-
-// Whole-row variant for short rows (cols == NT <= 16, tokens_per_patch == 1): every load of the row
-// (NT + 6 tokens, kept packed as loaded) is issued before the first conv, so a wave pays the memory
-// latency once per row instead of once per tile -- these launches have < 2 waves per SIMD and hide
-// nothing.  Token addresses are affine in the (compile-time) position: no integer division.
-template <typename T, int VEC, int NT, bool PMAX>
-__global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_row_kernel(FwdParams p) {
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = blockIdx.x, b = blockIdx.y;
-  const int c0 = (wv * 64 + lane) * VEC;
-  const bool act = c0 < p.d_in;
-  const Geo g = p.geo;
-  const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in + c0;
-  const int m_row = i * g.s_i;                       // memory token of (i, 0)
-  RawVec<T, VEC> xr[NT + 6];
-#pragma unroll
-  for (int k = 0; k < NT + 6; ++k) {
-    // position k-3 of row i: rows i-1 / i / i+1 of the sequence grid
-    const int di = k < 3 ? -1 : (k >= NT + 3 ? 1 : 0);
-    const int j = k - 3 - di * NT;
-    const bool ok = act && (di == 0 || (di < 0 ? i > 0 : i + 1 < g.rows));
-    if (ok) xr[k].load(xz_b + (size_t)(m_row + di * g.s_i + j * g.s_j) * 2 * p.d_in);
-    else xr[k].zero();
-  }
-  ChanParams<VEC> cp;
-  cp.load(p.wf, p.bf, p.wb, p.bb, c0, act);
-  float Df[VEC], Db[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    Df[v] = act && p.skip ? p.Df[c0 + v] : 0.f;
-    Db[v] = act && p.skip ? p.Db[c0 + v] : 0.f;
-  }
-  T* sk_b = (T*)p.skip + (size_t)b * g.L * p.d_in + c0;
-  float accf[VEC], accb[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) accf[v] = accb[v] = PMAX ? -INFINITY : 0.f;
-  float xw[7][VEC];                       // sliding window: tokens jj-3 .. jj+3
-#pragma unroll
-  for (int k = 0; k < 6; ++k) xr[k].get(xw[k + 1]);
-#pragma unroll
-  for (int jj = 0; jj < NT; ++jj) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) xw[k][v] = xw[k + 1][v];
-    xr[jj + 6].get(xw[6]);
-    float xf[VEC], xb[VEC];
-    conv_silu_both<VEC>(cp, xw, xf, xb);
-    if (p.skip && act) {
-      float sk[VEC];
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) sk[v] = fmaf(Df[v], xf[v], Db[v] * xb[v]);
-      VecIO<T, VEC>::store(sk_b + (size_t)(m_row + jj * g.s_j) * p.d_in, sk);
-    }
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      accf[v] = PMAX ? fmaxf(accf[v], xf[v]) : accf[v] + xf[v];
-      accb[v] = PMAX ? fmaxf(accb[v], xb[v]) : accb[v] + xb[v];
-    }
-  }
-  if (act) {
-    T* xc = (T*)p.xc;
-    const size_t dstride = (size_t)p.B * g.rows * p.d_in;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      accf[v] *= p.pool_scale;
-      accb[v] *= p.pool_scale;
-    }
-    const size_t o = ((size_t)b * g.rows + i) * p.d_in + c0;
-    VecIO<T, VEC>::store(xc + o, accf);
-    VecIO<T, VEC>::store(xc + dstride + o, accb);
   }
 }
 
@@ -386,9 +299,12 @@ int launch_conv_pool(const FwdParams& p, int pool_max, hipStream_t st) {
     if (pool_max) hipLaunchKernelGGL((K<__VA_ARGS__, true>), grid, block, smem, st, p);      \
     else hipLaunchKernelGGL((K<__VA_ARGS__, false>), grid, block, smem, st, p);              \
   } while (0)
+  static const bool rowk = !(getenv("FASTVIM_FWD_ROWK") && atoi(getenv("FASTVIM_FWD_ROWK")) == 0);   // tuning hook
+  if (!tp && rowk) {     // short rows: the whole-row packed-math kernel (convpool_fwd_row.hip)
+    int rc = fvi::conv_pool_fwd_row(p, pool_max, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
+    if (rc != FV_ERR_UNSUPPORTED) return rc;
+  }
   if (tp) FV_CP(conv_pool_fwd_kernel, T, VEC, 8, true);
-  else if (p.geo.cols == 14) FV_CP(conv_pool_fwd_row_kernel, T, VEC, 14);
-  else if (p.geo.cols == 16) FV_CP(conv_pool_fwd_row_kernel, T, VEC, 16);
   else if (p.geo.cols % 7 == 0) FV_CP(conv_pool_fwd_kernel, T, VEC, 7, false);
   else FV_CP(conv_pool_fwd_kernel, T, VEC, 8, false);
 #undef FV_CP

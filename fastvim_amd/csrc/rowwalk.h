@@ -213,8 +213,10 @@ __device__ __forceinline__ void fv_buf_store_words(__amdgpu_buffer_rsrc_t r, int
     fv_u32x2 t; t.x = w[0]; t.y = w[1];
     __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
   } else if constexpr (W == 3) {
-    fv_u32x3 t; t.x = w[0]; t.y = w[1]; t.z = w[2];
-    __builtin_amdgcn_raw_buffer_store_b96(t, r, voff, soff, 0);
+    // as 8 + 4 bytes: the single buffer_store_dwordx3 form produced corrupt data here (gfx950, ROCm 7.2 hipcc)
+    fv_u32x2 t; t.x = w[0]; t.y = w[1];
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(w[2], r, voff + 8, soff, 0);
   } else if constexpr (W == 4) {
     fv_u32x4 t; t.x = w[0]; t.y = w[1]; t.z = w[2]; t.w = w[3];
     __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
