@@ -146,6 +146,29 @@ def kernel_table(B, rows, cols, d, depth, dtype):
         out[name] = {"us": round(t * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3),
                      "GBps": round(nbytes / t / 1e9, 1), "launches_per_step": per_block * depth,
                      "us_per_step": round(t * 1e6 * per_block * depth, 1)}
+    if dtype == torch.bfloat16:
+        # the six projection GEMMs of a block (hand-written MFMA kernel, csrc/gemm_mfma.hip): HBM bytes AND
+        # MFMA flops -- at FastVim-T widths (K or N = 192) they sit below the ridge, i.e. are HBM-bound
+        from fastvim_amd.gemm import gemm_nn, gemm_nt, gemm_tn
+        Mt = B * L
+        h2, g2, xz2, do2 = rn(Mt, d), rn(Mt, d_in), rn(Mt, 2 * d_in), rn(Mt, d)
+        W_in, W_out = rn(2 * d_in, d), rn(d, d_in)
+        gemms = {
+            "gemm_in_proj_fwd": (lambda: gemm_nt(h2, W_in), Mt, 2 * d_in, d, 0),
+            "gemm_out_proj_fwd": (lambda: gemm_nt(g2, W_out), Mt, d, d_in, 0),
+            "gemm_out_proj_dgrad": (lambda: gemm_nn(do2, W_out), Mt, d_in, d, 0),
+            "gemm_in_proj_dgrad": (lambda: gemm_nn(xz2, W_in), Mt, d, 2 * d_in, 0),
+            "gemm_in_proj_wgrad": (lambda: gemm_tn(xz2, h2, splits=28), 2 * d_in, d, Mt, 28),
+            "gemm_out_proj_wgrad": (lambda: gemm_tn(do2, g2, splits=28), d, d_in, Mt, 28),
+        }
+        for name, (fn, m_, n_, k_, splits) in gemms.items():
+            t = time_kernel(fn)
+            nbytes = 2 * (m_ * k_ + n_ * k_) + (2 * m_ * n_ if not splits else 4 * m_ * n_ * (2 * splits + 1))
+            fl = 2.0 * m_ * n_ * k_
+            out[name] = {"us": round(t * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3),
+                         "GBps": round(nbytes / t / 1e9, 1), "TFLOPs": round(fl / t / 1e12, 1),
+                         "mfma_frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "launches_per_step": depth, "us_per_step": round(t * 1e6 * depth, 1)}
     return out
 
 
@@ -326,7 +349,7 @@ def main():
         }
         if not args.no_kernels and args.model != "C":
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
-            dom = max((k for k in kt if k not in ("scan_fwd", "scan_bwd")), key=lambda k: kt[k]["us_per_step"])
+            dom = max(kt, key=lambda k: kt[k]["us_per_step"])     # the kernel that costs the most time per step
             out["kernels"] = kt
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
             try:

@@ -4,6 +4,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert
 import torch
 from fastvim_amd import mixer_ops as M
 from fastvim_amd.layernorm import layer_norm_fn
+from fastvim_amd.gemm import gemm_nn, gemm_nt, gemm_tn
 B, rows, cols, d = 128, 14, 14, 192
 dtype = torch.bfloat16
 dev = "cuda"
@@ -27,11 +28,20 @@ for _ in range(n):
     dg = rn(B, L, d_in)
     dxz = torch.empty_like(xz)
     d_o, dyc, _ = M.combine_bwd(dg, xz, skip, yc, lnw, lnb, mean, rstd, dxz, rows, cols, False)
-    dxc, dxd, _ = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc)
+    dxc, dxd, _ = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc, keep_chunks=True)
     M.conv_pool_bwd(xz, d_o, dxc, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 0, 1.0)
     hid, res = rn(B, L, d), torch.randn(B, L, d, device=dev, generator=g)
     nw = torch.ones(d, device=dev, requires_grad=True)
     hid.requires_grad_(); res.requires_grad_()
     y, ro = layer_norm_fn(hid, nw, None, residual=res, eps=1e-5, prenorm=True, residual_in_fp32=True, is_rms_norm=True)
     torch.autograd.backward((y, ro), (torch.randn_like(y), torch.randn_like(ro)))
+    # the six projection GEMMs of a block (in_proj / out_proj: forward, data gradient, weight gradient)
+    Mtok = B * L
+    h2, g2 = rn(Mtok, d), rn(Mtok, d_in)
+    W_in, W_out = rn(2 * d_in, d), rn(d, d_in)
+    xz2, do2 = rn(Mtok, 2 * d_in), rn(Mtok, d)
+    gemm_nt(h2, W_in); gemm_nt(g2, W_out)
+    gemm_nn(do2, W_out); gemm_nn(xz2, W_in)
+    gemm_tn(xz2, h2, splits=28); gemm_tn(do2, g2, splits=28)
+    M.xproj_bwd(dxd, xc, rn(R_ + 2 * N, d_in, dt=torch.float32), rn(R_ + 2 * N, d_in, dt=torch.float32), dxc)
 torch.cuda.synchronize()
