@@ -134,24 +134,55 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_kernel(ScanClParams p) {
   }
 }
 
-// butterfly over the 16 channel-lanes of a wave (lane bits 2..5); PV values per lane, PV in {16, 32}.
+// Reduce-scatter over the 16 channel-lanes of a wave (lane bits 2..5); PV values per lane, PV in {16, 32}.
 // On return the lane whose channel index is c holds the totals of value indices [c*PV/16, (c+1)*PV/16).
-template <int H, int OFF, int PV>
-__device__ __forceinline__ void rs_step(float (&v)[PV], int lane) {
-  const bool up = lane & OFF;
+// Lane bits 5 and 4 use the gfx950 cross-row swaps (v_permlane32_swap / v_permlane16_swap: one swap + one
+// add per value pair, no select); bits 3 and 2 stay inside a 16-lane row: DPP row rotates.
+template <int CTRL>
+__device__ __forceinline__ float add_dpp(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int H, int PV>
+__device__ __forceinline__ void rs_swap32(float (&v)[PV]) {
 #pragma unroll
   for (int e = 0; e < H; ++e) {
-    const float keep = up ? v[e + H] : v[e];
-    const float send = up ? v[e] : v[e + H];
-    v[e] = keep + __shfl_xor(send, OFF, 64);
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[e]), __float_as_uint(v[e + H]), false, false);
+    v[e] = __uint_as_float(r[0]) + __uint_as_float(r[1]);     // lanes < 32: v[e] + partner's; lanes >= 32: v[e+H] pair
+  }
+}
+template <int H, int PV>
+__device__ __forceinline__ void rs_swap16(float (&v)[PV]) {
+#pragma unroll
+  for (int e = 0; e < H; ++e) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[e]), __float_as_uint(v[e + H]), false, false);
+    v[e] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+}
+template <int H, int PV>
+__device__ __forceinline__ void rs_row8(float (&v)[PV], int lane) {
+  const bool up = lane & 8;
+#pragma unroll
+  for (int e = 0; e < H; ++e) {
+    const float lo = add_dpp<0x128>(v[e]), hi = add_dpp<0x128>(v[e + H]);      // row_ror:8 == lane ^ 8
+    v[e] = up ? hi : lo;
+  }
+}
+template <int H, int PV>
+__device__ __forceinline__ void rs_row4(float (&v)[PV], int lane) {
+  const bool up = lane & 4;
+#pragma unroll
+  for (int e = 0; e < H; ++e) {
+    const float lo = add_dpp<0x12C>(v[e]);          // row_ror:12: lane i reads lane i+4 (valid where bit 2 is clear)
+    const float hi = add_dpp<0x124>(v[e + H]);      // row_ror:4 : lane i reads lane i-4 (valid where bit 2 is set)
+    v[e] = up ? hi : lo;
   }
 }
 template <int PV>
 __device__ __forceinline__ void chan_reduce_scatter(float (&v)[PV], int lane) {
-  rs_step<PV / 2, 32, PV>(v, lane);
-  rs_step<PV / 4, 16, PV>(v, lane);
-  rs_step<PV / 8, 8, PV>(v, lane);
-  rs_step<PV / 16, 4, PV>(v, lane);
+  rs_swap32<PV / 2, PV>(v);
+  rs_swap16<PV / 4, PV>(v);
+  rs_row8<PV / 8, PV>(v, lane);
+  rs_row4<PV / 16, PV>(v, lane);
 }
 
 // Backward.  Segments of KS = 4 steps: the states entering every segment are checkpointed by a
@@ -168,12 +199,18 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
   const int nseg = (p.Lc + KS - 1) / KS;
   float* s_dbl = smem;                      // Lc * WP
   float* s_part = s_dbl + p.Lc * WP;        // KS * NWV * 4 * PV   [k][wave][q][value]
-  float* s_ck = s_part + KS * NWV * 4 * PV; // nseg * 256 * 4 (CK_LDS only)
+  float* s_dt = s_part + KS * NWV * 4 * PV; // Lc * CPB: softplus(dt_proj) of every (row, channel), computed once
+  float* s_ck = s_dt + p.Lc * CPB;          // nseg * 256 * 4 (CK_LDS only)
   Lane<T, RQ> ln;
   ln.init(p);
   stage_dbl<T>(p, ln.dir, ln.b, s_dbl, RP);
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int l = 0; l < p.Lc; ++l) {
+    const float dt = ln.delta(s_dbl + l * WP);
+    if (ln.q == 0) s_dt[l * CPB + (tid >> 2)] = dt;
+  }
+  __syncthreads();
   const int dd = ln.act ? ln.d : 0;
   const T* u = (const T*)p.xc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
   const float* gy = p.dyc + (size_t)ln.b * p.Lc * p.d_in + dd;
@@ -196,7 +233,7 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
         const int step = seg * KS + k;
         const int l = ln.dir ? p.Lc - 1 - step : step;
         const float* row = s_dbl + l * WP;
-        const float dt = ln.delta(row);
+        const float dt = s_dt[l * CPB + (tid >> 2)];
         const float du = dt * uv[k];
 #pragma unroll
         for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * ln.A2[j]), st[j], du * row[RP + ln.q * 4 + j]);
@@ -233,17 +270,18 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
       else if (ln.act) c4 = *reinterpret_cast<const float4*>(ckg + (size_t)seg * ck_seg);
       cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
     }
-    float xs[KS][4], dtv[KS];
+    float xs[KS][4], aq[KS][4], dtv[KS];   // states, decay factors exp(delta*A) (reused by the adjoint), deltas
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       const float* row = s_dbl + lk[k] * WP;
       const bool on = k < ns && ln.act;
-      dtv[k] = on ? ln.delta(row) : 0.f;      // delta = 0: a = 1, b = 0 -> the step is an identity
+      dtv[k] = on ? s_dt[lk[k] * CPB + (tid >> 2)] : 0.f;      // delta = 0: a = 1, b = 0 -> the step is an identity
       if (!on) gq[k] = 0.f;
       const float du = dtv[k] * uv[k];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        cur[j] = fmaf(fv_exp2(dtv[k] * ln.A2[j]), cur[j], du * row[RP + ln.q * 4 + j]);
+        aq[k][j] = fv_exp2(dtv[k] * ln.A2[j]);
+        cur[j] = fmaf(aq[k][j], cur[j], du * row[RP + ln.q * 4 + j]);
         xs[k][j] = cur[j];
       }
     }
@@ -260,7 +298,7 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float Bn = row[RP + ln.q * 4 + j], Cn = row[RP + N + ln.q * 4 + j];
-          const float a = fv_exp2(dtv[k] * ln.A2[j]);
+          const float a = aq[k][j];
           const float dx = fmaf(gq[k], Cn, dxa[j]);
           const float ax = xs[k][j] - dtu * Bn;               // a_t * x_{t-1}
           du_acc = fmaf(dx, Bn, du_acc);
@@ -362,7 +400,7 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
 
 extern "C" int fv_mixer_scan_bwd_chunks(int d_inner) { return fv_cdiv(d_inner, CPB); }
 
-static bool ck_in_lds(int Lc) { return ((Lc + 3) / 4) * 4096 <= 32 * 1024; }
+static bool ck_in_lds(int Lc) { return ((Lc + 3) / 4) * 4096 + Lc * CPB * 4 <= 32 * 1024; }
 
 extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state) {
   if (ck_in_lds(Lc)) return 0;
@@ -391,9 +429,17 @@ extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float*
   hipStream_t st = (hipStream_t)stream;
 #define FV_B(TT, RQQ, PVV, CKK)                                                              \
   do {                                                                                       \
-    size_t smem = ((size_t)Lc * (4 * RQQ + 2 * N) + (size_t)4 * 4 * 4 * PVV +                \
+    size_t smem = ((size_t)Lc * (4 * RQQ + 2 * N) + (size_t)4 * 4 * 4 * PVV + (size_t)Lc * CPB + \
                    (CKK ? (size_t)((Lc + 3) / 4) * 1024 : 0)) * 4;                           \
-    FV_CHECK(smem <= 64 * 1024, "mixer_scan_bwd: pooled length %d too long for the LDS stage", Lc); \
+    FV_CHECK(smem <= 160 * 1024, "mixer_scan_bwd: pooled length %d too long for the LDS stage", Lc); \
+    if (smem > 64 * 1024) {                                                                  \
+      static bool done = false;                                                              \
+      if (!done) {                                                                           \
+        (void)hipFuncSetAttribute((const void*)scan_cl_bwd_kernel<TT, RQQ, PVV, CKK>,        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+        done = true;                                                                         \
+      }                                                                                      \
+    }                                                                                        \
     hipLaunchKernelGGL((scan_cl_bwd_kernel<TT, RQQ, PVV, CKK>), grid, block, smem, st, p);   \
   } while (0)
 #define FV_BK(TT, RQQ, PVV)                                                                  \
