@@ -205,7 +205,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
 // Purely per-channel (no cross-lane traffic): a lane owns VEC channels and streams the row's tokens
 // through 4-deep register windows.  Step n consumes token n+3 and produces
 //   dpre_f[n+3] (needs x[n..n+3]),  dpre_b[n] (needs x[n..n+3]),  dx[n] (needs dpre_f[n..n+3], dpre_b[n-3..n]).
-template <typename T, int VEC, int CH, bool TP>   // CH tokens are fetched (packed, as loaded) ahead of the arithmetic that consumes them
+template <typename T, int VEC, int CH, bool TP, bool PM>   // PM: max pooling (gradient goes to the saved argmax column); CH tokens are fetched (packed, as loaded) ahead of the arithmetic that consumes them
 __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
   const int lane = threadIdx.x & 63;
@@ -244,6 +244,20 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
           const size_t o = ((size_t)b * g.rows + (ok ? ii : 0)) * p.d_in + (act ? c0 + v : 0);
           dcf[r][v] = ok ? p.dxc[o] * p.pool_scale : 0.f;
           dcb[r][v] = ok ? p.dxc[dstride + o] * p.pool_scale : 0.f;
+        }
+      }
+      float af[3][VEC], ab[3][VEC];     // PM: argmax columns of rows i-1, i, i+1
+      if constexpr (PM && !TP) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int ii = i - 1 + r;
+          const bool ok = act && ii >= 0 && ii < g.rows;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const size_t o = ((size_t)b * g.rows + (ok ? ii : 0)) * p.d_in + (act ? c0 + v : 0);
+            af[r][v] = ok ? io<T>::ld((const T*)p.amax + o) : -1.f;
+            ab[r][v] = ok ? io<T>::ld((const T*)p.amax + dstride + o) : -1.f;
+          }
         }
       }
       const T* xz_b = (const T*)p.xz + (size_t)b * g.L * 2 * p.d_in;
@@ -306,20 +320,32 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
         float cf_t[VEC], cb_t[VEC];                       // channel-wise tokenization: pooled gradient of (row, channel slot)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) cf_t[v] = cb_t[v] = 0.f;
+        float af_t[VEC], ab_t[VEC];                       // PM: argmax column of that (row, channel slot)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) af_t[v] = ab_t[v] = -1.f;
+        const int jf3 = n + 3 >= g.cols ? n + 3 - g.cols : n + 3;      // position of token n+3 inside its own row
+        const int jf0 = n < 0 ? n + g.cols : n;
         if (TP && act) {
           const int i3 = i - 1 + r3, i0 = i - 1 + r0;
           const int sl3 = (n + 3 + tpp * 4) % tpp, sl0 = (n + tpp * 4) % tpp;     // n >= -3 > -4*tpp
           if (i3 >= 0 && i3 < g.rows) {
             const size_t o = (((size_t)b * g.rows + i3) * tpp + sl3) * p.d_in + c0;
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) cf_t[v] = p.dxc[o + v] * p.pool_scale;
+            for (int v = 0; v < VEC; ++v) {
+              cf_t[v] = p.dxc[o + v] * p.pool_scale;
+              if constexpr (PM) af_t[v] = io<T>::ld((const T*)p.amax + o + v);
+            }
           }
           if (i0 >= 0 && i0 < g.rows) {
             const size_t o = (((size_t)b * g.rows + i0) * tpp + sl0) * p.d_in + c0;
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) cb_t[v] = p.dxc[dstride + o + v] * p.pool_scale;
+            for (int v = 0; v < VEC; ++v) {
+              cb_t[v] = p.dxc[dstride + o + v] * p.pool_scale;
+              if constexpr (PM) ab_t[v] = io<T>::ld((const T*)p.amax + dstride + o + v);
+            }
           }
         }
+        const float col3 = (float)(TP ? jf3 / tpp : jf3), col0 = (float)(TP ? jf0 / tpp : jf0);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           float pf = cp.bf[v], pb = cp.bb[v];
@@ -330,8 +356,14 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
           }
           const float sgf = fv_sigmoid(pf), sgb = fv_sigmoid(pb);
           const float dsf = sgf * (1.f + pf * (1.f - sgf)), dsb = sgb * (1.f + pb * (1.f - sgb));
-          const float cf = TP ? cf_t[v] : (r3 == 2 ? dcf[2][v] : dcf[1][v]);
-          const float cb = TP ? cb_t[v] : (r0 == 0 ? dcb[0][v] : dcb[1][v]);
+          float cf = TP ? cf_t[v] : (r3 == 2 ? dcf[2][v] : dcf[1][v]);
+          float cb = TP ? cb_t[v] : (r0 == 0 ? dcb[0][v] : dcb[1][v]);
+          if constexpr (PM) {      // max pooling: only the argmax token of a pooling group receives the gradient
+            const float a3 = TP ? af_t[v] : (r3 == 2 ? af[2][v] : af[1][v]);
+            const float a0 = TP ? ab_t[v] : (r0 == 0 ? ab[0][v] : ab[1][v]);
+            cf = a3 == col3 ? cf : 0.f;
+            cb = a0 == col0 ? cb : 0.f;
+          }
           const float nf = v3 ? (Dfh[v] * dw[3][v] + cf) * dsf : 0.f;
           const float nb = v0 ? (Dbh[v] * dw[0][v] + cb) * dsb : 0.f;
           dpf[3][v] = nf;
@@ -465,21 +497,35 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
     static bool done = false;
     if (!done) {
-      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 17, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 17, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       done = true;
     }
   }
   // short rows: the whole-row kernel (convpool_bwd_row.hip) over the same persistent grid / partial layout
   static const bool rowk = !(getenv("FASTVIM_BWD_ROWK") && atoi(getenv("FASTVIM_BWD_ROWK")) == 0);   // tuning hook
-  if (rowk && VEC == 2) {
+  if (rowk && VEC == 2 && !p.amax) {
     int rc = fvi::conv_pool_bwd_row(p, nch, rg, (int)grid.x, smem, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
     if (rc != FV_ERR_UNSUPPORTED) return rc;
   }
-  if (p.geo.tpp > 1) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, true>), grid, block, smem, st, p, nch, rg);
-  else if (p.geo.cols + 3 <= 17) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 17, false>), grid, block, smem, st, p, nch, rg);   // whole row in flight
-  else hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, false>), grid, block, smem, st, p, nch, rg);
+  if (p.amax) {      // max pooling: generic kernels only
+    if (smem > 64 * 1024) {
+      static bool done_pm = false;
+      if (!done_pm) {
+        (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done_pm = true;
+      }
+    }
+    if (p.geo.tpp > 1) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, true, true>), grid, block, smem, st, p, nch, rg);
+    else hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, false, true>), grid, block, smem, st, p, nch, rg);
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
+  if (p.geo.tpp > 1) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, true, false>), grid, block, smem, st, p, nch, rg);
+  else if (p.geo.cols + 3 <= 17) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 17, false, false>), grid, block, smem, st, p, nch, rg);   // whole row in flight
+  else hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, false, false>), grid, block, smem, st, p, nch, rg);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
@@ -536,7 +582,8 @@ extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* 
 
 extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, const float* conv_w,
                                       const float* conv_b, const float* conv_w_b, const float* conv_b_b,
-                                      const float* D, const float* D_b, void* dxz, float* partials, int batch,
+                                      const float* D, const float* D_b, const void* amax, void* dxz,
+                                      float* partials, int batch,
                                       int rows, int cols, int tok_stride_row, int tok_stride_col,
                                       int tokens_per_patch, int d_inner, int d_conv, int pool_max,
                                       float scaling_factor, int dtype, fv_stream_t stream) {
@@ -544,10 +591,7 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
   FV_CHECK(tokens_per_patch > 0, "mixer_conv_pool_bwd: tokens_per_patch must be positive");
   if (rc) return rc;
   FV_CHECK(d_conv == CW, "mixer: only d_conv == %d is built (got %d)", CW, d_conv);
-  if (pool_max) {
-    fv_set_error("mixer_conv_pool_bwd: collapse_method='max' has no backward kernel yet");
-    return FV_ERR_UNSUPPORTED;
-  }
+  FV_CHECK(!pool_max || amax, "mixer_conv_pool_bwd: max pooling needs the argmax columns saved by the forward");
   FV_CHECK(cols * tokens_per_patch >= 3, "mixer_conv_pool_bwd: needs at least 3 tokens per pooling row (got %d)", cols * tokens_per_patch);
   FV_CHECK(xz && d_o && dxc && conv_w && conv_w_b && D && D_b && dxz && partials, "mixer_conv_pool_bwd: null pointer");
   BwdParams p{};
@@ -555,7 +599,8 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
   p.Df = D; p.Db = D_b; p.dxz = dxz; p.part = partials;
   p.geo = make_geo(rows, cols, tok_stride_row, tok_stride_col, tokens_per_patch);
   p.B = batch; p.d_in = d_inner;
-  p.pool_scale = scaling_factor / (float)cols;
+  p.pool_scale = pool_max ? 1.f : scaling_factor / (float)cols;
+  p.amax = pool_max ? amax : nullptr;
   return dtype == FV_F32 ? dispatch_bwd<float>(1, p, (hipStream_t)stream)
                          : dispatch_bwd<bf16_t>(1, p, (hipStream_t)stream);
 }

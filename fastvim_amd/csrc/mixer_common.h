@@ -7,6 +7,7 @@ namespace fvi {   // shared between the mixer translation units
 struct BwdParams {
   const void *xz, *dg, *skip, *dob_in;
   const float *wf, *bf, *wb, *bb, *Df, *Db, *lnw, *lnb, *mean, *rstd, *dxc, *yc;
+  const void* amax;                     // max pooling: argmax columns saved by the forward (else null)
   void *dxz, *dob;
   float *dyc, *part;
   Geo geo;
@@ -19,6 +20,7 @@ struct FwdParams {
   const float *wf, *bf, *wb, *bb;       // conv1d / conv1d_b: (d_in, CW), (d_in)
   void* xc;                             // (2, B, rows*tpp, d_in) pooled conv output [dir 0 = fwd]
   void* skip;                           // (B, L, d_in) D*conv_f + D_b*conv_b, memory token order (nullable in conv_pool)
+  void* amax;                           // (2, B, rows*tpp, d_in) max pooling: column of the maximum (storage dtype; nullable)
   const float* yc;                      // (2, B, rows*tpp, d_in) scan output
   const float *Df, *Db, *lnw, *lnb;     // (d_in)
   void* g;                              // (B, L, d_in) gated LayerNorm output

@@ -62,13 +62,15 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
   extern __shared__ __attribute__((aligned(16))) float s_pool[];
   const int tpp = TP ? g.tpp : 1, nthr = blockDim.x;
   float accf[VEC], accb[VEC];
+  float argf[VEC], argb[VEC];            // PMAX: column of the (first) maximum, for the backward pass
   const float init = PMAX ? -INFINITY : 0.f;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) accf[v] = accb[v] = init;
+  for (int v = 0; v < VEC; ++v) { accf[v] = accb[v] = init; argf[v] = argb[v] = 0.f; }
+  // tpp > 1: slots [0, 2 tpp) hold the pooled values, PMAX adds [2 tpp, 4 tpp) for the argmax columns
   if constexpr (TP)
-    for (int c = 0; c < 2 * tpp; ++c)
+    for (int c = 0; c < (PMAX ? 4 : 2) * tpp; ++c)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) s_pool[(c * nthr + threadIdx.x) * VEC + v] = init;
+      for (int v = 0; v < VEC; ++v) s_pool[(c * nthr + threadIdx.x) * VEC + v] = c < 2 * tpp ? init : 0.f;
   for (int j0 = 0; j0 < g.cols; j0 += TJ) {
     float x[TJ + 6][VEC];
     load_x_tile<T, VEC, TJ, 3, TP>(xz_b, g, p.d_in, i, j0, c0, act, x);
@@ -90,8 +92,14 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
         if constexpr (!TP) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            accf[v] = PMAX ? fmaxf(accf[v], xf[v]) : accf[v] + xf[v];
-            accb[v] = PMAX ? fmaxf(accb[v], xb[v]) : accb[v] + xb[v];
+            if constexpr (PMAX) {
+              const float col = (float)(j0 + jj);
+              if (xf[v] > accf[v]) { accf[v] = xf[v]; argf[v] = col; }
+              if (xb[v] > accb[v]) { accb[v] = xb[v]; argb[v] = col; }
+            } else {
+              accf[v] += xf[v];
+              accb[v] += xb[v];
+            }
           }
         } else {
           const int slot = (j0 + jj) % tpp;
@@ -99,8 +107,16 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
           float* ab = s_pool + ((tpp + slot) * nthr + threadIdx.x) * VEC;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            af[v] = PMAX ? fmaxf(af[v], xf[v]) : af[v] + xf[v];
-            ab[v] = PMAX ? fmaxf(ab[v], xb[v]) : ab[v] + xb[v];
+            if constexpr (PMAX) {
+              const float col = (float)((j0 + jj) / tpp);
+              float* gf = af + (size_t)2 * tpp * nthr * VEC;
+              float* gb = ab + (size_t)2 * tpp * nthr * VEC;
+              if (xf[v] > af[v]) { af[v] = xf[v]; gf[v] = col; }
+              if (xb[v] > ab[v]) { ab[v] = xb[v]; gb[v] = col; }
+            } else {
+              af[v] += xf[v];
+              ab[v] += xb[v];
+            }
           }
         }
       }
@@ -125,6 +141,19 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
       const size_t o = (((size_t)b * g.rows + i) * tpp + c) * p.d_in + c0;
       VecIO<T, VEC>::store(xc + o, accf);
       VecIO<T, VEC>::store(xc + dstride + o, accb);
+      if constexpr (PMAX) {
+        if (p.amax) {
+          if constexpr (TP) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              argf[v] = s_pool[((2 * tpp + c) * nthr + threadIdx.x) * VEC + v];
+              argb[v] = s_pool[((3 * tpp + c) * nthr + threadIdx.x) * VEC + v];
+            }
+          }
+          VecIO<T, VEC>::store((T*)p.amax + o, argf);
+          VecIO<T, VEC>::store((T*)p.amax + dstride + o, argb);
+        }
+      }
     }
   }
 }
@@ -284,7 +313,7 @@ int launch_conv_pool(const FwdParams& p, int pool_max, hipStream_t st) {
   FV_CHECK(nch <= (VEC == 1 ? 16 : 8), "mixer: d_inner %d too large for the VEC=%d row-walker", p.d_in, VEC);
   dim3 grid(p.geo.rows, p.B), block(64 * nch);
   const bool tp = p.geo.tpp > 1;
-  const size_t smem = tp ? (size_t)2 * p.geo.tpp * 64 * nch * VEC * 4 : 0;
+  const size_t smem = tp ? (size_t)(pool_max ? 4 : 2) * p.geo.tpp * 64 * nch * VEC * 4 : 0;
   FV_CHECK(smem <= 160 * 1024, "mixer_conv_pool_fwd: tokens_per_patch %d too large", p.geo.tpp);
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
     static bool done = false;
@@ -300,7 +329,7 @@ int launch_conv_pool(const FwdParams& p, int pool_max, hipStream_t st) {
     else hipLaunchKernelGGL((K<__VA_ARGS__, false>), grid, block, smem, st, p);              \
   } while (0)
   static const bool rowk = !(getenv("FASTVIM_FWD_ROWK") && atoi(getenv("FASTVIM_FWD_ROWK")) == 0);   // tuning hook
-  if (!tp && rowk) {     // short rows: the whole-row packed-math kernel (convpool_fwd_row.hip)
+  if (!tp && rowk && !pool_max) {     // short rows, mean pooling: the whole-row packed-math kernel (convpool_fwd_row.hip)
     int rc = fvi::conv_pool_fwd_row(p, pool_max, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
     if (rc != FV_ERR_UNSUPPORTED) return rc;
   }
@@ -363,7 +392,7 @@ int check_geo(int B, int rows, int cols, int s_i, int s_j, int d_in, int dtype, 
 
 extern "C" int fv_mixer_conv_pool_fwd(const void* xz, const float* conv_w, const float* conv_b,
                                       const float* conv_w_b, const float* conv_b_b, const float* D,
-                                      const float* D_b, void* xc, void* skip, int batch, int rows, int cols,
+                                      const float* D_b, void* xc, void* skip, void* amax, int batch, int rows, int cols,
                                       int tok_stride_row, int tok_stride_col, int tokens_per_patch, int d_inner,
                                       int d_conv, int pool_max, float scaling_factor, int dtype,
                                       fv_stream_t stream) {
@@ -374,7 +403,8 @@ extern "C" int fv_mixer_conv_pool_fwd(const void* xz, const float* conv_w, const
   FV_CHECK(!skip || (D && D_b), "mixer_conv_pool_fwd: skip output needs D and D_b");
   FwdParams p{};
   p.xz = xz; p.wf = conv_w; p.bf = conv_b; p.wb = conv_w_b; p.bb = conv_b_b; p.xc = xc;
-  p.Df = D; p.Db = D_b; p.skip = skip;
+  p.Df = D; p.Db = D_b; p.skip = skip; p.amax = pool_max ? amax : nullptr;
+  FV_CHECK(!(pool_max && amax) || cols <= 256, "mixer_conv_pool_fwd: argmax columns are stored in the activation dtype (cols <= 256)");
   p.geo = make_geo(rows, cols, tok_stride_row, tok_stride_col, tokens_per_patch);
   p.B = batch; p.d_in = d_inner;
   p.pool_scale = pool_max ? 1.f : scaling_factor / (float)cols;

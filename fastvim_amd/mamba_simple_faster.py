@@ -165,8 +165,13 @@ class FastVimMixerFn(torch.autograd.Function):
             W_in_c, W_out_c = _shadow(W_in, cdt), _shadow(W_out, cdt)
             xz = linear_fwd(h_c.view(B * Ltok, d), W_in_c, b_in).view(B, Ltok, 2 * d_in)  # (B, L, 2 d_in)
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
-            xc, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
-                                       D=D, D_b=D_b)
+            amax = None
+            if pool_max:
+                xc, skip, amax = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
+                                                 D=D, D_b=D_b)
+            else:
+                xc, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
+                                           D=D, D_b=D_b)
             if fv is not None and "Wx2" in fv:          # x_proj / x_proj_b adjacent in the flat buffers
                 Wx2 = fv["Wx2"]
                 Wx2_c = fv["Wx2_shadow"] if fv["Wx2_shadow"].dtype == cdt else Wx2.to(cdt)
@@ -178,7 +183,7 @@ class FastVimMixerFn(torch.autograd.Function):
             g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
             out = linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
         ctx.save_for_backward(h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b,
-                              ln_w, ln_b, W_out, xz, xc, x_dbl, g, skip, yc, mean, rstd)
+                              ln_w, ln_b, W_out, xz, xc, x_dbl, g, skip, yc, mean, rstd, amax)
         ctx.geo = (rows, cols, transposed, pool_max, scaling, tpp)
         ctx.has_bias = (b_in is not None, b_out is not None)
         ctx.cdt = cdt
@@ -189,7 +194,7 @@ class FastVimMixerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b, ln_w, ln_b, W_out,
-         xz, xc, x_dbl, g, skip, yc, mean, rstd) = ctx.saved_tensors
+         xz, xc, x_dbl, g, skip, yc, mean, rstd, amax) = ctx.saved_tensors
         rows, cols, transposed, pool_max, scaling, tpp = ctx.geo
         cdt = ctx.cdt
         B, Ltok, d = h_c.shape
@@ -224,7 +229,7 @@ class FastVimMixerFn(torch.autograd.Function):
                 dxc = torch.baddbmm(dxc.view(2, B * rows * tpp, d_in), dx_dbl, Wx2)            # + dx_dbl @ Wx
             p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
                                  pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None,
-                                 tpp=tpp)
+                                 tpp=tpp, amax=amax)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
             dhidden = linear_dgrad(dxz2, _shadow(W_in, cdt)).view(B, Ltok, d).to(ctx.in_dtype)
             dW_in = _SideStream.run(lambda: linear_wgrad(dxz2, h_c.view(B * Ltok, d), W_in), dxz2, h_c)

@@ -16,17 +16,21 @@ def _geo(rows, cols, transposed):
 
 def conv_pool_fwd(xz, conv_w, conv_b, conv_w_b, conv_b_b, rows, cols, transposed, pool_max, scaling, tpp=1,
                   D=None, D_b=None):
-    """Returns xc (2, B, rows*tpp, d_in); with D / D_b also skip (B, L, d_in) = D*conv_f + D_b*conv_b."""
+    """Returns xc (2, B, rows*tpp, d_in); with D / D_b also skip (B, L, d_in) = D*conv_f + D_b*conv_b; with
+    ``pool_max`` also amax (like xc: column of each maximum, for the backward pass)."""
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     xc = torch.empty(2, B, rows * tpp, d_in, device=xz.device, dtype=xz.dtype)
     skip = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype) if D is not None else None
+    amax = torch.empty_like(xc) if pool_max else None
     rc = L.lib().fv_mixer_conv_pool_fwd(
         L.ptr(xz), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(D), L.ptr(D_b), L.ptr(xc),
-        L.ptr(skip), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in),
+        L.ptr(skip), L.ptr(amax), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in),
         L.i32(conv_w.shape[-1]), L.i32(pool_max), f32(scaling), L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_conv_pool_fwd")
+    if pool_max:
+        return (xc, amax) if D is None else (xc, skip, amax)
     return xc if D is None else (xc, skip)
 
 
@@ -165,7 +169,7 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
 
 
 def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed,
-                  pool_max, scaling, grad_out=None, tpp=1):
+                  pool_max, scaling, grad_out=None, tpp=1, amax=None):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
@@ -174,7 +178,7 @@ def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz,
     part = torch.empty(nb, 12 * d_in, device=xz.device, dtype=torch.float32)
     rc = lib.fv_mixer_conv_pool_bwd(
         L.ptr(xz), L.ptr(d_o), L.ptr(dxc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
-        L.ptr(D), L.ptr(D_b), L.ptr(dxz), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i),
+        L.ptr(D), L.ptr(D_b), L.ptr(amax), L.ptr(dxz), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i),
         L.i32(s_j), L.i32(tpp), L.i32(d_in), L.i32(conv_w.shape[-1]), L.i32(pool_max), f32(scaling),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
     L.check(rc, "mixer_conv_pool_bwd")

@@ -120,10 +120,12 @@ int fv_scan_expand_skip_fwd(const void* yc, const void* u_full, const float* D, 
  * ---------------------------------------------------------------------- */
 /* Both depthwise convs + SiLU, the pooling over `cols` -> xc, and (skip != NULL) the D-weighted skip term
  * skip[b, token, :] = D*conv_f(x) + D_b*conv_b(x)  (batch, L, d_inner), memory token order, storage `dtype`
- * (mamba_simple_faster.py:356-358, 412-416): each conv+SiLU is evaluated once per forward pass. */
+ * (mamba_simple_faster.py:356-358, 412-416): each conv+SiLU is evaluated once per forward pass.
+ * pool_max != 0 (collapse_method="max", mamba_simple_faster.py:299-305): xc holds the row maxima and amax
+ * (same shape and dtype as xc, nullable) receives the column of the first maximum, for the backward pass. */
 int fv_mixer_conv_pool_fwd(const void* xz, const float* conv_w, const float* conv_b,
                            const float* conv_w_b, const float* conv_b_b, const float* D, const float* D_b,
-                           void* xc, void* skip, int batch, int rows, int cols, int tok_stride_row,
+                           void* xc, void* skip, void* amax, int batch, int rows, int cols, int tok_stride_row,
                            int tok_stride_col, int tokens_per_patch, int d_inner, int d_conv, int pool_max,
                            float scaling_factor, int dtype, fv_stream_t stream);
 
@@ -176,12 +178,13 @@ int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, cons
 /* Adjoint of fv_mixer_conv_pool_fwd plus the D-skip path: consumes d_o and the total gradient
  * wrt the pooled conv output dxc (2, batch, rows, d_inner) fp32; writes dx into the x half of
  * dxz and per-block partials [d conv_w (d_inner*4) | d conv_w_b (d_inner*4) | d conv_b | d conv_b_b |
- * dD | dD_b] (12*d_inner floats). */
+ * dD | dD_b] (12*d_inner floats).  pool_max != 0: `amax` is the argmax tensor the forward wrote; the
+ * pooled gradient goes to that column only (autograd of `.max(dim).values`, mamba_simple_faster.py:299-305). */
 int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, const float* conv_w,
                            const float* conv_b, const float* conv_w_b, const float* conv_b_b, const float* D,
-                           const float* D_b, void* dxz, float* partials, int batch, int rows, int cols,
-                           int tok_stride_row, int tok_stride_col, int tokens_per_patch, int d_inner, int d_conv,
-                           int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
+                           const float* D_b, const void* amax, void* dxz, float* partials, int batch, int rows,
+                           int cols, int tok_stride_row, int tok_stride_col, int tokens_per_patch, int d_inner,
+                           int d_conv, int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
 
 /* out[i] (+)= sum_{s < n_partials} partials[s*n + i], fixed order (deterministic); accumulate != 0
  * adds into `out` (gradient accumulation straight into a parameter's .grad). */

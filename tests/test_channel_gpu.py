@@ -139,3 +139,27 @@ def test_channelvim_small_config5_shape_vs_oracle():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         lb = m(x.cuda())
     assert _err(lb, ref) <= 5e-2 * s, _err(lb, ref)
+
+
+def test_channel_mixer_max_pool_vs_oracle():
+    """collapse_method="max" with tokens_per_patch > 1 (mamba_simple_channel_faster.py:258-283)."""
+    from fastvim_amd.mamba_simple_channel_faster import Mamba
+    from oracle import fastvim_mixer_oracle
+    torch.manual_seed(7)
+    d_model, grid, tpp = 64, (4, 6), 3
+    m = Mamba(d_model, token_size=list(grid), collapse_method="max").cuda()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    h = torch.randn(2, grid[0] * grid[1] * tpp, d_model)
+    g = torch.randn_like(h)
+    p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    hc = h.clone().requires_grad_()
+    yref = fastvim_mixer_oracle(p, hc, grid, tokens_per_patch=tpp, collapse_method="max", compute_dtype=F64, out_dtype=F64)
+    yref.backward(g.double())
+    hg = h.cuda().requires_grad_()
+    y = m(hg, tpp)
+    assert _err(y, yref) <= 1e-5 * max(1.0, yref.abs().max().item())
+    y.backward(g.cuda())
+    assert _err(hg.grad, hc.grad) <= 5e-5 * max(1.0, hc.grad.abs().max().item())
+    for n, q in m.named_parameters():
+        e = _err(q.grad, p[n].grad)
+        assert e <= 2e-4 * max(1.0, p[n].grad.abs().max().item()), (n, e)

@@ -110,17 +110,37 @@ def test_mixer_options_vs_oracle():
             assert e <= 1e-4 * max(1.0, p[n].grad.abs().max().item()), (kw, n, e)
 
 
-def test_mixer_max_pool_forward():
+@pytest.mark.parametrize("d_model,grid,transposed", [(64, (4, 7), False), (192, (14, 14), False), (192, (14, 14), True),
+                                                     (96, (3, 5), True), (768, (2, 16), False)])
+def test_mixer_max_pool_vs_oracle(d_model, grid, transposed):
+    """collapse_method="max" (mamba_simple_faster.py:299-305): forward and every gradient -- the pooled
+    gradient is routed to the argmax column the forward kernel saved."""
     from fastvim_amd.mamba_simple_faster import Mamba
     from oracle import fastvim_mixer_oracle
-    torch.manual_seed(1)
-    m = Mamba(64, token_size=[4, 7], collapse_method="max").cuda()
-    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-    h = torch.randn(2, 28, 64)
+    torch.manual_seed(d_model)
+    rows, cols = grid
+    m = Mamba(d_model, token_size=list(grid), collapse_method="max").cuda()
     with torch.no_grad():
-        y = m(h.cuda())
-    yref = fastvim_mixer_oracle(sd, h, (4, 7), collapse_method="max", compute_dtype=F64, out_dtype=F64)
-    assert _err(y, yref) <= 1e-5 * max(1.0, yref.abs().max().item())
+        for n, p_ in m.named_parameters():
+            if n in ("D", "D_b", "layernorm.weight") or n.endswith("bias"):
+                p_.add_(0.1 * torch.randn_like(p_))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    Bsz, Ltok = 2, rows * cols
+    h = torch.randn(Bsz, Ltok, d_model)
+    perm = (lambda t: t.reshape(Bsz, rows, cols, -1).transpose(1, 2).reshape(Bsz, Ltok, -1)) if transposed else (lambda t: t)
+    hg = perm(h).contiguous().cuda().requires_grad_()
+    y = m(hg, transposed_grid=transposed)
+    p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    hc = h.clone().requires_grad_()
+    yref = fastvim_mixer_oracle(p, hc, grid, collapse_method="max", compute_dtype=F64, out_dtype=F64)
+    assert _err(y, perm(yref)) <= 1e-5 * max(1.0, yref.abs().max().item())
+    g = torch.randn(Bsz, Ltok, d_model)
+    y.backward(perm(g).contiguous().cuda())
+    yref.backward(g.double())
+    assert _err(hg.grad, perm(hc.grad)) <= 5e-5 * max(1.0, hc.grad.abs().max().item())
+    for n, q in m.named_parameters():
+        e = _err(q.grad, p[n].grad)
+        assert e <= 2e-4 * max(1.0, p[n].grad.abs().max().item()), (n, e, p[n].grad.abs().max().item())
 
 
 def test_mixer_full_size_deterministic_and_linear_in_out_proj():
