@@ -149,7 +149,7 @@ def kernel_table(B, rows, cols, d, depth, dtype):
     if dtype == torch.bfloat16:
         # the six projection GEMMs of a block (hand-written MFMA kernel, csrc/gemm_mfma.hip): HBM bytes AND
         # MFMA flops -- at FastVim-T widths (K or N = 192) they sit below the ridge, i.e. are HBM-bound
-        from fastvim_amd.gemm import gemm_nn, gemm_nt, gemm_tn
+        from fastvim_amd.gemm import auto_splits, gemm_nn, gemm_nt, gemm_tn
         Mt = B * L
         h2, g2, xz2, do2 = rn(Mt, d), rn(Mt, d_in), rn(Mt, 2 * d_in), rn(Mt, d)
         W_in, W_out = rn(2 * d_in, d), rn(d, d_in)
@@ -158,8 +158,8 @@ def kernel_table(B, rows, cols, d, depth, dtype):
             "gemm_out_proj_fwd": (lambda: gemm_nt(g2, W_out), Mt, d, d_in, 0),
             "gemm_out_proj_dgrad": (lambda: gemm_nn(do2, W_out), Mt, d_in, d, 0),
             "gemm_in_proj_dgrad": (lambda: gemm_nn(xz2, W_in), Mt, d, 2 * d_in, 0),
-            "gemm_in_proj_wgrad": (lambda: gemm_tn(xz2, h2, splits=28), 2 * d_in, d, Mt, 28),
-            "gemm_out_proj_wgrad": (lambda: gemm_tn(do2, g2, splits=28), d, d_in, Mt, 28),
+            "gemm_in_proj_wgrad": (lambda: gemm_tn(xz2, h2, splits=None), 2 * d_in, d, Mt, auto_splits(Mt, 2 * d_in, d)),
+            "gemm_out_proj_wgrad": (lambda: gemm_tn(do2, g2, splits=None), d, d_in, Mt, auto_splits(Mt, d, d_in)),
         }
         for name, (fn, m_, n_, k_, splits) in gemms.items():
             t = time_kernel(fn)

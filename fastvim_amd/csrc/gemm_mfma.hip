@@ -17,6 +17,8 @@
 // LDS read ds_read_b64_tr_b16, so no operand is ever transposed in HBM.  The MFMA is issued with the
 // roles swapped (weight-side operand in the A slot), which leaves each lane with 4 consecutive output
 // columns of one row: the epilogue stores 8-byte (bf16) / 16-byte (fp32) vectors.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -90,6 +92,44 @@ struct Stage {
   }
 };
 
+// ---- LDS-DMA staging (global_load_lds_dwordx4): the tile goes global -> LDS with no VGPR destination and no
+// ds_write.  A wave instruction writes 1 KiB linearly (M0 base + lane * 16), so the XOR swizzles of the two LDS
+// layouts above are applied to the SOURCE address instead: lane -> physical 16-byte slot -> the logical vector
+// that slot must hold.  Rows / columns past the operand edge are clamped onto valid memory (they only feed
+// output rows / columns that the epilogue never stores); the K range must be whole 64-deep tiles.
+template <int MODE, int EXT>
+struct GldsPlan {
+  static constexpr int NV = EXT * BK / 8 / 256;   // 16-byte vectors per thread == 1-KiB pieces per wave
+  const bf16_t* src[NV];                          // source of vector i at k = 0 of the operand
+  long kstep;                                     // elements per unit of k
+  __device__ __forceinline__ void init(const bf16_t* base, long ld, int r0, int rmax, int tid) {
+    kstep = MODE == KC ? 1 : ld;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * 256;                // physical slot: LDS byte offset e * 16
+      if (MODE == KC) {
+        const int r = e >> 3, c = (e & 7) ^ (r & 7);
+        const int gr = min(r0 + r, rmax - 1);
+        src[i] = base + (long)gr * ld + c * 8;
+      } else {
+        const int kq = e / (EXT / 8), cbp = (e % (EXT / 8)) * 16;
+        const int cbl = ((((cbp >> 5) ^ ks_swz<EXT>(kq)) << 5) | (cbp & 16));
+        const int gc = min(r0 + cbl / 2, rmax - 8);
+        src[i] = base + (long)kq * ld + gc;
+      }
+    }
+  }
+  __device__ __forceinline__ void issue(char* lds, int k0, int tid) const {
+    const int wv = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      typedef __attribute__((address_space(1))) const void* gptr;
+      typedef __attribute__((address_space(3))) void* lptr;
+      __builtin_amdgcn_global_load_lds((gptr)(src[i] + (long)k0 * kstep), (lptr)(lds + (i * 256 + wv * 64) * 16), 16, 0, 0);
+    }
+  }
+};
+
 // fragment of a 16-wide block `blk` (rows for KC, cols for KS) at k-step ks (32 k) of the staged tile
 template <int MODE, int EXT>
 __device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lane) {
@@ -112,7 +152,7 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lan
 }
 
 // WM x WN waves, each 64x64: tile BM = 64*WM rows (m), BN = 64*WN cols (n)
-template <int AMODE, int BMODE, int WM, int WN>
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -141,19 +181,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  Stage<AMODE, BM> ra;
-  Stage<BMODE, BN> rb;
-  ra.load(p.A, p.lda, m0, kbeg, p.M, kend, tid);
-  rb.load(p.B, p.ldb, n0, kbeg, p.N, kend, tid);
-  ra.store(sA(0), tid);
-  rb.store(sB(0), tid);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) {
-      ra.load(p.A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, tid);
-      rb.load(p.B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, tid);
-    }
+  auto compute = [&](int cur) {
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 fa[4], fb[4];
@@ -168,11 +196,48 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         for (int b = 0; b < 4; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[a], fa[b], acc[a][b], 0, 0, 0);
     }
+  };
+  if constexpr (GLDS) {
+    // LDS-DMA: the next tile streams into the other buffer while this one is multiplied; __syncthreads() is
+    // exactly the wait it needs (vmcnt(0): my pieces have landed; barrier: everyone's have, and everyone is
+    // done reading the buffer that is overwritten next).
+    GldsPlan<AMODE, BM> ga;
+    GldsPlan<BMODE, BN> gb;
+    ga.init(p.A, p.lda, m0, p.M, tid);
+    gb.init(p.B, p.ldb, n0, p.N, tid);
+    ga.issue(sA(0), kbeg, tid);
+    gb.issue(sB(0), kbeg, tid);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < nt) {
+        ga.issue(sA(cur ^ 1), kbeg + (t + 1) * BK, tid);
+        gb.issue(sB(cur ^ 1), kbeg + (t + 1) * BK, tid);
+      }
+      compute(cur);
+      __syncthreads();
+    }
+  } else {
+  Stage<AMODE, BM> ra;
+  Stage<BMODE, BN> rb;
+  ra.load(p.A, p.lda, m0, kbeg, p.M, kend, tid);
+  rb.load(p.B, p.ldb, n0, kbeg, p.N, kend, tid);
+  ra.store(sA(0), tid);
+  rb.store(sB(0), tid);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      ra.load(p.A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, tid);
+      rb.load(p.B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, tid);
+    }
+    compute(cur);
     if (t + 1 < nt) {
       ra.store(sA(cur ^ 1), tid);
       rb.store(sB(cur ^ 1), tid);
     }
     __syncthreads();
+  }
   }
   // epilogue: acc[a][b][j] = C[m = m0 + wm*64 + b*16 + (lane&15)][n = n0 + wn*64 + a*16 + (lane>>4)*4 + j]
   const long zoff = (long)blockIdx.z * p.c_split_stride;
@@ -244,20 +309,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-template <int AMODE, int BMODE, int WM, int WN>
-int launch(const GemmParams& p, int splits, hipStream_t st) {
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS>
+int launch_k(const GemmParams& p, int splits, hipStream_t st) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   const int tiles = fv_cdiv(p.M, BM) * fv_cdiv(p.N, BN);
   const size_t smem = (size_t)2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, BMODE, WM, WN>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, BMODE, WM, WN>), dim3(tiles, 1, splits), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS>), dim3(tiles, 1, splits), dim3(256), smem, st, p);
   FV_LAUNCH_CHECK();
   return FV_OK;
+}
+
+template <int AMODE, int BMODE, int WM, int WN>
+int launch(const GemmParams& p, int splits, hipStream_t st) {
+  // LDS-DMA staging needs whole 64-deep K tiles in every split and >= 8 columns in K-slow operands
+  static const bool allow = !(getenv("FASTVIM_GEMM_GLDS") && atoi(getenv("FASTVIM_GEMM_GLDS")) == 0);   // tuning hook
+  // (measured: a win for K-contiguous A -- forward and data-gradient GEMMs, -8..-20 % -- and a loss for the
+  //  K-slow x K-slow weight-gradient form, +10 %, which keeps register staging)
+  const bool whole = AMODE == KC && p.K % BK == 0 && p.k_per_split % BK == 0 && (BMODE == KC || p.N >= 8);
+  if (allow && whole) return launch_k<AMODE, BMODE, WM, WN, true>(p, splits, st);
+  return launch_k<AMODE, BMODE, WM, WN, false>(p, splits, st);
 }
 
 template <int AMODE, int BMODE>

@@ -32,11 +32,26 @@ def gemm_nn(a, b, out_dtype=torch.bfloat16):
     return c
 
 
+def auto_splits(Kd, M, N, target_wgs=768, cap=28):
+    """Split-K factor of a weight gradient: enough (tile, K slice) workgroups to fill the 256 CUs about three
+    times, no more (every slice writes and re-reads an (M, N) fp32 partial), each slice whole 64-deep K tiles."""
+    tiles = -(-M // 128) * -(-N // 128)
+    want = max(1, min(cap, target_wgs // tiles))
+    kt = Kd // 64
+    best = 1
+    for s in range(1, want + 1):
+        if Kd % 64 == 0 and kt % s == 0:
+            best = s
+    return best
+
+
 def gemm_tn(x, y, splits=1, out=None, accumulate=False, defer=True):
     """x (Kd, M)^T @ y (Kd, N) -> (M, N) fp32: weight gradient, reduction over the leading (token) dim
     cut into `splits` slices whose fp32 partials are summed in fixed order (deterministic split-K)."""
     Kd, M = x.shape
     N = y.shape[1]
+    if splits is None:
+        splits = auto_splits(Kd, M, N)
     while splits > 1 and (Kd % (splits * 64)):
         splits //= 2
     part = torch.empty(splits, M, N, device=x.device, dtype=torch.float32)

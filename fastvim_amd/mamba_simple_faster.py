@@ -101,7 +101,7 @@ class _SideStream:
         cls.pending = []
 
 
-def linear_wgrad(g2, a2, W=None, splits=28):
+def linear_wgrad(g2, a2, W=None, splits=None):
     """dW (N, K) fp32 = g2 (M, N)^T a2 (M, K), deterministic split-K; accumulates into W's flat .grad if present."""
     if _mfma_ok(g2, a2) and g2.shape[1] % 8 == 0 and a2.shape[1] % 8 == 0 and g2.shape[0] % 64 == 0:
         gdir = _direct_grad(W) if W is not None else None
