@@ -220,6 +220,58 @@ def cpu_baseline(seconds_budget=15.0):
             "scan_ref_ms_128x384x14x16": round(scan_ms, 2)}
 
 
+# --------------------------------------------------------------------------- scan op at the config shapes
+SCAN_SHAPES = {      # BASELINE configs -> (B, d_in, Lc, N) of one selective_scan_fn call  
+    "cfg2_FastVimT_224_bs128": (128, 384, 14, 16),
+    "cfg3_FastVimB_224_bs128": (128, 1536, 14, 16),
+    "cfg4_FastVimB_2048_bs8": (8, 1536, 128, 16),
+    "cfg5_ChannelVimS_8ch_bs64": (64, 768, 112, 16),
+}
+
+
+def scan_op_table(cpu=True):
+    """The reference-layout op `selective_scan_fn` (csrc/scan_bdl.hip: wave-level associative scan) at every
+    config's (B, d_in, Lc, N): device time fwd and fwd+bwd, HBM GB/s on the ALGORITHMIC bytes of SURVEY.md
+    section 8d, and the CPU oracle's port of selective_scan_ref on the same inputs beside it."""
+    from fastvim_amd.selective_scan_interface import selective_scan_fn
+    out = {}
+    for name, (B, D, Lc, N) in SCAN_SHAPES.items():
+        g = torch.Generator().manual_seed(0)
+        u, dl = torch.randn(B, D, Lc, generator=g), 0.5 * torch.rand(B, D, Lc, generator=g)
+        A = -0.5 * torch.rand(D, N, generator=g)
+        Bm, Cm = torch.randn(B, N, Lc, generator=g), torch.randn(B, N, Lc, generator=g)
+        db = 0.5 * torch.rand(D, generator=g)
+        e = 2
+        q = [t.cuda().bfloat16().requires_grad_() for t in (u, dl, Bm, Cm)]
+        Ag, dbg = A.cuda().requires_grad_(), db.cuda().requires_grad_()
+        go = torch.randn(B, D, Lc, device="cuda").bfloat16()
+
+        def fwd():
+            with torch.no_grad():
+                return selective_scan_fn(q[0], q[1], Ag, q[2], q[3], None, None, dbg, True)
+
+        def fwd_bwd():
+            y = selective_scan_fn(q[0], q[1], Ag, q[2], q[3], None, None, dbg, True)
+            torch.autograd.grad(y, q + [Ag, dbg], go)
+
+        tf = time_kernel(fwd, iters=10)
+        tfb = time_kernel(fwd_bwd, iters=10)
+        bytes_f = e * (3 * B * D * Lc + 2 * B * N * Lc) + 4 * (D * N + D)
+        bytes_b = e * (5 * B * D * Lc + 2 * B * N * Lc) + 4 * (2 * B * N * Lc + 2 * D * N + 2 * D)
+        row = {"shape_B_D_L_N": [B, D, Lc, N], "fwd_us": round(tf * 1e6, 1), "fwd_GBps": round(bytes_f / tf / 1e9, 1),
+               "fwd_hbm_frac": round(bytes_f / tf / 1e9 / HBM_PEAK_GBS, 4), "fwd_bwd_us": round(tfb * 1e6, 1),
+               "bwd_GBps": round(bytes_b / max(tfb - tf, 1e-9) / 1e9, 1), "algorithmic_MB_fwd": round(bytes_f / 1e6, 2),
+               "algorithmic_MB_bwd": round(bytes_b / 1e6, 2)}
+        if cpu:
+            from oracle import selective_scan_ref_port
+            selective_scan_ref_port(u, dl, A, Bm, Cm, None, None, db, True)
+            t1 = time.perf_counter()
+            selective_scan_ref_port(u, dl, A, Bm, Cm, None, None, db, True)
+            row["cpu_ref_fwd_ms"] = round((time.perf_counter() - t1) * 1e3, 1)
+        out[name] = row
+    return out
+
+
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -235,6 +287,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--scan-op", action="store_true",
+                    help="also time the reference-layout op selective_scan_fn at every config's (B, d_in, Lc, N)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -364,6 +418,8 @@ def main():
                                "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6)}
         if not args.no_cpu_baseline and world == 1 and args.model != "C":
             out["cpu_baseline"] = cpu_baseline()
+        if args.scan_op and world == 1:
+            out["scan_op"] = scan_op_table(cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
