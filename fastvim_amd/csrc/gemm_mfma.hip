@@ -49,7 +49,8 @@ struct GemmParams {
 template <int EXT>
 __device__ __forceinline__ int ks_swz(int k) {
   const int code = (k & 3) | (((k >> 3) & 1) << 2);
-  return EXT >= 128 ? code : (code & (EXT / 16 - 1));
+  // 192-wide tiles have 12 32-byte chunks = 3 groups of 4: XOR inside a group only
+  return EXT == 192 ? (code & 3) : (EXT >= 128 ? code : (code & (EXT / 16 - 1)));
 }
 
 // ---- staging: 256 threads move a (ROWS x 64) KC tile or a (64 x COLS) KS tile, 16 B per access ----
@@ -151,10 +152,11 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lan
   }
 }
 
-// WM x WN waves, each 64x64: tile BM = 64*WM rows (m), BN = 64*WN cols (n)
-template <int AMODE, int BMODE, int WM, int WN, bool GLDS>
+// WM x WN waves, each 64 rows x 16*NB columns (NB = 4 or 6): tile BM = 64*WM rows (m), BN = 16*NB*WN cols (n).
+// NB = 6 gives 128x192 tiles: an N = 192 output is one tile wide, so the A panel is read once instead of 3 times.
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int BM = 64 * WM, BN = 16 * NB * WN, WNC = 16 * NB;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto sA = [&](int i) { return smem + i * (A_BYTES + B_BYTES); };             // [A0 | B0 | A1 | B1]
@@ -175,23 +177,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
-  f32x4 acc[4][4];   // [n tile][m tile]: rows = n (MFMA A slot = B operand), cols = m
+  f32x4 acc[NB][4];   // [n tile][m tile]: rows = n (MFMA A slot = B operand), cols = m
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NB; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int cur) {
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[4], fb[NB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = frag<AMODE, BM>(sA(cur), wm * 4 + i, ks, lane);
-        fb[i] = frag<BMODE, BN>(sB(cur), wn * 4 + i, ks, lane);
-      }
+      for (int i = 0; i < 4; ++i) fa[i] = frag<AMODE, BM>(sA(cur), wm * 4 + i, ks, lane);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int i = 0; i < NB; ++i) fb[i] = frag<BMODE, BN>(sB(cur), wn * NB + i, ks, lane);
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[a], fa[b], acc[a][b], 0, 0, 0);
@@ -239,12 +240,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     __syncthreads();
   }
   }
-  // epilogue: acc[a][b][j] = C[m = m0 + wm*64 + b*16 + (lane&15)][n = n0 + wn*64 + a*16 + (lane>>4)*4 + j]
+  // epilogue: acc[a][b][j] = C[m = m0 + wm*64 + b*16 + (lane&15)][n = n0 + wn*WNC + a*16 + (lane>>4)*4 + j]
   const long zoff = (long)blockIdx.z * p.c_split_stride;
   if (p.bias) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+    for (int a = 0; a < NB; ++a) {
+      const int n = n0 + wn * WNC + a * 16 + (lane >> 4) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float bj = (n + j < p.N) ? p.bias[n + j] : 0.f;
@@ -254,9 +255,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
   }
   if (!p.c_fp32) {
-    // bf16 C: the wave's 64x64 tile goes through LDS (two 32-row halves, 144-byte padded rows) so that
-    // every global store is 16 B per lane and a wave instruction writes 8 whole 128-byte row segments
-    constexpr int RS = 144;
+    // bf16 C: the wave's 64 x WNC tile goes through LDS (two 32-row halves, rows padded by 16 B) so that
+    // every global store is 16 B per lane and a wave instruction writes whole 128-byte row segments
+    constexpr int RS = WNC * 2 + 16, CH = WNC / 8;
     __syncthreads();                                  // all waves are done reading the operand tiles
     char* my = smem + wv * (32 * RS);
     bf16_t* Cb = (bf16_t*)p.C + zoff;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       for (int bb = 0; bb < 2; ++bb) {
         const int b = 2 * h + bb;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < NB; ++a) {
           const f32x4 v = acc[a][b];
           uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
           *reinterpret_cast<uint2*>(my + (bb * 16 + (lane & 15)) * RS + (a * 16 + (lane >> 4) * 4) * 2) = pk;
@@ -274,9 +275,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = i * 64 + lane, r = idx >> 3, ch = idx & 7;
-        const int m = m0 + wm * 64 + h * 32 + r, n = n0 + wn * 64 + ch * 8;
+      for (int i = 0; i < NB; ++i) {
+        const int idx = i * 64 + lane, r = idx / CH, ch = idx - r * CH;
+        const int m = m0 + wm * 64 + h * 32 + r, n = n0 + wn * WNC + ch * 8;
         if (m < p.M && n < p.N) {
           const u32x4 q = *reinterpret_cast<const u32x4*>(my + r * RS + ch * 16);
           bf16_t* dst = Cb + (long)m * p.ldc + n;
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int m = m0 + wm * 64 + b * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+    for (int a = 0; a < NB; ++a) {
+      const int n = n0 + wn * WNC + a * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
       const f32x4 v = acc[a][b];
       float* dst = (float*)p.C + zoff + (long)m * p.ldc + n;
@@ -309,18 +310,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-template <int AMODE, int BMODE, int WM, int WN, bool GLDS>
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4>
 int launch_k(const GemmParams& p, int splits, hipStream_t st) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int BM = 64 * WM, BN = 16 * NB * WN;
   const int tiles = fv_cdiv(p.M, BM) * fv_cdiv(p.N, BN);
   const size_t smem = (size_t)2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS, NB>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS>), dim3(tiles, 1, splits), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS, NB>), dim3(tiles, 1, splits), dim3(256), smem, st, p);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
@@ -338,6 +339,13 @@ int launch(const GemmParams& p, int splits, hipStream_t st) {
 
 template <int AMODE, int BMODE>
 int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
+  // N a multiple of 192 (FastVim-T/S/B: d, 2*d_in): 128x192 tiles, the A panel is read N/192 times instead of
+  // N/128.  Measured on MI355X: N = 384 -9 %, FastVim-S/B steps -3 %; N = 192 neutral (K-contiguous B) or +12 %
+  // (K-slow B, 4-way swizzle), N = 768 with K = 192 +3 % -- those keep the 128-wide tiles.
+  static const bool wide = !(getenv("FASTVIM_GEMM_N192") && atoi(getenv("FASTVIM_GEMM_N192")) == 0);   // tuning hook
+  if (wide && AMODE == KC && p.N % 192 == 0 && p.N >= 384 && !(p.N == 768 && p.K <= 192) && p.K % BK == 0 &&
+      p.k_per_split % BK == 0)
+    return launch_k<AMODE, BMODE, 2, 2, true, 6>(p, splits, st);
   // 128x128 tiles unless N (<= 64 mod 128) wastes half a tile: then 256x64
   const int rem = p.N % 128;
   if (rem != 0 && rem <= 64 && p.M >= 256) return launch<AMODE, BMODE, 4, 1>(p, splits, st);
