@@ -8,6 +8,8 @@
 // reductions (two exact passes: mean, then centred second moment).  The per-sample DropPath scale
 // of the mixer branch (timm DropPath applied in models/fastvim.py:182-190) is folded into the add,
 // and the output cast to the mixer's compute dtype is folded into the store.
+#include <stdlib.h>
+
 #include "rowwalk.h"
 
 namespace {
@@ -226,6 +228,207 @@ __global__ __launch_bounds__(256) void add_norm_bwd_kernel(NormParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Hidden sizes 192 / 384 / 768 (FastVim-T / S / B): a row is 3 x 4 channels per lane over LPR = 16 / 32 / 64
+// lanes, so a wave carries 4 / 2 / 1 rows at full lane occupancy (the generic mapping above, one row per
+// wave and 4 channels per lane per step, leaves a quarter of the lanes idle at 192 and 384).  Row sums are
+// DPP adds inside a 16-lane row plus the gfx950 cross-row swaps.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#define FV_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+  FV_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  FV_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  FV_DPP_ADD(0x141);   // row_half_mirror
+  FV_DPP_ADD(0x140);   // row_mirror -> every lane holds its 16-lane sum
+#undef FV_DPP_ADD
+  if constexpr (LPR >= 32) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  if constexpr (LPR >= 64) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return v;
+}
+// sum over the 64 / LPR row groups of a wave (same lane-in-row), result in every group
+template <int LPR>
+__device__ __forceinline__ float cross_group_sum(float v) {
+  if constexpr (LPR <= 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  if constexpr (LPR <= 32) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void add_norm_fwd3_kernel(NormParams p) {
+  constexpr int RPW = 64 / LPR, RU = 2, N = 12 * LPR;   // rows per wave step, row groups in flight
+  const int lane = threadIdx.x & 63;
+  const int lr = lane % LPR, gr = lane / LPR;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float inv_n = 1.f / (float)N;
+  float w[3][4], bb[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    VecIO<float, 4>::load(p.w + (k * LPR + lr) * 4, w[k]);
+    if (p.b) VecIO<float, 4>::load(p.b + (k * LPR + lr) * 4, bb[k]);
+  }
+  for (int row0 = wave * RPW * RU; row0 < p.M; row0 += nwaves * RPW * RU) {
+    float v[RU][3][4], r[RU][3][4];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u * RPW + gr;
+      const size_t base = (size_t)(row < p.M ? row : p.M - 1) * N;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = (k * LPR + lr) * 4;
+        ld4(p.x, p.x_dt, base + c, v[u][k]);
+        if (p.res) ld4(p.res, p.res_dt, base + c, r[u][k]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u * RPW + gr;
+      const bool live = row < p.M;
+      const size_t base = (size_t)(live ? row : p.M - 1) * N;
+      const float sc = p.row_scale ? p.row_scale[(live ? row : p.M - 1) / p.rows_per_scale] : 1.f;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = (k * LPR + lr) * 4;
+        if (p.res) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][k][e] = fmaf(v[u][k][e], sc, r[u][k][e]);
+        } else if (p.row_scale) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][k][e] *= sc;
+        }
+        if (p.res_out && live) st4(p.res_out, p.ro_dt, base + c, v[u][k]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[u][k][e];
+      }
+      float mu = 0.f;
+      if (!p.is_rms) mu = group_sum<LPR>(s) * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[u][k][e] - mu;
+          q = fmaf(d, d, q);
+        }
+      const float rstd = rsqrtf(group_sum<LPR>(q) * inv_n + p.eps);
+      if (lr == 0 && live) {
+        p.rstd[row] = rstd;
+        if (!p.is_rms && p.mean) p.mean[row] = mu;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = (k * LPR + lr) * 4;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[u][k][e] - mu) * rstd * w[k][e] + (p.b ? bb[k][e] : 0.f);
+        if (live) st4(p.y, p.y_dt, base + c, o);
+      }
+    }
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void add_norm_bwd3_kernel(NormParams p) {
+  constexpr int RPW = 64 / LPR, RU = 2, N = 12 * LPR;
+  __shared__ float s_acc[4][N];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane % LPR, gr = lane / LPR;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float inv_n = 1.f / (float)N;
+  float w[3][4], aw[3][4], ab[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    VecIO<float, 4>::load(p.w + (k * LPR + lr) * 4, w[k]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) aw[k][e] = ab[k][e] = 0.f;
+  }
+  for (int row0 = wave * RPW * RU; row0 < p.M; row0 += nwaves * RPW * RU) {
+    float rr[RU][3][4], dyv[RU][3][4], gg[RU][3][4];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u * RPW + gr;
+      const size_t base = (size_t)(row < p.M ? row : p.M - 1) * N;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = (k * LPR + lr) * 4;
+        ld4(p.r, p.r_dt, base + c, rr[u][k]);
+        ld4(p.dy, p.dy_dt, base + c, dyv[u][k]);
+        if (p.dres_out) ld4(p.dres_out, p.dro_dt, base + c, gg[u][k]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u * RPW + gr;
+      const bool live = row < p.M;
+      const int rowc = live ? row : p.M - 1;
+      const size_t base = (size_t)rowc * N;
+      const float rstd = p.rstd_in[rowc];
+      const float mu = p.is_rms ? 0.f : p.mean_in[rowc];
+      const float lv = live ? 1.f : 0.f;                 // a clamped (repeated) row adds nothing
+      float xh[3][4], dxh[3][4];
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dyl = dyv[u][k][e] * lv;
+          xh[k][e] = (rr[u][k][e] - mu) * rstd;
+          dxh[k][e] = dyl * w[k][e];
+          aw[k][e] = fmaf(dyl, xh[k][e], aw[k][e]);
+          ab[k][e] += dyl;
+          c1 += dxh[k][e];
+          c2 = fmaf(dxh[k][e], xh[k][e], c2);
+        }
+      c2 = group_sum<LPR>(c2) * inv_n;
+      c1 = p.is_rms ? 0.f : group_sum<LPR>(c1) * inv_n;
+      const float sc = p.row_scale ? p.row_scale[rowc / p.rows_per_scale] : 1.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = (k * LPR + lr) * 4;
+        float dr[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dr[e] = rstd * (dxh[k][e] - c1 - xh[k][e] * c2) + (p.dres_out ? gg[u][k][e] : 0.f);
+        if (p.dres_in && live) st4(p.dres_in, p.dri_dt, base + c, dr);
+        if (p.dx && live) {
+          if (p.row_scale)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dr[e] *= sc;
+          st4(p.dx, p.dx_dt, base + c, dr);
+        }
+      }
+    }
+  }
+  // row groups of the wave first (cross-row swaps), then the 4 waves through LDS, fixed order
+  for (int pass = 0; pass < (p.pb ? 2 : 1); ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = cross_group_sum<LPR>(pass ? ab[k][e] : aw[k][e]);
+        if (gr == 0) s_acc[wv][(k * LPR + lr) * 4 + e] = t;
+      }
+    __syncthreads();
+    float* dst = (pass ? p.pb : p.pw) + (size_t)blockIdx.x * N;
+    for (int c = threadIdx.x; c < N; c += blockDim.x)
+      dst[c] = (s_acc[0][c] + s_acc[1][c]) + (s_acc[2][c] + s_acc[3][c]);
+  }
+}
+
 int dt_ok(int dt) { return dt == FV_F32 || dt == FV_BF16; }
 
 }  // namespace
@@ -254,7 +457,11 @@ extern "C" int fv_add_norm_fwd(const void* x, int x_dtype, const void* residual,
   p.M = M; p.N = N; p.rows_per_scale = rows_per_scale; p.is_rms = is_rms_norm; p.eps = eps;
   const dim3 grid(fv_add_norm_blocks(M)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (N <= 256) hipLaunchKernelGGL(add_norm_fwd_kernel<1>, grid, block, 0, st, p);
+  static const bool k3 = !(getenv("FASTVIM_NORM3") && atoi(getenv("FASTVIM_NORM3")) == 0);   // tuning hook
+  if (k3 && N == 192) hipLaunchKernelGGL(add_norm_fwd3_kernel<16>, grid, block, 0, st, p);
+  else if (k3 && N == 384) hipLaunchKernelGGL(add_norm_fwd3_kernel<32>, grid, block, 0, st, p);
+  else if (k3 && N == 768) hipLaunchKernelGGL(add_norm_fwd3_kernel<64>, grid, block, 0, st, p);
+  else if (N <= 256) hipLaunchKernelGGL(add_norm_fwd_kernel<1>, grid, block, 0, st, p);
   else if (N <= 512) hipLaunchKernelGGL(add_norm_fwd_kernel<2>, grid, block, 0, st, p);
   else if (N <= 1024) hipLaunchKernelGGL(add_norm_fwd_kernel<4>, grid, block, 0, st, p);
   else hipLaunchKernelGGL(add_norm_fwd_kernel<8>, grid, block, 0, st, p);
@@ -281,7 +488,11 @@ extern "C" int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidu
   p.M = M; p.N = N; p.rows_per_scale = rows_per_scale; p.is_rms = is_rms_norm;
   const dim3 grid(fv_add_norm_blocks(M)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (N <= 256) hipLaunchKernelGGL(add_norm_bwd_kernel<1>, grid, block, 0, st, p);
+  static const bool k3 = !(getenv("FASTVIM_NORM3") && atoi(getenv("FASTVIM_NORM3")) == 0);   // tuning hook
+  if (k3 && N == 192) hipLaunchKernelGGL(add_norm_bwd3_kernel<16>, grid, block, 0, st, p);
+  else if (k3 && N == 384) hipLaunchKernelGGL(add_norm_bwd3_kernel<32>, grid, block, 0, st, p);
+  else if (k3 && N == 768) hipLaunchKernelGGL(add_norm_bwd3_kernel<64>, grid, block, 0, st, p);
+  else if (N <= 256) hipLaunchKernelGGL(add_norm_bwd_kernel<1>, grid, block, 0, st, p);
   else if (N <= 512) hipLaunchKernelGGL(add_norm_bwd_kernel<2>, grid, block, 0, st, p);
   else if (N <= 1024) hipLaunchKernelGGL(add_norm_bwd_kernel<4>, grid, block, 0, st, p);
   else hipLaunchKernelGGL(add_norm_bwd_kernel<8>, grid, block, 0, st, p);
