@@ -287,8 +287,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
-    ap.add_argument("--scan-op", action="store_true",
-                    help="also time the reference-layout op selective_scan_fn at every config's (B, d_in, Lc, N)")
+    ap.add_argument("--no-scan-op", action="store_true",
+                    help="skip timing the reference-layout op selective_scan_fn at every config's (B, d_in, Lc, N)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -418,7 +418,7 @@ def main():
                                "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6)}
         if not args.no_cpu_baseline and world == 1 and args.model != "C":
             out["cpu_baseline"] = cpu_baseline()
-        if args.scan_op and world == 1:
+        if not args.no_scan_op and not args.no_kernels and world == 1 and args.model == "T":
             out["scan_op"] = scan_op_table(cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -12,7 +12,10 @@
 //    in LDS and runs the adjoint recurrence as the mirrored (high-to-low) three-phase scan;
 //  * dB/dC (sum over channels) are accumulated by the single wave that owns a
 //    (batch, group, split) slice, so there are no float atomics and results are deterministic.
+#include <stdlib.h>
+
 #include "common.h"
+#include "lane_reduce.h"
 
 namespace {
 
@@ -70,6 +73,7 @@ struct ScanParams {
   float *last_state;
   float *dB_part, *dC_part;              // variable: (S, batch, G, N, L); constant: unused
   float *pA, *pD, *pbias, *pBc, *pCc;    // per-batch partials (batch, dim[, N])
+  float* ckpt;                           // short-sequence backward: states entering every 4-step segment
   int batch, dim, L, N, G, S;
   int B_var, C_var, softplus;
 };
@@ -449,6 +453,244 @@ __global__ __launch_bounds__(64) void scan_bdl_bwd_kernel(ScanParams p, int ntil
   }
 }
 
+// ------------------------------------------------------------------ short sequences (L <= 128)
+// The three-phase wave scan above puts a whole wave on one (batch, channel) row: right for L >= 1k, but at the
+// FastVim lengths (14 pooled rows, <= 128 elsewhere) > 75 % of the lanes idle and every state costs a wave scan.
+// Short sequences use the mapping of the fused mixer scan (scan_cl.hip) instead: the recurrence runs serially in
+// registers and parallelism comes from batch x channels x state quads -- a lane owns 4 of the 16 states of one
+// channel (sums over states = two DPP quad adds), B_t / C_t are LDS broadcasts, a 256-thread block covers 64
+// channels of one batch element.  Backward: a forward sweep checkpoints the state entering every 4-step segment,
+// segments are walked high-to-low (recompute 4 states, adjoint), dB / dC are reduced over the 16 channel lanes of
+// a wave by the swap/DPP reduce-scatter, over waves through LDS, over 64-channel chunks by reduce_leading.
+// Requires d_state == 16, variable B and C, and whole 64-channel chunks per group.
+constexpr int SN = 16, SCPB = 64, SKS = 4;
+
+static const bool g_short_on = !(getenv("FASTVIM_SCAN_SHORT") && atoi(getenv("FASTVIM_SCAN_SHORT")) == 0);   // tuning hook
+inline bool short_path(int L, int N, int dim, int G, int Bv, int Cv) {
+  return g_short_on && L <= 128 && N == SN && Bv && Cv && (dim / G) % SCPB == 0;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_bc(const ScanParams& p, int b, int g, float* s_bc) {
+  const T* Bg = (const T*)p.B + (size_t)(b * p.G + g) * SN * p.L;
+  const T* Cg = (const T*)p.C + (size_t)(b * p.G + g) * SN * p.L;
+  for (int e = threadIdx.x; e < SN * p.L; e += blockDim.x) {
+    const int n = e / p.L, l = e - n * p.L;
+    s_bc[l * 2 * SN + n] = io<T>::ld(Bg + e);
+    s_bc[l * 2 * SN + SN + n] = io<T>::ld(Cg + e);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scan_short_fwd_kernel(ScanParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [L][B(16) | C(16)]
+  const int tid = threadIdx.x, q = tid & 3;
+  const int cpg = p.dim / p.G, chunks = cpg / SCPB;
+  const int g = blockIdx.x / chunks, cx = blockIdx.x - g * chunks, b = blockIdx.y;
+  const int d = g * cpg + cx * SCPB + (tid >> 2);
+  stage_bc<T>(p, b, g, smem);
+  __syncthreads();
+  float A2[4], st[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) A2[j] = p.A[(size_t)d * SN + q * 4 + j] * FV_LOG2E;
+  const float Dd = p.D ? p.D[d] : 0.f, bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+  const size_t row = ((size_t)b * p.dim + d) * p.L;
+  const T* u = (const T*)p.u + row;
+  const T* dl = (const T*)p.delta + row;
+  const T* z = p.z ? (const T*)p.z + row : nullptr;
+  T* out = (T*)p.out + row;
+  for (int l0 = 0; l0 < p.L; l0 += 4) {
+    float uv[4], dv[4], zv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {          // the group's loads first, then the arithmetic
+      const int l = min(l0 + k, p.L - 1);
+      uv[k] = io<T>::ld(u + l);
+      dv[k] = io<T>::ld(dl + l);
+      zv[k] = z ? io<T>::ld(z + l) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (l0 + k < p.L) {
+        const float* r = smem + (l0 + k) * 2 * SN;
+        float dt = dv[k] + bias;
+        if (p.softplus) dt = fv_softplus(dt);
+        const float du = dt * uv[k];
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], du * r[q * 4 + j]);
+          acc = fmaf(r[SN + q * 4 + j], st[j], acc);
+        }
+        float y = quad_sum(acc) + Dd * uv[k];
+        if (z) y *= fv_silu(zv[k]);
+        if (q == 0) io<T>::st(out + l0 + k, y);
+      }
+    }
+  }
+  if (p.last_state) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.last_state[((size_t)b * p.dim + d) * SN + q * 4 + j] = st[j];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scan_short_bwd_kernel(ScanParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int PV = 16, NWV = 4;
+  float* s_bc = smem;                              // L * 32
+  float* s_part = s_bc + p.L * 2 * SN;             // SKS * NWV * 4 * PV
+  const int tid = threadIdx.x, q = tid & 3, lane = tid & 63, wv = tid >> 6;
+  const int cpg = p.dim / p.G, chunks = cpg / SCPB;
+  const int g = blockIdx.x / chunks, cx = blockIdx.x - g * chunks, b = blockIdx.y;
+  const int d = g * cpg + cx * SCPB + (tid >> 2);
+  const int nseg = (p.L + SKS - 1) / SKS;
+  stage_bc<T>(p, b, g, s_bc);
+  __syncthreads();
+  float A2[4], Ar[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    Ar[j] = p.A[(size_t)d * SN + q * 4 + j];
+    A2[j] = Ar[j] * FV_LOG2E;
+  }
+  const float Dd = p.D ? p.D[d] : 0.f, bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+  const size_t row = ((size_t)b * p.dim + d) * p.L;
+  const T* u = (const T*)p.u + row;
+  const T* dl = (const T*)p.delta + row;
+  const T* z = p.z ? (const T*)p.z + row : nullptr;
+  const T* go = (const T*)p.dout + row;
+  T* du_o = (T*)p.du + row;
+  T* dd_o = (T*)p.ddelta + row;
+  T* dz_o = p.dz ? (T*)p.dz + row : nullptr;
+  float* ck = p.ckpt + (((size_t)b * nseg) * p.dim + d) * SN + q * 4;
+  const size_t ck_seg = (size_t)p.dim * SN;
+
+  {  // forward sweep: state entering every segment but the first
+    float st[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int seg = 0; seg + 1 < nseg; ++seg) {
+      float uv[SKS], dv[SKS];
+#pragma unroll
+      for (int k = 0; k < SKS; ++k) {
+        uv[k] = io<T>::ld(u + seg * SKS + k);
+        dv[k] = io<T>::ld(dl + seg * SKS + k);
+      }
+#pragma unroll
+      for (int k = 0; k < SKS; ++k) {
+        const float* r = s_bc + (seg * SKS + k) * 2 * SN;
+        float dt = dv[k] + bias;
+        if (p.softplus) dt = fv_softplus(dt);
+        const float dub = dt * uv[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], dub * r[q * 4 + j]);
+      }
+      *reinterpret_cast<float4*>(ck + (size_t)(seg + 1) * ck_seg) = make_float4(st[0], st[1], st[2], st[3]);
+    }
+  }
+  float dxa[4] = {0.f, 0.f, 0.f, 0.f}, dA[4] = {0.f, 0.f, 0.f, 0.f}, dD_acc = 0.f, dbias_acc = 0.f;
+  const int s_chunk = cx;                           // split index of the dB / dC partials
+  for (int seg = nseg - 1; seg >= 0; --seg) {
+    const int s0 = seg * SKS, ns = min(SKS, p.L - s0);
+    float uv[SKS], dv[SKS], gq[SKS], zv[SKS];
+#pragma unroll
+    for (int k = 0; k < SKS; ++k) {
+      const int l = min(s0 + k, p.L - 1);
+      uv[k] = io<T>::ld(u + l);
+      dv[k] = io<T>::ld(dl + l);
+      gq[k] = io<T>::ld(go + l);
+      zv[k] = z ? io<T>::ld(z + l) : 0.f;
+    }
+    float cur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (seg > 0) {
+      const float4 c4 = *reinterpret_cast<const float4*>(ck + (size_t)seg * ck_seg);
+      cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
+    }
+    float xs[SKS][4], aq[SKS][4], dtv[SKS], raw[SKS];
+#pragma unroll
+    for (int k = 0; k < SKS; ++k) {
+      const float* r = s_bc + min(s0 + k, p.L - 1) * 2 * SN;
+      const bool on = k < ns;
+      raw[k] = dv[k] + bias;
+      float dt = p.softplus ? fv_softplus(raw[k]) : raw[k];
+      dtv[k] = on ? dt : 0.f;                      // delta = 0: the step is an identity
+      if (!on) gq[k] = 0.f;
+      const float dub = dtv[k] * uv[k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        aq[k][j] = fv_exp2(dtv[k] * A2[j]);
+        cur[j] = fmaf(aq[k][j], cur[j], dub * r[q * 4 + j]);
+        xs[k][j] = cur[j];
+      }
+    }
+#pragma unroll
+    for (int k = SKS - 1; k >= 0; --k) {
+      if (k < ns) {          // uniform across the block
+        const int l = s0 + k;
+        const float* r = s_bc + l * 2 * SN;
+        float gk = gq[k];
+        if (z) {             // out = y * silu(z): gradient wrt y and wrt z
+          float ypre = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ypre = fmaf(r[SN + q * 4 + j], xs[k][j], ypre);
+          ypre = quad_sum(ypre) + Dd * uv[k];
+          const float sg = fv_sigmoid(zv[k]);
+          if (q == 0 && dz_o) io<T>::st(dz_o + l, gq[k] * ypre * sg * (1.f + zv[k] * (1.f - sg)));
+          gk = gq[k] * zv[k] * sg;
+        }
+        float vals[PV];
+#pragma unroll
+        for (int e = 0; e < PV; ++e) vals[e] = 0.f;
+        float du_acc = 0.f, ddt_acc = 0.f;
+        const float dtu = dtv[k] * uv[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float Bn = r[q * 4 + j], Cn = r[SN + q * 4 + j];
+          const float dx = fmaf(gk, Cn, dxa[j]);
+          const float ax = xs[k][j] - dtu * Bn;               // a_t * x_{t-1}
+          du_acc = fmaf(dx, Bn, du_acc);
+          ddt_acc += dx * fmaf(Ar[j], ax, Bn * uv[k]);
+          dA[j] = fmaf(dx * dtv[k], ax, dA[j]);
+          vals[j] = dx * dtu;                                  // dB[4q+j]
+          vals[4 + j] = gk * xs[k][j];                         // dC[4q+j]
+          dxa[j] = aq[k][j] * dx;
+        }
+        du_acc = quad_sum(du_acc);
+        ddt_acc = quad_sum(ddt_acc);
+        // d softplus: sigmoid(raw) = 1 - exp(-softplus(raw))
+        const float ddraw = p.softplus ? ddt_acc * (1.f - __expf(-dtv[k])) : ddt_acc;
+        if (q == 0) {
+          dbias_acc += ddraw;
+          dD_acc = fmaf(gk, uv[k], dD_acc);
+          io<T>::st(du_o + l, fmaf(dtv[k], du_acc, Dd * gk));
+          io<T>::st(dd_o + l, ddraw);
+        }
+        chan_reduce_scatter<PV>(vals, lane);
+        s_part[((k * NWV + wv) * 4 + q) * PV + (lane >> 2)] = vals[0];
+      }
+    }
+    __syncthreads();
+    // the 4 waves in fixed order -> this chunk's partial of dB / dC, layout (split, batch, G, N, L)
+    for (int e = tid; e < ns * 4 * PV; e += blockDim.x) {
+      const int k = e / (4 * PV), rem = e - k * 4 * PV;
+      const int qq = rem / PV, v = rem - qq * PV;
+      if (v < 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t += s_part[((k * NWV + w) * 4 + qq) * PV + v];
+        const int n = qq * 4 + (v & 3);
+        float* dst = (v < 4 ? p.dB_part : p.dC_part) + ((((size_t)s_chunk * p.batch + b) * p.G + g) * SN + n) * p.L;
+        dst[s0 + k] = t;
+      }
+    }
+    __syncthreads();
+  }
+  const size_t bd = (size_t)b * p.dim + d;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p.pA[bd * SN + q * 4 + j] = dA[j];
+  if (q == 0) {
+    if (p.pD) p.pD[bd] = dD_acc;
+    if (p.pbias) p.pbias[bd] = dbias_acc;
+  }
+}
+
 // out[i] = sum_s in[s*n + i], fixed order (deterministic)
 __global__ void reduce_leading_kernel(const float* __restrict__ in, float* __restrict__ out, int S, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -470,11 +712,14 @@ int bwd_splits(int batch, int dim, int G) {
 }
 
 struct BwdWs {
-  size_t pA, pD, pbias, pBc, pCc, dBp, dCp, total;
+  size_t pA, pD, pbias, pBc, pCc, dBp, dCp, ckpt, total;
+  int S;
 };
 BwdWs bwd_ws(int batch, int dim, int L, int N, int G, int Bv, int Cv) {
   BwdWs w{};
-  int S = bwd_splits(batch, dim, G);
+  const bool sp = short_path(L, N, dim, G, Bv, Cv);
+  int S = sp ? (dim / G) / SCPB : bwd_splits(batch, dim, G);     // short path: one dB / dC partial per 64-channel chunk
+  w.S = S;
   size_t o = 0;
   auto take = [&](size_t nfloats) { size_t r = o; o += (nfloats * 4 + 255) / 256 * 256; return r; };
   w.pA = take((size_t)batch * dim * N);
@@ -484,6 +729,7 @@ BwdWs bwd_ws(int batch, int dim, int L, int N, int G, int Bv, int Cv) {
   w.pCc = take(Cv ? 0 : (size_t)batch * dim * N);
   w.dBp = take((Bv && S > 1) ? (size_t)S * batch * G * N * L : 0);
   w.dCp = take((Cv && S > 1) ? (size_t)S * batch * G * N * L : 0);
+  w.ckpt = take(sp ? (size_t)batch * ((L + SKS - 1) / SKS) * dim * N : 0);
   w.total = o;
   return w;
 }
@@ -524,6 +770,20 @@ int launch_bwd(const ScanParams& p, hipStream_t st) {
   return FV_OK;
 }
 
+template <typename T>
+int launch_short(const ScanParams& p, int bwd, hipStream_t st) {
+  const dim3 grid(p.dim / SCPB, p.batch), block(256);
+  FV_CHECK(p.batch <= 65535, "selective_scan: batch %d exceeds the launch grid", p.batch);
+  if (!bwd) {
+    hipLaunchKernelGGL((scan_short_fwd_kernel<T>), grid, block, (size_t)p.L * 2 * SN * 4, st, p);
+  } else {
+    const size_t smem = ((size_t)p.L * 2 * SN + SKS * 4 * 4 * 16) * 4;
+    hipLaunchKernelGGL((scan_short_bwd_kernel<T>), grid, block, smem, st, p);
+  }
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
 int reduce_leading(const float* in, float* out, int S, size_t n, hipStream_t st) {
   if (n == 0) return FV_OK;
   hipLaunchKernelGGL(reduce_leading_kernel, dim3(fv_cdiv((long)n, 256)), dim3(256), 0, st, in, out, S, n);
@@ -555,6 +815,11 @@ extern "C" int fv_selective_scan_fwd(const void* u, const void* delta, const flo
   p.batch = batch; p.dim = dim; p.L = seqlen; p.N = dstate; p.G = n_groups; p.S = 1;
   p.B_var = B_variable; p.C_var = C_variable; p.softplus = delta_softplus;
   hipStream_t st = (hipStream_t)stream;
+  if (short_path(seqlen, dstate, dim, n_groups, B_variable, C_variable)) {
+    if (dtype == FV_F32) return launch_short<float>(p, 0, st);
+    if (dtype == FV_BF16) return launch_short<bf16_t>(p, 0, st);
+    return launch_short<__half>(p, 0, st);
+  }
   if (dtype == FV_F32) return launch_fwd<float>(p, st);
   if (dtype == FV_BF16) return launch_fwd<bf16_t>(p, st);
   return launch_fwd<__half>(p, st);
@@ -583,7 +848,9 @@ extern "C" int fv_selective_scan_bwd(const void* u, const void* delta, const flo
   p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C; p.D = D; p.z = z; p.delta_bias = delta_bias;
   p.dout = dout; p.du = du; p.ddelta = ddelta; p.dz = dz;
   p.batch = batch; p.dim = dim; p.L = seqlen; p.N = dstate; p.G = n_groups;
-  p.S = bwd_splits(batch, dim, n_groups);
+  const bool sp = short_path(seqlen, dstate, dim, n_groups, B_variable, C_variable);
+  p.S = sp ? w.S : bwd_splits(batch, dim, n_groups);
+  p.ckpt = (float*)(ws + w.ckpt);
   p.B_var = B_variable; p.C_var = C_variable; p.softplus = delta_softplus;
   p.pA = (float*)(ws + w.pA);
   p.pD = (float*)(ws + w.pD);
@@ -593,7 +860,11 @@ extern "C" int fv_selective_scan_bwd(const void* u, const void* delta, const flo
   p.dB_part = B_variable ? (p.S > 1 ? (float*)(ws + w.dBp) : dB) : nullptr;
   p.dC_part = C_variable ? (p.S > 1 ? (float*)(ws + w.dCp) : dC) : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FV_F32) rc = launch_bwd<float>(p, st);
+  if (sp) {
+    if (dtype == FV_F32) rc = launch_short<float>(p, 1, st);
+    else if (dtype == FV_BF16) rc = launch_short<bf16_t>(p, 1, st);
+    else rc = launch_short<__half>(p, 1, st);
+  } else if (dtype == FV_F32) rc = launch_bwd<float>(p, st);
   else if (dtype == FV_BF16) rc = launch_bwd<bf16_t>(p, st);
   else rc = launch_bwd<__half>(p, st);
   if (rc) return rc;
