@@ -35,6 +35,9 @@ def build_model(name, img_size, drop_path, channels=8):
         from fastvim_amd.models_channel_mamba_faster import (
             channelvim_small_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2 as chan_s)
         return chan_s(img_size=img_size, channels=channels, hcs=False, drop_path_rate=drop_path)
+    if name == "V":      # Vim-T baseline (models/vim.py): un-pooled scan, middle class token -- the paper's comparison point
+        from fastvim_amd.vim import vim_tiny_patch16_224_final_pool_mean_abs_pos_embed_with_midclstok_div2 as vim_t
+        return vim_t(img_size=img_size, drop_path_rate=drop_path)
     from fastvim_amd import fastvim as fv
     factory = {"T": fv.FastVimT, "S": fv.FastVimS, "B": fv.FastVimB}[name]
     return factory(img_size=img_size, drop_path_rate=drop_path)
@@ -278,8 +281,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C"],
-                    help="FastVim-T/S/B, or C = FastChannelVim-S/16 (use --batch 64 for BASELINE configs[4])")
+    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C", "V"],
+                    help="FastVim-T/S/B, C = FastChannelVim-S/16 (use --batch 64 for BASELINE configs[4]), V = Vim-T baseline")
     ap.add_argument("--channels", type=int, default=8, help="input channels of the channel model (--model C)")
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
     ap.add_argument("--img", type=int, default=224)
@@ -307,7 +310,7 @@ def main():
     from fastvim_amd.flat import FlatAdamW, FlatTrainingState
 
     torch.manual_seed(1234)                    # identical init on every rank (DDP broadcast equivalent)
-    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
+    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1, "V": 0.05}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
     model = build_model(args.model, args.img, drop_path, args.channels).to(dev).train()
     gen = torch.Generator().manual_seed(100 + rank)
     in_ch = args.channels if args.model == "C" else 3
@@ -386,8 +389,9 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         gs = args.img // 16
-        d = {"T": 192, "S": 384, "B": 768, "C": 384}[args.model]
-        mname = f"FastChannelVim-S/16 {args.channels}ch" if args.model == "C" else f"FastVim-{args.model}"
+        d = {"T": 192, "S": 384, "B": 768, "C": 384, "V": 192}[args.model]
+        mname = (f"FastChannelVim-S/16 {args.channels}ch" if args.model == "C" else
+                 "Vim-T (un-pooled baseline)" if args.model == "V" else f"FastVim-{args.model}")
         out = {
             "metric": "images/sec %s %dpx bs=%d/GPU fwd+bwd (+all-reduce +AdamW +EMA), whole job" % (mname, args.img, args.batch),
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -401,7 +405,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "hip_graph": use_graph, "optimizer_in_step": True, "final_loss": round(loss_val, 4)},
         }
-        if not args.no_kernels and args.model != "C":
+        if not args.no_kernels and args.model not in ("C", "V"):
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
             dom = max(kt, key=lambda k: kt[k]["us_per_step"])     # the kernel that costs the most time per step
             out["kernels"] = kt
@@ -416,7 +420,7 @@ def main():
                                "unit": "GB/s", "frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "avg_us": kt[dom]["us"],
                                "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6)}
-        if not args.no_cpu_baseline and world == 1 and args.model != "C":
+        if not args.no_cpu_baseline and world == 1 and args.model not in ("C", "V"):
             out["cpu_baseline"] = cpu_baseline()
         if not args.no_scan_op and not args.no_kernels and world == 1 and args.model == "T":
             out["scan_op"] = scan_op_table(cpu=not args.no_cpu_baseline)

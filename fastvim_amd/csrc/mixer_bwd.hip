@@ -62,10 +62,12 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
     float dyc_acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) dyc_acc[v] = 0.f;
+    const bool nopool = TP && g.pcols == 1;     // un-pooled (Vim) form: dyc is written per token, no accumulators
     if constexpr (TP)
-      for (int c = 0; c < tpp; ++c)
+      if (!nopool)
+        for (int c = 0; c < tpp; ++c)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) s_dyc[(c * nthr + threadIdx.x) * VEC + v] = 0.f;
+          for (int v = 0; v < VEC; ++v) s_dyc[(c * nthr + threadIdx.x) * VEC + v] = 0.f;
     // software pipeline: the (packed) loads of token group j0+TT are in flight while group j0 is processed
     RawVec<T, VEC> n_dg[TT], n_z[TT], n_xh[TT];
     auto fetch = [&](int j0) {
@@ -166,9 +168,18 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
           dyc_acc[v] += 0.5f * d_o;
         }
         if constexpr (TP) {
-          float* sl = s_dyc + (((j0 + t) % tpp) * nthr + threadIdx.x) * VEC;
+          if (nopool) {
+            if (tv[t] && act) {
+              float h[VEC];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) sl[v] += 0.5f * dov[v];
+              for (int v = 0; v < VEC; ++v) h[v] = 0.5f * dov[v];
+              VecIO<float, VEC>::store(p.dyc + ((size_t)row * tpp + (j0 + t)) * p.d_in + c0, h);
+            }
+          } else {
+            float* sl = s_dyc + (((j0 + t) % tpp) * nthr + threadIdx.x) * VEC;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) sl[v] += 0.5f * dov[v];
+          }
         }
         if (tv[t] && act) VecIO<T, VEC>::store(dob_b + (size_t)mtok[t] * p.d_in + c0, dov);
       }
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void combine_bwd_kernel(BwdP
     if (rv && act) {
       if constexpr (!TP) {
         VecIO<float, VEC>::store(p.dyc + (size_t)row * p.d_in + c0, dyc_acc);
-      } else {
+      } else if (!nopool) {
         for (int c = 0; c < tpp; ++c) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) dyc_acc[v] = s_dyc[(c * nthr + threadIdx.x) * VEC + v];
@@ -470,7 +481,7 @@ int launch_combine_bwd(const BwdParams& p, hipStream_t st) {
   FV_CHECK(nch <= (VEC == 1 ? 16 : 8), "mixer_combine_bwd: d_inner %d too large for the VEC=%d row walker", p.d_in, VEC);
   const int rg = rg_combine(p.d_in, VEC);
   dim3 grid(persistent_blocks((long)p.B * p.geo.rows, rg)), block(64 * nch * rg);
-  const size_t extra = p.geo.tpp > 1 ? (size_t)p.geo.tpp * 64 * nch * rg * VEC : 0;
+  const size_t extra = (p.geo.tpp > 1 && p.geo.pcols > 1) ? (size_t)p.geo.tpp * 64 * nch * rg * VEC : 0;
   FV_CHECK((RGMAX * 64 + 2 * p.d_in + extra) * 4 <= 64 * 1024, "mixer_combine_bwd: tokens_per_patch %d too large", p.geo.tpp);
   const bool tp = p.geo.tpp > 1;
   if (p.geo.cols % 2 == 0) {

@@ -67,10 +67,14 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { accf[v] = accb[v] = init; argf[v] = argb[v] = 0.f; }
   // tpp > 1: slots [0, 2 tpp) hold the pooled values, PMAX adds [2 tpp, 4 tpp) for the argmax columns
+  // pcols == 1: nothing is pooled (every token is its own group -- the un-pooled Vim mixer runs as rows x 1 x tpp):
+  // the conv output goes straight to xc, no accumulators
+  const bool nopool = TP && g.pcols == 1;
   if constexpr (TP)
-    for (int c = 0; c < (PMAX ? 4 : 2) * tpp; ++c)
+    if (!nopool)
+      for (int c = 0; c < (PMAX ? 4 : 2) * tpp; ++c)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) s_pool[(c * nthr + threadIdx.x) * VEC + v] = c < 2 * tpp ? init : 0.f;
+        for (int v = 0; v < VEC; ++v) s_pool[(c * nthr + threadIdx.x) * VEC + v] = c < 2 * tpp ? init : 0.f;
   for (int j0 = 0; j0 < g.cols; j0 += TJ) {
     float x[TJ + 6][VEC];
     load_x_tile<T, VEC, TJ, 3, TP>(xz_b, g, p.d_in, i, j0, c0, act, x);
@@ -101,6 +105,25 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
               accb[v] += xb[v];
             }
           }
+        } else if (nopool) {
+          if (act) {
+            const size_t o = (((size_t)b * g.rows + i) * tpp + (j0 + jj)) * p.d_in + c0;
+            const size_t dstr = (size_t)p.B * g.rows * tpp * p.d_in;
+            float of[VEC], ob[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { of[v] = xf[v] * p.pool_scale; ob[v] = xb[v] * p.pool_scale; }
+            VecIO<T, VEC>::store((T*)p.xc + o, of);
+            VecIO<T, VEC>::store((T*)p.xc + dstr + o, ob);
+            if constexpr (PMAX) {
+              if (p.amax) {
+                float zero[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) zero[v] = 0.f;
+                VecIO<T, VEC>::store((T*)p.amax + o, zero);
+                VecIO<T, VEC>::store((T*)p.amax + dstr + o, zero);
+              }
+            }
+          }
         } else {
           const int slot = (j0 + jj) % tpp;
           float* af = s_pool + (slot * nthr + threadIdx.x) * VEC;
@@ -122,7 +145,7 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 512) void conv_pool_fwd_kernel(Fw
       }
     }
   }
-  if (act) {
+  if (act && !nopool) {
     T* xc = (T*)p.xc;
     const size_t dstride = (size_t)p.B * g.rows * tpp * p.d_in;
     for (int c = 0; c < tpp; ++c) {
@@ -313,7 +336,7 @@ int launch_conv_pool(const FwdParams& p, int pool_max, hipStream_t st) {
   FV_CHECK(nch <= (VEC == 1 ? 16 : 8), "mixer: d_inner %d too large for the VEC=%d row-walker", p.d_in, VEC);
   dim3 grid(p.geo.rows, p.B), block(64 * nch);
   const bool tp = p.geo.tpp > 1;
-  const size_t smem = tp ? (size_t)(pool_max ? 4 : 2) * p.geo.tpp * 64 * nch * VEC * 4 : 0;
+  const size_t smem = (tp && p.geo.pcols > 1) ? (size_t)(pool_max ? 4 : 2) * p.geo.tpp * 64 * nch * VEC * 4 : 0;
   FV_CHECK(smem <= 160 * 1024, "mixer_conv_pool_fwd: tokens_per_patch %d too large", p.geo.tpp);
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
     static bool done = false;

@@ -216,8 +216,11 @@ class Block(nn.Module):
         # odd layers pool across the other grid axis: the mixer (built with the swapped token_size)
         # reads the un-transposed tokens through swapped strides
         rot = self.rotate_every_block is True and self.layer_idx % 2 != 0
-        hidden_states = self.mixer(hidden_states, inference_params=inference_params, transposed_grid=rot)
+        hidden_states = self._mix(hidden_states, inference_params, rot)
         return hidden_states, residual
+
+    def _mix(self, hidden_states, inference_params, rot):
+        return self.mixer(hidden_states, inference_params=inference_params, transposed_grid=rot)
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         raise NotImplementedError("FastVim mixers have no inference cache")

@@ -267,3 +267,38 @@ def channel_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, rot
     if final_pool_type == "max":
         logits = logits.max(1)[0]
     return logits
+
+
+# ------------------------------------------------------------------------------------------------
+# Vim baseline (models/vim.py, mamba_simple.py bidirectional v2): un-pooled mixer, middle class token
+# ------------------------------------------------------------------------------------------------
+def vim_mixer_oracle(p, hidden, **kw):
+    """mamba_simple.Mamba.forward with LayerNorm after the SSM (:293-400): the FastVim mixer on an
+    L x 1 grid -- pooling over one column and its expansion are identities."""
+    return fastvim_mixer_oracle(p, hidden, (hidden.shape[1], 1), **kw)
+
+
+def vim_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, use_middle_cls_token=True,
+                       compute_dtype=torch.float64, return_features=False):
+    """VisionMamba.forward of models/vim.py (:410-508) with if_cls_token, if_abs_pos_embed, fused_add_norm,
+    rms_norm, residual_in_fp32: the class token is inserted at M // 2 (or 0) and read back after norm_f."""
+    cd = compute_dtype
+    h, _ = patch_embed_oracle(sd, x, patch_size, cd)
+    Bsz, M, d = h.shape
+    cls = sd["cls_token"].to(cd).expand(Bsz, -1, -1)
+    pos = M // 2 if use_middle_cls_token else 0
+    h = torch.cat((h[:, :pos], cls, h[:, pos:]), dim=1)
+    h = h + sd["pos_embed"].to(cd)
+    h = h.to(cd if cd == torch.float64 else torch.float32)
+    residual = None
+    for i in range(depth):
+        sdl = _sub(sd, f"layers.{i}.")
+        hn, residual = fused_add_norm_oracle(h, sdl["norm.weight"], None, residual, norm_eps, prenorm=True,
+                                             residual_in_fp32=True, is_rms_norm=True, compute_dtype=cd)
+        h = vim_mixer_oracle(_sub(sdl, "mixer."), hn, compute_dtype=cd)
+    h = fused_add_norm_oracle(h, sd["norm_f.weight"], None, residual, norm_eps, prenorm=False,
+                              residual_in_fp32=True, is_rms_norm=True, compute_dtype=cd)
+    feat = h[:, pos, :].to(cd)
+    if return_features:
+        return feat
+    return feat @ sd["head.weight"].to(cd).t() + sd["head.bias"].to(cd)

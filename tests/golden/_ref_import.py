@@ -162,6 +162,14 @@ def load_reference():
     from mamba_ssm.modules import mamba_simple_faster as msf
     import models.fastvim as fastvim
 
+    from mamba_ssm.modules import mamba_simple as ms            # Vim mixer
+    ms.selective_scan_fn = ssi.selective_scan_ref
+    ms.causal_conv1d_fn = causal_conv1d_fn
+    import models.vim as vim
+    for m in (vim, ms):
+        m.rms_norm_fn = rms_norm_fn
+        m.layer_norm_fn = layer_norm_fn
+        m.RMSNorm = RMSNorm
     from mamba_ssm.modules import mamba_simple_channel_faster as mscf
     import importlib
     chan = importlib.import_module("models.channel_wise_tokenization.models_channel_mamba_faster")
@@ -172,7 +180,7 @@ def load_reference():
         m.RMSNorm = RMSNorm
 
     ns = types.SimpleNamespace(
-        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, rms_norm_fn=rms_norm_fn,
+        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, ms=ms, vim=vim, rms_norm_fn=rms_norm_fn,
         layer_norm_fn=layer_norm_fn, RMSNorm=RMSNorm, causal_conv1d_fn=causal_conv1d_fn,
     )
     _loaded = ns

@@ -306,7 +306,60 @@ def gen_channel():
     save("channel.pt", cases)
 
 
+def gen_vim():
+    """Vim baseline (models/vim.py + mamba_simple.py, bidirectional v2 with LayerNorm after the SSM): mixer and a
+    tiny backbone with the middle class token.  The reference's fused CUDA path is replaced by its own reference
+    path (use_fast_path=False: causal_conv1d_fn + selective_scan_ref), which computes the same function."""
+    cases = {}
+    for name, d_model, L, Bsz, seed in (("mixer_d32_L9", 32, 9, 2, 41), ("mixer_d32_L13", 32, 13, 2, 42),
+                                        ("mixer_d64_L20", 64, 20, 1, 43)):
+        torch.manual_seed(seed)
+        m = ref.ms.Mamba(d_model, use_fast_path=False)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n in ("D", "D_b", "layernorm.weight"):
+                    p.add_(0.2 * torch.randn_like(p))
+                elif n in ("layernorm.bias", "conv1d.bias", "conv1d_b.bias"):
+                    p.add_(0.1 * torch.randn_like(p))
+                elif n in ("A_log", "A_b_log"):
+                    p.add_(0.1 * torch.randn_like(p))
+        h = torch.randn(Bsz, L, d_model, requires_grad=True)
+        y = m(h)
+        g = torch.randn_like(y)
+        y.backward(g)
+        cases[name] = dict(hidden=h.detach(), out=y.detach(), g=g, dhidden=h.grad.clone(),
+                           grads={n: p.grad.clone() for n, p in m.named_parameters()},
+                           state_dict={k: v.clone() for k, v in m.state_dict().items()})
+    torch.manual_seed(51)
+    model = ref.vim.VisionMamba(img_size=64, patch_size=16, depth=4, embed_dim=32, channels=3, num_classes=10,
+                                rms_norm=True, residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean",
+                                if_abs_pos_embed=True, if_cls_token=True, use_middle_cls_token=True,
+                                drop_path_rate=0.0, ssm_cfg={"use_fast_path": False})
+    init_sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(("D", "D_b", "norm.weight", "layernorm.weight", "norm_f.weight")):
+                p.add_(0.2 * torch.randn_like(p))
+            elif n.endswith(("layernorm.bias", "head.bias", "patch_embed.proj.bias")):
+                p.add_(0.1 * torch.randn_like(p))
+    model.eval()
+    x = torch.randn(2, 3, 64, 64)
+    logits = model(x)
+    g = torch.randn_like(logits)
+    logits.backward(g)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()
+             if n in ("pos_embed", "cls_token", "head.weight", "layers.0.mixer.in_proj.weight", "layers.1.mixer.A_b_log",
+                      "layers.3.mixer.x_proj_b.weight", "layers.2.norm.weight", "patch_embed.proj.bias", "norm_f.weight",
+                      "layers.1.mixer.conv1d.weight", "layers.2.mixer.dt_proj.bias")}
+    cases["tiny_64x64_cls"] = dict(img=(64, 64), init_seed=51, init_probe={k: init_sd[k] for k in
+                                   ("cls_token", "layers.0.mixer.in_proj.weight", "layers.3.mixer.dt_proj.bias", "pos_embed")},
+                                   state_dict={k: v.clone() for k, v in model.state_dict().items()},
+                                   x=x, logits=logits.detach(), g=g, grads=grads,
+                                   cfg=dict(patch_size=16, depth=4, embed_dim=32, num_classes=10))
+    save("vim.pt", cases)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel"]
+    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim"]
     for w in which:
         globals()["gen_" + w]()

@@ -160,3 +160,29 @@ def test_channel_model_oracle(case):
     logits.backward(c["g"].double())
     for k, gref in c["grads"].items():
         close(sd[k].grad, gref, 0, 5e-4 * max(1.0, gref.abs().max().item()))
+
+
+# ---- Vim baseline (un-pooled bidirectional mixer, middle class token): oracle vs the imported reference
+@pytest.mark.parametrize("case", ["mixer_d32_L9", "mixer_d32_L13", "mixer_d64_L20"])
+def test_vim_mixer_oracle(case):
+    from oracle import vim_mixer_oracle
+    c = load_golden("vim.pt")[case]
+    p = {k: v.clone().requires_grad_() for k, v in c["state_dict"].items()}
+    h = c["hidden"].clone().requires_grad_()
+    y = vim_mixer_oracle(p, h, compute_dtype=F64, out_dtype=F64)
+    close(y, c["out"], 0, 2e-5 * max(1.0, c["out"].abs().max().item()))
+    y.backward(c["g"].double())
+    close(h.grad, c["dhidden"], 0, 1e-4 * max(1.0, c["dhidden"].abs().max().item()))
+    for k, gref in c["grads"].items():
+        close(p[k].grad, gref, 0, 2e-4 * max(1.0, gref.abs().max().item()))
+
+
+def test_vim_model_oracle():
+    from oracle import vim_forward_oracle
+    c = load_golden("vim.pt")["tiny_64x64_cls"]
+    sd = {k: v.clone().requires_grad_() for k, v in c["state_dict"].items()}
+    logits = vim_forward_oracle(sd, c["x"], patch_size=16, depth=4, compute_dtype=F64)
+    close(logits, c["logits"], 0, 5e-5 * max(1.0, c["logits"].abs().max().item()))
+    logits.backward(c["g"].double())
+    for k, gref in c["grads"].items():
+        close(sd[k].grad, gref, 0, 5e-4 * max(1.0, gref.abs().max().item()))
