@@ -384,6 +384,61 @@ class VisionMamba(nn.Module):
         return x
 
 
+class MM_FastVim(VisionMamba):
+    """Multi-scale feature backbone for detection / segmentation heads (models/fastvim.py:560-691), without the
+    mmdet / mmseg registry decorators: ``forward(x)`` returns the LayerNorm-ed hidden states of ``out_indices`` as
+    (B, C, H, W) maps; ``load_pretrained`` reads a Lightning checkpoint (``state_dict_ema`` preferred, ``backbone.``
+    prefix stripped, square ``pos_embed`` bicubically resized to this model's grid)."""
+
+    def __init__(self, img_size=224, patch_size=16, stride=16, in_chans=3, embed_dim=192, depth=24, pretrained=None,
+                 out_indices=(5, 11, 17, 23), scanpath_type="rowwise", load_ema=True, **kwargs):
+        super().__init__(img_size, patch_size, stride, depth, embed_dim, in_chans, scanpath_type=scanpath_type, **kwargs)
+        self.load_ema = load_ema
+        self.scanpath_type = scanpath_type
+        self.out_indices = list(out_indices)
+        for i in range(len(self.out_indices)):
+            self.add_module(f"outnorm_{i}", nn.LayerNorm(self.embed_dim))
+        del self.head
+        del self.norm_f
+        self.load_pretrained(pretrained)
+
+    def load_pretrained(self, pretrained):
+        if pretrained is None:
+            return None
+        ckpt = torch.load(pretrained, map_location="cpu")
+        state_dict = ckpt["state_dict_ema"] if (self.load_ema and "state_dict_ema" in ckpt) else ckpt["state_dict"]
+        sd = {k.replace("backbone.", ""): v for k, v in state_dict.items()}
+        if "pos_embed" in sd:
+            pos_size = int(math.sqrt(sd["pos_embed"].shape[1]))
+            sd["pos_embed"] = self.resize_pos_embed(sd["pos_embed"], self.token_size, (pos_size, pos_size), "bicubic",
+                                                    self.scanpath_type)
+        if "patch_embed.proj.weight" in sd and \
+                self.patch_embed.patch_size[-1] != sd["patch_embed.proj.weight"].shape[-1]:
+            sd.pop("patch_embed.proj.weight")
+            sd.pop("patch_embed.proj.bias", None)
+        return self.load_state_dict(sd, strict=False)
+
+    @staticmethod
+    def resize_pos_embed(pos_embed, input_shape, pos_shape, mode, scanpath_type):
+        """(1, L, C) position table of a ``pos_shape`` grid -> ``input_shape`` grid (models/fastvim.py:645-680)."""
+        assert pos_embed.ndim == 3, "shape of pos_embed must be [B, L, C]"
+        pos_h, pos_w = pos_shape
+        w = pos_embed.reshape(1, pos_h, pos_w, pos_embed.shape[2]).permute(0, 3, 1, 2)
+        if scanpath_type == "colwise":
+            w = w.transpose(2, 3)
+        w = F.interpolate(w, size=tuple(input_shape), mode=mode, align_corners=False)
+        if scanpath_type == "colwise":
+            w = w.transpose(2, 3)
+        return torch.flatten(w, 2).transpose(1, 2)
+
+    def forward(self, x):
+        C = self.embed_dim
+        outs, (H, W) = self.forward_features(x, out_indices=self.out_indices)
+        outs = [getattr(self, f"outnorm_{i}")(o.float()) for i, o in enumerate(outs)]
+        outs = [o.view(-1, H, W, C).permute(0, 3, 1, 2).contiguous() for o in outs]
+        return outs[0] if len(self.out_indices) == 1 else outs
+
+
 def _factory(embed_dim, depth, img_size, patch_size, stride, kwargs):
     return VisionMamba(img_size=img_size, patch_size=patch_size, stride=stride, embed_dim=embed_dim, depth=depth,
                        rms_norm=True, residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean",

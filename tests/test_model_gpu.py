@@ -200,3 +200,23 @@ def test_flat_adamw_matches_torch_adamw():
         assert (e - ema_ref[n]).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item()), n
     from fastvim_amd.mixer_ops import defer_reductions
     defer_reductions(False)
+
+
+def test_mm_fastvim_multiscale_features():
+    """MM_FastVim.forward (models/fastvim.py:682-690): (B, C, H, W) maps of the LayerNorm-ed hidden states at
+    out_indices equal what the oracle's block stack produces."""
+    from fastvim_amd.fastvim import MM_FastVim
+    from oracle import fastvim_forward_oracle
+    torch.manual_seed(3)
+    m = MM_FastVim(img_size=(64, 96), depth=4, embed_dim=32, out_indices=[1, 3], fused_add_norm=True,
+                   residual_in_fp32=True, drop_path_rate=0.0).cuda().eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    sd.update({"head.weight": torch.zeros(1, 32), "head.bias": torch.zeros(1), "norm_f.weight": torch.ones(32)})
+    x = torch.randn(2, 3, 64, 96)
+    outs = m(x.cuda())
+    assert len(outs) == 2 and outs[0].shape == (2, 32, 4, 6)
+    _, hiddens = fastvim_forward_oracle(sd, x, patch_size=16, depth=4, compute_dtype=F64, return_hidden=True)
+    for k, idx in enumerate((1, 3)):
+        ref = torch.nn.functional.layer_norm(hiddens[idx].float(), (32,), sd[f"outnorm_{k}.weight"], sd[f"outnorm_{k}.bias"])
+        ref = ref.view(2, 4, 6, 32).permute(0, 3, 1, 2)
+        assert _err(outs[k], ref) <= 5e-5 * max(1.0, ref.abs().max().item())
