@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_kernel(ScanClParams p) {
 // Backward.  Segments of KS = 4 steps: the states entering every segment are checkpointed by a
 // forward sweep (in LDS when the pooled length is short, else in global scratch), then segments are
 // walked high-to-low: recompute the 4 states (registers), run the adjoint, reduce over channels.
-template <typename T, int RQ, int PV, bool CK_LDS>
+template <typename T, int RQ, int PV, bool CK_LDS, bool DTC>
 __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KS = 4;
@@ -144,18 +144,22 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
   const int nseg = (p.Lc + KS - 1) / KS;
   float* s_dbl = smem;                      // Lc * WP
   float* s_part = s_dbl + p.Lc * WP;        // KS * NWV * 4 * PV   [k][wave][q][value]
-  float* s_dt = s_part + KS * NWV * 4 * PV; // Lc * CPB: softplus(dt_proj) of every (row, channel), computed once
-  float* s_ck = s_dt + p.Lc * CPB;          // nseg * 256 * 4 (CK_LDS only)
+  // DTC (short pooled lengths): softplus(dt_proj) of every (row, channel) is computed once into LDS; for long
+  // sequences that table would cost occupancy (Lc * 256 B per block), so delta is recomputed where it is used
+  float* s_dt = s_part + KS * NWV * 4 * PV; // Lc * CPB (DTC only)
+  float* s_ck = s_dt + (DTC ? p.Lc * CPB : 0);   // nseg * 256 * 4 (CK_LDS only)
   Lane<T, RQ> ln;
   ln.init(p);
   stage_dbl<T>(p, ln.dir, ln.b, s_dbl, RP);
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int l = 0; l < p.Lc; ++l) {
-    const float dt = ln.delta(s_dbl + l * WP);
-    if (ln.q == 0) s_dt[l * CPB + (tid >> 2)] = dt;
+  if constexpr (DTC) {
+    for (int l = 0; l < p.Lc; ++l) {
+      const float dt = ln.delta(s_dbl + l * WP);
+      if (ln.q == 0) s_dt[l * CPB + (tid >> 2)] = dt;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int dd = ln.act ? ln.d : 0;
   const T* u = (const T*)p.xc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
   const float* gy = p.dyc + (size_t)ln.b * p.Lc * p.d_in + dd;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
         const int step = seg * KS + k;
         const int l = ln.dir ? p.Lc - 1 - step : step;
         const float* row = s_dbl + l * WP;
-        const float dt = s_dt[l * CPB + (tid >> 2)];
+        const float dt = DTC ? s_dt[l * CPB + (tid >> 2)] : ln.delta(row);
         const float du = dt * uv[k];
 #pragma unroll
         for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * ln.A2[j]), st[j], du * row[RP + ln.q * 4 + j]);
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
     for (int k = 0; k < KS; ++k) {
       const float* row = s_dbl + lk[k] * WP;
       const bool on = k < ns && ln.act;
-      dtv[k] = on ? s_dt[lk[k] * CPB + (tid >> 2)] : 0.f;      // delta = 0: a = 1, b = 0 -> the step is an identity
+      dtv[k] = on ? (DTC ? s_dt[lk[k] * CPB + (tid >> 2)] : ln.delta(row)) : 0.f;      // delta = 0: a = 1, b = 0 -> identity step
       if (!on) gq[k] = 0.f;
       const float du = dtv[k] * uv[k];
 #pragma unroll
@@ -372,24 +376,24 @@ extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float*
   const bool ckl = ck_in_lds(Lc);
   dim3 grid(fv_cdiv(d_inner, CPB), batch, 2), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define FV_B(TT, RQQ, PVV, CKK)                                                              \
+#define FV_B(TT, RQQ, PVV, CKK, DTT)                                                         \
   do {                                                                                       \
-    size_t smem = ((size_t)Lc * (4 * RQQ + 2 * N) + (size_t)4 * 4 * 4 * PVV + (size_t)Lc * CPB + \
+    size_t smem = ((size_t)Lc * (4 * RQQ + 2 * N) + (size_t)4 * 4 * 4 * PVV + (DTT ? (size_t)Lc * CPB : 0) + \
                    (CKK ? (size_t)((Lc + 3) / 4) * 1024 : 0)) * 4;                           \
     FV_CHECK(smem <= 160 * 1024, "mixer_scan_bwd: pooled length %d too long for the LDS stage", Lc); \
     if (smem > 64 * 1024) {                                                                  \
       static bool done = false;                                                              \
       if (!done) {                                                                           \
-        (void)hipFuncSetAttribute((const void*)scan_cl_bwd_kernel<TT, RQQ, PVV, CKK>,        \
+        (void)hipFuncSetAttribute((const void*)scan_cl_bwd_kernel<TT, RQQ, PVV, CKK, DTT>,   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
         done = true;                                                                         \
       }                                                                                      \
     }                                                                                        \
-    hipLaunchKernelGGL((scan_cl_bwd_kernel<TT, RQQ, PVV, CKK>), grid, block, smem, st, p);   \
+    hipLaunchKernelGGL((scan_cl_bwd_kernel<TT, RQQ, PVV, CKK, DTT>), grid, block, smem, st, p); \
   } while (0)
 #define FV_BK(TT, RQQ, PVV)                                                                  \
   do {                                                                                       \
-    if (ckl) FV_B(TT, RQQ, PVV, true); else FV_B(TT, RQQ, PVV, false);                       \
+    if (ckl) FV_B(TT, RQQ, PVV, true, true); else FV_B(TT, RQQ, PVV, false, false);          \
   } while (0)
 #define FV_BD(TT)                                                                            \
   do {                                                                                       \
