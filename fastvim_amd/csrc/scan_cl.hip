@@ -17,6 +17,8 @@
 // dB/dC/d dt_low need a sum over channels: a wave reduce-scatters its 16 channel lanes
 // (__shfl_xor butterfly on lane bits 2..5), waves are summed through LDS in fixed order, blocks
 // write per-chunk partials that fv_reduce_partials sums -- deterministic, no float atomics.
+#include <stdlib.h>
+
 #include "common.h"
 #include "lane_reduce.h"
 
@@ -36,8 +38,9 @@ struct ScanClParams {
   float* dxc;            // (2, B, Lc, d_in)   bwd out: gradient wrt u
   float* dxdbl;          // (nchunks, 2, B*Lc, R+2N) bwd out: per-chunk partial gradient wrt x_dbl
   float* ckpt;           // (2, B, nseg, d_in, N)
-  float* pP;             // (B, 2, d_in*(N+R+1)) per-batch partials, per direction [dA_log | d dt_w | d dt_bias]
+  float* pP;             // (B / NBB, 2, d_in*(N+R+1)) partials, per direction [dA_log | d dt_w | d dt_bias]
   int B, Lc, d_in, R;
+  int NBB;               // backward: batch elements one block walks (its parameter-gradient partial covers them all)
 };
 
 
@@ -150,9 +153,15 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
   float* s_ck = s_dt + (DTC ? p.Lc * CPB : 0);   // nseg * 256 * 4 (CK_LDS only)
   Lane<T, RQ> ln;
   ln.init(p);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float dA[4] = {0.f, 0.f, 0.f, 0.f}, dW[RQ], dbias = 0.f;     // parameter gradients: summed over this block's batch elements
+#pragma unroll
+  for (int i = 0; i < RQ; ++i) dW[i] = 0.f;
+  for (int bi = 0; bi < p.NBB; ++bi) {
+  ln.b = blockIdx.y * p.NBB + bi;
+  if (bi) __syncthreads();                  // the previous element's readers are done with the LDS stage
   stage_dbl<T>(p, ln.dir, ln.b, s_dbl, RP);
   __syncthreads();
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if constexpr (DTC) {
     for (int l = 0; l < p.Lc; ++l) {
       const float dt = ln.delta(s_dbl + l * WP);
@@ -195,9 +204,7 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
     }
   }
 
-  float dxa[4] = {0.f, 0.f, 0.f, 0.f}, dA[4] = {0.f, 0.f, 0.f, 0.f}, dW[RQ], dbias = 0.f;
-#pragma unroll
-  for (int i = 0; i < RQ; ++i) dW[i] = 0.f;
+  float dxa[4] = {0.f, 0.f, 0.f, 0.f};
 
   for (int seg = nseg - 1; seg >= 0; --seg) {
     const int s0 = seg * KS;
@@ -295,10 +302,11 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
     }
     __syncthreads();
   }
+  }   // batch elements of this block
   if (ln.act) {
-    // per-batch partial row, segment layout per direction: [dA_log (d_in*N) | d dt_w (d_in*R) | d dt_bias (d_in)]
+    // one partial row per block row (NBB batch elements), per direction: [dA_log (d_in*N) | d dt_w (d_in*R) | d dt_bias (d_in)]
     const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
-    float* base = p.pP + ((size_t)ln.b * 2 + ln.dir) * per_dir;
+    float* base = p.pP + ((size_t)blockIdx.y * 2 + ln.dir) * per_dir;
 #pragma unroll
     for (int j = 0; j < 4; ++j) base[(size_t)ln.d * N + ln.q * 4 + j] = dA[j] * ln.Araw[j];   // dA_log = dA * A
 #pragma unroll
@@ -349,6 +357,15 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
 
 extern "C" int fv_mixer_scan_bwd_chunks(int d_inner) { return fv_cdiv(d_inner, CPB); }
 
+// A block can walk several batch elements (fewer, longer blocks; parameter-gradient partials shrink by the same
+// factor).  Measured on FastVim-T: 2 per block 49.0 us vs 47-48 us, 4 per block 65 us -- so one, unless forced.
+static int scan_bwd_nbb(int batch, int Lc) {
+  static const int force = getenv("FASTVIM_SCAN_NBB") ? atoi(getenv("FASTVIM_SCAN_NBB")) : 0;   // tuning hook
+  (void)Lc;
+  return (force > 0 && batch % force == 0) ? force : 1;
+}
+extern "C" int fv_mixer_scan_bwd_partials(int batch, int Lc) { return batch / scan_bwd_nbb(batch, Lc); }
+
 static bool ck_in_lds(int Lc) { return ((Lc + 3) / 4) * 4096 + Lc * CPB * 4 <= 32 * 1024; }
 
 extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state) {
@@ -374,7 +391,8 @@ extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float*
   p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
   const int RQ = rq_of(dt_rank);
   const bool ckl = ck_in_lds(Lc);
-  dim3 grid(fv_cdiv(d_inner, CPB), batch, 2), block(256);
+  p.NBB = scan_bwd_nbb(batch, Lc);
+  dim3 grid(fv_cdiv(d_inner, CPB), batch / p.NBB, 2), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define FV_B(TT, RQQ, PVV, CKK, DTT)                                                         \
   do {                                                                                       \

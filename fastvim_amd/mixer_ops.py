@@ -182,7 +182,8 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     dx_dbl = torch.empty(nchunks, 2, B * Lc, W, **f32o)
     nck = lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N))
     ckpt = torch.empty(nck, **f32o) if nck else None
-    part = torch.empty(B, 2 * d_in * (N + R + 1), **f32o)
+    nprt = lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc))
+    part = torch.empty(nprt, 2 * d_in * (N + R + 1), **f32o)
     rc = lib.fv_mixer_scan_bwd(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
         L.ptr(A_log_b), L.ptr(dyc), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(part),
@@ -191,9 +192,9 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     if not keep_chunks:       # keep_chunks: the x_proj adjoint kernel sums the chunk partials itself
         dx_dbl = dx_dbl[0] if nchunks == 1 else reduce_partials(dx_dbl, nchunks)
     if grad_out is not None:
-        reduce_partials(part, B, out=grad_out, accumulate=True)
+        reduce_partials(part, nprt, out=grad_out, accumulate=True)
         return dxc, dx_dbl, None
-    return dxc, dx_dbl, reduce_partials(part, B).view(2, d_in * (N + R + 1))
+    return dxc, dx_dbl, reduce_partials(part, nprt).view(2, d_in * (N + R + 1))
 
 
 def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed,
