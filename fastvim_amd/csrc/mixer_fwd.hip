@@ -352,7 +352,7 @@ int launch_conv_pool(const FwdParams& p, int pool_max, hipStream_t st) {
     else hipLaunchKernelGGL((K<__VA_ARGS__, false>), grid, block, smem, st, p);              \
   } while (0)
   static const bool rowk = !(getenv("FASTVIM_FWD_ROWK") && atoi(getenv("FASTVIM_FWD_ROWK")) == 0);   // tuning hook
-  if (!tp && rowk && !pool_max) {     // short rows, mean pooling: the whole-row packed-math kernel (convpool_fwd_row.hip)
+  if (rowk && !pool_max) {     // short rows / 8-token cells, mean pooling: the packed-math kernels (convpool_fwd_row.hip): the whole-row packed-math kernel (convpool_fwd_row.hip)
     int rc = fvi::conv_pool_fwd_row(p, pool_max, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
     if (rc != FV_ERR_UNSUPPORTED) return rc;
   }
