@@ -22,6 +22,35 @@
 namespace {
 
 using fvi::BwdParams;
+
+// One partial row per block: [d w (d_in*4) | d w_b (d_in*4) | d b | d b_b | dD | dD_b]; the row groups of a block are
+// summed through LDS in a fixed order.
+__device__ __forceinline__ void flush_partials(const BwdParams& p, float* smem, int c0, int rg, int RG, const f2 (&a_wf)[CW],
+                                               const f2 (&a_wb)[CW], f2 a_bf, f2 a_bb, f2 a_Df, f2 a_Db) {
+  const int D = p.d_in;
+  for (int r = 0; r < RG; ++r) {
+    __syncthreads();
+    if (r == rg) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int c = c0 + v;
+#pragma unroll
+        for (int k = 0; k < CW; ++k) {
+          smem[c * 4 + k] = (r == 0 ? 0.f : smem[c * 4 + k]) + a_wf[k][v];
+          smem[4 * D + c * 4 + k] = (r == 0 ? 0.f : smem[4 * D + c * 4 + k]) + a_wb[k][v];
+        }
+        smem[8 * D + c] = (r == 0 ? 0.f : smem[8 * D + c]) + a_bf[v];
+        smem[9 * D + c] = (r == 0 ? 0.f : smem[9 * D + c]) + a_bb[v];
+        smem[10 * D + c] = (r == 0 ? 0.f : smem[10 * D + c]) + a_Df[v];
+        smem[11 * D + c] = (r == 0 ? 0.f : smem[11 * D + c]) + a_Db[v];
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = p.part + (size_t)blockIdx.x * 12 * D;
+  for (int e = threadIdx.x; e < 12 * D; e += blockDim.x) dst[e] = smem[e];
+}
+
 template <typename T, int NT>
 __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
@@ -127,29 +156,202 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
       }
     }
   }
-  // one partial row per block: [d w (d_in*4) | d w_b (d_in*4) | d b | d b_b | dD | dD_b]
-  const int D = p.d_in;
-  for (int r = 0; r < RG; ++r) {
-    __syncthreads();
-    if (r == rg) {
+  flush_partials(p, smem, c0, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
+}
+
+// Channel-wise tokenization (tokens_per_patch == TPP, Channel-First; mamba_simple_channel_faster.py:242-256, 333-340):
+// the adjoint walked cell by cell like conv_pool_fwd_chan_kernel.  Body j runs the TPP steps n = TPP*j - 3 + c, so the
+// pooling slots of both positions a step touches (n + 3 -> slot c; n -> slot c - 3 of this cell or TPP - 3 + c of the
+// previous one) are compile-time and the slot gradients stay in registers; one extra 3-step body closes the row.
+template <typename T, int TPP>
+__global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, int nch, int RG) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
+  typedef PairVec<T, 1> P;
+  static_assert(TPP >= 6, "slot bookkeeping assumes the three carried tokens and the three halo tokens do not overlap");
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rg = wv / nch, cw = wv - rg * nch;
+  const int c0 = (cw * 64 + lane) * 2;
+  const Geo g = p.geo;
+  const int pcols = g.pcols;
+  f2 wf[CW], wb[CW], bf, bb, Dfh, Dbh;
+  load_taps2(p.wf, c0, wf);
+  load_taps2(p.wb, c0, wb);
+  bf = load_f2(p.bf, c0);
+  bb = load_f2(p.bb, c0);
+  Dfh = load_f2(p.Df, c0) * 0.5f;
+  Dbh = load_f2(p.Db, c0) * 0.5f;
+  f2 a_wf[CW], a_wb[CW], a_bf = splat(0.f), a_bb = splat(0.f), a_Df = splat(0.f), a_Db = splat(0.f);
 #pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const int c = c0 + v;
+  for (int k = 0; k < CW; ++k) a_wf[k] = a_wb[k] = splat(0.f);
+  const int nrows = p.B * g.rows;
+  const size_t dstride = (size_t)p.B * g.rows * TPP * p.d_in;
+  const int nit = (nrows + gridDim.x * RG - 1) / (gridDim.x * RG);
+  const int tok_x = 2 * p.d_in * (int)sizeof(T), tok_d = p.d_in * (int)sizeof(T);
+  const int voff = c0 * (int)sizeof(T);
+  for (int it = 0; it < nit; ++it) {
+    const int row = (it * gridDim.x + blockIdx.x) * RG + rg;
+    if (row < nrows) {          // uniform per wave; no block-level sync inside
+      const int b = row / g.rows, i = row - b * g.rows;
+      const __amdgpu_buffer_rsrc_t bx = fv_make_buf((const T*)p.xz + (size_t)b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
+      const __amdgpu_buffer_rsrc_t bd = fv_make_buf((const T*)p.dob_in + (size_t)b * g.L * p.d_in, (size_t)g.L * tok_d);
+      const __amdgpu_buffer_rsrc_t bo = fv_make_buf((T*)p.dxz + (size_t)b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
+      const bool up = i > 0, down = i + 1 < g.rows;
+      const float m_up = up ? 1.f : 0.f, m_dn = down ? 1.f : 0.f;
+      // first memory token of cell jj; jj = -1 / pcols: the neighbouring rows' last / first cell (a missing neighbour
+      // reads this row's own cell -- always mapped -- and is masked)
+      auto cell = [&](int jj) {
+        int ri = i, cj = jj;
+        if (jj < 0) { ri = up ? i - 1 : i; cj = pcols - 1; }
+        else if (jj >= pcols) { ri = down ? i + 1 : i; cj = 0; }
+        return (ri * g.s_i + cj * g.s_j) * TPP;
+      };
+      // pooled gradients (x pool_scale): every slot of this row, slots 0..2 of row i+1 (forward conv halo) and slots
+      // TPP-3.. of row i-1 (backward conv halo)
+      f2 dcf[TPP], dcb[TPP], dcf_dn[3], dcb_up[3];
+      {
+        const float* dq = p.dxc + ((size_t)b * g.rows + i) * TPP * p.d_in + c0;
 #pragma unroll
-        for (int k = 0; k < CW; ++k) {
-          smem[c * 4 + k] = (r == 0 ? 0.f : smem[c * 4 + k]) + a_wf[k][v];
-          smem[4 * D + c * 4 + k] = (r == 0 ? 0.f : smem[4 * D + c * 4 + k]) + a_wb[k][v];
+        for (int c = 0; c < TPP; ++c) {
+          dcf[c] = *reinterpret_cast<const f2*>(dq + (size_t)c * p.d_in) * p.pool_scale;
+          dcb[c] = *reinterpret_cast<const f2*>(dq + dstride + (size_t)c * p.d_in) * p.pool_scale;
         }
-        smem[8 * D + c] = (r == 0 ? 0.f : smem[8 * D + c]) + a_bf[v];
-        smem[9 * D + c] = (r == 0 ? 0.f : smem[9 * D + c]) + a_bb[v];
-        smem[10 * D + c] = (r == 0 ? 0.f : smem[10 * D + c]) + a_Df[v];
-        smem[11 * D + c] = (r == 0 ? 0.f : smem[11 * D + c]) + a_Db[v];
+        const float* dn = dq + (down ? (size_t)TPP * p.d_in : 0);
+        const float* du = dq + dstride - (up ? (size_t)TPP * p.d_in : 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          dcf_dn[k] = *reinterpret_cast<const f2*>(dn + (size_t)k * p.d_in) * (p.pool_scale * m_dn);
+          dcb_up[k] = *reinterpret_cast<const f2*>(du + (size_t)(TPP - 3 + k) * p.d_in) * (p.pool_scale * m_up);
+        }
+      }
+      // body arrays: X / DO / PF index = position - (TPP*j - 3); PB index = position - (TPP*j - 6)
+      f2 X[TPP + 3], DO[TPP + 3], PF[TPP + 3], PB[TPP + 3];
+      P xr1[TPP], xr2[TPP], dr1[TPP], dr2[TPP];      // packed cells j+1, j+2
+      int m_prev = cell(-1), m_cur = cell(0);
+      {
+        P xa[3], da[3], xc[TPP], dc[TPP];
+        const int m1 = cell(1), m2 = cell(2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          xa[k].load(bx, voff, (m_prev + TPP - 3 + k) * tok_x);
+          da[k].load(bd, voff, (m_prev + TPP - 3 + k) * tok_d);
+        }
+#pragma unroll
+        for (int c = 0; c < TPP; ++c) {
+          xc[c].load(bx, voff, (m_cur + c) * tok_x);
+          dc[c].load(bd, voff, (m_cur + c) * tok_d);
+        }
+#pragma unroll
+        for (int c = 0; c < TPP; ++c) {
+          xr1[c].load(bx, voff, (m1 + c) * tok_x);
+          dr1[c].load(bd, voff, (m1 + c) * tok_d);
+        }
+#pragma unroll
+        for (int c = 0; c < TPP; ++c) {
+          xr2[c].load(bx, voff, (m2 + c) * tok_x);
+          dr2[c].load(bd, voff, (m2 + c) * tok_d);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          X[k] = xa[k].get(0) * m_up;
+          DO[k] = da[k].get(0);
+          PF[k] = PB[k] = splat(0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < TPP; ++c) {
+          X[3 + c] = xc[c].get(0);
+          DO[3 + c] = dc[c].get(0);
+        }
+      }
+      for (int j = 0; j <= pcols; ++j) {
+        const bool tail = j == pcols, first = j == 0;
+        const float e3 = tail ? m_dn : 1.f;
+#pragma unroll
+        for (int c = 0; c < TPP; ++c) {
+          if (c < 3 || !tail) {
+            // step n = TPP*j - 3 + c: pre_f of position n+3 and pre_b of position n, both from x[n .. n+3]
+            f2 pf = bf, pb = bb;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+              pf = fma2(wf[k], X[c + k], pf);
+              pb = fma2(wb[k], X[c + 3 - k], pb);
+            }
+            const f2 sgf = sigmoid2(pf), sgb = sigmoid2(pb);
+            const f2 dsf = sgf * fma2(pf, 1.f - sgf, splat(1.f)), dsb = sgb * fma2(pb, 1.f - sgb, splat(1.f));
+            const f2 cfs = c < 3 ? (tail ? dcf_dn[c < 3 ? c : 0] : dcf[c]) : dcf[c];
+            const f2 cbs = c < 3 ? (first ? dcb_up[c < 3 ? c : 0] : dcb[TPP - 3 + (c < 3 ? c : 0)]) : dcb[c < 3 ? 0 : c - 3];
+            const float e0 = (c < 3 && first) ? m_up : 1.f;
+            const f2 nf = fma2(Dfh, DO[c + 3], cfs) * dsf * e3;
+            const f2 nb = fma2(Dbh, DO[c], cbs) * dsb * e0;
+            PF[c + 3] = nf;
+            PB[c + 3] = nb;
+            if (!tail) {          // position n+3 belongs to this row
+#pragma unroll
+              for (int k = 0; k < CW; ++k) a_wf[k] = fma2(nf, X[c + k], a_wf[k]);
+              a_bf += nf;
+              a_Df = fma2(DO[c + 3] * 0.5f, pf * sgf, a_Df);
+            }
+            if (c >= 3 || !first) {   // position n belongs to this row
+#pragma unroll
+              for (int k = 0; k < CW; ++k) a_wb[k] = fma2(nb, X[c + 3 - k], a_wb[k]);
+              a_bb += nb;
+              a_Db = fma2(DO[c] * 0.5f, pb * sgb, a_Db);
+              // dx[n] = sum_k wf[k] dpre_f[n+3-k] + wb[k] dpre_b[n-3+k]
+              f2 dx = splat(0.f);
+#pragma unroll
+              for (int k = 0; k < CW; ++k) {
+                dx = fma2(wf[k], PF[c + 3 - k], dx);
+                dx = fma2(wb[k], PB[c + k], dx);
+              }
+              const int m = c < 3 ? m_prev + TPP - 3 + c : m_cur + c - 3;
+              { const f2 dxa[1] = {dx}; P::store(bo, voff, m * tok_x, dxa); }
+            }
+          }
+        }
+        if (!tail) {
+          // carry the last three positions, make cell j+1 current, fetch cell j+3
+          const float m_nx = j + 1 < pcols ? 1.f : m_dn;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            X[k] = X[TPP + k];
+            DO[k] = DO[TPP + k];
+            PF[k] = PF[TPP + k];
+            PB[k] = PB[TPP + k];
+          }
+#pragma unroll
+          for (int c = 0; c < TPP; ++c) {
+            X[3 + c] = xr1[c].get(0) * m_nx;
+            DO[3 + c] = dr1[c].get(0);
+            xr1[c] = xr2[c];
+            dr1[c] = dr2[c];
+          }
+          m_prev = m_cur;
+          m_cur = cell(j + 1);
+          const int m3 = cell(j + 3 > pcols ? pcols : j + 3);
+#pragma unroll
+          for (int c = 0; c < TPP; ++c) {
+            xr2[c].load(bx, voff, (m3 + c) * tok_x);
+            dr2[c].load(bd, voff, (m3 + c) * tok_d);
+          }
+        }
       }
     }
   }
-  __syncthreads();
-  float* dst = p.part + (size_t)blockIdx.x * 12 * D;
-  for (int e = threadIdx.x; e < 12 * D; e += blockDim.x) dst[e] = smem[e];
+  flush_partials(p, smem, c0, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
+}
+
+template <typename T, int TPP>
+int launch_chan(const BwdParams& p, int nch, int rgr, int grid, size_t smem, hipStream_t st) {
+  if (smem > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_chan_kernel<T, TPP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL((conv_pool_bwd_chan_kernel<T, TPP>), dim3(grid), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
 }
 
 template <typename T, int NT>
@@ -170,9 +372,16 @@ int launch_row(const BwdParams& p, int nch, int rgr, int grid, size_t smem, hipS
 
 int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t smem, int dtype, hipStream_t st) {
   // nch counts 128-channel waves (a lane owns a channel pair)
-  if (p.geo.tpp != 1 || p.d_in != nch * 128 || nch > 8 || (p.geo.cols != 14 && p.geo.cols != 16))
-    return FV_ERR_UNSUPPORTED;
+  if (p.d_in != nch * 128 || nch > 8) return FV_ERR_UNSUPPORTED;
   if ((size_t)p.geo.L * 2 * p.d_in * 4 > 0xfffff000ull) return FV_ERR_UNSUPPORTED;   // one batch element per descriptor
+  if (p.geo.tpp == 8 && p.geo.pcols >= 2) {
+    static const bool chan = !(getenv("FASTVIM_BWD_CHAN") && atoi(getenv("FASTVIM_BWD_CHAN")) == 0);   // tuning hook
+    if (!chan) return FV_ERR_UNSUPPORTED;
+    const int capc = 8 / nch < 1 ? 1 : 8 / nch;
+    const int rgc = rg < capc ? rg : capc;
+    return dtype == FV_F32 ? launch_chan<float, 8>(p, nch, rgc, grid, smem, st) : launch_chan<bf16_t, 8>(p, nch, rgc, grid, smem, st);
+  }
+  if (p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16)) return FV_ERR_UNSUPPORTED;
   // a whole row lives in registers: blocks of <= 512 threads (256 VGPRs per wave), i.e. fewer row groups per
   // block than the generic kernel, over the same persistent grid
   const int cap = 8 / nch < 1 ? 1 : 8 / nch;

@@ -544,6 +544,10 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
 template <typename T>
 int dispatch_bwd(int which, const BwdParams& p, hipStream_t st) {
   if (which == 0) {
+    {
+      int rc = fvi::combine_bwd_wave(p, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
+      if (rc != FV_ERR_UNSUPPORTED) return rc;
+    }
     const int v = vec_combine(p.d_in, p.geo.tpp);
     if (v == 6) return launch_combine_bwd<T, 6>(p, st);
     if (v == 4) return launch_combine_bwd<T, 4>(p, st);
@@ -566,6 +570,10 @@ int check_geo_b(int B, int rows, int cols, int s_i, int s_j, int d_in, int dtype
 
 extern "C" int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int tokens_per_patch, int which) {
   const long n = (long)batch * rows;
+  if (which == 0) {
+    const int wb = fvi::combine_wave_blocks(batch, rows, tokens_per_patch, d_inner);
+    if (wb) return wb;
+  }
   return which == 0 ? persistent_blocks(n, rg_combine(d_inner, vec_combine(d_inner, tokens_per_patch)))
                     : persistent_blocks(n, rg_convpool(d_inner, vec_convpool(d_inner)));
 }

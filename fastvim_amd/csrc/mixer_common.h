@@ -41,6 +41,12 @@ constexpr int RGMAX = 4;   // a block walks up to RGMAX pooling rows concurrentl
 // returns FV_ERR_UNSUPPORTED when the shape is not one it is built for (the caller then runs the generic one).
 int conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t smem, int dtype, hipStream_t st);
 
+// Wave-per-token combine kernels (combine_wave.hip); FV_ERR_UNSUPPORTED -> caller runs the generic kernel.
+// combine_wave_blocks: grid (= rows of dLN partials) of the backward, 0 when the wave kernels do not apply.
+int combine_wave_blocks(int B, int rows, int tpp, int d_in);
+int combine_fwd_wave(const FwdParams& p, int dtype, hipStream_t st);
+int combine_bwd_wave(const BwdParams& p, int dtype, hipStream_t st);
+
 }  // namespace fvi
 
 namespace {

@@ -388,6 +388,10 @@ int launch_combine(const FwdParams& p, hipStream_t st) {
 template <typename T>
 int dispatch_fwd(int which, const FwdParams& p, int pool_max, hipStream_t st) {
   if (which == 1) {
+    {
+      int rc = fvi::combine_fwd_wave(p, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
+      if (rc != FV_ERR_UNSUPPORTED) return rc;
+    }
     const int v = vec_combine_f(p.d_in);
     if (v == 6) return launch_combine<T, 6>(p, st);
     if (v == 4) return launch_combine<T, 4>(p, st);
