@@ -54,15 +54,15 @@ __device__ __forceinline__ int ks_swz(int k) {
 }
 
 // ---- staging: 256 threads move a (ROWS x 64) KC tile or a (64 x COLS) KS tile, 16 B per access ----
-template <int MODE, int EXT>   // EXT = tile extent along the non-K dim (128 or 256 or 64)
+template <int MODE, int EXT, int NT = 256>   // EXT = tile extent along the non-K dim (64 .. 256), NT = threads per block
 struct Stage {
-  static constexpr int NV = EXT * BK / 8 / 256;   // 16-byte vectors per thread
+  static constexpr int NV = EXT * BK / 8 / NT;   // 16-byte vectors per thread
   u32x4 v[NV];
   // global -> registers.  r0 = first row/col of the tile in the non-K dim, k0 = first k.
   __device__ __forceinline__ void load(const bf16_t* base, long ld, int r0, int k0, int rmax, int kmax, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NT;
       int r, k;
       if (MODE == KC) { r = e >> 3; k = (e & 7) * 8; }                 // 8 vectors per 64-k row
       else { k = e / (EXT / 8); r = (e % (EXT / 8)) * 8; }             // EXT/8 vectors per k row
@@ -79,7 +79,7 @@ struct Stage {
   __device__ __forceinline__ void store(char* lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NT;
       int off;
       if (MODE == KC) {
         const int r = e >> 3, c = e & 7;
@@ -98,16 +98,16 @@ struct Stage {
 // layouts above are applied to the SOURCE address instead: lane -> physical 16-byte slot -> the logical vector
 // that slot must hold.  Rows / columns past the operand edge are clamped onto valid memory (they only feed
 // output rows / columns that the epilogue never stores); the K range must be whole 64-deep tiles.
-template <int MODE, int EXT>
+template <int MODE, int EXT, int NT = 256>
 struct GldsPlan {
-  static constexpr int NV = EXT * BK / 8 / 256;   // 16-byte vectors per thread == 1-KiB pieces per wave
+  static constexpr int NV = EXT * BK / 8 / NT;   // 16-byte vectors per thread == 1-KiB pieces per wave
   const bf16_t* src[NV];                          // source of vector i at k = 0 of the operand
   long kstep;                                     // elements per unit of k
   __device__ __forceinline__ void init(const bf16_t* base, long ld, int r0, int rmax, int tid) {
     kstep = MODE == KC ? 1 : ld;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = tid + i * 256;                // physical slot: LDS byte offset e * 16
+      const int e = tid + i * NT;                 // physical slot: LDS byte offset e * 16
       if (MODE == KC) {
         const int r = e >> 3, c = (e & 7) ^ (r & 7);
         const int gr = min(r0 + r, rmax - 1);
@@ -126,7 +126,7 @@ struct GldsPlan {
     for (int i = 0; i < NV; ++i) {
       typedef __attribute__((address_space(1))) const void* gptr;
       typedef __attribute__((address_space(3))) void* lptr;
-      __builtin_amdgcn_global_load_lds((gptr)(src[i] + (long)k0 * kstep), (lptr)(lds + (i * 256 + wv * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(src[i] + (long)k0 * kstep), (lptr)(lds + (i * NT + wv * 64) * 16), 16, 0, 0);
     }
   }
 };
@@ -152,11 +152,15 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lan
   }
 }
 
-// WM x WN waves, each 64 rows x 16*NB columns (NB = 4 or 6): tile BM = 64*WM rows (m), BN = 16*NB*WN cols (n).
+// WM x WN waves, each 16*MB rows x 16*NB columns: tile BM = 16*MB*WM rows (m), BN = 16*NB*WN cols (n).
 // NB = 6 gives 128x192 tiles: an N = 192 output is one tile wide, so the A panel is read once instead of 3 times.
-template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
-  constexpr int BM = 64 * WM, BN = 16 * NB * WN, WNC = 16 * NB;
+// MB = 8 (128-row wave tiles, 256-row block tiles) is for the compute-bound FastVim-S/B widths: a k-step of a
+// 64x64 wave tile reads 8 KiB of fragments for 16 MFMAs -- at the full MFMA rate that is exactly the 128 B/clk the
+// LDS delivers -- while a 128x64 wave tile reads 12 KiB for 32.
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN, WNC = 16 * NB, WMR = 16 * MB;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto sA = [&](int i) { return smem + i * (A_BYTES + B_BYTES); };             // [A0 | B0 | A1 | B1]
@@ -177,24 +181,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
-  f32x4 acc[NB][4];   // [n tile][m tile]: rows = n (MFMA A slot = B operand), cols = m
+  f32x4 acc[NB][MB];   // [n tile][m tile]: rows = n (MFMA A slot = B operand), cols = m
 #pragma unroll
   for (int a = 0; a < NB; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int cur) {
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 fa[4], fb[NB];
+      bf16x8 fa[MB], fb[NB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag<AMODE, BM>(sA(cur), wm * 4 + i, ks, lane);
+      for (int i = 0; i < MB; ++i) fa[i] = frag<AMODE, BM>(sA(cur), wm * MB + i, ks, lane);
 #pragma unroll
       for (int i = 0; i < NB; ++i) fb[i] = frag<BMODE, BN>(sB(cur), wn * NB + i, ks, lane);
 #pragma unroll
       for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < MB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[a], fa[b], acc[a][b], 0, 0, 0);
     }
   };
@@ -202,8 +206,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     // LDS-DMA: the next tile streams into the other buffer while this one is multiplied; __syncthreads() is
     // exactly the wait it needs (vmcnt(0): my pieces have landed; barrier: everyone's have, and everyone is
     // done reading the buffer that is overwritten next).
-    GldsPlan<AMODE, BM> ga;
-    GldsPlan<BMODE, BN> gb;
+    GldsPlan<AMODE, BM, NT> ga;
+    GldsPlan<BMODE, BN, NT> gb;
     ga.init(p.A, p.lda, m0, p.M, tid);
     gb.init(p.B, p.ldb, n0, p.N, tid);
     ga.issue(sA(0), kbeg, tid);
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       __syncthreads();
     }
   } else {
-  Stage<AMODE, BM> ra;
-  Stage<BMODE, BN> rb;
+  Stage<AMODE, BM, NT> ra;
+  Stage<BMODE, BN, NT> rb;
   ra.load(p.A, p.lda, m0, kbeg, p.M, kend, tid);
   rb.load(p.B, p.ldb, n0, kbeg, p.N, kend, tid);
   ra.store(sA(0), tid);
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     __syncthreads();
   }
   }
-  // epilogue: acc[a][b][j] = C[m = m0 + wm*64 + b*16 + (lane&15)][n = n0 + wn*WNC + a*16 + (lane>>4)*4 + j]
+  // epilogue: acc[a][b][j] = C[m = m0 + wm*WMR + b*16 + (lane&15)][n = n0 + wn*WNC + a*16 + (lane>>4)*4 + j]
   const long zoff = (long)blockIdx.z * p.c_split_stride;
   if (p.bias) {
 #pragma unroll
@@ -250,19 +254,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       for (int j = 0; j < 4; ++j) {
         const float bj = (n + j < p.N) ? p.bias[n + j] : 0.f;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b][j] += bj;
+        for (int b = 0; b < MB; ++b) acc[a][b][j] += bj;
       }
     }
   }
   if (!p.c_fp32) {
-    // bf16 C: the wave's 64 x WNC tile goes through LDS (two 32-row halves, rows padded by 16 B) so that
+    // bf16 C: the wave's WMR x WNC tile goes through LDS (32-row slabs, rows padded by 16 B) so that
     // every global store is 16 B per lane and a wave instruction writes whole 128-byte row segments
     constexpr int RS = WNC * 2 + 16, CH = WNC / 8;
     __syncthreads();                                  // all waves are done reading the operand tiles
     char* my = smem + wv * (32 * RS);
     bf16_t* Cb = (bf16_t*)p.C + zoff;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < MB / 2; ++h) {
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
         const int b = 2 * h + bb;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = i * 64 + lane, r = idx / CH, ch = idx - r * CH;
-        const int m = m0 + wm * 64 + h * 32 + r, n = n0 + wn * WNC + ch * 8;
+        const int m = m0 + wm * WMR + h * 32 + r, n = n0 + wn * WNC + ch * 8;
         if (m < p.M && n < p.N) {
           const u32x4 q = *reinterpret_cast<const u32x4*>(my + r * RS + ch * 16);
           bf16_t* dst = Cb + (long)m * p.ldc + n;
@@ -294,8 +298,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     return;
   }
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int m = m0 + wm * 64 + b * 16 + (lane & 15);
+  for (int b = 0; b < MB; ++b) {
+    const int m = m0 + wm * WMR + b * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
@@ -310,18 +314,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4>
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
 int launch_k(const GemmParams& p, int splits, hipStream_t st) {
-  constexpr int BM = 64 * WM, BN = 16 * NB * WN;
+  constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
   const int tiles = fv_cdiv(p.M, BM) * fv_cdiv(p.N, BN);
   const size_t smem = (size_t)2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS, NB>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS, NB, MB>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS, NB>), dim3(tiles, 1, splits), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS, NB, MB>), dim3(tiles, 1, splits), dim3(64 * WM * WN), smem, st, p);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
@@ -342,6 +346,23 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   // N a multiple of 192 (FastVim-T/S/B: d, 2*d_in): 128x192 tiles, the A panel is read N/192 times instead of
   // N/128.  Measured on MI355X: N = 384 -9 %, FastVim-S/B steps -3 %; N = 192 neutral (K-contiguous B) or +12 %
   // (K-slow B, 4-way swizzle), N = 768 with K = 192 +3 % -- those keep the 128-wide tiles.
+  static const int tall = getenv("FASTVIM_GEMM_TALL") ? atoi(getenv("FASTVIM_GEMM_TALL")) : 0;   // tuning hook: 1 = 256x128, 2 = 256x192, 3 = 256x256 tiles
+  const bool whole_k = p.K % BK == 0 && p.k_per_split % BK == 0;
+  if (tall && p.M >= 256 && p.N >= 128 && (AMODE != KC || whole_k)) {
+    constexpr bool G = AMODE == KC;
+    if (tall == 1) return launch_k<AMODE, BMODE, 2, 2, G, 4, 8>(p, splits, st);
+    if (tall == 2 && p.N % 192 == 0) return launch_k<AMODE, BMODE, 2, 2, G, 6, 8>(p, splits, st);
+    if (tall == 3) return launch_k<AMODE, BMODE, 2, 2, G, 8, 8>(p, splits, st);
+    if (tall == 4) return launch_k<AMODE, BMODE, 4, 2, G, 8, 4>(p, splits, st);     // 8 waves of 64x128: 256x256
+    if (tall == 5) return launch_k<AMODE, BMODE, 2, 4, G, 4, 8>(p, splits, st);     // 8 waves of 128x64: 256x256
+    if (tall == 6) return launch_k<AMODE, BMODE, 4, 2, G, 4, 4>(p, splits, st);     // 8 waves of 64x64: 256x128
+    if (tall == 7 && p.N % 192 == 0) return launch_k<AMODE, BMODE, 4, 2, G, 6, 4>(p, splits, st);   // 8 waves of 64x96: 256x192
+  }
+  // FastVim-B in_proj forward (N = 3072, K = 768): eight waves of 128x64 on a 256x256 tile, -10 % (161 -> 144 us);
+  // measured slower at every FastVim-T/S shape and for the data-gradient forms, which keep the 4-wave tiles
+  static const bool big = !(getenv("FASTVIM_GEMM_BIG") && atoi(getenv("FASTVIM_GEMM_BIG")) == 0);   // tuning hook
+  if (big && !tall && AMODE == KC && BMODE == KC && p.N % 256 == 0 && p.N >= 2048 && p.K >= 512 && p.M >= 4096 && whole_k)
+    return launch_k<AMODE, BMODE, 2, 4, true, 4, 8>(p, splits, st);
   static const bool wide = !(getenv("FASTVIM_GEMM_N192") && atoi(getenv("FASTVIM_GEMM_N192")) == 0);   // tuning hook
   if (wide && AMODE == KC && p.N % 192 == 0 && p.N >= 384 && !(p.N == 768 && p.K <= 192) && p.K % BK == 0 &&
       p.k_per_split % BK == 0)

@@ -32,16 +32,24 @@ def gemm_nn(a, b, out_dtype=torch.bfloat16):
     return c
 
 
-def auto_splits(Kd, M, N, target_wgs=768, cap=28):
-    """Split-K factor of a weight gradient: enough (tile, K slice) workgroups to fill the 256 CUs about three
-    times, no more (every slice writes and re-reads an (M, N) fp32 partial), each slice whole 64-deep K tiles."""
+def auto_splits(Kd, M, N, resident=512, cap=28):
+    """Split-K factor of a weight gradient.  The (tile, K slice) workgroups should fill WHOLE rounds of the
+    512 workgroups the chip holds at once (2 x 256 CUs): measured at FastVim-B, in_proj 4 slices (576 workgroups,
+    1.1 rounds) 248 us vs 7 slices (1008, 2.0 rounds) 210 us; out_proj 8 slices 132 us vs 7 slices 95 us.  Among
+    the factors that divide the K tiles, take the best round efficiency, then the fewest slices (every slice
+    writes and re-reads an (M, N) fp32 partial); each slice is whole 64-deep K tiles."""
+    if Kd % 64:
+        return 1
     tiles = -(-M // 128) * -(-N // 128)
-    want = max(1, min(cap, target_wgs // tiles))
     kt = Kd // 64
-    best = 1
-    for s in range(1, want + 1):
-        if Kd % 64 == 0 and kt % s == 0:
-            best = s
+    best, best_eff = 1, 0.0
+    for s in range(1, min(cap, kt) + 1):
+        if kt % s:
+            continue
+        w = tiles * s
+        eff = w / (-(-w // resident) * resident)
+        if eff > best_eff + 0.02:
+            best, best_eff = s, eff
     return best
 
 
