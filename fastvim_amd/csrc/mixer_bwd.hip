@@ -437,21 +437,29 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
 
 // out[i] = sum_s in[s*n + i] in a fixed order.  Block = 32 outputs x 8 row-slices: slice q sums rows
 // q, q+8, ... (independent 128-B coalesced loads), then the 8 slice sums are added in order.
+// Sum of rows q, q+8, q+16, ... of column i.  Eight independent loads are in flight per thread: the reduction is
+// bound by memory-level parallelism (a block column is only 128 B wide), not by bandwidth per request.
+__device__ __forceinline__ float column_sum(const float* __restrict__ in, int S, size_t n, size_t i, int q) {
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  int s = q;
+  for (; s + 56 < S; s += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += in[(size_t)(s + 8 * u) * n + i];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (s + 8 * u < S) a[u] += in[(size_t)(s + 8 * u) * n + i];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               int S, size_t n, int accumulate) {
   __shared__ float s_acc[8][33];
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
   const size_t i = (size_t)blockIdx.x * 32 + c;
-  float a0 = 0.f, a1 = 0.f;
-  if (i < n) {
-    int s = q;
-    for (; s + 8 < S; s += 16) {
-      a0 += in[(size_t)s * n + i];
-      a1 += in[(size_t)(s + 8) * n + i];
-    }
-    if (s < S) a0 += in[(size_t)s * n + i];
-  }
-  s_acc[q][c] = a0 + a1;
+  s_acc[q][c] = i < n ? column_sum(in, S, n, i, q) : 0.f;
   __syncthreads();
   if (q == 0 && i < n) {
     float t = 0.f;
@@ -646,16 +654,7 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J
   const size_t n = (size_t)J.n[job];
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
   const size_t i = (size_t)blk * 32 + c;
-  float a0 = 0.f, a1 = 0.f;
-  if (i < n) {
-    int s = q;
-    for (; s + 8 < S; s += 16) {
-      a0 += in[(size_t)s * n + i];
-      a1 += in[(size_t)(s + 8) * n + i];
-    }
-    if (s < S) a0 += in[(size_t)s * n + i];
-  }
-  s_acc[q][c] = a0 + a1;
+  s_acc[q][c] = i < n ? column_sum(in, S, n, i, q) : 0.f;
   __syncthreads();
   if (q == 0 && i < n) {
     float t = 0.f;
