@@ -277,7 +277,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
           *reinterpret_cast<uint2*>(my + (bb * 16 + (lane & 15)) * RS + (a * 16 + (lane >> 4) * 4) * 2) = pk;
         }
       }
-      __syncthreads();
+      // the slab is private to the wave and LDS operations of one wave execute in order: no block barrier
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = i * 64 + lane, r = idx / CH, ch = idx - r * CH;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
           }
         }
       }
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
     }
     return;
   }
