@@ -434,7 +434,8 @@ int dt_ok(int dt) { return dt == FV_F32 || dt == FV_BF16; }
 }  // namespace
 
 extern "C" int fv_add_norm_blocks(int M) {
-  long waves = M < 4096 ? M : 4096;   // persistent: at most 1024 blocks of 4 waves
+  static const int cap = getenv("FASTVIM_NORM_WAVES") ? atoi(getenv("FASTVIM_NORM_WAVES")) : 4096;   // tuning hook
+  long waves = M < cap ? M : cap;   // persistent: at most 1024 blocks of 4 waves
   return (int)((waves + 3) / 4);
 }
 

@@ -34,7 +34,8 @@ struct ScanClParams {
   const float* dtb[2];   // (d_in)
   const float* Alog[2];  // (d_in, N)
   float* yc;             // (2, B, Lc, d_in)   fwd out
-  const float* dyc;      // (B, Lc, d_in)      bwd in (same for both directions)
+  const float* dyc;      // (B, Lc, d_in)      bwd in (same for both directions) or (2, B, Lc, d_in)
+  size_t dyc_dir;        // elements between the two directions' dyc (0: shared)
   float* dxc;            // (2, B, Lc, d_in)   bwd out: gradient wrt u
   float* dxdbl;          // (nchunks, 2, B*Lc, R+2N) bwd out: per-chunk partial gradient wrt x_dbl
   float* ckpt;           // (2, B, nseg, d_in, N)
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
   }
   const int dd = ln.act ? ln.d : 0;
   const T* u = (const T*)p.xc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
-  const float* gy = p.dyc + (size_t)ln.b * p.Lc * p.d_in + dd;
+  const float* gy = p.dyc + (size_t)ln.dir * p.dyc_dir + (size_t)ln.b * p.Lc * p.d_in + dd;
   float* ckg = p.ckpt + (((size_t)ln.dir * p.B + ln.b) * nseg * p.d_in + dd) * N + ln.q * 4;
   const size_t ck_seg = (size_t)p.d_in * N;
 
@@ -378,6 +379,15 @@ extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float*
                                  const float* A_log_b, const float* dyc, float* dxc, float* dx_dbl, float* ckpt,
                                  float* partials, int batch, int Lc, int d_inner, int dt_rank, int d_state,
                                  int dtype, fv_stream_t stream) {
+  return fv_mixer_scan_bwd_dir(xc, x_dbl, dt_w, dt_bias, A_log, dt_w_b, dt_bias_b, A_log_b, dyc, 0, dxc, dx_dbl, ckpt,
+                               partials, batch, Lc, d_inner, dt_rank, d_state, dtype, stream);
+}
+
+extern "C" int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                     const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                     const float* A_log_b, const float* dyc, int dyc_per_direction, float* dxc,
+                                     float* dx_dbl, float* ckpt, float* partials, int batch, int Lc, int d_inner,
+                                     int dt_rank, int d_state, int dtype, fv_stream_t stream) {
   FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_bwd: empty dimension");
   FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_bwd: dtype must be fp32 or bf16");
   FV_CHECK(d_state == N, "mixer_scan_bwd: only d_state == 16 is built (got %d)", d_state);
@@ -386,6 +396,7 @@ extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float*
                partials && (ckpt || ck_in_lds(Lc)), "mixer_scan_bwd: null pointer");
   ScanClParams p{};
   p.xc = xc; p.xdbl = x_dbl; p.dyc = dyc; p.dxc = dxc; p.dxdbl = dx_dbl; p.ckpt = ckpt; p.pP = partials;
+  p.dyc_dir = dyc_per_direction ? (size_t)batch * Lc * d_inner : 0;
   p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
   p.Alog[0] = A_log; p.Alog[1] = A_log_b;
   p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;

@@ -167,11 +167,14 @@ def combine_bwd(dg, xz, skip, yc, ln_w, ln_b, mean, rstd, dxz, rows, cols, trans
     return d_o, dyc, reduce_partials(part, nb)      # (2, d_in): [dln_w, dln_b]
 
 
-def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_out=None, keep_chunks=False):
+def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_out=None, keep_chunks=False,
+             dyc_per_direction=False):
     """Returns (dxc, dx_dbl, pr) with pr (2, d_in*(N+R+1)) = per direction [dA_log | d dt_w | d dt_bias];
     when ``grad_out`` (flat fp32 view of exactly that layout) is given, the sums are accumulated into
-    it instead and pr is None."""
+    it instead and pr is None.  ``dyc_per_direction``: dyc is (2, B, Lc, d_in) instead of one (B, Lc, d_in)
+    shared by both directions (the MAE masked mixer)."""
     _, B, Lc, d_in = xc.shape
+    assert dyc.numel() == (2 if dyc_per_direction else 1) * B * Lc * d_in and dyc.dtype == torch.float32
     R, N = dt_w.shape[1], A_log.shape[1]
     W = R + 2 * N
     dev = xc.device
@@ -184,9 +187,9 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     ckpt = torch.empty(nck, **f32o) if nck else None
     nprt = lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc))
     part = torch.empty(nprt, 2 * d_in * (N + R + 1), **f32o)
-    rc = lib.fv_mixer_scan_bwd(
+    rc = lib.fv_mixer_scan_bwd_dir(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
-        L.ptr(A_log_b), L.ptr(dyc), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(part),
+        L.ptr(A_log_b), L.ptr(dyc), L.i32(int(dyc_per_direction)), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(part),
         L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
     L.check(rc, "mixer_scan_bwd")
     if not keep_chunks:       # keep_chunks: the x_proj adjoint kernel sums the chunk partials itself
@@ -237,3 +240,30 @@ def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None):
         reduce_partials(part, ns, out=grad_out.view(-1), accumulate=True)
         return None
     return reduce_partials(part, ns)
+
+
+def rows_segment_sum(x, idx, rows, scale=1.0, out_dtype=None):
+    """out (2, B, rows, d) = scale * sum of the tokens of each pooling row, per direction.  x: (2, B, Lk, d) or
+    (B, Lk, d) shared by both directions; idx (2, B, Lk) int32 = pooling row of token t per direction."""
+    per_dir = x.dim() == 4
+    B, Lk, d = x.shape[-3:]
+    assert idx.shape == (2, B, Lk) and idx.dtype == torch.int32 and idx.is_contiguous() and x.is_contiguous()
+    out = torch.empty(2, B, rows, d, device=x.device, dtype=out_dtype or x.dtype)
+    rc = L.lib().fv_rows_segment_sum(L.ptr(x), L.i32(L.dtype_code(x.dtype)), L.i32(int(per_dir)), L.ptr(idx), L.ptr(out),
+                                     L.i32(L.dtype_code(out.dtype)), L.i32(B), L.i32(Lk), L.i32(rows), L.i32(d),
+                                     f32(scale), L.stream_of(x))
+    L.check(rc, "rows_segment_sum")
+    return out
+
+
+def rows_gather(x, idx, scale=1.0, out_dtype=None):
+    """out (2, B, Lk, d)[dir, b, t] = scale * x[dir, b, idx[dir, b, t]].  x: (2, B, rows, d)."""
+    _, B, rows, d = x.shape
+    Lk = idx.shape[-1]
+    assert idx.shape == (2, B, Lk) and idx.dtype == torch.int32 and idx.is_contiguous() and x.is_contiguous()
+    out = torch.empty(2, B, Lk, d, device=x.device, dtype=out_dtype or x.dtype)
+    rc = L.lib().fv_rows_gather(L.ptr(x), L.i32(L.dtype_code(x.dtype)), L.ptr(idx), L.ptr(out),
+                                L.i32(L.dtype_code(out.dtype)), L.i32(B), L.i32(Lk), L.i32(rows), L.i32(d), f32(scale),
+                                L.stream_of(x))
+    L.check(rc, "rows_gather")
+    return out

@@ -176,6 +176,31 @@ int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, cons
                       const float* A_log, const float* dt_w_b, const float* dt_bias_b, const float* A_log_b,
                       const float* dyc, float* dxc, float* dx_dbl, float* ckpt, float* partials, int batch,
                       int Lc, int d_inner, int dt_rank, int d_state, int dtype, fv_stream_t stream);
+/* Same with one output gradient per direction: dyc_per_direction != 0 -> dyc is (2, batch, Lc, d_inner).  The MAE
+ * masked mixer needs it: its two branches gather different rows per token
+ * (mamba_simple_masked_faster.py:281-283, 311-314), so their pooled gradients differ. */
+int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                          const float* A_log, const float* dt_w_b, const float* dt_bias_b, const float* A_log_b,
+                          const float* dyc, int dyc_per_direction, float* dxc, float* dx_dbl, float* ckpt,
+                          float* partials, int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
+                          fv_stream_t stream);
+
+/* ---- MAE masked mixer: kept tokens <-> pooling rows --------------------------
+ * Replaces compute_row_means_constantdivide (index_add_ over the kept tokens, divide by cols;
+ * mamba_simple_masked_faster.py:376-416) and the torch.gather that expands the scan output back to the kept tokens
+ * (:281-283, 311-314), plus their adjoints -- the adjoint of one is the other.  Deterministic (no atomics).
+ *   idx (2, batch, n_tokens) int32: pooling row of token t, per direction; values outside [0, rows) contribute /
+ *       receive nothing.
+ * fv_rows_segment_sum: out[dir][b][r][:] = scale * sum_{t : idx[dir][b][t] == r} in[dir][b][t][:]
+ *   in  (2, batch, n_tokens, d_inner), or (batch, n_tokens, d_inner) shared by both directions when
+ *       in_per_direction == 0;   out (2, batch, rows, d_inner).
+ * fv_rows_gather: out[dir][b][t][:] = scale * in[dir][b][idx[dir][b][t]][:]
+ *   in  (2, batch, rows, d_inner);   out (2, batch, n_tokens, d_inner).
+ * dtypes FV_F32 / FV_BF16 per tensor; d_inner a multiple of 4. */
+int fv_rows_segment_sum(const void* in, int in_dtype, int in_per_direction, const int* idx, void* out, int out_dtype,
+                        int batch, int n_tokens, int rows, int d_inner, float scale, fv_stream_t stream);
+int fv_rows_gather(const void* in, int in_dtype, const int* idx, void* out, int out_dtype, int batch, int n_tokens,
+                   int rows, int d_inner, float scale, fv_stream_t stream);
 
 /* Adjoint of fv_mixer_conv_pool_fwd plus the D-skip path: consumes d_o and the total gradient
  * wrt the pooled conv output dxc (2, batch, rows, d_inner) fp32; writes dx into the x half of

@@ -86,3 +86,68 @@ def fastvim_mixer_oracle(p, hidden, token_size, tokens_per_patch=1, collapse_met
     if p.get("gamma") is not None:                                       # :455-456
         y = y * p["gamma"].to(cd)
     return y.to(out_dtype)
+
+
+def _pooled_direction(pooled, p, sfx, cd):
+    """x_proj -> dt_proj -> selective scan (ascending) over the pooled rows.  pooled: (B, d_in, rows)."""
+    Bsz, d_in, Lc = pooled.shape
+    Wx = p[f"x_proj{sfx}.weight"].to(cd)
+    Wdt = p[f"dt_proj{sfx}.weight"].to(cd)
+    R = Wdt.shape[1]
+    N = (Wx.shape[0] - R) // 2
+    x_dbl = pooled.permute(0, 2, 1).reshape(Bsz * Lc, d_in) @ Wx.t()
+    dt = (x_dbl[:, :R] @ Wdt.t()).reshape(Bsz, Lc, d_in).permute(0, 2, 1)
+    Bm = x_dbl[:, R:R + N].reshape(Bsz, Lc, N).permute(0, 2, 1)
+    Cm = x_dbl[:, R + N:].reshape(Bsz, Lc, N).permute(0, 2, 1)
+    A = -torch.exp(p[f"A{sfx}_log"].float()).to(cd)
+    return selective_scan_oracle(pooled, dt, A, Bm, Cm, None, None, p[f"dt_proj{sfx}.bias"].float(),
+                                 True, False, compute_dtype=cd, out_dtype=cd)
+
+
+def masked_mixer_oracle(p, hidden, ids_keep, token_size, use_norm_after_ssm=True, ln_eps=1e-5,
+                        compute_dtype=torch.float64, out_dtype=None):
+    """MAE masked FastVim mixer: ``Mamba_masked.forward(hidden_states, ids_keep)``
+    (mamba-1p1p1/mamba_ssm/modules/mamba_simple_masked_faster.py:167-325) with the constant-divide row means
+    (``compute_row_means_constantdivide``, :376-416).  hidden: (B, Lk, d_model) kept tokens only; ids_keep:
+    (B, Lk) their positions in the rows x cols grid.  Written flip-free; position t of the kept sequence has row
+    ``r(t) = ids_keep[t] // cols`` and mirrored row ``m(t) = r(Lk-1-t)``:
+
+      * forward branch : causal conv, pooled_f[r] = sum_{r(t)=r} conv_f[t] / cols, ascending scan,
+        out_f[t] = scan_f[r(t)] + D * conv_f[t];
+      * backward branch: the reference pools the conv of the FLIPPED sequence with the UN-flipped ids (:236-239),
+        scans it ascending as well, gathers with the un-flipped ids (:311-314) and flips back, i.e. in original
+        order pooled_b[r] = sum_{m(t)=r} conv_b[t] / cols and out_b[t] = scan_b[m(t)] + D_b * conv_b[t]
+        with conv_b the anti-causal conv."""
+    cd = compute_dtype
+    out_dtype = hidden.dtype if out_dtype is None else out_dtype
+    rows, cols = token_size
+    Bsz, Lk, d = hidden.shape
+    W_in = p["in_proj.weight"].to(cd)
+    d_in = W_in.shape[0] // 2
+    xz = hidden.to(cd) @ W_in.t()
+    if p.get("in_proj.bias") is not None:
+        xz = xz + p["in_proj.bias"].to(cd)
+    x = xz[..., :d_in].permute(0, 2, 1)                                  # (B, d_in, Lk)
+    z = xz[..., d_in:]
+    r = (ids_keep // cols).long()                                        # (B, Lk)
+    m = r.flip(1)
+    outs = []
+    for sfx, anti, idx in (("", False, r), ("_b", True, m)):
+        w = p[f"conv1d{sfx}.weight"].to(cd).reshape(d_in, -1)
+        conv = causal_conv1d_oracle(x, w, p.get(f"conv1d{sfx}.bias"), "silu", anticausal=anti,
+                                    compute_dtype=cd, out_dtype=cd)      # (B, d_in, Lk)
+        pooled = torch.zeros(Bsz, d_in, rows, dtype=cd)
+        pooled = pooled.scatter_add(2, idx[:, None, :].expand(Bsz, d_in, Lk), conv) / cols
+        y = _pooled_direction(pooled, p, sfx, cd)                        # (B, d_in, rows)
+        y = torch.gather(y, 2, idx[:, None, :].expand(Bsz, d_in, Lk))
+        outs.append(y + p[f"D{sfx}"].float().to(cd)[None, :, None] * conv)
+    o = ((outs[0] + outs[1]) / 2).permute(0, 2, 1)
+    if use_norm_after_ssm:
+        o = F.layer_norm(o, (d_in,), p["layernorm.weight"].to(cd), p["layernorm.bias"].to(cd), ln_eps)
+    g = o * F.silu(z)
+    y = g @ p["out_proj.weight"].to(cd).t()
+    if p.get("out_proj.bias") is not None:
+        y = y + p["out_proj.bias"].to(cd)
+    if p.get("gamma") is not None:
+        y = y * p["gamma"].to(cd)
+    return y.to(out_dtype)

@@ -174,13 +174,16 @@ def load_reference():
     import importlib
     chan = importlib.import_module("models.channel_wise_tokenization.models_channel_mamba_faster")
 
+    from mamba_ssm.modules import mamba_simple_masked_faster as msmf     # MAE masked mixer
+    msmf.causal_conv1d_fn = causal_conv1d_fn
+
     for m in (fastvim, msf, chan, mscf):
         m.rms_norm_fn = rms_norm_fn
         m.layer_norm_fn = layer_norm_fn
         m.RMSNorm = RMSNorm
 
     ns = types.SimpleNamespace(
-        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, ms=ms, vim=vim, rms_norm_fn=rms_norm_fn,
+        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, ms=ms, vim=vim, msmf=msmf, rms_norm_fn=rms_norm_fn,
         layer_norm_fn=layer_norm_fn, RMSNorm=RMSNorm, causal_conv1d_fn=causal_conv1d_fn,
     )
     _loaded = ns

@@ -359,7 +359,42 @@ def gen_vim():
     save("vim.pt", cases)
 
 
+def _masked_case(d_model, token_size, Bsz, n_keep, seed, sorted_ids=True):
+    """MAE masked mixer (mamba_simple_masked_faster.py:167-325): hidden holds only the kept tokens, ids_keep their
+    positions in the full rows x cols grid (ascending per sample, as random_masking / the MAE Block produce them,
+    models_mamba_faster_mae_vimdecoder.py:381-386, 757)."""
+    torch.manual_seed(seed)
+    m = ref.msmf.Mamba_masked(d_model, token_size=list(token_size))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n in ("D", "D_b", "layernorm.weight"):
+                p.add_(0.2 * torch.randn_like(p))
+            elif n in ("layernorm.bias", "conv1d.bias", "conv1d_b.bias", "A_log", "A_b_log"):
+                p.add_(0.1 * torch.randn_like(p))
+    L = token_size[0] * token_size[1]
+    ids = torch.stack([torch.randperm(L)[:n_keep] for _ in range(Bsz)])
+    if sorted_ids:
+        ids = ids.sort(dim=1).values
+    h = torch.randn(Bsz, n_keep, d_model, requires_grad=True)
+    y = m(h, ids.clone())
+    g = torch.randn_like(y)
+    y.backward(g)
+    grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    return dict(hidden=h.detach(), ids_keep=ids, out=y.detach(), g=g, dhidden=h.grad.clone(), grads=grads,
+                token_size=tuple(token_size), state_dict={k: v.clone() for k, v in m.state_dict().items()})
+
+
+def gen_masked():
+    cases = {
+        "d32_4x4_keep6": _masked_case(32, (4, 4), 2, 6, seed=21),
+        "d32_3x5_keep9": _masked_case(32, (3, 5), 3, 9, seed=22),
+        "d32_4x4_keep7_unsorted": _masked_case(32, (4, 4), 2, 7, seed=23, sorted_ids=False),
+        "d64_6x6_keep9": _masked_case(64, (6, 6), 2, 9, seed=24),      # 25 % kept, some rows empty
+    }
+    save("masked.pt", cases)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim"]
+    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked"]
     for w in which:
         globals()["gen_" + w]()

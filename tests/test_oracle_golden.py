@@ -186,3 +186,19 @@ def test_vim_model_oracle():
     logits.backward(c["g"].double())
     for k, gref in c["grads"].items():
         close(sd[k].grad, gref, 0, 5e-4 * max(1.0, gref.abs().max().item()))
+
+
+@pytest.mark.parametrize("case", ["d32_4x4_keep6", "d32_3x5_keep9", "d32_4x4_keep7_unsorted", "d64_6x6_keep9"])
+def test_masked_mixer_oracle_matches_reference(case):
+    """MAE masked mixer: the flip-free oracle against Mamba_masked of the imported reference, forward,
+    input gradient and every parameter gradient (sorted and unsorted ids_keep, rows without kept tokens)."""
+    from oracle import masked_mixer_oracle
+    c = load_golden("masked.pt")[case]
+    p = {k: v.clone().requires_grad_() for k, v in c["state_dict"].items()}
+    h = c["hidden"].clone().requires_grad_()
+    y = masked_mixer_oracle(p, h, c["ids_keep"], c["token_size"], compute_dtype=torch.float64, out_dtype=torch.float64)
+    y.backward(c["g"].double())
+    assert (y - c["out"].double()).abs().max().item() <= 2e-6 * max(1.0, c["out"].abs().max().item())
+    assert (h.grad - c["dhidden"]).abs().max().item() <= 5e-6 * max(1.0, c["dhidden"].abs().max().item())
+    for k, g in c["grads"].items():
+        assert (p[k].grad - g).abs().max().item() <= 1e-5 * max(1.0, g.abs().max().item()), k
