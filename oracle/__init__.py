@@ -26,4 +26,4 @@ from .norm import fused_add_norm_oracle  # noqa: F401
 from .mixer import fastvim_mixer_oracle, masked_mixer_oracle  # noqa: F401
 from .model import (fastvim_block_oracle, fastvim_forward_oracle, make_state_dict,  # noqa: F401
                     channel_forward_oracle, channel_block_oracle, make_channel_state_dict,
-                    vim_forward_oracle, vim_mixer_oracle)
+                    vim_forward_oracle, vim_mixer_oracle, mae_forward_oracle, mae_random_masking_oracle)

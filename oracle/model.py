@@ -302,3 +302,77 @@ def vim_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, use_mid
     if return_features:
         return feat
     return feat @ sd["head.weight"].to(cd).t() + sd["head.bias"].to(cd)
+
+
+# ------------------------------------------------------------------------------------------------
+# FastVim MAE pre-training model (models/mae/models_mamba_faster_mae_vimdecoder.py)
+# ------------------------------------------------------------------------------------------------
+def mae_random_masking_oracle(L, mask_ratio, noise):
+    """random_masking (:738-772) from given uniform noise (N, L): ids_keep (sorted), ids_restore, mask."""
+    len_keep = int(L * (1 - mask_ratio))
+    ids_shuffle = torch.argsort(noise, dim=1)
+    ids_shuffle[:, :len_keep] = ids_shuffle[:, :len_keep].sort().values
+    ids_restore = torch.argsort(ids_shuffle, dim=1)
+    mask = torch.ones(noise.shape[0], L, dtype=torch.float64)
+    mask[:, :len_keep] = 0
+    return ids_shuffle[:, :len_keep].contiguous(), ids_restore, torch.gather(mask, 1, ids_restore)
+
+
+def mae_forward_oracle(sd, imgs, noise, *, mask_ratio=0.75, patch_size=16, depth=24, decoder_depth=2,
+                       norm_eps=1e-5, norm_pix_loss=True, rotate_every_block=True, compute_dtype=torch.float64):
+    """MaskedAutoencoderViM.forward (:882-893) with fused_add_norm, rms_norm, residual_in_fp32 (the
+    mae_FastVim_* factories, :897-950).  ``noise`` (N, L) replaces the torch.rand draw of random_masking.
+    Returns (loss, pred (N, L, p*p*3), mask (N, L))."""
+    from .mixer import masked_mixer_oracle
+    cd = compute_dtype
+    h, (gh, gw) = patch_embed_oracle(sd, imgs, patch_size, cd)
+    h = h + sd["pos_embed"].to(cd)                                        # :780
+    Bsz, L, d = h.shape
+    ids_keep, ids_restore, mask = mae_random_masking_oracle(L, mask_ratio, noise)
+    h = torch.gather(h, 1, ids_keep[..., None].expand(-1, -1, d))
+    bidx = torch.arange(Bsz)[:, None]
+    rotate_indices = (torch.arange(L) % gw) * gh + torch.arange(L) // gw  # Block_masked.compute_rotate_indices (:320-323)
+    residual = None
+    for i in range(depth):                                                # Block_masked.forward (:325-396)
+        sdl = _sub(sd, f"layers.{i}.")
+        hn, residual = fused_add_norm_oracle(h, sdl["norm.weight"], None, residual, norm_eps, prenorm=True,
+                                             residual_in_fp32=True, is_rms_norm=True, compute_dtype=cd)
+        rot = rotate_every_block and i % 2 != 0
+        ids, ts = ids_keep, (gh, gw)
+        if rot:
+            ids = rotate_indices[ids_keep]
+            order = torch.argsort(ids, dim=1)
+            inverse = torch.argsort(order, 1)
+            ids = ids[bidx, order]
+            hn = hn[bidx, order]
+            ts = (gw, gh)
+        h = masked_mixer_oracle(_sub(sdl, "mixer."), hn, ids, ts, compute_dtype=cd)
+        if rot:
+            h = h[bidx, inverse]
+    h = fused_add_norm_oracle(h, sd["norm_f.weight"], None, residual, norm_eps, prenorm=False,
+                              residual_in_fp32=True, is_rms_norm=True, compute_dtype=cd)
+    # decoder (:819-862)
+    x = h.to(cd) @ sd["decoder_embed.weight"].to(cd).t() + sd["decoder_embed.bias"].to(cd)
+    dd = x.shape[-1]
+    x = torch.cat([x, sd["mask_token"].to(cd).expand(Bsz, L - x.shape[1], dd)], dim=1)
+    x = torch.gather(x, 1, ids_restore[..., None].expand(-1, -1, dd))
+    x = x + sd["decoder_pos_embed"].to(cd)
+    residual = None
+    for i in range(decoder_depth):
+        sdl = _sub(sd, f"decoder_blocks.{i}.")
+        xn, residual = fused_add_norm_oracle(x, sdl["norm.weight"], None, residual, norm_eps, prenorm=True,
+                                             residual_in_fp32=True, is_rms_norm=True, compute_dtype=cd)
+        x = vim_mixer_oracle(_sub(sdl, "mixer."), xn, compute_dtype=cd)
+    x = fused_add_norm_oracle(x, sd["decoder_norm.weight"], None, residual, norm_eps, prenorm=False,
+                              residual_in_fp32=True, is_rms_norm=True, compute_dtype=cd)
+    pred = x.to(cd) @ sd["decoder_pred.weight"].to(cd).t() + sd["decoder_pred.bias"].to(cd)
+    # loss (:864-880)
+    p = patch_size
+    C = imgs.shape[1]
+    target = imgs.to(cd).reshape(Bsz, C, gh, p, gw, p)
+    target = torch.einsum("nchpwq->nhwpqc", target).reshape(Bsz, gh * gw, p * p * C)
+    if norm_pix_loss:
+        target = (target - target.mean(-1, keepdim=True)) / (target.var(-1, keepdim=True) + 1.0e-6) ** 0.5
+    loss = ((pred - target) ** 2).mean(-1)
+    loss = (loss * mask.to(cd)).sum() / mask.to(cd).sum()
+    return loss, pred, mask

@@ -177,13 +177,15 @@ def load_reference():
     from mamba_ssm.modules import mamba_simple_masked_faster as msmf     # MAE masked mixer
     msmf.causal_conv1d_fn = causal_conv1d_fn
 
-    for m in (fastvim, msf, chan, mscf):
+    mae = importlib.import_module("models.mae.models_mamba_faster_mae_vimdecoder")
+
+    for m in (fastvim, msf, chan, mscf, mae):
         m.rms_norm_fn = rms_norm_fn
         m.layer_norm_fn = layer_norm_fn
         m.RMSNorm = RMSNorm
 
     ns = types.SimpleNamespace(
-        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, ms=ms, vim=vim, msmf=msmf, rms_norm_fn=rms_norm_fn,
+        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, ms=ms, vim=vim, msmf=msmf, mae=mae, rms_norm_fn=rms_norm_fn,
         layer_norm_fn=layer_norm_fn, RMSNorm=RMSNorm, causal_conv1d_fn=causal_conv1d_fn,
     )
     _loaded = ns

@@ -394,7 +394,49 @@ def gen_masked():
     save("masked.pt", cases)
 
 
+def gen_mae():
+    """Tiny MaskedAutoencoderViM (the mae_FastVim_* recipe: rms_norm, fused_add_norm, residual_in_fp32) with the
+    masking noise captured: loss, prediction, mask and a few gradients of one pre-training step."""
+    cases = {}
+    for name, img, seed in (("tiny_64_keep4", 64, 31), ("tiny_96_keep9", 96, 32)):
+        torch.manual_seed(seed)
+        m = ref.mae.MaskedAutoencoderViM(img_size=img, patch_size=16, depth=4, embed_dim=32, decoder_embed_dim=32,
+                                         decoder_depth=2, rms_norm=True, residual_in_fp32=True, fused_add_norm=True,
+                                         ssm_cfg={"use_fast_path": False})
+        with torch.no_grad():                      # move the symmetric inits so every parameter matters
+            for n, p in m.named_parameters():
+                if n.endswith((".D", ".D_b", "layernorm.weight", "norm.weight", "norm_f.weight", "decoder_norm.weight")):
+                    p.add_(0.1 * torch.randn_like(p))
+                elif n.endswith("bias") and p.requires_grad:
+                    p.add_(0.05 * torch.randn_like(p))
+        x = torch.randn(2, 3, img, img)
+        L = (img // 16) ** 2
+        noise = torch.rand(2, L)
+        rand = torch.rand
+        torch.rand = lambda *a, **k: noise.clone()     # random_masking draws torch.rand(N, L, device=...) (:750)
+        try:
+            loss, pred, mask = m(x, mask_ratio=0.75)
+        finally:
+            torch.rand = rand
+        loss.backward()
+        keep = ("patch_embed.proj.weight", "layers.0.mixer.in_proj.weight", "layers.1.mixer.A_b_log", "layers.3.mixer.D",
+                "layers.2.mixer.conv1d_b.weight", "norm_f.weight", "decoder_embed.weight", "mask_token",
+                "decoder_blocks.1.mixer.x_proj.weight", "decoder_pred.bias")
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if n in keep}
+        cases[name] = dict(x=x, noise=noise, loss=loss.detach(), pred=pred.detach(), mask=mask, grads=grads,
+                           state_dict={k: v.clone() for k, v in m.state_dict().items()},
+                           cfg=dict(img_size=img, patch_size=16, depth=4, embed_dim=32, decoder_embed_dim=32, decoder_depth=2))
+    # initialisation contract: parameters of a freshly built model for a fixed torch seed
+    torch.manual_seed(77)
+    m = ref.mae.MaskedAutoencoderViM(img_size=64, patch_size=16, depth=2, embed_dim=32, decoder_embed_dim=32,
+                                     decoder_depth=1, rms_norm=True, residual_in_fp32=True, fused_add_norm=True,
+                                     ssm_cfg={"use_fast_path": False})
+    cases["init_seed77"] = dict(state_dict={k: v.clone() for k, v in m.state_dict().items()},
+                                cfg=dict(img_size=64, patch_size=16, depth=2, embed_dim=32, decoder_embed_dim=32, decoder_depth=1))
+    save("mae.pt", cases)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked"]
+    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked", "mae"]
     for w in which:
         globals()["gen_" + w]()

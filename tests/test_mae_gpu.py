@@ -1,0 +1,72 @@
+"""GPU parity of the FastVim MAE pre-training model: ``MaskedAutoencoderViM`` on the
+HIP kernels against golden vectors captured from the imported reference
+(models/mae/models_mamba_faster_mae_vimdecoder.py) and against the fp64 oracle."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _err(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+def _build(cfg):
+    from fastvim_amd.models_mae import MaskedAutoencoderViM
+    return MaskedAutoencoderViM(img_size=cfg["img_size"], patch_size=cfg["patch_size"], depth=cfg["depth"],
+                                embed_dim=cfg["embed_dim"], decoder_embed_dim=cfg["decoder_embed_dim"],
+                                decoder_depth=cfg["decoder_depth"], rms_norm=True, residual_in_fp32=True,
+                                fused_add_norm=True).cuda()
+
+
+@pytest.mark.parametrize("case", ["tiny_64_keep4", "tiny_96_keep9"])
+def test_mae_fp32_vs_reference_golden(case):
+    c = load_golden("mae.pt")[case]
+    m = _build(c["cfg"])
+    m.load_state_dict(c["state_dict"], strict=True)
+    loss, pred, mask = m(c["x"].cuda(), mask_ratio=0.75, noise=c["noise"].cuda())
+    assert torch.equal(mask.cpu().float(), c["mask"].float())
+    assert abs(loss.item() - c["loss"].item()) <= 2e-5 * max(1.0, abs(c["loss"].item()))
+    assert _err(pred, c["pred"]) <= 2e-5 * max(1.0, c["pred"].abs().max().item()), _err(pred, c["pred"])
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k, gref in c["grads"].items():
+        e = _err(params[k].grad, gref)
+        assert e <= 2e-4 * max(1e-3, gref.abs().max().item()), (k, e, gref.abs().max().item())
+
+
+def test_mae_bf16_step_vs_oracle():
+    """One pre-training step at a FastVim-T-like width (embed 192, 14 x 14 grid, 49 kept tokens), depth cut to 3 so
+    the fp64 oracle finishes in seconds: fp32 against the oracle, then bf16 autocast close to it; the draw of the
+    masking noise without ``noise=`` is exercised too."""
+    from fastvim_amd.models_mae import MaskedAutoencoderViM
+    from oracle import mae_forward_oracle
+    torch.manual_seed(3)
+    m = MaskedAutoencoderViM(img_size=224, patch_size=16, depth=3, embed_dim=192, decoder_embed_dim=128,
+                             decoder_depth=1, rms_norm=True, residual_in_fp32=True, fused_add_norm=True).cuda()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(4))
+    noise = torch.rand(2, 196, generator=torch.Generator().manual_seed(5))
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    lref, pref, mref = mae_forward_oracle(p, x, noise, depth=3, decoder_depth=1, compute_dtype=F64)
+    lref.backward()
+    loss, pred, mask = m(x.cuda(), noise=noise.cuda())
+    assert torch.equal(mask.cpu().double(), mref)
+    assert abs(loss.item() - lref.item()) <= 5e-5 * max(1.0, abs(lref.item()))
+    assert _err(pred, pref) <= 1e-4 * max(1.0, pref.abs().max().item())
+    loss.backward()
+    for n, q in m.named_parameters():
+        if q.grad is None:
+            assert not q.requires_grad, n
+            continue
+        e = _err(q.grad, p[n].grad)
+        assert e <= 1e-3 * max(1e-3, p[n].grad.abs().max().item()), (n, e, p[n].grad.abs().max().item())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lb, pb, _ = m(x.cuda(), noise=noise.cuda())
+    assert abs(lb.item() - lref.item()) <= 5e-2 * max(1.0, abs(lref.item()))
+    assert _err(pb, pref) <= 8e-2 * max(1.0, pref.abs().max().item())
+    l2, p2, m2 = m(x.cuda())                       # noise drawn on the device, like the reference
+    assert p2.shape == pred.shape and int(m2.sum().item()) == 2 * (196 - 49) and torch.isfinite(l2)

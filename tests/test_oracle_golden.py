@@ -202,3 +202,21 @@ def test_masked_mixer_oracle_matches_reference(case):
     assert (h.grad - c["dhidden"]).abs().max().item() <= 5e-6 * max(1.0, c["dhidden"].abs().max().item())
     for k, g in c["grads"].items():
         assert (p[k].grad - g).abs().max().item() <= 1e-5 * max(1.0, g.abs().max().item()), k
+
+
+@pytest.mark.parametrize("case", ["tiny_64_keep4", "tiny_96_keep9"])
+def test_mae_oracle_matches_reference(case):
+    """FastVim MAE pre-training step: the oracle against MaskedAutoencoderViM of the imported
+    reference -- loss, per-patch prediction, mask and parameter gradients, with the masking noise captured."""
+    from oracle import mae_forward_oracle
+    c = load_golden("mae.pt")[case]
+    cfg = c["cfg"]
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in c["state_dict"].items()}
+    loss, pred, mask = mae_forward_oracle(sd, c["x"], c["noise"], patch_size=cfg["patch_size"], depth=cfg["depth"],
+                                          decoder_depth=cfg["decoder_depth"])
+    loss.backward()
+    assert abs(loss.item() - c["loss"].item()) <= 1e-6 * max(1.0, abs(c["loss"].item()))
+    assert (pred - c["pred"].double()).abs().max().item() <= 5e-6 * max(1.0, c["pred"].abs().max().item())
+    assert torch.equal(mask.float(), c["mask"].float())
+    for k, g in c["grads"].items():
+        assert (sd[k].grad - g).abs().max().item() <= 1e-5 * max(1.0, g.abs().max().item()), k
