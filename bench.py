@@ -38,6 +38,9 @@ def build_model(name, img_size, drop_path, channels=8):
     if name == "V":      # Vim-T baseline (models/vim.py): un-pooled scan, middle class token -- the paper's comparison point
         from fastvim_amd.vim import vim_tiny_patch16_224_final_pool_mean_abs_pos_embed_with_midclstok_div2 as vim_t
         return vim_t(img_size=img_size, drop_path_rate=drop_path)
+    if name == "M":      # FastVim-B masked autoencoder, the reference's MAE pre-training model (mae/config/pretrain_FastVimB.yaml:25)
+        from fastvim_amd.models_mae import mae_FastVim_base_dec512d2b
+        return mae_FastVim_base_dec512d2b(img_size=img_size)
     from fastvim_amd import fastvim as fv
     factory = {"T": fv.FastVimT, "S": fv.FastVimS, "B": fv.FastVimB}[name]
     return factory(img_size=img_size, drop_path_rate=drop_path)
@@ -281,7 +284,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C", "V"],
+    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C", "V", "M"],
                     help="FastVim-T/S/B, C = FastChannelVim-S/16 (use --batch 64 for BASELINE configs[4]), V = Vim-T baseline")
     ap.add_argument("--channels", type=int, default=8, help="input channels of the channel model (--model C)")
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
@@ -310,7 +313,7 @@ def main():
     from fastvim_amd.flat import FlatAdamW, FlatTrainingState
 
     torch.manual_seed(1234)                    # identical init on every rank (DDP broadcast equivalent)
-    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1, "V": 0.05}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
+    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1, "V": 0.05, "M": 0.0}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
     model = build_model(args.model, args.img, drop_path, args.channels).to(dev).train()
     gen = torch.Generator().manual_seed(100 + rank)
     in_ch = args.channels if args.model == "C" else 3
@@ -320,20 +323,32 @@ def main():
     no_decay = {n for n, p in model.named_parameters()
                 if p.ndim <= 1 or n.endswith(".bias") or n in model.no_weight_decay() or getattr(p, "_no_weight_decay", False)}
     # one fused kernel: AdamW (the reference recipe's two param groups) + ModelEmaV2 lerp + bf16 shadow refresh
-    opt = FlatAdamW(flat, model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05, no_decay=no_decay, ema_decay=0.9999)
+    # MAE pre-training recipe: lr = blr * batch / 256 with blr 1.5e-4, betas (0.9, 0.95) (mae/config/pretrain_FastVimB.yaml:20,
+    # mae/mae_imagenet.py); the classification recipe's 1e-3 without warm-up diverges on it within ~10 steps
+    lr, betas = (1.5e-4 * args.batch * world / 256, (0.9, 0.95)) if args.model == "M" else (1e-3, (0.9, 0.999))
+    opt = FlatAdamW(flat, model, lr=lr, betas=betas, weight_decay=0.05, no_decay=no_decay, ema_decay=0.9999)
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(5678 + rank)             # per-rank DropPath streams
 
     def fwd_bwd():
         flat.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
-            logits = model(x)
-        loss = torch.sum(-tgt * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()   # SoftTargetCrossEntropy
+            if args.model == "M":
+                loss = model(x, mask_ratio=0.75)[0]      # norm-pix MSE on the 75 % removed patches (mae_imagenet.py SSLModule)
+            else:
+                logits = model(x)
+        if args.model != "M":
+            loss = torch.sum(-tgt * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()   # SoftTargetCrossEntropy
         loss.backward()
         flat.finish_backward()
         return loss.detach()
 
     use_graph = not args.no_graph
+    if args.model == "M" and os.environ.get("FASTVIM_MAE_GRAPH") != "1":
+        # OPEN ISSUE: the graph-captured MAE step turns non-finite after a few replays on ROCm 7.2,
+        # while the same step is finite eagerly (also with NaN-poisoned allocator memory) and when extra kernels are
+        # captured between its stages; until that is understood the MAE model is benchmarked with eager launches
+        use_graph = False
     if use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -363,8 +378,11 @@ def main():
             opt.step()
             return l
 
-    for _ in range(args.warmup):
+    trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)
+    for i in range(args.warmup):
         loss = step()
+        if trace and rank == 0:
+            print(f"warmup {i} loss {float(loss):.5f}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -389,9 +407,10 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         gs = args.img // 16
-        d = {"T": 192, "S": 384, "B": 768, "C": 384, "V": 192}[args.model]
+        d = {"T": 192, "S": 384, "B": 768, "C": 384, "V": 192, "M": 768}[args.model]
         mname = (f"FastChannelVim-S/16 {args.channels}ch" if args.model == "C" else
-                 "Vim-T (un-pooled baseline)" if args.model == "V" else f"FastVim-{args.model}")
+                 "Vim-T (un-pooled baseline)" if args.model == "V" else
+                 "FastVim-B MAE pre-training (mask 0.75, decoder 512x2)" if args.model == "M" else f"FastVim-{args.model}")
         out = {
             "metric": "images/sec %s %dpx bs=%d/GPU fwd+bwd (+all-reduce +AdamW +EMA), whole job" % (mname, args.img, args.batch),
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -405,7 +424,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "hip_graph": use_graph, "optimizer_in_step": True, "final_loss": round(loss_val, 4)},
         }
-        if not args.no_kernels and args.model not in ("C", "V"):
+        if not args.no_kernels and args.model not in ("C", "V", "M"):
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
             dom = max(kt, key=lambda k: kt[k]["us_per_step"])     # the kernel that costs the most time per step
             out["kernels"] = kt
@@ -420,7 +439,7 @@ def main():
                                "unit": "GB/s", "frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "avg_us": kt[dom]["us"],
                                "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6)}
-        if not args.no_cpu_baseline and world == 1 and args.model not in ("C", "V"):
+        if not args.no_cpu_baseline and world == 1 and args.model not in ("C", "V", "M"):
             out["cpu_baseline"] = cpu_baseline()
         if not args.no_scan_op and not args.no_kernels and world == 1 and args.model == "T":
             out["scan_op"] = scan_op_table(cpu=not args.no_cpu_baseline)

@@ -94,7 +94,6 @@ class MaskedFastVimMixerFn(torch.autograd.Function):
             dhidden = linear_dgrad(dxz2, _shadow(W_in, cdt)).view(B, Lk, d).to(ctx.in_dtype)
             dW_in = linear_wgrad(dxz2, h_c.view(B * Lk, d))
             db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
-        M.flush_reductions()
         n4 = 4 * d_in
         N_, R_ = A_log.shape[1], Wdt.shape[1]
         g_cw, g_cwb = p2[0:n4].view(cw.shape), p2[n4:2 * n4].view(cw_b.shape)

@@ -92,15 +92,14 @@ class Block_masked(nn.Module):
         if rot:
             if self.rotate_indices.device != hidden_states.device:
                 self.rotate_indices = self.rotate_indices.to(hidden_states.device)
-            batch_indices = torch.arange(hidden_states.shape[0], device=hidden_states.device).unsqueeze(-1)
             ids_keep = self.rotate_indices[ids_keep]
-            order = torch.argsort(ids_keep, dim=1)
+            ids_keep, order = torch.sort(ids_keep, dim=1)        # kept tokens in the transposed grid's scan order
             inverse = torch.argsort(order, 1)
-            ids_keep = ids_keep[batch_indices, order].contiguous()
-            hidden_states = hidden_states[batch_indices, order].contiguous()
+            d = hidden_states.shape[-1]
+            hidden_states = torch.gather(hidden_states, 1, order.unsqueeze(-1).expand(-1, -1, d))
         hidden_states = self.mixer(hidden_states, ids_keep, inference_params=inference_params)
         if rot:
-            hidden_states = hidden_states[batch_indices, inverse].contiguous()
+            hidden_states = torch.gather(hidden_states, 1, inverse.unsqueeze(-1).expand(-1, -1, d))
         return hidden_states, residual
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
