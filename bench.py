@@ -347,7 +347,8 @@ def main():
     if args.model == "M" and os.environ.get("FASTVIM_MAE_GRAPH") != "1":
         # OPEN ISSUE: the graph-captured MAE step turns non-finite after a few replays on ROCm 7.2,
         # while the same step is finite eagerly (also with NaN-poisoned allocator memory) and when extra kernels are
-        # captured between its stages; until that is understood the MAE model is benchmarked with eager launches
+        # captured between its stages, and finite with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (no pre-recorded AQL packets);
+        # graph replay is not faster than eager at this step size (42.4 vs 41.8 ms), so the MAE model launches eagerly
         use_graph = False
     if use_graph:
         side = torch.cuda.Stream()
