@@ -24,31 +24,41 @@ namespace {
 using fvi::BwdParams;
 
 // One partial row per block: [d w (d_in*4) | d w_b (d_in*4) | d b | d b_b | dD | dD_b]; the row groups of a block are
-// summed through LDS in a fixed order.
-__device__ __forceinline__ void flush_partials(const BwdParams& p, float* smem, int c0, int rg, int RG, const f2 (&a_wf)[CW],
-                                               const f2 (&a_wb)[CW], f2 a_bf, f2 a_bb, f2 a_Df, f2 a_Db) {
+// summed through LDS in a fixed order.  A block owns the channels [c_lo, c_lo + nc) (all of them unless the channels
+// are split over blockIdx.y) and writes only their entries of the row.
+__device__ __forceinline__ void flush_partials(const BwdParams& p, float* smem, int c0, int c_lo, int nc, int rg, int RG,
+                                               const f2 (&a_wf)[CW], const f2 (&a_wb)[CW], f2 a_bf, f2 a_bb, f2 a_Df, f2 a_Db) {
   const int D = p.d_in;
   for (int r = 0; r < RG; ++r) {
     __syncthreads();
     if (r == rg) {
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
-        const int c = c0 + v;
+        const int c = c0 - c_lo + v;          // local channel
 #pragma unroll
         for (int k = 0; k < CW; ++k) {
           smem[c * 4 + k] = (r == 0 ? 0.f : smem[c * 4 + k]) + a_wf[k][v];
-          smem[4 * D + c * 4 + k] = (r == 0 ? 0.f : smem[4 * D + c * 4 + k]) + a_wb[k][v];
+          smem[4 * nc + c * 4 + k] = (r == 0 ? 0.f : smem[4 * nc + c * 4 + k]) + a_wb[k][v];
         }
-        smem[8 * D + c] = (r == 0 ? 0.f : smem[8 * D + c]) + a_bf[v];
-        smem[9 * D + c] = (r == 0 ? 0.f : smem[9 * D + c]) + a_bb[v];
-        smem[10 * D + c] = (r == 0 ? 0.f : smem[10 * D + c]) + a_Df[v];
-        smem[11 * D + c] = (r == 0 ? 0.f : smem[11 * D + c]) + a_Db[v];
+        smem[8 * nc + c] = (r == 0 ? 0.f : smem[8 * nc + c]) + a_bf[v];
+        smem[9 * nc + c] = (r == 0 ? 0.f : smem[9 * nc + c]) + a_bb[v];
+        smem[10 * nc + c] = (r == 0 ? 0.f : smem[10 * nc + c]) + a_Df[v];
+        smem[11 * nc + c] = (r == 0 ? 0.f : smem[11 * nc + c]) + a_Db[v];
       }
     }
   }
   __syncthreads();
   float* dst = p.part + (size_t)blockIdx.x * 12 * D;
-  for (int e = threadIdx.x; e < 12 * D; e += blockDim.x) dst[e] = smem[e];
+  for (int e = threadIdx.x; e < 12 * nc; e += blockDim.x) {
+    int gi;
+    if (e < 4 * nc) gi = c_lo * 4 + e;
+    else if (e < 8 * nc) gi = 4 * D + c_lo * 4 + (e - 4 * nc);
+    else {
+      const int q = (e - 8 * nc) / nc, r = (e - 8 * nc) - q * nc;
+      gi = (8 + q) * D + c_lo + r;
+    }
+    dst[gi] = smem[e];
+  }
 }
 
 template <typename T, int NT>
@@ -156,24 +166,29 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
       }
     }
   }
-  flush_partials(p, smem, c0, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
+  flush_partials(p, smem, c0, 0, p.d_in, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
 }
 
-// Channel-wise tokenization (tokens_per_patch == TPP, Channel-First; mamba_simple_channel_faster.py:242-256, 333-340):
-// the adjoint walked cell by cell like conv_pool_fwd_chan_kernel.  Body j runs the TPP steps n = TPP*j - 3 + c, so the
+// Long rows, walked cell by cell like conv_pool_fwd_chan_kernel: CHAN = channel-wise tokenization (tokens_per_patch ==
+// TPP, Channel-First; mamba_simple_channel_faster.py:242-256, 333-340), !CHAN = the dense path with cols a multiple
+// of TPP (one pooling slot per row; the 512 / 1024 / 2048 px grids).  Channels beyond 1024 are split over blockIdx.y.  Body j runs the TPP steps n = TPP*j - 3 + c, so the
 // pooling slots of both positions a step touches (n + 3 -> slot c; n -> slot c - 3 of this cell or TPP - 3 + c of the
 // previous one) are compile-time and the slot gradients stay in registers; one extra 3-step body closes the row.
-template <typename T, int TPP>
+template <typename T, int TPP, bool CHAN>
 __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, int nch, int RG) {
+  constexpr int NS = CHAN ? TPP : 1;          // pooling slots per row
+  constexpr int NH = CHAN ? 3 : 1;            // slots of a neighbouring row that the 3-token halo touches
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
   typedef PairVec<T, 1> P;
   static_assert(TPP >= 6, "slot bookkeeping assumes the three carried tokens and the three halo tokens do not overlap");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rg = wv / nch, cw = wv - rg * nch;
-  const int c0 = (cw * 64 + lane) * 2;
+  const int c_lo = blockIdx.y * nch * 128;
+  const int c0 = c_lo + (cw * 64 + lane) * 2;
   const Geo g = p.geo;
-  const int pcols = g.pcols;
+  const int pcols = CHAN ? g.pcols : g.cols / TPP;      // cells per row
+  const int ts = CHAN ? 1 : g.s_j;                      // memory tokens between consecutive tokens of a cell
   f2 wf[CW], wb[CW], bf, bb, Dfh, Dbh;
   load_taps2(p.wf, c0, wf);
   load_taps2(p.wb, c0, wb);
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
 #pragma unroll
   for (int k = 0; k < CW; ++k) a_wf[k] = a_wb[k] = splat(0.f);
   const int nrows = p.B * g.rows;
-  const size_t dstride = (size_t)p.B * g.rows * TPP * p.d_in;
+  const size_t dstride = (size_t)p.B * g.rows * NS * p.d_in;
   const int nit = (nrows + gridDim.x * RG - 1) / (gridDim.x * RG);
   const int tok_x = 2 * p.d_in * (int)sizeof(T), tok_d = p.d_in * (int)sizeof(T);
   const int voff = c0 * (int)sizeof(T);
@@ -204,24 +219,24 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
         int ri = i, cj = jj;
         if (jj < 0) { ri = up ? i - 1 : i; cj = pcols - 1; }
         else if (jj >= pcols) { ri = down ? i + 1 : i; cj = 0; }
-        return (ri * g.s_i + cj * g.s_j) * TPP;
+        return CHAN ? (ri * g.s_i + cj * g.s_j) * TPP : ri * g.s_i + cj * TPP * g.s_j;
       };
-      // pooled gradients (x pool_scale): every slot of this row, slots 0..2 of row i+1 (forward conv halo) and slots
-      // TPP-3.. of row i-1 (backward conv halo)
-      f2 dcf[TPP], dcb[TPP], dcf_dn[3], dcb_up[3];
+      // pooled gradients (x pool_scale): every slot of this row, the slots of row i+1 that its first three tokens
+      // pool into (forward conv halo) and the slots of row i-1 that its last three tokens pool into (backward halo)
+      f2 dcf[NS], dcb[NS], dcf_dn[NH], dcb_up[NH];
       {
-        const float* dq = p.dxc + ((size_t)b * g.rows + i) * TPP * p.d_in + c0;
+        const float* dq = p.dxc + ((size_t)b * g.rows + i) * NS * p.d_in + c0;
 #pragma unroll
-        for (int c = 0; c < TPP; ++c) {
+        for (int c = 0; c < NS; ++c) {
           dcf[c] = *reinterpret_cast<const f2*>(dq + (size_t)c * p.d_in) * p.pool_scale;
           dcb[c] = *reinterpret_cast<const f2*>(dq + dstride + (size_t)c * p.d_in) * p.pool_scale;
         }
-        const float* dn = dq + (down ? (size_t)TPP * p.d_in : 0);
-        const float* du = dq + dstride - (up ? (size_t)TPP * p.d_in : 0);
+        const float* dn = dq + (down ? (size_t)NS * p.d_in : 0);
+        const float* du = dq + dstride - (up ? (size_t)NS * p.d_in : 0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < NH; ++k) {
           dcf_dn[k] = *reinterpret_cast<const f2*>(dn + (size_t)k * p.d_in) * (p.pool_scale * m_dn);
-          dcb_up[k] = *reinterpret_cast<const f2*>(du + (size_t)(TPP - 3 + k) * p.d_in) * (p.pool_scale * m_up);
+          dcb_up[k] = *reinterpret_cast<const f2*>(du + (size_t)(NS - NH + k) * p.d_in) * (p.pool_scale * m_up);
         }
       }
       // body arrays: X / DO / PF index = position - (TPP*j - 3); PB index = position - (TPP*j - 6)
@@ -233,23 +248,23 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
         const int m1 = cell(1), m2 = cell(2);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          xa[k].load(bx, voff, (m_prev + TPP - 3 + k) * tok_x);
-          da[k].load(bd, voff, (m_prev + TPP - 3 + k) * tok_d);
+          xa[k].load(bx, voff, (m_prev + (TPP - 3 + k) * ts) * tok_x);
+          da[k].load(bd, voff, (m_prev + (TPP - 3 + k) * ts) * tok_d);
         }
 #pragma unroll
         for (int c = 0; c < TPP; ++c) {
-          xc[c].load(bx, voff, (m_cur + c) * tok_x);
-          dc[c].load(bd, voff, (m_cur + c) * tok_d);
+          xc[c].load(bx, voff, (m_cur + c * ts) * tok_x);
+          dc[c].load(bd, voff, (m_cur + c * ts) * tok_d);
         }
 #pragma unroll
         for (int c = 0; c < TPP; ++c) {
-          xr1[c].load(bx, voff, (m1 + c) * tok_x);
-          dr1[c].load(bd, voff, (m1 + c) * tok_d);
+          xr1[c].load(bx, voff, (m1 + c * ts) * tok_x);
+          dr1[c].load(bd, voff, (m1 + c * ts) * tok_d);
         }
 #pragma unroll
         for (int c = 0; c < TPP; ++c) {
-          xr2[c].load(bx, voff, (m2 + c) * tok_x);
-          dr2[c].load(bd, voff, (m2 + c) * tok_d);
+          xr2[c].load(bx, voff, (m2 + c * ts) * tok_x);
+          dr2[c].load(bd, voff, (m2 + c * ts) * tok_d);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -278,8 +293,13 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
             }
             const f2 sgf = sigmoid2(pf), sgb = sigmoid2(pb);
             const f2 dsf = sgf * fma2(pf, 1.f - sgf, splat(1.f)), dsb = sgb * fma2(pb, 1.f - sgb, splat(1.f));
-            const f2 cfs = c < 3 ? (tail ? dcf_dn[c < 3 ? c : 0] : dcf[c]) : dcf[c];
-            const f2 cbs = c < 3 ? (first ? dcb_up[c < 3 ? c : 0] : dcb[TPP - 3 + (c < 3 ? c : 0)]) : dcb[c < 3 ? 0 : c - 3];
+            // pooling slot of position n+3 (token c of this cell) and of position n (token c-3, or TPP-3+c of the
+            // previous cell); the dense path has one slot
+            const int c3 = c < 3 ? c : 0;
+            const int sf = CHAN ? c : 0, sf_dn = CHAN ? c3 : 0;
+            const int sb = CHAN ? (c < 3 ? TPP - 3 + c3 : c - 3) : 0, sb_up = CHAN ? c3 : 0;
+            const f2 cfs = (c < 3 && tail) ? dcf_dn[sf_dn] : dcf[sf];
+            const f2 cbs = (c < 3 && first) ? dcb_up[sb_up] : dcb[sb];
             const float e0 = (c < 3 && first) ? m_up : 1.f;
             const f2 nf = fma2(Dfh, DO[c + 3], cfs) * dsf * e3;
             const f2 nb = fma2(Dbh, DO[c], cbs) * dsb * e0;
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
                 dx = fma2(wf[k], PF[c + 3 - k], dx);
                 dx = fma2(wb[k], PB[c + k], dx);
               }
-              const int m = c < 3 ? m_prev + TPP - 3 + c : m_cur + c - 3;
+              const int m = c < 3 ? m_prev + (TPP - 3 + c) * ts : m_cur + (c - 3) * ts;
               { const f2 dxa[1] = {dx}; P::store(bo, voff, m * tok_x, dxa); }
             }
           }
@@ -330,26 +350,26 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
           const int m3 = cell(j + 3 > pcols ? pcols : j + 3);
 #pragma unroll
           for (int c = 0; c < TPP; ++c) {
-            xr2[c].load(bx, voff, (m3 + c) * tok_x);
-            dr2[c].load(bd, voff, (m3 + c) * tok_d);
+            xr2[c].load(bx, voff, (m3 + c * ts) * tok_x);
+            dr2[c].load(bd, voff, (m3 + c * ts) * tok_d);
           }
         }
       }
     }
   }
-  flush_partials(p, smem, c0, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
+  flush_partials(p, smem, c0, c_lo, nch * 128, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
 }
 
-template <typename T, int TPP>
-int launch_chan(const BwdParams& p, int nch, int rgr, int grid, size_t smem, hipStream_t st) {
+template <typename T, int TPP, bool CHAN>
+int launch_chan(const BwdParams& p, int nch, int rgr, int grid, int groups, size_t smem, hipStream_t st) {
   if (smem > 64 * 1024) {
     static bool done = false;
     if (!done) {
-      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_chan_kernel<T, TPP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_chan_kernel<T, TPP, CHAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       done = true;
     }
   }
-  hipLaunchKernelGGL((conv_pool_bwd_chan_kernel<T, TPP>), dim3(grid), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
+  hipLaunchKernelGGL((conv_pool_bwd_chan_kernel<T, TPP, CHAN>), dim3(grid, groups), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
@@ -372,15 +392,24 @@ int launch_row(const BwdParams& p, int nch, int rgr, int grid, size_t smem, hipS
 
 int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t smem, int dtype, hipStream_t st) {
   // nch counts 128-channel waves (a lane owns a channel pair)
-  if (p.d_in != nch * 128 || nch > 8) return FV_ERR_UNSUPPORTED;
+  if (p.d_in != nch * 128) return FV_ERR_UNSUPPORTED;
   if ((size_t)p.geo.L * 2 * p.d_in * 4 > 0xfffff000ull) return FV_ERR_UNSUPPORTED;   // one batch element per descriptor
-  if (p.geo.tpp == 8 && p.geo.pcols >= 2) {
+  const bool chan8 = p.geo.tpp == 8 && p.geo.pcols >= 2;
+  const bool dense8 = p.geo.tpp == 1 && p.geo.cols % 8 == 0 && p.geo.cols >= 24;      // 512 / 1024 / 2048 px grids
+  if (chan8 || dense8) {
     static const bool chan = !(getenv("FASTVIM_BWD_CHAN") && atoi(getenv("FASTVIM_BWD_CHAN")) == 0);   // tuning hook
     if (!chan) return FV_ERR_UNSUPPORTED;
-    const int capc = 8 / nch < 1 ? 1 : 8 / nch;
+    int groups = (nch + 7) / 8;                 // channel groups of at most 8 waves over blockIdx.y
+    while (nch % groups) ++groups;
+    const int nchg = nch / groups;
+    const int capc = 8 / nchg < 1 ? 1 : 8 / nchg;
     const int rgc = rg < capc ? rg : capc;
-    return dtype == FV_F32 ? launch_chan<float, 8>(p, nch, rgc, grid, smem, st) : launch_chan<bf16_t, 8>(p, nch, rgc, grid, smem, st);
+#define FV_CH(TT, CC) launch_chan<TT, 8, CC>(p, nchg, rgc, grid, groups, smem, st)
+    if (dtype == FV_F32) return chan8 ? FV_CH(float, true) : FV_CH(float, false);
+    return chan8 ? FV_CH(bf16_t, true) : FV_CH(bf16_t, false);
+#undef FV_CH
   }
+  if (nch > 8) return FV_ERR_UNSUPPORTED;
   if (p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16)) return FV_ERR_UNSUPPORTED;
   // a whole row lives in registers: blocks of <= 512 threads (256 VGPRs per wave), i.e. fewer row groups per
   // block than the generic kernel, over the same persistent grid

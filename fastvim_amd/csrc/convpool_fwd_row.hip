@@ -90,62 +90,68 @@ __global__ __launch_bounds__(NP == 1 ? 1024 : 512) void conv_pool_fwd_row_kernel
   VecIO<T, 2 * NP>::store(xc + dstride + o, ob);
 }
 
-// Channel-wise tokenization (tokens_per_patch == TPP, Channel-First): a pooling row is pcols cells of TPP tokens and
-// token c of every cell pools into slot c.  The row is walked cell by cell: the TPP tokens of a cell are compile-time
-// positions (slot accumulators are registers, cell addresses are affine in the cell index -- no division, no LDS),
-// two cells of packed loads are always in flight ahead of the arithmetic.
-template <typename T, int TPP, bool PMAX>
+// Cell-walking kernel for rows that are too long to hold in registers.  A pooling row is walked in cells of TPP = 8
+// tokens whose positions inside the cell are compile-time (register windows, affine cell addresses -- no division, no
+// LDS), two cells of packed loads always in flight ahead of the arithmetic.
+//   CHAN  (channel-wise tokenization, tokens_per_patch == TPP, Channel-First): a cell is one patch, token c of every
+//         cell pools into slot c (TPP slot accumulators in registers);
+//   !CHAN (tokens_per_patch == 1, cols a multiple of TPP -- the 512 / 1024 / 2048 px grids): a cell is TPP consecutive
+//         positions of the row, everything pools into one slot.
+// Channels beyond 1024 are split over blockIdx.z (a lane owns a channel pair, a block at most 8 waves).
+template <typename T, int TPP, bool PMAX, bool CHAN>
 __global__ __launch_bounds__(512) void conv_pool_fwd_chan_kernel(FwdParams p) {
   typedef PairVec<T, 1> P;
   static_assert(TPP >= 3, "the conv halo (3 tokens) must fit in one neighbouring cell");
+  constexpr int NS = CHAN ? TPP : 1;                     // pooling slots per row
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.x, b = blockIdx.y;
-  const int c0 = (wv * 64 + lane) * 2;
+  const int c0 = ((blockIdx.z * (blockDim.x >> 6) + wv) * 64 + lane) * 2;
   const Geo g = p.geo;
-  const int pcols = g.pcols;
+  const int ncell = CHAN ? g.pcols : g.cols / TPP;
+  const int ts = CHAN ? 1 : g.s_j;                       // memory tokens between consecutive tokens of a cell
   const int tok_x = 2 * p.d_in * (int)sizeof(T), tok_s = p.d_in * (int)sizeof(T);
   const int voff = c0 * (int)sizeof(T);
   const __amdgpu_buffer_rsrc_t bx = fv_make_buf((const T*)p.xz + (size_t)b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
   const __amdgpu_buffer_rsrc_t bs = fv_make_buf((T*)p.skip + (size_t)b * g.L * p.d_in, p.skip ? (size_t)g.L * tok_s : 0);
   const bool up = i > 0, down = i + 1 < g.rows;
-  // first memory token of cell jj of this row; jj = -1 / pcols are the neighbouring rows' last / first cell
+  // first memory token of cell jj of this row; jj = -1 / ncell are the neighbouring rows' last / first cell
   // (a missing neighbour row reads this row's own cell instead -- always mapped -- and is masked to zero)
   auto cell = [&](int jj) {
     int ri = i, cj = jj;
-    if (jj < 0) { ri = up ? i - 1 : i; cj = pcols - 1; }
-    else if (jj >= pcols) { ri = down ? i + 1 : i; cj = 0; }
-    return (ri * g.s_i + cj * g.s_j) * TPP;
+    if (jj < 0) { ri = up ? i - 1 : i; cj = ncell - 1; }
+    else if (jj >= ncell) { ri = down ? i + 1 : i; cj = 0; }
+    return CHAN ? (ri * g.s_i + cj * g.s_j) * TPP : ri * g.s_i + cj * TPP * g.s_j;
   };
   f2 wf[CW], wb[CW];
   load_taps2(p.wf, c0, wf);
   load_taps2(p.wb, c0, wb);
   const f2 bf = load_f2(p.bf, c0), bb = load_f2(p.bb, c0);
   const f2 Df = load_f2(p.skip ? p.Df : nullptr, c0), Db = load_f2(p.skip ? p.Db : nullptr, c0);
-  f2 accf[TPP], accb[TPP];
+  f2 accf[NS], accb[NS];
 #pragma unroll
-  for (int c = 0; c < TPP; ++c) accf[c] = accb[c] = splat(PMAX ? -INFINITY : 0.f);
+  for (int c = 0; c < NS; ++c) accf[c] = accb[c] = splat(PMAX ? -INFINITY : 0.f);
   P r1[TPP], r2[TPP];                    // packed cells j+1 and j+2
   f2 prev[3], cur[TPP];
   {
     P rp[3], rc[TPP];
     const int mp = cell(-1), mc = cell(0), m1 = cell(1), m2 = cell(2);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) rp[k].load(bx, voff, (mp + TPP - 3 + k) * tok_x);
+    for (int k = 0; k < 3; ++k) rp[k].load(bx, voff, (mp + (TPP - 3 + k) * ts) * tok_x);
 #pragma unroll
-    for (int c = 0; c < TPP; ++c) rc[c].load(bx, voff, (mc + c) * tok_x);
+    for (int c = 0; c < TPP; ++c) rc[c].load(bx, voff, (mc + c * ts) * tok_x);
 #pragma unroll
-    for (int c = 0; c < TPP; ++c) r1[c].load(bx, voff, (m1 + c) * tok_x);
+    for (int c = 0; c < TPP; ++c) r1[c].load(bx, voff, (m1 + c * ts) * tok_x);
 #pragma unroll
-    for (int c = 0; c < TPP; ++c) r2[c].load(bx, voff, (m2 + c) * tok_x);
+    for (int c = 0; c < TPP; ++c) r2[c].load(bx, voff, (m2 + c * ts) * tok_x);
     const float m_up = up ? 1.f : 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) prev[k] = rp[k].get(0) * m_up;
 #pragma unroll
     for (int c = 0; c < TPP; ++c) cur[c] = rc[c].get(0);
   }
-  for (int j = 0; j < pcols; ++j) {
+  for (int j = 0; j < ncell; ++j) {
     // window of cell j: prev[0..2] | cur[0..TPP) | next[0..2]
-    const float m_nx = (j + 1 < pcols || down) ? 1.f : 0.f;
+    const float m_nx = (j + 1 < ncell || down) ? 1.f : 0.f;
     f2 xw[TPP + 6];
 #pragma unroll
     for (int k = 0; k < 3; ++k) xw[k] = prev[k];
@@ -165,14 +171,15 @@ __global__ __launch_bounds__(512) void conv_pool_fwd_chan_kernel(FwdParams p) {
       const f2 xf = silu2(pf), xb = silu2(pb);
       if (p.skip) {
         const f2 sk[1] = {fma2(Df, xf, Db * xb)};
-        P::store(bs, voff, (mc + c) * tok_s, sk);
+        P::store(bs, voff, (mc + c * ts) * tok_s, sk);
       }
+      constexpr int sl = CHAN ? 1 : 0;               // slot of token c: c (channel path) or 0
       if (PMAX) {
-        accf[c] = __builtin_elementwise_max(accf[c], xf);
-        accb[c] = __builtin_elementwise_max(accb[c], xb);
+        accf[c * sl] = __builtin_elementwise_max(accf[c * sl], xf);
+        accb[c * sl] = __builtin_elementwise_max(accb[c * sl], xb);
       } else {
-        accf[c] += xf;
-        accb[c] += xb;
+        accf[c * sl] += xf;
+        accb[c * sl] += xb;
       }
     }
     // rotate: cell j+1 becomes current, j+2 waits, j+3 is fetched
@@ -182,15 +189,15 @@ __global__ __launch_bounds__(512) void conv_pool_fwd_chan_kernel(FwdParams p) {
     for (int c = 0; c < TPP; ++c) cur[c] = r1[c].get(0) * m_nx;
 #pragma unroll
     for (int c = 0; c < TPP; ++c) r1[c] = r2[c];
-    const int m3 = cell(j + 3 > pcols ? pcols : j + 3);
+    const int m3 = cell(j + 3 > ncell ? ncell : j + 3);
 #pragma unroll
-    for (int c = 0; c < TPP; ++c) r2[c].load(bx, voff, (m3 + c) * tok_x);
+    for (int c = 0; c < TPP; ++c) r2[c].load(bx, voff, (m3 + c * ts) * tok_x);
   }
   T* xc = (T*)p.xc;
-  const size_t dstride = (size_t)p.B * g.rows * TPP * p.d_in;
+  const size_t dstride = (size_t)p.B * g.rows * NS * p.d_in;
 #pragma unroll
-  for (int c = 0; c < TPP; ++c) {
-    const size_t o = (((size_t)b * g.rows + i) * TPP + c) * p.d_in + c0;
+  for (int c = 0; c < NS; ++c) {
+    const size_t o = (((size_t)b * g.rows + i) * NS + c) * p.d_in + c0;
     const f2 a = accf[c] * p.pool_scale, d = accb[c] * p.pool_scale;
     const float of[2] = {a.x, a.y}, ob[2] = {d.x, d.y};
     VecIO<T, 2>::store(xc + o, of);
@@ -198,12 +205,20 @@ __global__ __launch_bounds__(512) void conv_pool_fwd_chan_kernel(FwdParams p) {
   }
 }
 
-template <typename T, int TPP>
+// channel groups: the smallest split of d_in / 128 waves into blocks of at most 8 waves
+inline int chan_groups(int d_in) {
+  const int nw = d_in / 128;
+  int gq = (nw + 7) / 8;
+  while (nw % gq) ++gq;
+  return gq;
+}
+
+template <typename T, int TPP, bool CHAN>
 int launch_chan(const FwdParams& p, int pool_max, hipStream_t st) {
-  const int nch = p.d_in / 128;
-  dim3 grid(p.geo.rows, p.B), block(64 * nch);
-  if (pool_max) hipLaunchKernelGGL((conv_pool_fwd_chan_kernel<T, TPP, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((conv_pool_fwd_chan_kernel<T, TPP, false>), grid, block, 0, st, p);
+  const int gq = chan_groups(p.d_in), nch = p.d_in / 128 / gq;
+  dim3 grid(p.geo.rows, p.B, gq), block(64 * nch);
+  if (pool_max) hipLaunchKernelGGL((conv_pool_fwd_chan_kernel<T, TPP, true, CHAN>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((conv_pool_fwd_chan_kernel<T, TPP, false, CHAN>), grid, block, 0, st, p);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
@@ -231,13 +246,15 @@ int pick_np(const FwdParams& p, int pool_max, hipStream_t st) {
 }  // namespace
 
 int fvi::conv_pool_fwd_row(const FwdParams& p, int pool_max, int dtype, hipStream_t st) {
-  if (p.geo.tpp == 8 && p.geo.pcols >= 2 && !pool_max && p.d_in % 128 == 0 && p.d_in <= 8 * 128 &&
-      (size_t)p.geo.L * 2 * p.d_in * 4 <= 0xfffff000ull) {
-    static const bool chan = !(getenv("FASTVIM_FWD_CHAN") && atoi(getenv("FASTVIM_FWD_CHAN")) == 0);   // tuning hook
-    if (chan) return dtype == FV_F32 ? launch_chan<float, 8>(p, pool_max, st) : launch_chan<bf16_t, 8>(p, pool_max, st);
-  }
+  const bool fits = p.d_in % 128 == 0 && (size_t)p.geo.L * 2 * p.d_in * 4 <= 0xfffff000ull;   // one batch element per descriptor
+  static const bool chan = !(getenv("FASTVIM_FWD_CHAN") && atoi(getenv("FASTVIM_FWD_CHAN")) == 0);   // tuning hook
+  if (chan && fits && !pool_max && p.geo.tpp == 8 && p.geo.pcols >= 2 && p.d_in <= 8 * 128)
+    return dtype == FV_F32 ? launch_chan<float, 8, true>(p, pool_max, st) : launch_chan<bf16_t, 8, true>(p, pool_max, st);
+  // long rows of the dense path (cols = 32 / 64 / 128: the 512 / 1024 / 2048 px grids)
+  if (chan && fits && !pool_max && p.geo.tpp == 1 && p.geo.cols % 8 == 0 && p.geo.cols >= 24)
+    return dtype == FV_F32 ? launch_chan<float, 8, false>(p, pool_max, st) : launch_chan<bf16_t, 8, false>(p, pool_max, st);
   if (p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16)) return FV_ERR_UNSUPPORTED;
-  if ((size_t)p.geo.L * 2 * p.d_in * 4 > 0xfffff000ull) return FV_ERR_UNSUPPORTED;   // one batch element per descriptor
+  if (!fits) return FV_ERR_UNSUPPORTED;
   if (dtype == FV_F32) return p.geo.cols == 14 ? pick_np<float, 14>(p, pool_max, st) : pick_np<float, 16>(p, pool_max, st);
   return p.geo.cols == 14 ? pick_np<bf16_t, 14>(p, pool_max, st) : pick_np<bf16_t, 16>(p, pool_max, st);
 }

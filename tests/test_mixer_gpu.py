@@ -169,7 +169,10 @@ def test_mixer_full_size_deterministic_and_linear_in_out_proj():
     assert _err(y2, 2 * y1) <= 1e-5 * max(1.0, y2.abs().max().item())
 
 
-@pytest.mark.parametrize("d_model,grid", [(384, (6, 7)), (768, (4, 14)), (96, (5, 3)), (512, (3, 16))])
+@pytest.mark.parametrize("d_model,grid", [(384, (6, 7)), (768, (4, 14)), (96, (5, 3)), (512, (3, 16)),
+                                          # long rows (cols a multiple of 8: the 512 / 1024 / 2048 px grids) take the
+                                          # cell-walking conv kernels; d_inner = 1536 splits its channels over two blocks
+                                          (192, (3, 32)), (768, (2, 24)), (64, (2, 40))])
 def test_mixer_wide_models_vs_oracle(d_model, grid):
     """FastVim-S / -B widths (2 and 4 waves per pooling row, cross-wave LayerNorm statistics) and
     widths that take the generic lane mapping, fp32, forward + all gradients against the fp64 oracle."""
