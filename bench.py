@@ -19,6 +19,12 @@ import os
 import sys
 import time
 
+# ROCm 7.2's HIP-graph "packet capture" path (pre-recorded AQL packets) replays some captured training steps wrongly:
+# FastVim-T at 512 px bs=32 and the MAE step at bs >= 64 turn non-finite after a few replays while the same steps are
+# finite eagerly and with this switch off.  Off costs nothing measurable (8.74 vs 8.74 ms at
+# FastVim-T 224 px) -- it must be set before the HIP runtime initialises.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -344,12 +350,6 @@ def main():
         return loss.detach()
 
     use_graph = not args.no_graph
-    if args.model == "M" and os.environ.get("FASTVIM_MAE_GRAPH") != "1":
-        # OPEN ISSUE: the graph-captured MAE step turns non-finite after a few replays on ROCm 7.2,
-        # while the same step is finite eagerly (also with NaN-poisoned allocator memory) and when extra kernels are
-        # captured between its stages, and finite with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (no pre-recorded AQL packets);
-        # graph replay is not faster than eager at this step size (42.4 vs 41.8 ms), so the MAE model launches eagerly
-        use_graph = False
     if use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
