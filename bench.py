@@ -310,11 +310,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hook: FASTVIM_BENCH_ONE_GPU=1 puts every rank on GPU 0 and exchanges gradients through gloo, so the
+    # multi-rank code path (graph replay -> all-reduce -> optimizer) can be exercised on a one-GPU box
+    one_gpu = os.environ.get("FASTVIM_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
     from fastvim_amd.flat import FlatAdamW, FlatTrainingState
 
