@@ -448,6 +448,22 @@ def main():
                                "unit": "GB/s", "frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "avg_us": kt[dom]["us"],
                                "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6)}
+            if dom.startswith("scan"):
+                # the pooled scan moves 1/cols of a full-length tensor: it is bound by VALU issue, not by HBM
+                # (profiles/r01_pmc_scan_bwd.json: ~85 % of the SIMD issue slots busy at 4 waves/SIMD); the
+                # HBM-bound and MFMA-bound kernels of the step are reported next to it
+                out["roofline"]["note"] = "VALU-issue bound (pooled tensors are 1/cols of full length); see roofline_others"
+            hbm_rows = [k for k in kt if not k.startswith(("scan", "gemm"))]
+            gemm_rows = [k for k in kt if k.startswith("gemm")]
+            hb = max(hbm_rows, key=lambda k: kt[k]["us_per_step"])
+            gm = max(gemm_rows, key=lambda k: kt[k]["us_per_step"])
+            out["roofline_others"] = {
+                "largest_hbm_bound_kernel": {"kernel": hb, "bound": "hbm", "achieved": kt[hb]["GBps"], "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": round(kt[hb]["GBps"] / HBM_PEAK_GBS, 4),
+                                             "avg_us": kt[hb]["us"]},
+                "largest_gemm": {"kernel": gm, "bound": "mfma", "achieved": kt[gm]["TFLOPs"], "peak": 2500.0,
+                                 "unit": "TFLOP/s", "frac": kt[gm]["mfma_frac"], "hbm_GBps": kt[gm]["GBps"],
+                                 "avg_us": kt[gm]["us"]}}
         if not args.no_cpu_baseline and world == 1 and args.model not in ("C", "V", "M"):
             out["cpu_baseline"] = cpu_baseline()
         if not args.no_scan_op and not args.no_kernels and world == 1 and args.model == "T":
