@@ -68,7 +68,8 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rg = wv / nch, cw = wv - rg * nch;
-  const int c0 = (cw * 64 + lane) * 2;                 // first channel of this lane's pair
+  const int c_lo = blockIdx.y * nch * 128;             // channels beyond 1024 are split over blockIdx.y
+  const int c0 = c_lo + (cw * 64 + lane) * 2;          // first channel of this lane's pair
   const Geo g = p.geo;
   f2 wf[CW], wb[CW], bf, bb, Dfh, Dbh;
   load_taps2(p.wf, c0, wf);
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
       }
     }
   }
-  flush_partials(p, smem, c0, 0, p.d_in, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
+  flush_partials(p, smem, c0, c_lo, nch * 128, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
 }
 
 // Long rows, walked cell by cell like conv_pool_fwd_chan_kernel: CHAN = channel-wise tokenization (tokens_per_patch ==
@@ -375,7 +376,7 @@ int launch_chan(const BwdParams& p, int nch, int rgr, int grid, int groups, size
 }
 
 template <typename T, int NT>
-int launch_row(const BwdParams& p, int nch, int rgr, int grid, size_t smem, hipStream_t st) {
+int launch_row(const BwdParams& p, int nch, int rgr, int grid, int groups, size_t smem, hipStream_t st) {
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
     static bool done = false;
     if (!done) {
@@ -383,7 +384,7 @@ int launch_row(const BwdParams& p, int nch, int rgr, int grid, size_t smem, hipS
       done = true;
     }
   }
-  hipLaunchKernelGGL((conv_pool_bwd_row_kernel<T, NT>), dim3(grid), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
+  hipLaunchKernelGGL((conv_pool_bwd_row_kernel<T, NT>), dim3(grid, groups), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
@@ -396,26 +397,27 @@ int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t
   if ((size_t)p.geo.L * 2 * p.d_in * 4 > 0xfffff000ull) return FV_ERR_UNSUPPORTED;   // one batch element per descriptor
   const bool chan8 = p.geo.tpp == 8 && p.geo.pcols >= 2;
   const bool dense8 = p.geo.tpp == 1 && p.geo.cols % 8 == 0 && p.geo.cols >= 24;      // 512 / 1024 / 2048 px grids
+  int groups = (nch + 7) / 8;                   // channel groups of at most 8 waves over blockIdx.y
+  while (nch % groups) ++groups;
+  const int nchg = nch / groups;
+  // rows live in registers: blocks of <= 512 threads (256 VGPRs per wave), i.e. fewer row groups per block than the
+  // generic kernel, over the same persistent grid
+  const int cap = 8 / nchg < 1 ? 1 : 8 / nchg;
+  const int rgr = rg < cap ? rg : cap;
   if (chan8 || dense8) {
     static const bool chan = !(getenv("FASTVIM_BWD_CHAN") && atoi(getenv("FASTVIM_BWD_CHAN")) == 0);   // tuning hook
     if (!chan) return FV_ERR_UNSUPPORTED;
-    int groups = (nch + 7) / 8;                 // channel groups of at most 8 waves over blockIdx.y
-    while (nch % groups) ++groups;
-    const int nchg = nch / groups;
-    const int capc = 8 / nchg < 1 ? 1 : 8 / nchg;
-    const int rgc = rg < capc ? rg : capc;
-#define FV_CH(TT, CC) launch_chan<TT, 8, CC>(p, nchg, rgc, grid, groups, smem, st)
+#define FV_CH(TT, CC) launch_chan<TT, 8, CC>(p, nchg, rgr, grid, groups, smem, st)
     if (dtype == FV_F32) return chan8 ? FV_CH(float, true) : FV_CH(float, false);
     return chan8 ? FV_CH(bf16_t, true) : FV_CH(bf16_t, false);
 #undef FV_CH
   }
-  if (nch > 8) return FV_ERR_UNSUPPORTED;
   if (p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16)) return FV_ERR_UNSUPPORTED;
-  // a whole row lives in registers: blocks of <= 512 threads (256 VGPRs per wave), i.e. fewer row groups per
-  // block than the generic kernel, over the same persistent grid
-  const int cap = 8 / nch < 1 ? 1 : 8 / nch;
-  const int rgr = rg < cap ? rg : cap;
+  static const bool wide = !(getenv("FASTVIM_BWD_ROWK_WIDE") && atoi(getenv("FASTVIM_BWD_ROWK_WIDE")) == 0);   // tuning hook
+  if (groups > 1 && !wide) return FV_ERR_UNSUPPORTED;
   if (dtype == FV_F32)
-    return p.geo.cols == 14 ? launch_row<float, 14>(p, nch, rgr, grid, smem, st) : launch_row<float, 16>(p, nch, rgr, grid, smem, st);
-  return p.geo.cols == 14 ? launch_row<bf16_t, 14>(p, nch, rgr, grid, smem, st) : launch_row<bf16_t, 16>(p, nch, rgr, grid, smem, st);
+    return p.geo.cols == 14 ? launch_row<float, 14>(p, nchg, rgr, grid, groups, smem, st)
+                            : launch_row<float, 16>(p, nchg, rgr, grid, groups, smem, st);
+  return p.geo.cols == 14 ? launch_row<bf16_t, 14>(p, nchg, rgr, grid, groups, smem, st)
+                          : launch_row<bf16_t, 16>(p, nchg, rgr, grid, groups, smem, st);
 }
