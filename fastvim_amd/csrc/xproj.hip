@@ -7,6 +7,8 @@
 // One lane per channel d: it keeps column d of the weight (W values) and W accumulators of the
 // weight gradient in registers; the dx_dbl rows of the block's row slice are LDS broadcasts.  Blocks
 // emit per-slice partials of the weight gradient for the fixed-order reduction (no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -20,7 +22,7 @@ struct XprojParams {
   int nchunks, M, d_in, rows_per_block;
 };
 
-template <typename T, int W>
+template <typename T, int W, int RB>
 __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
   extern __shared__ __attribute__((aligned(16))) float s_dx[];     // rows_per_block * W
   const int dir = blockIdx.z, slice = blockIdx.y;
@@ -45,16 +47,16 @@ __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
   }
   const T* xc = (const T*)p.xc + ((size_t)dir * p.M + m0) * p.d_in + dd;
   float* dxc = p.dxc + ((size_t)dir * p.M + m0) * p.d_in + dd;
-  for (int r0 = 0; r0 < nr; r0 += 4) {
-    float xv[4], base[4];
+  for (int r0 = 0; r0 < nr; r0 += RB) {       // RB rows of loads in flight per lane
+    float xv[RB], base[RB];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RB; ++k) {
       const int r = min(r0 + k, nr - 1);
       xv[k] = io<T>::ld(xc + (size_t)r * p.d_in);
       base[k] = dxc[(size_t)r * p.d_in];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RB; ++k) {
       if (r0 + k < nr) {
         const float* row = s_dx + (r0 + k) * W;
         float o = base[k];
@@ -77,7 +79,11 @@ __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
 
 }  // namespace
 
-extern "C" int fv_mixer_xproj_bwd_slices(int M) { return fv_cdiv(M, 16); }
+static int xproj_rows() {
+  static const int r = getenv("FASTVIM_XPROJ_ROWS") ? atoi(getenv("FASTVIM_XPROJ_ROWS")) : 16;   // tuning hook
+  return r;
+}
+extern "C" int fv_mixer_xproj_bwd_slices(int M) { return fv_cdiv(M, xproj_rows()); }
 
 extern "C" int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
                                   const float* x_proj_w_b, float* dxc, float* dW_partials, int M, int d_inner,
@@ -87,11 +93,17 @@ extern "C" int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, con
   FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_xproj_bwd: dtype must be fp32 or bf16");
   XprojParams p{};
   p.dxdbl_part = dx_dbl_partials; p.xc = xc; p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.dxc = dxc;
-  p.dW_part = dW_partials; p.nchunks = nchunks; p.M = M; p.d_in = d_inner; p.rows_per_block = 16;
+  p.dW_part = dW_partials; p.nchunks = nchunks; p.M = M; p.d_in = d_inner; p.rows_per_block = xproj_rows();
   const int bs = d_inner >= 256 ? 128 : 64;
+  static const int rb = getenv("FASTVIM_XPROJ_RB") ? atoi(getenv("FASTVIM_XPROJ_RB")) : 8;   // tuning hook (rows of loads in flight; 8: 25.7 vs 26.8 us)
   dim3 grid(fv_cdiv(d_inner, bs), fv_mixer_xproj_bwd_slices(M), 2), block(bs);
   hipStream_t st = (hipStream_t)stream;
-#define FV_XP(TT, WW) hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW>), grid, block, (size_t)16 * WW * 4, st, p)
+#define FV_XP(TT, WW)                                                                                        \
+  do {                                                                                                       \
+    if (rb == 8) hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW, 8>), grid, block, (size_t)xproj_rows() * WW * 4, st, p);   \
+    else if (rb == 16) hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW, 16>), grid, block, (size_t)xproj_rows() * WW * 4, st, p); \
+    else hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW, 4>), grid, block, (size_t)xproj_rows() * WW * 4, st, p); \
+  } while (0)
 #define FV_XPD(WW) do { if (dtype == FV_F32) FV_XP(float, WW); else FV_XP(bf16_t, WW); } while (0)
   switch (width) {   // dt_rank + 2 * d_state for d_model = 192 / 384 / 768 / 1024 / 1280 (d_state 16) and small test models
     case 44: FV_XPD(44); break;

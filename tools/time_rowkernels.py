@@ -35,4 +35,10 @@ out["combine_fwd"] = time_kernel(lambda: M.combine_fwd(xz, skip, yc, lnw, lnb, 1
 out["combine_bwd"] = time_kernel(lambda: M.combine_bwd(dg, xz, skip, yc, lnw, lnb, mean, rstd, dxz, rows, cols, False, tpp=tpp))
 out["scan_bwd"] = time_kernel(lambda: M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc))
 out["conv_pool_bwd"] = time_kernel(lambda: M.conv_pool_bwd(xz, d_o, dxc, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 0, 1.0, tpp=tpp))
+W_ = R_ + 2 * N
+if W_ in M.XPROJ_WIDTHS:
+    Wx = rn(W_, d_in, dt=torch.float32)
+    dxc2, dxd_chunks, _ = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc, keep_chunks=True)
+    gW = torch.zeros(2, W_, d_in, device=dev)
+    out["xproj_bwd"] = time_kernel(lambda: M.xproj_bwd(dxd_chunks, xc, Wx, Wx, dxc2, grad_out=gW))
 print(os.environ.get("FASTVIM_DBG", ""), " ".join(f"{k}={v * 1e6:.1f}" for k, v in out.items()), flush=True)
