@@ -158,7 +158,7 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lan
 // 64x64 wave tile reads 8 KiB of fragments for 16 MFMAs -- at the full MFMA rate that is exactly the 128 B/clk the
 // LDS delivers -- while a 128x64 wave tile reads 12 KiB for 32.
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id, int split) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN, WNC = 16 * NB, WMR = 16 * MB;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -170,14 +170,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
   // XCD-aware tile order: the N tiles that share an A row panel are consecutive on one XCD
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
+  int bid = block_id;
   {
     const int q8 = nblk / 8, r8 = nblk % 8, xcd = bid % 8, j = bid / 8;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;   // bijective remap
   }
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
   }
   }
   // epilogue: acc[a][b][j] = C[m = m0 + wm*WMR + b*16 + (lane&15)][n = n0 + wn*WNC + a*16 + (lane>>4)*4 + j]
-  const long zoff = (long)blockIdx.z * p.c_split_stride;
+  const long zoff = (long)split * p.c_split_stride;
   if (p.bias) {
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
@@ -313,6 +313,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
         for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = v[j];
     }
   }
+}
+
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
+  gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB>(p, blockIdx.x, blockIdx.z);
+}
+
+// Several independent problems in ONE launch (the weight gradients of a whole backward pass, queued until its end):
+// a single weight-gradient GEMM at FastVim-T is 168-336 workgroups -- a third to two thirds of what the chip holds at
+// once -- and every launch pays that tail; the grouped launch is one long queue of workgroups.
+constexpr int GROUP_MAX = 16;
+struct GroupedParams {
+  GemmParams p[GROUP_MAX];
+  int blk_end[GROUP_MAX];     // exclusive prefix of (tiles x splits) workgroups per problem
+  int count;
+};
+
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_grouped_kernel(GroupedParams G) {
+  int j = 0;
+  while (j + 1 < G.count && (int)blockIdx.x >= G.blk_end[j]) ++j;
+  const GemmParams& p = G.p[j];
+  const int local = blockIdx.x - (j ? G.blk_end[j - 1] : 0);
+  constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int split = local / tiles;
+  gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB>(p, local - split * tiles, split);
 }
 
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
@@ -402,4 +429,40 @@ extern "C" int fv_gemm_bf16(const void* A, const void* B, void* C, const float* 
   if (a_k_slow && b_k_slow) return launch_shape<KS, KS>(p, splits, st);
   fv_set_error("gemm_bf16: A K-slow with B K-contiguous is not built");
   return FV_ERR_UNSUPPORTED;
+}
+
+// Grouped weight gradients: problem i is x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32,
+// both operands K-slow (rows = tokens), split-K over whole 64-deep tiles, 128x128 tiles, register staging -- exactly
+// the form fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1) launches one at a time.
+extern "C" int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
+                                       const int* M, const int* N, const int* splits, int count, fv_stream_t stream) {
+  FV_CHECK(x && y && parts && Kd && M && N && splits && count > 0, "gemm_bf16_tn_grouped: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < count; base += GROUP_MAX) {
+    GroupedParams G{};
+    const int n = count - base < GROUP_MAX ? count - base : GROUP_MAX;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+      const int q = base + i;
+      FV_CHECK(x[q] && y[q] && parts[q] && Kd[q] > 0 && M[q] > 0 && N[q] > 0 && splits[q] >= 1,
+               "gemm_bf16_tn_grouped: bad problem %d", q);
+      FV_CHECK(M[q] % 8 == 0 && N[q] % 8 == 0 && ((uintptr_t)x[q] & 15) == 0 && ((uintptr_t)y[q] & 15) == 0 &&
+                   ((uintptr_t)parts[q] & 15) == 0 && N[q] % 4 == 0,
+               "gemm_bf16_tn_grouped: problem %d: operands must be 16-byte aligned with M, N multiples of 8", q);
+      GemmParams& p = G.p[i];
+      p.A = (const bf16_t*)x[q]; p.B = (const bf16_t*)y[q]; p.C = parts[q]; p.bias = nullptr;
+      p.M = M[q]; p.N = N[q]; p.K = Kd[q]; p.lda = M[q]; p.ldb = N[q]; p.ldc = N[q]; p.c_fp32 = 1;
+      p.k_per_split = fv_cdiv(fv_cdiv(Kd[q], splits[q]), BK) * BK;
+      p.c_split_stride = (long)M[q] * N[q];
+      FV_CHECK(fv_cdiv(Kd[q], p.k_per_split) == splits[q],
+               "gemm_bf16_tn_grouped: problem %d: K=%d cannot be cut into %d slices of whole 64-deep tiles", q, Kd[q], splits[q]);
+      blocks += fv_cdiv(M[q], 128) * fv_cdiv(N[q], 128) * splits[q];
+      G.blk_end[i] = blocks;
+    }
+    G.count = n;
+    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256),
+                       (size_t)2 * (128 + 128) * BK * 2, st, G);
+    FV_LAUNCH_CHECK();
+  }
+  return FV_OK;
 }

@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from .layernorm import RMSNorm
-from .mamba_simple_faster import Mamba, _SideStream
+from .mamba_simple_faster import Mamba, _SideStream, flush_wgrads, group_wgrads
 from .mixer_ops import defer_reductions, flush_reductions
 
 # per-mixer parameter order; each group is one contiguous region matching a kernel's partial layout
@@ -94,6 +94,7 @@ class FlatTrainingState:
                     mod.weight._fv_direct = True     # my backward kernels may accumulate into .grad directly
         self.refresh_shadow()
         defer_reductions(True)
+        group_wgrads(True)
         # weight-gradient GEMMs on a second stream (joined in finish_backward): measured neutral-to-slower
         # on MI355X under graph replay (12.35 vs 12.04 ms/step), so opt-in only
         _SideStream.enabled = os.environ.get("FASTVIM_WGRAD_STREAM", "0") == "1"
@@ -101,6 +102,7 @@ class FlatTrainingState:
     # ------------------------------------------------------------------ per-step operations
     def zero_grad(self):
         _SideStream.join()
+        flush_wgrads()
         flush_reductions()
         self.grad_flat.zero_()
 
@@ -108,7 +110,8 @@ class FlatTrainingState:
         """Join the weight-gradient stream and issue the queued gradient reductions; call after
         loss.backward(), before reading any .grad."""
         _SideStream.join()
-        flush_reductions()
+        flush_wgrads()            # grouped weight-gradient GEMMs queue their partial sums ...
+        flush_reductions()        # ... which are issued here
 
     def refresh_shadow(self):
         self.shadow_flat.copy_(self.param_flat)

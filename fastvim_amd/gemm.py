@@ -1,5 +1,6 @@
 """Host wrappers of the bf16 MFMA GEMM (csrc/gemm_mfma.hip, C ABI fv_gemm_bf16)."""
 import ctypes
+import os
 
 import torch
 
@@ -69,3 +70,48 @@ def gemm_tn(x, y, splits=1, out=None, accumulate=False, defer=True):
         reduce_partials(part, splits, out=out, accumulate=accumulate, defer=defer)
         return None
     return part[0] if splits == 1 else reduce_partials(part, splits)
+
+
+def grouped_splits(Kd, target=None):
+    """Split-K factor inside a grouped launch: the queue of workgroups is long whatever the factor, so it only trades
+    the length of one workgroup's K loop against the fp32 partial traffic -- the largest divisor of the K tiles not
+    above ``target`` (default 7, FASTVIM_WGRAD_GROUP_SPLITS overrides)."""
+    if target is None:
+        target = int(os.environ.get("FASTVIM_WGRAD_GROUP_SPLITS", "7"))
+    if Kd % 64:
+        return 1
+    kt = Kd // 64
+    best = 1
+    for s_ in range(1, min(target, kt) + 1):
+        if kt % s_ == 0:
+            best = s_
+    return best
+
+
+def gemm_tn_grouped(jobs):
+    """jobs: list of (x (Kd, M) bf16, y (Kd, N) bf16, out flat fp32 view of (M, N), splits).  ONE launch per 16
+    problems computes every problem's split-K partials; the partials are then summed (deferred, fixed order) into
+    ``out`` (accumulate)."""
+    if not jobs:
+        return
+    k = len(jobs)
+    parts = []
+    for x, y, out, sp in jobs:
+        Kd, M = x.shape
+        N = y.shape[1]
+        assert x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and x.is_contiguous() and y.is_contiguous()
+        assert out.numel() == M * N and out.dtype == torch.float32
+        parts.append(torch.empty(sp, M, N, device=x.device, dtype=torch.float32))
+    P = ctypes.c_void_p
+    xs = (P * k)(*[j[0].data_ptr() for j in jobs])
+    ys = (P * k)(*[j[1].data_ptr() for j in jobs])
+    ps = (P * k)(*[p_.data_ptr() for p_ in parts])
+    I = ctypes.c_int
+    Kds = (I * k)(*[j[0].shape[0] for j in jobs])
+    Ms = (I * k)(*[j[0].shape[1] for j in jobs])
+    Ns = (I * k)(*[j[1].shape[1] for j in jobs])
+    sps = (I * k)(*[j[3] for j in jobs])
+    rc = L.lib().fv_gemm_bf16_tn_grouped(xs, ys, ps, Kds, Ms, Ns, sps, L.i32(k), L.stream_of(jobs[0][0]))
+    L.check(rc, "gemm_bf16_tn_grouped")
+    for (x, y, out, sp), part in zip(jobs, parts):
+        reduce_partials(part, sp, out=out, accumulate=True)

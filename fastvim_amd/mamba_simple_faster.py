@@ -9,6 +9,7 @@ backward; activations stay token-major so in_proj/out_proj are plain row-major G
 odd-layer grid transpose of ``Block`` is a stride pair, not a copy (``transposed_grid``).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -101,10 +102,44 @@ class _SideStream:
         cls.pending = []
 
 
+class _GroupedWgrad:
+    """Weight gradients are only needed before the optimizer step.  With the flat training state they are queued
+    (operands kept alive) and computed by grouped launches (fv_gemm_bf16_tn_grouped, 16 problems each) at the end of
+    the backward pass: one weight-gradient GEMM at FastVim-T is 168-336 workgroups, a fraction of what the chip holds
+    at once, so each separate launch pays a tail; the grouped queue does not, and with the tail gone a smaller
+    split-K factor (less fp32 partial traffic) is affordable.  FASTVIM_WGRAD_GROUP=0 turns it off."""
+    enabled = False
+    jobs = []
+
+    @classmethod
+    def add(cls, g2, a2, out):
+        from .gemm import grouped_splits
+        cls.jobs.append((g2, a2, out, grouped_splits(g2.shape[0])))
+
+    @classmethod
+    def flush(cls):
+        if cls.jobs:
+            from .gemm import gemm_tn_grouped
+            jobs, cls.jobs = cls.jobs, []
+            gemm_tn_grouped(jobs)
+
+
+def group_wgrads(on):
+    _GroupedWgrad.flush()
+    _GroupedWgrad.enabled = bool(on) and os.environ.get("FASTVIM_WGRAD_GROUP", "1") != "0"
+
+
+def flush_wgrads():
+    _GroupedWgrad.flush()
+
+
 def linear_wgrad(g2, a2, W=None, splits=None):
     """dW (N, K) fp32 = g2 (M, N)^T a2 (M, K), deterministic split-K; accumulates into W's flat .grad if present."""
     if _mfma_ok(g2, a2) and g2.shape[1] % 8 == 0 and a2.shape[1] % 8 == 0 and g2.shape[0] % 64 == 0:
         gdir = _direct_grad(W) if W is not None else None
+        if gdir is not None and _GroupedWgrad.enabled and splits is None and g2.is_contiguous() and a2.is_contiguous():
+            _GroupedWgrad.add(g2, a2, gdir.view(-1))
+            return None
         if gdir is not None:
             gemm_tn(g2, a2, splits=splits, out=gdir.view(-1), accumulate=True, defer=not _SideStream.enabled)
             return None

@@ -76,7 +76,7 @@ class MaskedFastVimMixerFn(torch.autograd.Function):
             dout = dout.to(cdt).contiguous()
             do2 = dout.view(B * Lk, d)
             dg = linear_dgrad(do2, _shadow(W_out, cdt))
-            dW_out = linear_wgrad(do2, g.view(B * Lk, d_in))
+            dW_out = linear_wgrad(do2, g.view(B * Lk, d_in), W_out)      # None when queued / accumulated into the flat gradient
             db_out = do2.float().sum(0) if ctx.has_bias[1] else None
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
@@ -92,7 +92,7 @@ class MaskedFastVimMixerFn(torch.autograd.Function):
             p2 = M.conv_pool_bwd(xz, d_o, dxc_tok, cw2, cb, cwb2, cb_b, D, D_b, dxz, srows, 1, False, False, 1.0, tpp=t)
             dxz2 = dxz.view(B * Lk, 2 * d_in)
             dhidden = linear_dgrad(dxz2, _shadow(W_in, cdt)).view(B, Lk, d).to(ctx.in_dtype)
-            dW_in = linear_wgrad(dxz2, h_c.view(B * Lk, d))
+            dW_in = linear_wgrad(dxz2, h_c.view(B * Lk, d), W_in)
             db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
         n4 = 4 * d_in
         N_, R_ = A_log.shape[1], Wdt.shape[1]

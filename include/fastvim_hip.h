@@ -256,6 +256,12 @@ int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidual_out, int
 int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                  long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits, fv_stream_t stream);
 
+/* Several weight gradients in one launch (queued until the end of the backward pass): problem i is
+ * x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32 partials (sum with fv_reduce_partials);
+ * the same arithmetic, tiling and fixed split order as fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1). */
+int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
+                            const int* M, const int* N, const int* splits, int count, fv_stream_t stream);
+
 /* Adjoint of x_proj for both directions, fused with the sum of the scan backward's chunk partials
  * (replaces the einsum/addmm chain of selective_scan_interface.py:698-734):
  *   dx_dbl = sum_c dx_dbl_partials[c];  dxc += dx_dbl @ W;  dW_partials[slice] = dx_dbl[slice]^T @ xc[slice].

@@ -58,3 +58,26 @@ def test_gemm_strided_views():
     y = torch.randn(512, 64, device="cuda").bfloat16()
     ref2 = _ref(a.t(), y)
     assert (gemm_tn(a, y).double().cpu() - ref2).abs().max().item() <= 2e-4 * ref2.abs().max().item()
+
+
+def test_grouped_weight_gradients_match_single_launches():
+    """fv_gemm_bf16_tn_grouped: several x^T y problems of different shapes and split factors in one launch (more
+    than 16 problems -> two launches) against fp64 and, for equal split factors, bit for bit against gemm_tn."""
+    from fastvim_amd.gemm import gemm_tn, gemm_tn_grouped
+    torch.manual_seed(0)
+    shapes = [(1792, 768, 192, 7), (1792, 192, 384, 4), (896, 192, 768, 14), (640, 64, 40, 1), (1280, 136, 8, 5)] * 4
+    jobs, refs, singles = [], [], []
+    for Kd, M_, N_, sp in shapes:
+        x = torch.randn(Kd, M_, device="cuda").bfloat16()
+        y = torch.randn(Kd, N_, device="cuda").bfloat16()
+        out = torch.zeros(M_ * N_, device="cuda")
+        jobs.append((x, y, out, sp))
+        refs.append(x.double().t() @ y.double())
+        singles.append(gemm_tn(x, y, splits=sp))
+    gemm_tn_grouped(jobs)
+    from fastvim_amd.mixer_ops import flush_reductions
+    flush_reductions()
+    for (x, y, out, sp), ref, single in zip(jobs, refs, singles):
+        got = out.view(ref.shape)
+        assert (got.double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+        assert torch.equal(got, single)
