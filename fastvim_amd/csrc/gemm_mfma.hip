@@ -460,8 +460,25 @@ extern "C" int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* 
       G.blk_end[i] = blocks;
     }
     G.count = n;
-    hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256),
-                       (size_t)2 * (128 + 128) * BK * 2, st, G);
+    static const int tile = getenv("FASTVIM_WGRAD_GROUP_TILE") ? atoi(getenv("FASTVIM_WGRAD_GROUP_TILE")) : 0;   // tuning hook
+    if (tile == 7) {          // 8 waves, 256x192 tiles (every N = 192 problem reads its wide operand once)
+      int b2 = 0;
+      for (int i = 0; i < n; ++i) {
+        b2 += fv_cdiv(G.p[i].M, 256) * fv_cdiv(G.p[i].N, 192) * fv_cdiv(G.p[i].K, G.p[i].k_per_split);
+        G.blk_end[i] = b2;
+      }
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 4, 2, false, 6, 4>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * BK * 2);
+        attr = true;
+      }
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 4, 2, false, 6, 4>), dim3(b2), dim3(512),
+                         (size_t)2 * (256 + 192) * BK * 2, st, G);
+    } else {
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256),
+                         (size_t)2 * (128 + 128) * BK * 2, st, G);
+    }
     FV_LAUNCH_CHECK();
   }
   return FV_OK;

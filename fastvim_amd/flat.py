@@ -89,7 +89,7 @@ class FlatTrainingState:
                 fv["Wx2_shadow"] = self.shadow_flat[lo:hi].view(shp)
                 fv["Wx2_grad"] = self.grad_flat[lo:hi].view(shp)
         for mod in model.modules():
-            if isinstance(mod, (RMSNorm, torch.nn.LayerNorm, torch.nn.Linear)) and getattr(mod, "weight", None) is not None:
+            if isinstance(mod, (RMSNorm, torch.nn.LayerNorm, torch.nn.Linear, torch.nn.Conv2d)) and getattr(mod, "weight", None) is not None:
                 if mod.weight.requires_grad:
                     mod.weight._fv_direct = True     # my backward kernels may accumulate into .grad directly
         self.refresh_shadow()
