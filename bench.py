@@ -153,15 +153,24 @@ def kernel_table(B, rows, cols, d, depth, dtype):
                             B * L * d * (2 * e + 8), 1),
     }
     out = {}
+    # the backward wrappers sum their per-block gradient partials right away when no flat gradient is attached; in
+    # the training step those sums are deferred into reduce_partials_multi launches (timed by the step, not here), so
+    # they are switched off while a row's own kernel is timed
+    real_reduce = M.reduce_partials
+    M.reduce_partials = lambda part, n, out=None, **kw: out if out is not None else part[0]
+    try:
+        timed = {name: time_kernel(fn) for name, (fn, _, _) in table.items()}
+    finally:
+        M.reduce_partials = real_reduce
     for name, (fn, nbytes, per_block) in table.items():
-        t = time_kernel(fn)
+        t = timed[name]
         out[name] = {"us": round(t * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3),
                      "GBps": round(nbytes / t / 1e9, 1), "launches_per_step": per_block * depth,
                      "us_per_step": round(t * 1e6 * per_block * depth, 1)}
     if dtype == torch.bfloat16:
         # the six projection GEMMs of a block (hand-written MFMA kernel, csrc/gemm_mfma.hip): HBM bytes AND
         # MFMA flops -- at FastVim-T widths (K or N = 192) they sit below the ridge, i.e. are HBM-bound
-        from fastvim_amd.gemm import auto_splits, gemm_nn, gemm_nt, gemm_tn
+        from fastvim_amd.gemm import gemm_nn, gemm_nt
         Mt = B * L
         h2, g2, xz2, do2 = rn(Mt, d), rn(Mt, d_in), rn(Mt, 2 * d_in), rn(Mt, d)
         W_in, W_out = rn(2 * d_in, d), rn(d, d_in)
@@ -170,9 +179,24 @@ def kernel_table(B, rows, cols, d, depth, dtype):
             "gemm_out_proj_fwd": (lambda: gemm_nt(g2, W_out), Mt, d, d_in, 0),
             "gemm_out_proj_dgrad": (lambda: gemm_nn(do2, W_out), Mt, d_in, d, 0),
             "gemm_in_proj_dgrad": (lambda: gemm_nn(xz2, W_in), Mt, d, 2 * d_in, 0),
-            "gemm_in_proj_wgrad": (lambda: gemm_tn(xz2, h2, splits=None), 2 * d_in, d, Mt, auto_splits(Mt, 2 * d_in, d)),
-            "gemm_out_proj_wgrad": (lambda: gemm_tn(do2, g2, splits=None), d, d_in, Mt, auto_splits(Mt, d, d_in)),
         }
+        # weight gradients run as grouped launches of 16 problems at the end of backward: one
+        # launch of 8 in_proj + 8 out_proj problems is timed here (reductions of the fp32 partials included)
+        from fastvim_amd.gemm import gemm_tn_grouped, grouped_splits
+        from fastvim_amd.mixer_ops import flush_reductions
+        sp = grouped_splits(Mt)
+        gi, go = torch.zeros(2 * d_in * d, device=dev), torch.zeros(d * d_in, device=dev)
+
+        def wgrad_group():
+            gemm_tn_grouped([(xz2, h2, gi, sp), (do2, g2, go, sp)] * 8)
+            flush_reductions()
+        t = time_kernel(wgrad_group)
+        fl = 8 * 2.0 * Mt * (2 * d_in * d + d * d_in)
+        nbytes = 8 * (2 * Mt * (2 * d_in + d + d + d_in) + 4 * (2 * sp + 1) * (2 * d_in * d + d * d_in))
+        out["gemm_wgrad_grouped_x16"] = {
+            "us": round(t * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3), "GBps": round(nbytes / t / 1e9, 1),
+            "TFLOPs": round(fl / t / 1e12, 1), "mfma_frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "launches_per_step": depth / 8.0, "us_per_step": round(t * 1e6 * depth / 8.0, 1), "split_k": sp}
         for name, (fn, m_, n_, k_, splits) in gemms.items():
             t = time_kernel(fn)
             nbytes = 2 * (m_ * k_ + n_ * k_) + (2 * m_ * n_ if not splits else 4 * m_ * n_ * (2 * splits + 1))
