@@ -1,0 +1,12 @@
+"""Achievable HBM write / copy rates on this GPU for tensors of the projection-output size (probe)."""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import torch
+from bench import time_kernel
+for mb in (9.6, 19.3, 38.5, 77, 308):
+    n = int(mb * 1e6 / 2)
+    x = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    y = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    tf = time_kernel(lambda: x.fill_(1.0))
+    tc = time_kernel(lambda: y.copy_(x))
+    print(f"{mb:6.1f} MB: fill {tf*1e6:6.1f} us = {mb/tf/1e6:5.2f} TB/s   copy {tc*1e6:6.1f} us = {2*mb/tc/1e6:5.2f} TB/s (r+w)")
