@@ -300,6 +300,8 @@ int chunks(int d_in) {
 int fvi::combine_wave_blocks(int B, int rows, int tpp, int d_in) {
   if (!chunks(d_in)) return 0;
   const long groups = ((long)B * rows * tpp + NW - 1) / NW;
+  static const int cap = getenv("FASTVIM_COMBINE_GRID") ? atoi(getenv("FASTVIM_COMBINE_GRID")) : 0;   // tuning hook
+  if (cap) return (int)(groups < cap ? groups : cap);
   const long per = (groups + 511) / 512;
   return (int)((groups + per - 1) / per);
 }

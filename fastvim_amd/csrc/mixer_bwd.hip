@@ -479,8 +479,11 @@ int vec_combine(int d_in, int tpp) {
 int vec_convpool(int d_in) { return (d_in % 128 == 0 && d_in <= 12 * 128) ? 2 : 1; }
 int persistent_blocks(long nrows, int rg) {
   long groups = (nrows + rg - 1) / rg;
-  long per = (groups + 511) / 512;
-  return (int)((groups + per - 1) / per);
+  // one block per CU: measured best for the persistent backward kernels (conv_pool_bwd at FastVim-T 32.6 us with 256
+  // blocks vs 37.8 with 448, 36.9 with 384, 33.3 with 224, 46.0 with 299) -- no CU carries two blocks while others
+  // carry one, and the per-block gradient partials halve
+  static const int cap = getenv("FASTVIM_BWD_GRID") ? atoi(getenv("FASTVIM_BWD_GRID")) : 256;   // tuning hook
+  return (int)(groups < cap ? groups : cap);
 }
 
 template <typename T, int VEC>
