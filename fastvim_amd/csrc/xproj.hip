@@ -77,6 +77,60 @@ __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
   }
 }
 
+// ---- x_proj forward: x_dbl[dir] = xc[dir] @ Wx[dir]^T, a (B*Lc, d_in) x (d_in, R+2N <= 112) product per direction
+// (mamba_simple_faster.py:321-327).  It is tiny (0.12 GFLOP at FastVim-T) and sits on the critical path between the
+// conv and the scan: one wave per 16 rows, operands straight from global memory into MFMA fragments (no LDS, no
+// barrier), every load of a row block in flight before the first MFMA.  hipBLASLt took 7.3 us for it.
+typedef __bf16 xp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float xp_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NBK, int NWV>      // 16-column blocks of the output (NBK * 16 >= width); waves that split K
+__global__ __launch_bounds__(64 * NWV) void xproj_fwd_kernel(const bf16_t* __restrict__ xc, const bf16_t* __restrict__ Wx,
+                                                        bf16_t* __restrict__ out, int M, int K, int W) {
+  // NWV waves split K (each keeps its share of loads in flight), then sum through LDS in a fixed order
+  __shared__ xp_f32x4 s_acc[NWV - 1][NBK][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kc = lane >> 4;
+  const int dir = blockIdx.y, m0 = blockIdx.x * 16;
+  const int m = min(m0 + r, M - 1);
+  const int ksteps = K / 32, per = (ksteps + NWV - 1) / NWV;
+  const int k_lo = wv * per * 32, k_hi = min(K, (wv + 1) * per * 32);
+  const bf16_t* a_row = xc + ((size_t)dir * M + m) * K + kc * 8;
+  const bf16_t* b_row[NBK];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) b_row[nb] = Wx + ((size_t)dir * W + min(nb * 16 + r, W - 1)) * K + kc * 8;
+  xp_f32x4 acc[NBK];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) acc[nb] = (xp_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 6
+  for (int k = k_lo; k < k_hi; k += 32) {
+    const xp_bf16x8 a = *reinterpret_cast<const xp_bf16x8*>(a_row + k);
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+      const xp_bf16x8 b = *reinterpret_cast<const xp_bf16x8*>(b_row[nb] + k);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc[nb], 0, 0, 0);   // rows = n, cols = m
+    }
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) s_acc[wv - 1][nb][lane] = acc[nb];
+  }
+  __syncthreads();
+  // acc[nb][j] = C[m0 + (lane & 15)][nb * 16 + (lane >> 4) * 4 + j]
+  if (wv == 0 && m0 + r < M) {
+    bf16_t* o = out + ((size_t)dir * M + m0 + r) * W;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+      xp_f32x4 t = acc[nb];
+#pragma unroll
+      for (int w = 0; w < NWV - 1; ++w) t += s_acc[w][nb][lane];
+      const int n = nb * 16 + kc * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < W) o[n + j] = __float2bfloat16(t[j]);
+    }
+  }
+}
+
 }  // namespace
 
 static int xproj_rows() {
@@ -121,6 +175,37 @@ extern "C" int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, con
   }
 #undef FV_XPD
 #undef FV_XP
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+extern "C" int fv_mixer_xproj_fwd(const void* xc, const void* x_proj_w2, void* x_dbl, int M, int d_inner, int width,
+                                  fv_stream_t stream) {
+  FV_CHECK(xc && x_proj_w2 && x_dbl, "mixer_xproj_fwd: null pointer");
+  FV_CHECK(M > 0 && width > 0 && width <= 112 && d_inner > 0 && d_inner % 32 == 0,
+           "mixer_xproj_fwd: needs d_inner %% 32 == 0 and width <= 112 (got %d, %d)", d_inner, width);
+  FV_CHECK(((uintptr_t)xc & 15) == 0 && ((uintptr_t)x_proj_w2 & 15) == 0, "mixer_xproj_fwd: operands must be 16-byte aligned");
+  const bool wide = d_inner >= 768;           // more K per row block: eight waves
+  const dim3 grid(fv_cdiv(M, 16), 2), block(wide ? 512 : 256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nbk = fv_cdiv(width, 16);
+#define FV_XF(NN)                                                                                                    \
+  do {                                                                                                               \
+    if (wide) hipLaunchKernelGGL((xproj_fwd_kernel<NN, 8>), grid, block, 0, st, (const bf16_t*)xc,                   \
+                                 (const bf16_t*)x_proj_w2, (bf16_t*)x_dbl, M, d_inner, width);                       \
+    else hipLaunchKernelGGL((xproj_fwd_kernel<NN, 4>), grid, block, 0, st, (const bf16_t*)xc,                        \
+                            (const bf16_t*)x_proj_w2, (bf16_t*)x_dbl, M, d_inner, width);                            \
+  } while (0)
+  switch (nbk) {
+    case 1: FV_XF(1); break;
+    case 2: FV_XF(2); break;
+    case 3: FV_XF(3); break;
+    case 4: FV_XF(4); break;
+    case 5: FV_XF(5); break;
+    case 6: FV_XF(6); break;
+    default: FV_XF(7); break;
+  }
+#undef FV_XF
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

@@ -213,7 +213,7 @@ class FastVimMixerFn(torch.autograd.Function):
             else:
                 Wx2 = torch.stack([Wx, Wx_b])                                           # (2, R+2N, d_in) fp32
                 Wx2_c = Wx2.to(cdt)
-            x_dbl = torch.bmm(xc.view(2, B * rows * tpp, d_in), Wx2_c.transpose(1, 2))        # (2, B*Lc, R+2N)
+            x_dbl = M.xproj_fwd(xc, Wx2_c)                                               # (2, B*Lc, R+2N)
             yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
             g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
             out = linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)

@@ -51,7 +51,7 @@ class MaskedFastVimMixerFn(torch.autograd.Function):
             xc_tok, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, srows, 1, False, False, 1.0, t, D=D, D_b=D_b)
             xcomp = M.rows_segment_sum(xc_tok, idx, rows, 1.0 / cols)                     # (2, B, rows, d_in)
             Wx2 = torch.stack([Wx, Wx_b])
-            x_dbl = torch.bmm(xcomp.view(2, B * rows, d_in), Wx2.to(cdt).transpose(1, 2))
+            x_dbl = M.xproj_fwd(xcomp, Wx2.to(cdt).contiguous())
             yc = M.scan_fwd(xcomp, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)        # (2, B, rows, d_in) fp32
             yct = M.rows_gather(yc, idx)                                                  # (2, B, Lk, d_in) fp32
             g, mean, rstd = M.combine_fwd(xz, skip, yct, ln_w, ln_b, ln_eps, srows, 1, False, tpp=t)

@@ -262,6 +262,12 @@ int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M
 int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
                             const int* M, const int* N, const int* splits, int count, fv_stream_t stream);
 
+/* x_proj of both directions, bf16: x_dbl (2, M, width) = xc (2, M, d_inner) @ x_proj_w2 (2, width, d_inner)^T, fp32
+ * accumulate (mamba_simple_faster.py:321-327; the F.linear behind `self.x_proj` / `self.x_proj_b`).  M = batch*Lc,
+ * width = dt_rank + 2*d_state <= 112, d_inner a multiple of 32. */
+int fv_mixer_xproj_fwd(const void* xc, const void* x_proj_w2, void* x_dbl, int M, int d_inner, int width,
+                       fv_stream_t stream);
+
 /* Adjoint of x_proj for both directions, fused with the sum of the scan backward's chunk partials
  * (replaces the einsum/addmm chain of selective_scan_interface.py:698-734):
  *   dx_dbl = sum_c dx_dbl_partials[c];  dxc += dx_dbl @ W;  dW_partials[slice] = dx_dbl[slice]^T @ xc[slice].
