@@ -159,7 +159,12 @@ def test_xproj_fwd_kernel_vs_torch(Mrows, d_in, W):
     torch.manual_seed(W)
     xc = torch.randn(2, 1, Mrows, d_in, device="cuda").bfloat16()
     Wx = (torch.randn(2, W, d_in, device="cuda") * d_in ** -0.5).bfloat16()
-    out = M.xproj_fwd(xc, Wx)
+    from fastvim_amd import _lib as L
+    out = torch.empty(2, Mrows, W, device="cuda", dtype=torch.bfloat16)      # the C entry point itself (the Python
+    rc = L.lib().fv_mixer_xproj_fwd(L.ptr(xc), L.ptr(Wx), L.ptr(out), L.i32(Mrows), L.i32(d_in), L.i32(W),   # wrapper
+                                    L.stream_of(xc))                          # routes wide models to hipBLASLt)
+    L.check(rc, "mixer_xproj_fwd")
+    assert torch.equal(M.xproj_fwd(xc, Wx), out) or d_in > 512
     ref = torch.bmm(xc.view(2, Mrows, d_in).double(), Wx.double().transpose(1, 2))
     assert out.shape == (2, Mrows, W) and out.dtype == torch.bfloat16
     assert (out.double() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
