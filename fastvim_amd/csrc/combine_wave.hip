@@ -329,7 +329,20 @@ int fvi::combine_wave_blocks(int B, int rows, int tpp, int d_in) {
     return FV_OK;                                                                                  \
   } while (0)
 
-int fvi::combine_fwd_wave(const FwdParams& p, int dtype, hipStream_t st) { FV_WAVE_LAUNCH(combine_fwd_wave_kernel, p, 0); }
+int fvi::combine_fwd_wave(const FwdParams& p, int dtype, hipStream_t st) {
+  // d_inner = 1536 (FastVim-B): four chunks per lane, one token in flight -- forward only (the backward's
+  // accumulators would not fit 256 VGPRs)
+  if (p.d_in == 4 * 384 && mode() >= 1 && (size_t)p.geo.L * 2 * p.d_in * 4 <= 0xfffff000ull) {
+    const long groups = ((long)p.B * p.geo.rows * p.geo.tpp + NW - 1) / NW;
+    const long per = (groups + 511) / 512;
+    const dim3 grid((int)((groups + per - 1) / per)), block(64 * NW);
+    if (dtype == FV_F32) hipLaunchKernelGGL((combine_fwd_wave_kernel<float, 3, 4, 1>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((combine_fwd_wave_kernel<bf16_t, 3, 4, 1>), grid, block, 0, st, p);
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
+  FV_WAVE_LAUNCH(combine_fwd_wave_kernel, p, 0);
+}
 
 int fvi::combine_bwd_wave(const BwdParams& p, int dtype, hipStream_t st) {
   FV_WAVE_LAUNCH(combine_bwd_wave_kernel, p, (size_t)2 * p.d_in * 4);
