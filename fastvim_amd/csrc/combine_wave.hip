@@ -297,8 +297,13 @@ int chunks(int d_in) {
 
 }  // namespace
 
+static bool wide_bwd(int d_in) {
+  static const bool on = !(getenv("FASTVIM_COMBINE_WAVE_B") && atoi(getenv("FASTVIM_COMBINE_WAVE_B")) == 0);   // tuning hook
+  return on && d_in == 4 * 384 && mode() >= 1;
+}
+
 int fvi::combine_wave_blocks(int B, int rows, int tpp, int d_in) {
-  if (!chunks(d_in)) return 0;
+  if (!chunks(d_in) && !wide_bwd(d_in)) return 0;
   const long groups = ((long)B * rows * tpp + NW - 1) / NW;
   static const int cap = getenv("FASTVIM_COMBINE_GRID") ? atoi(getenv("FASTVIM_COMBINE_GRID")) : 0;   // tuning hook
   if (cap) return (int)(groups < cap ? groups : cap);
@@ -330,8 +335,7 @@ int fvi::combine_wave_blocks(int B, int rows, int tpp, int d_in) {
   } while (0)
 
 int fvi::combine_fwd_wave(const FwdParams& p, int dtype, hipStream_t st) {
-  // d_inner = 1536 (FastVim-B): four chunks per lane, one token in flight -- forward only (the backward's
-  // accumulators would not fit 256 VGPRs)
+  // d_inner = 1536 (FastVim-B): four chunks per lane, one token in flight (the backward fits 255 VGPRs exactly)
   if (p.d_in == 4 * 384 && mode() >= 1 && (size_t)p.geo.L * 2 * p.d_in * 4 <= 0xfffff000ull) {
     const long groups = ((long)p.B * p.geo.rows * p.geo.tpp + NW - 1) / NW;
     const long per = (groups + 511) / 512;
@@ -345,5 +349,13 @@ int fvi::combine_fwd_wave(const FwdParams& p, int dtype, hipStream_t st) {
 }
 
 int fvi::combine_bwd_wave(const BwdParams& p, int dtype, hipStream_t st) {
+  if (wide_bwd(p.d_in) && (size_t)p.geo.L * 2 * p.d_in * 4 <= 0xfffff000ull) {
+    const dim3 grid(fvi::combine_wave_blocks(p.B, p.geo.rows, p.geo.tpp, p.d_in)), block(64 * NW);
+    const size_t smem = (size_t)2 * p.d_in * 4;
+    if (dtype == FV_F32) hipLaunchKernelGGL((combine_bwd_wave_kernel<float, 3, 4, 1>), grid, block, smem, st, p);
+    else hipLaunchKernelGGL((combine_bwd_wave_kernel<bf16_t, 3, 4, 1>), grid, block, smem, st, p);
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
   FV_WAVE_LAUNCH(combine_bwd_wave_kernel, p, (size_t)2 * p.d_in * 4);
 }
