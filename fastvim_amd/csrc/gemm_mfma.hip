@@ -50,7 +50,8 @@ template <int EXT>
 __device__ __forceinline__ int ks_swz(int k) {
   const int code = (k & 3) | (((k >> 3) & 1) << 2);
   // 192-wide tiles have 12 32-byte chunks = 3 groups of 4: XOR inside a group only
-  return EXT == 192 ? (code & 3) : (EXT >= 128 ? code : (code & (EXT / 16 - 1)));
+  // 96-wide tiles have 6 chunks = 3 groups of 2
+  return EXT == 192 ? (code & 3) : EXT == 96 ? (code & 1) : (EXT >= 128 ? code : (code & (EXT / 16 - 1)));
 }
 
 // ---- staging: 256 threads move a (ROWS x 64) KC tile or a (64 x COLS) KS tile, 16 B per access ----
@@ -391,6 +392,11 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   static const bool big = !(getenv("FASTVIM_GEMM_BIG") && atoi(getenv("FASTVIM_GEMM_BIG")) == 0);   // tuning hook
   if (big && !tall && AMODE == KC && BMODE == KC && p.N % 256 == 0 && p.N >= 2048 && p.K >= 512 && p.M >= 4096 && whole_k)
     return launch_k<AMODE, BMODE, 2, 4, true, 4, 8>(p, splits, st);
+  // N = 192 (FastVim-T: out_proj forward, in_proj data gradient, patch embed): two 96-wide tiles cover it exactly,
+  // two 128-wide ones compute and load a quarter too much
+  static const int n96 = getenv("FASTVIM_GEMM_N96") ? atoi(getenv("FASTVIM_GEMM_N96")) : 1;   // tuning hook (out_proj forward 11.2 -> 10.1 us, in_proj dgrad 18.0 -> 16.9)
+  if (n96 && !tall && AMODE == KC && p.N % 96 == 0 && p.N < 384 && whole_k)
+    return launch_k<AMODE, BMODE, 2, 2, true, 3>(p, splits, st);
   static const bool wide = !(getenv("FASTVIM_GEMM_N192") && atoi(getenv("FASTVIM_GEMM_N192")) == 0);   // tuning hook
   if (wide && AMODE == KC && p.N % 192 == 0 && p.N >= 384 && !(p.N == 768 && p.K <= 192) && p.K % BK == 0 &&
       p.k_per_split % BK == 0)
