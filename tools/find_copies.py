@@ -1,9 +1,10 @@
-"""Which ops of the training step launch device-to-device memcpys / torch elementwise kernels (profiling aid)."""
-import os, sys
+"""Which CPU ops of the training step issue device-to-device memcpys (profiling aid): chrome trace of one eager
+step, every hipMemcpyAsync matched to the innermost enclosing aten / autograd op."""
+import json, os, sys, tempfile, collections
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import torch
-from torch.profiler import profile, ProfilerActivity
 import torch.nn.functional as F
+from torch.profiler import profile, ProfilerActivity
 from fastvim_amd import fastvim as fv
 from fastvim_amd.flat import FlatAdamW, FlatTrainingState
 torch.manual_seed(0)
@@ -23,15 +24,20 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step()
     torch.cuda.synchronize()
-import collections
+path = os.path.join(tempfile.gettempdir(), "step_trace.json")
+prof.export_chrome_trace(path)
+ev = json.load(open(path))["traceEvents"]
+cpu = [e for e in ev if e.get("cat") in ("cpu_op", "user_annotation", "python_function") and "dur" in e]
+rt = [e for e in ev if e.get("cat") == "cuda_runtime" and "emcpy" in e.get("name", "")]
 cnt = collections.Counter()
-for e in prof.events():
-    if e.name.startswith("aten::") and e.name in ("aten::copy_", "aten::add_", "aten::add", "aten::fill_", "aten::zero_", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy", "aten::mul", "aten::sum", "aten::mean"):
-        shapes = str(e.input_shapes)[:80]
-        st = [s for s in (e.stack or []) if "fastvim_amd" in s or "bench" in s][:2]
-        cnt[(e.name, shapes, tuple(st))] += 1
-for (name, shapes, st), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:40]:
-    print(c, name, shapes, " <- ", [s.split("/")[-1][:70] for s in st])
+for r in rt:
+    t = r["ts"]
+    enc = [c for c in cpu if c["ts"] <= t <= c["ts"] + c["dur"] and c.get("tid") == r.get("tid")]
+    enc.sort(key=lambda c: c["dur"])
+    names = tuple(c["name"] for c in enc[:3])
+    cnt[(r["name"], names)] += 1
+for (name, names), c in cnt.most_common(20):
+    print(c, name, "<-", names)
