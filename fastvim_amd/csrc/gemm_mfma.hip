@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
 // Several independent problems in ONE launch (the weight gradients of a whole backward pass, queued until its end):
 // a single weight-gradient GEMM at FastVim-T is 168-336 workgroups -- a third to two thirds of what the chip holds at
 // once -- and every launch pays that tail; the grouped launch is one long queue of workgroups.
-constexpr int GROUP_MAX = 16;
+constexpr int GROUP_MAX = 40;      // 40 x 88-byte problems + prefix table stay under the 4 KiB kernel-argument limit
 struct GroupedParams {
   GemmParams p[GROUP_MAX];
   int blk_end[GROUP_MAX];     // exclusive prefix of (tiles x splits) workgroups per problem
@@ -442,22 +442,30 @@ extern "C" int fv_gemm_bf16(const void* A, const void* B, void* C, const float* 
 // the form fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1) launches one at a time.
 extern "C" int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
                                        const int* M, const int* N, const int* splits, int count, fv_stream_t stream) {
+  return fv_gemm_bf16_tn_grouped_ld(x, y, parts, Kd, M, N, nullptr, nullptr, splits, count, stream);
+}
+
+extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* const* y, float* const* parts,
+                                          const int* Kd, const int* M, const int* N, const int* ldx, const int* ldy,
+                                          const int* splits, int count, fv_stream_t stream) {
   FV_CHECK(x && y && parts && Kd && M && N && splits && count > 0, "gemm_bf16_tn_grouped: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  for (int base = 0; base < count; base += GROUP_MAX) {
+  const int launches = fv_cdiv(count, GROUP_MAX), per_launch = fv_cdiv(count, launches);   // balanced, no one-problem tail launch
+  for (int base = 0; base < count; base += per_launch) {
     GroupedParams G{};
-    const int n = count - base < GROUP_MAX ? count - base : GROUP_MAX;
+    const int n = count - base < per_launch ? count - base : per_launch;
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
       const int q = base + i;
       FV_CHECK(x[q] && y[q] && parts[q] && Kd[q] > 0 && M[q] > 0 && N[q] > 0 && splits[q] >= 1,
                "gemm_bf16_tn_grouped: bad problem %d", q);
-      FV_CHECK(M[q] % 8 == 0 && N[q] % 8 == 0 && ((uintptr_t)x[q] & 15) == 0 && ((uintptr_t)y[q] & 15) == 0 &&
-                   ((uintptr_t)parts[q] & 15) == 0 && N[q] % 4 == 0,
-               "gemm_bf16_tn_grouped: problem %d: operands must be 16-byte aligned with M, N multiples of 8", q);
+      const int la = ldx ? ldx[q] : M[q], lb = ldy ? ldy[q] : N[q];
+      FV_CHECK(la >= M[q] && lb >= N[q] && la % 8 == 0 && lb % 8 == 0 && ((uintptr_t)x[q] & 15) == 0 &&
+                   ((uintptr_t)y[q] & 15) == 0 && ((uintptr_t)parts[q] & 15) == 0 && N[q] % 4 == 0,
+               "gemm_bf16_tn_grouped: problem %d: operands must be 16-byte aligned, row strides multiples of 8", q);
       GemmParams& p = G.p[i];
       p.A = (const bf16_t*)x[q]; p.B = (const bf16_t*)y[q]; p.C = parts[q]; p.bias = nullptr;
-      p.M = M[q]; p.N = N[q]; p.K = Kd[q]; p.lda = M[q]; p.ldb = N[q]; p.ldc = N[q]; p.c_fp32 = 1;
+      p.M = M[q]; p.N = N[q]; p.K = Kd[q]; p.lda = la; p.ldb = lb; p.ldc = N[q]; p.c_fp32 = 1;
       p.k_per_split = fv_cdiv(fv_cdiv(Kd[q], splits[q]), BK) * BK;
       p.c_split_stride = (long)M[q] * N[q];
       FV_CHECK(fv_cdiv(Kd[q], p.k_per_split) == splits[q],

@@ -18,11 +18,12 @@ struct XprojParams {
   const void* xc;            // (2, M, d_in)
   const float* Wx[2];        // (W, d_in) fp32
   float* dxc;                // (2, M, d_in) fp32: in = through-the-scan part, out = total
-  float* dW_part;            // (nslices, 2, W, d_in) fp32
+  float* dW_part;            // (nslices, 2, W, d_in) fp32 (null: the weight gradient is computed elsewhere)
+  void* dxdbl_out;           // (2, M, WP) bf16, WP = W rounded up to 8, pad columns zero (nullable): summed dx_dbl
   int nchunks, M, d_in, rows_per_block;
 };
 
-template <typename T, int W, int RB>
+template <typename T, int W, int RB, bool DW>
 __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
   extern __shared__ __attribute__((aligned(16))) float s_dx[];     // rows_per_block * W
   const int dir = blockIdx.z, slice = blockIdx.y;
@@ -39,6 +40,14 @@ __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
     s_dx[e] = t;
   }
   __syncthreads();
+  if (p.dxdbl_out && blockIdx.x == 0) {      // one channel block publishes the summed rows (bf16, padded row stride)
+    constexpr int WP = (W + 7) / 8 * 8;
+    bf16_t* o = (bf16_t*)p.dxdbl_out + ((size_t)dir * p.M + m0) * WP;
+    for (int e = threadIdx.x; e < nr * WP; e += blockDim.x) {
+      const int r = e / WP, c = e - r * WP;
+      o[e] = __float2bfloat16(c < W ? s_dx[r * W + c] : 0.f);
+    }
+  }
   float wcol[W], acc[W];
 #pragma unroll
   for (int c = 0; c < W; ++c) {
@@ -64,13 +73,13 @@ __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
         for (int c = 0; c < W; ++c) {
           const float g = row[c];
           o = fmaf(g, wcol[c], o);
-          acc[c] = fmaf(g, xv[k], acc[c]);
+          if constexpr (DW) acc[c] = fmaf(g, xv[k], acc[c]);
         }
         if (act) dxc[(size_t)(r0 + k) * p.d_in] = o;
       }
     }
   }
-  if (act) {
+  if (DW && act) {
     float* dst = p.dW_part + (((size_t)slice * 2 + dir) * W) * p.d_in + d;
 #pragma unroll
     for (int c = 0; c < W; ++c) dst[(size_t)c * p.d_in] = acc[c];
@@ -142,21 +151,34 @@ extern "C" int fv_mixer_xproj_bwd_slices(int M) { return fv_cdiv(M, xproj_rows()
 extern "C" int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
                                   const float* x_proj_w_b, float* dxc, float* dW_partials, int M, int d_inner,
                                   int width, int dtype, fv_stream_t stream) {
-  FV_CHECK(dx_dbl_partials && xc && x_proj_w && x_proj_w_b && dxc && dW_partials, "mixer_xproj_bwd: null pointer");
+  return fv_mixer_xproj_bwd2(dx_dbl_partials, nchunks, xc, x_proj_w, x_proj_w_b, dxc, dW_partials, nullptr, M, d_inner,
+                             width, dtype, stream);
+}
+
+extern "C" int fv_mixer_xproj_bwd2(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
+                                   const float* x_proj_w_b, float* dxc, float* dW_partials, void* dx_dbl_bf16, int M,
+                                   int d_inner, int width, int dtype, fv_stream_t stream) {
+  FV_CHECK(dx_dbl_partials && xc && x_proj_w && x_proj_w_b && dxc && (dW_partials || dx_dbl_bf16),
+           "mixer_xproj_bwd: null pointer");
   FV_CHECK(M > 0 && d_inner > 0 && nchunks > 0, "mixer_xproj_bwd: empty dimension");
   FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_xproj_bwd: dtype must be fp32 or bf16");
   XprojParams p{};
   p.dxdbl_part = dx_dbl_partials; p.xc = xc; p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.dxc = dxc;
-  p.dW_part = dW_partials; p.nchunks = nchunks; p.M = M; p.d_in = d_inner; p.rows_per_block = xproj_rows();
+  p.dW_part = dW_partials; p.dxdbl_out = dx_dbl_bf16; p.nchunks = nchunks; p.M = M; p.d_in = d_inner; p.rows_per_block = xproj_rows();
   const int bs = d_inner >= 256 ? 128 : 64;
   static const int rb = getenv("FASTVIM_XPROJ_RB") ? atoi(getenv("FASTVIM_XPROJ_RB")) : 8;   // tuning hook (rows of loads in flight; 8: 25.7 vs 26.8 us)
   dim3 grid(fv_cdiv(d_inner, bs), fv_mixer_xproj_bwd_slices(M), 2), block(bs);
   hipStream_t st = (hipStream_t)stream;
-#define FV_XP(TT, WW)                                                                                        \
-  do {                                                                                                       \
-    if (rb == 8) hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW, 8>), grid, block, (size_t)xproj_rows() * WW * 4, st, p);   \
-    else if (rb == 16) hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW, 16>), grid, block, (size_t)xproj_rows() * WW * 4, st, p); \
-    else hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW, 4>), grid, block, (size_t)xproj_rows() * WW * 4, st, p); \
+#define FV_XPK(TT, WW, RR)                                                                                     \
+  do {                                                                                                         \
+    if (dW_partials) hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW, RR, true>), grid, block, (size_t)xproj_rows() * WW * 4, st, p);  \
+    else hipLaunchKernelGGL((xproj_bwd_kernel<TT, WW, RR, false>), grid, block, (size_t)xproj_rows() * WW * 4, st, p);             \
+  } while (0)
+#define FV_XP(TT, WW)                                                                                          \
+  do {                                                                                                         \
+    if (rb == 8) FV_XPK(TT, WW, 8);                                                                            \
+    else if (rb == 16) FV_XPK(TT, WW, 16);                                                                     \
+    else FV_XPK(TT, WW, 4);                                                                                    \
   } while (0)
 #define FV_XPD(WW) do { if (dtype == FV_F32) FV_XP(float, WW); else FV_XP(bf16_t, WW); } while (0)
   switch (width) {   // dt_rank + 2 * d_state for d_model = 192 / 384 / 768 / 1024 / 1280 (d_state 16) and small test models
@@ -175,6 +197,7 @@ extern "C" int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, con
   }
 #undef FV_XPD
 #undef FV_XP
+#undef FV_XPK
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

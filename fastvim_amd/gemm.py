@@ -99,7 +99,7 @@ def gemm_tn_grouped(jobs):
     for x, y, out, sp in jobs:
         Kd, M = x.shape
         N = y.shape[1]
-        assert x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and x.is_contiguous() and y.is_contiguous()
+        assert x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and x.stride(1) == 1 and y.stride(1) == 1
         assert out.numel() == M * N and out.dtype == torch.float32
         parts.append(torch.empty(sp, M, N, device=x.device, dtype=torch.float32))
     P = ctypes.c_void_p
@@ -111,7 +111,9 @@ def gemm_tn_grouped(jobs):
     Ms = (I * k)(*[j[0].shape[1] for j in jobs])
     Ns = (I * k)(*[j[1].shape[1] for j in jobs])
     sps = (I * k)(*[j[3] for j in jobs])
-    rc = L.lib().fv_gemm_bf16_tn_grouped(xs, ys, ps, Kds, Ms, Ns, sps, L.i32(k), L.stream_of(jobs[0][0]))
+    ldx = (I * k)(*[j[0].stride(0) for j in jobs])       # rows may be padded (a column slice of a wider buffer)
+    ldy = (I * k)(*[j[1].stride(0) for j in jobs])
+    rc = L.lib().fv_gemm_bf16_tn_grouped_ld(xs, ys, ps, Kds, Ms, Ns, ldx, ldy, sps, L.i32(k), L.stream_of(jobs[0][0]))
     L.check(rc, "gemm_bf16_tn_grouped")
     for (x, y, out, sp), part in zip(jobs, parts):
         reduce_partials(part, sp, out=out, accumulate=True)

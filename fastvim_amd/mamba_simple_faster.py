@@ -104,7 +104,7 @@ class _SideStream:
 
 class _GroupedWgrad:
     """Weight gradients are only needed before the optimizer step.  With the flat training state they are queued
-    (operands kept alive) and computed by grouped launches (fv_gemm_bf16_tn_grouped, 16 problems each) at the end of
+    (operands kept alive) and computed by grouped launches (fv_gemm_bf16_tn_grouped, up to 40 problems each) at the end of
     the backward pass: one weight-gradient GEMM at FastVim-T is 168-336 workgroups, a fraction of what the chip holds
     at once, so each separate launch pays a tail; the grouped queue does not, and with the tail gone a smaller
     split-K factor (less fp32 partial traffic) is affordable.  FASTVIM_WGRAD_GROUP=0 turns it off."""
@@ -250,7 +250,17 @@ class FastVimMixerFn(torch.autograd.Function):
             dxc, dx_dbl, ps = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
                                          grad_out=fv.get("scan_grad"), keep_chunks=fused_xproj)
             # x_proj adjoint (selective_scan_interface.py:726-734), both directions
-            if fused_xproj:
+            Mrows = B * rows * tpp
+            if (fused_xproj and _GroupedWgrad.enabled and "Wx2_grad" in fv and xc.dtype == torch.bfloat16
+                    and Mrows % 64 == 0 and d_in % 8 == 0):
+                # the weight gradient dx_dbl^T xc joins the grouped launch at the end of backward (bf16 dx_dbl, as in
+                # the reference's autocast backward); the kernel only adds dx_dbl @ Wx to dxc
+                dxb = M.xproj_bwd(dx_dbl, xc, Wx2[0], Wx2[1], dxc, dw=False)
+                xc2 = xc.view(2, Mrows, d_in)
+                for k_ in range(2):
+                    _GroupedWgrad.add(dxb[k_][:, :W_], xc2[k_], fv["Wx2_grad"][k_].reshape(-1))
+                dWx2 = (None, None)
+            elif fused_xproj:
                 dWx2 = M.xproj_bwd(dx_dbl, xc, Wx2[0], Wx2[1], dxc, grad_out=fv.get("Wx2_grad"))
                 if dWx2 is None:
                     dWx2 = (None, None)

@@ -241,12 +241,22 @@ def xproj_fwd(xc, Wx2_c):
     return out
 
 
-def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None):
+def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True):
     """dxc (2, B, Lc, d_in) fp32 += dx_dbl @ Wx (in place); returns d x_proj weights (2, W, d_in) fp32, or
-    accumulates them into ``grad_out`` (flat view of that shape) and returns None."""
+    accumulates them into ``grad_out`` (flat view of that shape) and returns None.  ``dw=False``: the weight gradient
+    is left to the caller (grouped GEMM); returns the summed dx_dbl rows as bf16, (2, M, W rounded up to 8) with zero
+    pad columns."""
     nchunks, _, Mrows, W = dx_dbl_chunks.shape
     d_in = xc.shape[-1]
     lib = L.lib()
+    if not dw:
+        WP = (W + 7) // 8 * 8
+        dxb = torch.empty(2, Mrows, WP, device=xc.device, dtype=torch.bfloat16)
+        rc = lib.fv_mixer_xproj_bwd2(L.ptr(dx_dbl_chunks), L.i32(nchunks), L.ptr(xc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(dxc),
+                                     None, L.ptr(dxb), L.i32(Mrows), L.i32(d_in), L.i32(W),
+                                     L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
+        L.check(rc, "mixer_xproj_bwd")
+        return dxb
     ns = lib.fv_mixer_xproj_bwd_slices(L.i32(Mrows))
     part = torch.empty(ns, 2, W, d_in, device=xc.device, dtype=torch.float32)
     rc = lib.fv_mixer_xproj_bwd(L.ptr(dx_dbl_chunks), L.i32(nchunks), L.ptr(xc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(dxc),

@@ -261,6 +261,11 @@ int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M
  * the same arithmetic, tiling and fixed split order as fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1). */
 int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
                             const int* M, const int* N, const int* splits, int count, fv_stream_t stream);
+/* Same with explicit row strides (elements) of x and y -- rows may be padded (ldx >= M, ldy >= N, multiples of 8; pad
+ * elements must be finite): M and N then need not be multiples of 8.  ldx / ldy null: dense rows. */
+int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
+                               const int* M, const int* N, const int* ldx, const int* ldy, const int* splits, int count,
+                               fv_stream_t stream);
 
 /* x_proj of both directions, bf16: x_dbl (2, M, width) = xc (2, M, d_inner) @ x_proj_w2 (2, width, d_inner)^T, fp32
  * accumulate (mamba_simple_faster.py:321-327; the F.linear behind `self.x_proj` / `self.x_proj_b`).  M = batch*Lc,
@@ -278,6 +283,13 @@ int fv_mixer_xproj_bwd_slices(int M);
 int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
                        const float* x_proj_w_b, float* dxc, float* dW_partials, int M, int d_inner, int width,
                        int dtype, fv_stream_t stream);
+/* Same; `dx_dbl_bf16` (2, M, WP) bf16 with WP = width rounded up to 8 (pad columns zero), nullable, receives the
+ * summed dx_dbl rows, and `dW_partials` may then be null: the weight gradient dx_dbl^T xc is left to a (grouped)
+ * GEMM over exactly those bf16 rows -- what the reference's autocast backward multiplies
+ * (selective_scan_interface.py:726-729). */
+int fv_mixer_xproj_bwd2(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
+                        const float* x_proj_w_b, float* dxc, float* dW_partials, void* dx_dbl_bf16, int M, int d_inner,
+                        int width, int dtype, fv_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused AdamW (decoupled weight decay, bias correction; torch.optim.AdamW semantics) over a flat fp32

@@ -40,5 +40,9 @@ if W_ in M.XPROJ_WIDTHS:
     Wx = rn(W_, d_in, dt=torch.float32)
     dxc2, dxd_chunks, _ = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc, keep_chunks=True)
     gW = torch.zeros(2, W_, d_in, device=dev)
+    real_reduce = M.reduce_partials
+    M.reduce_partials = lambda part, n, out=None, **kw: out if out is not None else part[0]     # kernel only
     out["xproj_bwd"] = time_kernel(lambda: M.xproj_bwd(dxd_chunks, xc, Wx, Wx, dxc2, grad_out=gW))
+    M.reduce_partials = real_reduce
+    out["xproj_bwd_nodw"] = time_kernel(lambda: M.xproj_bwd(dxd_chunks, xc, Wx, Wx, dxc2, dw=False))
 print(os.environ.get("FASTVIM_DBG", ""), " ".join(f"{k}={v * 1e6:.1f}" for k, v in out.items()), flush=True)
