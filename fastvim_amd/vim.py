@@ -170,6 +170,60 @@ class VisionMamba(nn.Module):
         return x
 
 
+class MM_Vim(VisionMamba):
+    """Multi-scale feature backbone on the Vim baseline for detection / segmentation heads (models/vim.py:511-639),
+    without the mmdet / mmseg registry decorators.  Built WITHOUT a class token (dense prediction); ``if_cls_token``
+    only says whether the checkpoint being loaded has one in the middle of its ``pos_embed``, which is then cut out
+    before the table is bicubically resized to this model's grid (:560-583).  ``forward(x)`` returns the LayerNorm-ed
+    hidden states of ``out_indices`` as (B, C, H, W) maps."""
+
+    def __init__(self, img_size=224, patch_size=16, stride=16, in_chans=3, embed_dim=192, depth=24, if_cls_token=True,
+                 use_middle_cls_token=False, pretrained=None, out_indices=(5, 11, 17, 23), load_ema=True, **kwargs):
+        super().__init__(img_size, patch_size, stride, depth, embed_dim, in_chans, if_cls_token=False,
+                         use_middle_cls_token=False, **kwargs)
+        self.remove_cls_token = if_cls_token
+        self.load_ema = load_ema
+        self.out_indices = list(out_indices)
+        for i in range(len(self.out_indices)):
+            self.add_module(f"outnorm_{i}", nn.LayerNorm(self.embed_dim))
+        del self.head
+        del self.norm_f
+        self.load_pretrained(pretrained)
+
+    def load_pretrained(self, pretrained):
+        if pretrained is None:
+            return None
+        ckpt = torch.load(pretrained, map_location="cpu")
+        state_dict = ckpt["state_dict_ema"] if (self.load_ema and "state_dict_ema" in ckpt) else ckpt["state_dict"]
+        sd = {k.replace("backbone.", ""): v for k, v in state_dict.items()}
+        if "pos_embed" in sd:
+            pe = sd["pos_embed"]
+            if self.remove_cls_token:
+                pos_size = int(math.sqrt(pe.shape[1] - 1))
+                mid = (pe.shape[1] - 1) // 2
+                pe = torch.cat([pe[:, :mid, :], pe[:, mid + 1:, :]], dim=1)
+            else:
+                pos_size = int(math.sqrt(pe.shape[1]))
+            sd["pos_embed"] = self.resize_pos_embed(pe, self.token_size, (pos_size, pos_size), "bicubic")
+        return self.load_state_dict(sd, strict=False)
+
+    @staticmethod
+    def resize_pos_embed(pos_embed, input_shape, pos_shape, mode):
+        """(1, L, C) position table of a ``pos_shape`` grid -> ``input_shape`` grid (models/vim.py:591-623)."""
+        assert pos_embed.ndim == 3, "shape of pos_embed must be [B, L, C]"
+        pos_h, pos_w = pos_shape
+        w = pos_embed.reshape(1, pos_h, pos_w, pos_embed.shape[2]).permute(0, 3, 1, 2)
+        w = torch.nn.functional.interpolate(w, size=tuple(input_shape), mode=mode, align_corners=False)
+        return torch.flatten(w, 2).transpose(1, 2)
+
+    def forward(self, x):
+        C = self.embed_dim
+        outs, (H, W) = self.forward_features(x, out_indices=self.out_indices)
+        outs = [getattr(self, f"outnorm_{i}")(o.float()) for i, o in enumerate(outs)]
+        outs = [o.view(-1, H, W, C).permute(0, 3, 1, 2).contiguous() for o in outs]
+        return outs[0] if len(self.out_indices) == 1 else outs
+
+
 def _factory(embed_dim, depth, patch_size, stride, kwargs):
     model = VisionMamba(patch_size=patch_size, stride=stride, embed_dim=embed_dim, depth=depth, rms_norm=True,
                         residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean", if_abs_pos_embed=True,

@@ -97,3 +97,32 @@ def test_vim_tiny_full_size_step():
     assert torch.isfinite(outs[0][0]).all() and y.shape == (4, 1000)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_mm_vim_multiscale_features():
+    """MM_Vim.forward (models/vim.py:624-636): no class token, (B, C, H, W) maps of the LayerNorm-ed hidden states of
+    out_indices, equal to the oracle's un-pooled block stack."""
+    from fastvim_amd.vim import MM_Vim
+    from oracle.model import _sub, fused_add_norm_oracle, patch_embed_oracle, vim_mixer_oracle
+    torch.manual_seed(5)
+    m = MM_Vim(img_size=(64, 96), depth=4, embed_dim=32, out_indices=[1, 3], rms_norm=True, fused_add_norm=True,
+               residual_in_fp32=True, if_abs_pos_embed=True, drop_path_rate=0.0).cuda().eval()
+    assert not hasattr(m, "cls_token") and not hasattr(m, "head") and m.pos_embed.shape == (1, 24, 32)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 3, 64, 96)
+    outs = m(x.cuda())
+    assert len(outs) == 2 and outs[0].shape == (2, 32, 4, 6)
+    cd = torch.float64
+    h, _ = patch_embed_oracle(sd, x, 16, cd)
+    h = h + sd["pos_embed"].to(cd)
+    residual, hiddens = None, {}
+    for i in range(4):
+        sdl = _sub(sd, f"layers.{i}.")
+        hn, residual = fused_add_norm_oracle(h, sdl["norm.weight"], None, residual, 1e-5, prenorm=True,
+                                             residual_in_fp32=True, is_rms_norm=True, compute_dtype=cd)
+        h = vim_mixer_oracle(_sub(sdl, "mixer."), hn, compute_dtype=cd)
+        hiddens[i] = h
+    for k, idx in enumerate((1, 3)):
+        ref = torch.nn.functional.layer_norm(hiddens[idx].float(), (32,), sd[f"outnorm_{k}.weight"], sd[f"outnorm_{k}.bias"])
+        ref = ref.view(2, 4, 6, 32).permute(0, 3, 1, 2)
+        assert _err(outs[k], ref) <= 5e-5 * max(1.0, ref.abs().max().item())
