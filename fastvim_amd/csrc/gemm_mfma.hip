@@ -153,6 +153,47 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lan
   }
 }
 
+// K-slow fragments with OPAQUE transposing reads.  The compiler orders every LDS access it can see through the
+// ds_read_tr builtin behind ALL outstanding LDS-DMA loads (it emitted s_waitcnt vmcnt(0) in front of the first
+// ds_read_b64_tr_b16 of every K step), which serialised the prefetch of stage t+1 with the multiply of stage t in
+// every <KC, KS> (data-gradient) GEMM.  As inline asm the reads carry no memory operand; the price is that their
+// completion is ours to wait for: all the reads of one staged tile (both 32-deep k steps) are issued, then one
+// s_waitcnt lgkmcnt(0), then empty asm statements that pin every consumer behind that wait.
+template <int EXT, int NB>
+struct KsFrags {
+  unsigned long long lo[BK / 32][NB], hi[BK / 32][NB];
+  __device__ __forceinline__ void read(const char* lds, int blk0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int kl = ks * 32 + g * 8 + q, kh = kl + 4;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint32_t al = base + kl * (EXT * 2) + (((blk0 + b) ^ ks_swz<EXT>(kl)) << 5) + pp * 8;
+        const uint32_t ah = base + kh * (EXT * 2) + (((blk0 + b) ^ ks_swz<EXT>(kh)) << 5) + pp * 8;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[ks][b]) : "v"(al));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[ks][b]) : "v"(ah));
+      }
+    }
+  }
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        asm volatile("" : "+v"(lo[ks][b]));
+        asm volatile("" : "+v"(hi[ks][b]));
+      }
+  }
+  __device__ __forceinline__ bf16x8 get(int ks, int b) const {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 t = {lo[ks][b], hi[ks][b]};
+    return __builtin_bit_cast(bf16x8, t);
+  }
+};
+
 // WM x WN waves, each 16*MB rows x 16*NB columns: tile BM = 16*MB*WM rows (m), BN = 16*NB*WN cols (n).
 // NB = 6 gives 128x192 tiles: an N = 192 output is one tile wide, so the A panel is read once instead of 3 times.
 // MB = 8 (128-row wave tiles, 256-row block tiles) is for the compute-bound FastVim-S/B widths: a k-step of a
@@ -189,13 +230,23 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int cur) {
+    // LDS-DMA staging with a K-slow B: opaque transposing reads (see KsFrags)
+    constexpr bool OPQ = GLDS && AMODE == KC && BMODE == KS;
+    KsFrags<BN, OPQ ? NB : 1> kb;
+    if constexpr (OPQ) {
+      kb.read(sB(cur), wn * NB, lane);
+      kb.wait();
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 fa[MB], fb[NB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) fa[i] = frag<AMODE, BM>(sA(cur), wm * MB + i, ks, lane);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) fb[i] = frag<BMODE, BN>(sB(cur), wn * NB + i, ks, lane);
+      for (int i = 0; i < NB; ++i) {
+        if constexpr (OPQ) fb[i] = kb.get(ks, i);
+        else fb[i] = frag<BMODE, BN>(sB(cur), wn * NB + i, ks, lane);
+      }
 #pragma unroll
       for (int a = 0; a < NB; ++a)
 #pragma unroll
@@ -290,8 +341,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
           if (n + 8 <= p.N && (((uintptr_t)dst) & 15) == 0) {
             *reinterpret_cast<u32x4*>(dst) = q;
           } else {
-            const bf16_t* e = reinterpret_cast<const bf16_t*>(&q);
-            for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = e[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)      // constant lane indices: no scratch copy of q
+              if (n + j < p.N) reinterpret_cast<uint16_t*>(dst)[j] = (uint16_t)((j & 1) ? (q[j >> 1] >> 16) : (q[j >> 1] & 0xffffu));
           }
         }
       }
@@ -370,6 +422,204 @@ int launch(const GemmParams& p, int splits, hipStream_t st) {
   return launch_k<AMODE, BMODE, WM, WN, false>(p, splits, st);
 }
 
+
+// ---- streaming form of the forward / data-gradient GEMMs ------------------------------------------------------
+// At the FastVim-T widths (K = 192 .. 768) a 128-row tile has 3 .. 12 K steps, and a workgroup of the kernel above
+// lives mostly in start-up and drain: with the phases switched off one at a time (tools/gemm_phase_probe.py,
+// HBM-cold), in_proj forward takes 24.5 us of which 10.8 us remain with no MFMA, no stores and a single staged K
+// step -- cold kernel arguments, cold instructions, the first load's full latency, an epilogue with nothing in
+// flight.  Here ONE persistent 8-wave workgroup per CU walks its tiles as a flat sequence of (tile, K step) stages
+// through an S-deep LDS ring: S-1 stages are in flight (s_waitcnt vmcnt(n) on the oldest only -- loads return in
+// order), the first stages of the next tile are issued before the last ones of this tile are multiplied, and the
+// epilogue stores (wave-private LDS slab -> 16-byte rows) run under them.  Two waves per SIMD matter: with four
+// waves (one per SIMD) the ~130 instructions of a stage run at single-wave issue latency and the same design was
+// 20-80 % SLOWER than the kernel above.  rows_per_tile <= BM trims the tile height so that every workgroup gets
+// the same number of tiles; the trimmed rows are computed but not stored.  Measured gain is small (in_proj forward
+// 24.3 -> 23.0 us, in_proj data gradient 20.4 -> 18.3 us, out_proj forms 0.5-1.4 us slower, whole FastVim-T step
+// 7.635 -> 7.59 ms): ring depth 2 vs 3 makes no difference, the fixed ~5-9 us of a launch at these sizes does.
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BMODE, int WM, int WN, int NB, int MB, int S>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_stream_kernel(GemmParams p, int rpt, int tiles_m, int tiles_n) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN, WNC = 16 * NB, WMR = 16 * MB;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int RS = WNC * 2 + 16, CH = WNC / 8, SLAB = 16 * RS;
+  constexpr int NL = GldsPlan<KC, BM, NT>::NV + GldsPlan<BMODE, BN, NT>::NV;      // loads per thread per stage
+  static_assert((S - 2) * NL < 64, "vmcnt is 6 bits");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WN, wn = wv % WN;
+  char* my = smem + S * STAGE + wv * SLAB;
+  const uint32_t my_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)my;
+  const int nblk = tiles_m * tiles_n, G = gridDim.x;
+  const int count = (nblk - (int)blockIdx.x + G - 1) / G;
+  const int nt = p.K / BK, total = count * nt;
+  const bool remap = (G & 7) == 0;
+  const int q8 = nblk / 8, r8 = nblk % 8;
+  // tile i of this workgroup.  Workgroup w runs on XCD w % 8; so does virtual block w + i * G: the XCD-aware order of
+  // the kernel above (the N tiles sharing an A row panel are neighbours on one XCD) carries over
+  auto origin = [&](int i, int& m0, int& n0) {
+    int v = blockIdx.x + i * G;
+    if (remap) {
+      const int xcd = v & 7, j = v >> 3;
+      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    const int tm = v / tiles_n;
+    m0 = tm * rpt;
+    n0 = (v - tm * tiles_n) * BN;
+  };
+
+  GldsPlan<KC, BM, NT> ga;
+  GldsPlan<BMODE, BN, NT> gb;
+  int iq = 0, ikt = 0, itile = 0, islot = 0;
+  auto issue_next = [&]() {
+    if (iq < total) {
+      if (ikt == 0) {
+        int m0, n0;
+        origin(itile, m0, n0);
+        ga.init(p.A, p.lda, m0, p.M, tid);
+        gb.init(p.B, p.ldb, n0, p.N, tid);
+      }
+      char* st = smem + islot * STAGE;
+      ga.issue(st, ikt * BK, tid);
+      gb.issue(st + A_BYTES, ikt * BK, tid);
+      if (++ikt == nt) { ikt = 0; ++itile; }
+      if (++islot == S) islot = 0;
+    }
+    ++iq;
+  };
+
+  f32x4 acc[NB][MB];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int j = 0; j < S - 1; ++j) issue_next();
+  int kt = 0, tile = 0, slot = 0;
+  for (int s = 0; s < total; ++s) {
+    // stage s has landed once at most the stages issued after it are outstanding
+    const int later = min(S - 2, total - 1 - s);
+    if (S >= 4 && later >= 2) wait_vm<(S >= 4 ? 2 : 0) * NL>();
+    else if (S >= 3 && later >= 1) wait_vm<(S >= 3 ? 1 : 0) * NL>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();       // everyone's pieces of stage s are in LDS; everyone is done with stage s - 1
+    asm volatile("" ::: "memory");
+    issue_next();                       // stage s + S - 1 -> the slot stage s - 1 was read from
+    const char* sA = smem + slot * STAGE;
+    const char* sB = sA + A_BYTES;
+    KsFrags<BN, BMODE == KS ? NB : 1> kb;
+    if constexpr (BMODE == KS) {
+      kb.read(sB, wn * NB, lane);
+      kb.wait();
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 fa[MB], fb[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) fa[i] = frag<KC, BM>(sA, wm * MB + i, ks, lane);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if constexpr (BMODE == KS) fb[i] = kb.get(ks, i);
+        else fb[i] = frag<BMODE, BN>(sB, wn * NB + i, ks, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[a], fa[b], acc[a][b], 0, 0, 0);
+    }
+    if (++slot == S) slot = 0;
+    if (++kt < nt) continue;
+    // ---- tile finished: bias, bf16, out through the wave's slab (16 rows at a time) ----
+    kt = 0;
+    int m0, n0;
+    origin(tile++, m0, n0);
+    const int mlim = min(p.M, m0 + rpt);
+    if (p.bias) {
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        const int n = n0 + wn * WNC + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float bj = (n + j < p.N) ? p.bias[n + j] : 0.f;
+#pragma unroll
+          for (int b = 0; b < MB; ++b) acc[a][b][j] += bj;
+        }
+      }
+    }
+    bf16_t* Cb = (bf16_t*)p.C;
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        const f32x4 v = acc[a][b];
+        const unsigned long long pk = (unsigned long long)pack_bf16x2(v[0], v[1]) | ((unsigned long long)pack_bf16x2(v[2], v[3]) << 32);
+        // written with an opaque ds_write: the compiler orders every LDS store it can see behind ALL outstanding
+        // LDS-DMA loads (s_waitcnt vmcnt(0)), which would drain the ring at every tile end; the slab is disjoint
+        // from the ring and private to this wave, and the LDS queue of a wave is in order
+        asm volatile("ds_write_b64 %0, %1" ::"v"(my_lds + (uint32_t)((lane & 15) * RS + (a * 16 + (lane >> 4) * 4) * 2)), "v"(pk) : "memory");
+        acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < (16 * CH + 63) / 64; ++i) {
+        const int idx = i * 64 + lane, r = idx / CH, ch = idx - r * CH;
+        const int m = m0 + wm * WMR + b * 16 + r, n = n0 + wn * WNC + ch * 8;
+        if (idx < 16 * CH && m < mlim && n < p.N) {
+          const u32x4 q = *reinterpret_cast<const u32x4*>(my + r * RS + ch * 16);
+          bf16_t* dst = Cb + (long)m * p.ldc + n;
+          if (n + 8 <= p.N && (((uintptr_t)dst) & 15) == 0) {
+            *reinterpret_cast<u32x4*>(dst) = q;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)      // constant lane indices: no scratch copy of q
+              if (n + j < p.N) reinterpret_cast<uint16_t*>(dst)[j] = (uint16_t)((j & 1) ? (q[j >> 1] >> 16) : (q[j >> 1] & 0xffffu));
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <int BMODE, int WM, int WN, int NB, int MB, int S>
+int launch_stream(const GemmParams& p, hipStream_t st) {
+  constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
+  constexpr size_t smem = (size_t)S * (BM + BN) * BK * 2 + (size_t)WM * WN * 16 * (16 * NB * 2 + 16);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<BMODE, WM, WN, NB, MB, S>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  }
+  static const int per_cu_env = getenv("FASTVIM_GEMM_STREAM_WG") ? atoi(getenv("FASTVIM_GEMM_STREAM_WG")) : 0;   // tuning hook
+  static const bool balance = !(getenv("FASTVIM_GEMM_STREAM_BAL") && atoi(getenv("FASTVIM_GEMM_STREAM_BAL")) == 0);   // tuning hook
+  const int fit = (int)((160 * 1024) / smem);
+  const int per_cu = per_cu_env > 0 ? (per_cu_env < fit ? per_cu_env : fit) : fit;
+  int G = cus * (per_cu < 1 ? 1 : per_cu);
+  const int tiles_n = fv_cdiv(p.N, BN);
+  int tiles_m = fv_cdiv(p.M, BM), rpt = BM;
+  const int total0 = tiles_m * tiles_n;
+  if (total0 <= G) {
+    G = total0;
+  } else if (balance) {
+    const int rounds = fv_cdiv(total0, G), want_m = rounds * G / tiles_n;
+    rpt = fv_cdiv(p.M, want_m);
+    if (rpt > BM) rpt = BM;
+    tiles_m = fv_cdiv(p.M, rpt);
+  }
+  hipLaunchKernelGGL((gemm_stream_kernel<BMODE, WM, WN, NB, MB, S>), dim3(G), dim3(64 * WM * WN), smem, st, p, rpt,
+                     tiles_m, tiles_n);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
 template <int AMODE, int BMODE>
 int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   // N a multiple of 192 (FastVim-T/S/B: d, 2*d_in): 128x192 tiles, the A panel is read N/192 times instead of
@@ -377,6 +627,15 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   // (K-slow B, 4-way swizzle), N = 768 with K = 192 +3 % -- those keep the 128-wide tiles.
   static const int tall = getenv("FASTVIM_GEMM_TALL") ? atoi(getenv("FASTVIM_GEMM_TALL")) : 0;   // tuning hook: 1 = 256x128, 2 = 256x192, 3 = 256x256 tiles
   const bool whole_k = p.K % BK == 0 && p.k_per_split % BK == 0;
+  // streaming form (gemm_stream_kernel): K-contiguous activations, bf16 output, no split-K, the FastVim-T weight
+  // sizes it was measured on (HBM-cold, M = 25088: in_proj forward 24.3 -> 23.0 us, in_proj data gradient
+  // 20.4 -> 18.3; whole step 7.635 -> 7.59 ms)
+  static const bool stream = !(getenv("FASTVIM_GEMM_STREAM") && atoi(getenv("FASTVIM_GEMM_STREAM")) == 0);   // tuning hook
+  if constexpr (AMODE == KC) {
+    if (stream && !tall && whole_k && splits == 1 && !p.c_fp32 && p.M >= 8192 && p.K >= 128 && p.N % 192 == 0 &&
+        (long)p.N * p.K <= 192 * 768)
+      return launch_stream<BMODE, 2, 4, 3, 4, 3>(p, st);
+  }
   if (tall && p.M >= 256 && p.N >= 128 && (AMODE != KC || whole_k)) {
     constexpr bool G = AMODE == KC;
     if (tall == 1) return launch_k<AMODE, BMODE, 2, 2, G, 4, 8>(p, splits, st);

@@ -29,6 +29,33 @@ def test_gemm_nt_nn(M, N, K):
     assert (c2.double().cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(25088, 768, 192), (25088, 192, 384), (25088, 192, 768), (25088, 384, 192),
+                                   (8200, 192, 128), (12345, 384, 192)])
+def test_gemm_streaming_form(M, N, K):
+    """bf16-output forward (NT) and data-gradient (NN) GEMMs at the FastVim-T shapes go through the persistent
+    streaming kernel (gemm_stream_kernel: M >= 8192, N % 192 == 0, N * K <= 192 * 768): trimmed tile heights, tiles
+    ending mid-ring, ragged last tile (12345 rows), bias in the epilogue.  It accumulates in the same K order as
+    the per-tile kernel, so the two must agree bit for bit (the fp32-output path always runs the per-tile kernel)."""
+    from fastvim_amd.gemm import gemm_nn, gemm_nt
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    w = torch.randn(N, K, device="cuda").bfloat16()
+    bias = torch.randn(N, device="cuda")
+    ref = _ref(a, w.t())
+    tol = 2.0 ** -7 * ref.abs().max().item()
+    c = gemm_nt(a, w)
+    assert (c.double().cpu() - ref).abs().max().item() <= tol
+    cb = gemm_nt(a, w, bias=bias)
+    assert (cb.double().cpu() - (ref + bias.double().cpu())).abs().max().item() <= tol
+    b = w.t().contiguous()
+    c2 = gemm_nn(a, b)
+    assert (c2.double().cpu() - ref).abs().max().item() <= tol
+    # the fp32-output path runs the per-tile kernel: rounding its result to bf16 must reproduce the streamed one
+    c32 = gemm_nt(a, w, out_dtype=torch.float32)
+    assert torch.equal(c32.bfloat16(), c)
+    assert torch.equal(gemm_nn(a, b, out_dtype=torch.float32).bfloat16(), c2)
+
+
 @pytest.mark.parametrize("Kd,M,N,splits", [(64, 128, 128, 1), (1024, 192, 384, 4), (25088, 768, 192, 16),
                                            (25088, 192, 384, 8), (640, 72, 40, 2)])
 def test_gemm_tn_splitk(Kd, M, N, splits):
