@@ -434,9 +434,10 @@ int launch(const GemmParams& p, int splits, hipStream_t st) {
 // epilogue stores (wave-private LDS slab -> 16-byte rows) run under them.  Two waves per SIMD matter: with four
 // waves (one per SIMD) the ~130 instructions of a stage run at single-wave issue latency and the same design was
 // 20-80 % SLOWER than the kernel above.  rows_per_tile <= BM trims the tile height so that every workgroup gets
-// the same number of tiles; the trimmed rows are computed but not stored.  Measured gain is small (in_proj forward
-// 24.3 -> 23.0 us, in_proj data gradient 20.4 -> 18.3 us, out_proj forms 0.5-1.4 us slower, whole FastVim-T step
-// 7.635 -> 7.59 ms): ring depth 2 vs 3 makes no difference, the fixed ~5-9 us of a launch at these sizes does.
+// the same number of tiles; the trimmed rows are computed but not stored.  Measured gain is small (HBM-cold:
+// in_proj forward 24.3 -> 23.0 us, in_proj data gradient 20.4 -> 18.3 us; inside the step the data gradients gain
+// 14 %, the forward GEMMs lose 6 % and keep the per-tile kernel): ring depth 2 vs 3 makes no difference, the fixed
+// ~5-9 us of a launch at these sizes does.
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -632,8 +633,10 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   // 20.4 -> 18.3; whole step 7.635 -> 7.59 ms)
   static const bool stream = !(getenv("FASTVIM_GEMM_STREAM") && atoi(getenv("FASTVIM_GEMM_STREAM")) == 0);   // tuning hook
   if constexpr (AMODE == KC) {
-    if (stream && !tall && whole_k && splits == 1 && !p.c_fp32 && p.M >= 8192 && p.K >= 128 && p.N % 192 == 0 &&
-        (long)p.N * p.K <= 192 * 768)
+    // (K-slow B only: inside the training step, where A was written by the previous kernel, the <KC, KC> forward
+    //  GEMMs measured 21.1 -> 22.4 ms per 27 steps with it, the <KC, KS> data gradients 23.8 -> 20.1 ms)
+    if (stream && BMODE == KS && !tall && whole_k && splits == 1 && !p.c_fp32 && p.M >= 8192 && p.K >= 128 &&
+        p.N % 192 == 0 && (long)p.N * p.K <= 192 * 768)
       return launch_stream<BMODE, 2, 4, 3, 4, 3>(p, st);
   }
   if (tall && p.M >= 256 && p.N >= 128 && (AMODE != KC || whole_k)) {
