@@ -638,6 +638,7 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
 // Several independent fixed-order reductions in ONE launch (gradient partials of different kernels /
 // layers whose sums are only needed before the optimizer step).
 constexpr int MAXJOBS = 16;
+constexpr int FLAT_S = 8;      // reduce_partials_multi: jobs with at most this many partials take one column per thread
 struct ReduceJobs {
   const float* in[MAXJOBS];
   float* out[MAXJOBS];
@@ -655,6 +656,21 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J
   const float* __restrict__ in = J.in[job];
   const int S = J.S[job];
   const size_t n = (size_t)J.n[job];
+  if (S <= FLAT_S) {
+    // few partials (split-K weight gradients: 7): one column per thread, every partial and the old value in flight
+    // at once, no LDS stage.  A 32-column block would move 32 x 7 floats behind two dependent memory round trips;
+    // at FastVim-T that was 31 872 such blocks per launch, 37 us for 26 MB.
+    const size_t i = (size_t)blk * 256 + threadIdx.x;
+    if (i < n) {
+      float v[FLAT_S];
+#pragma unroll
+      for (int u = 0; u < FLAT_S; ++u) v[u] = u < S ? in[(size_t)u * n + i] : 0.f;
+      float* out = J.out[job];
+      const float o = J.accumulate ? out[i] : 0.f;
+      out[i] = o + (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+    }
+    return;
+  }
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
   const size_t i = (size_t)blk * 32 + c;
   s_acc[q][c] = i < n ? column_sum(in, S, n, i, q) : 0.f;
@@ -677,7 +693,7 @@ extern "C" int fv_reduce_partials_multi(const float* const* partials, float* con
   for (int j = 0; j < njobs; ++j) {
     FV_CHECK(partials[j] && outs[j] && n_partials[j] > 0, "reduce_partials_multi: bad job %d", j);
     J.in[j] = partials[j]; J.out[j] = outs[j]; J.S[j] = n_partials[j]; J.n[j] = (long)ns[j];
-    blocks += fv_cdiv((long)ns[j], 32);
+    blocks += fv_cdiv((long)ns[j], n_partials[j] <= FLAT_S ? 256 : 32);
     J.blk_end[j] = blocks;
   }
   J.njobs = njobs; J.accumulate = accumulate;

@@ -168,3 +168,38 @@ def test_xproj_fwd_kernel_vs_torch(Mrows, d_in, W):
     ref = torch.bmm(xc.view(2, Mrows, d_in).double(), Wx.double().transpose(1, 2))
     assert out.shape == (2, Mrows, W) and out.dtype == torch.bfloat16
     assert (out.double() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_deferred_partial_reductions_match_single_launches():
+    """fv_reduce_partials_multi (up to 16 queued gradient-partial reductions in one launch) against the one-job
+    kernel and fp64; the fixed summation order makes a repeat bitwise identical."""
+    from fastvim_amd import mixer_ops as M
+    torch.manual_seed(0)
+    shapes = [(7, 768 * 192), (256, 768), (256, 4608), (37, 384 * 29), (1, 1000), (9, 44 * 384), (64, 20)]
+    for ragged in (False, True):          # odd element counts: no alignment assumptions
+        parts = [torch.randn(S, n + (1 if ragged and k == 2 else 0), device="cuda") for k, (S, n) in enumerate(shapes)]
+        base = [torch.randn(p.shape[1], device="cuda") for p in parts]
+        single = [b.clone() for b in base]
+        for p, o in zip(parts, single):
+            M.reduce_partials(p, p.shape[0], out=o, accumulate=True, defer=False)
+        multi = [b.clone() for b in base]
+        M.defer_reductions(True)
+        try:
+            for p, o in zip(parts, multi):
+                M.reduce_partials(p, p.shape[0], out=o, accumulate=True)
+            M.flush_reductions()
+        finally:
+            M.defer_reductions(False)
+        for p, b, s_, m_ in zip(parts, base, single, multi):
+            ref = b.double() + p.double().sum(0)
+            tol = 1e-5 * max(1.0, ref.abs().max().item())
+            assert (m_.double() - ref).abs().max().item() <= tol and (s_.double() - ref).abs().max().item() <= tol
+        again = [b.clone() for b in base]
+        M.defer_reductions(True)
+        try:
+            for p, o in zip(parts, again):
+                M.reduce_partials(p, p.shape[0], out=o, accumulate=True)
+            M.flush_reductions()
+        finally:
+            M.defer_reductions(False)
+        assert all(torch.equal(a_, m_) for a_, m_ in zip(again, multi))
