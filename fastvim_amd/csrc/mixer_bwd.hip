@@ -440,6 +440,23 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
 // Sum of rows q, q+8, q+16, ... of column i.  Eight independent loads are in flight per thread: the reduction is
 // bound by memory-level parallelism (a block column is only 128 B wide), not by bandwidth per request.
 __device__ __forceinline__ float column_sum(const float* __restrict__ in, int S, size_t n, size_t i, int q) {
+  if (S >= 128) {
+    // many partials (one per block of a persistent backward kernel: 256): sixteen loads in flight per thread, the
+    // block's life is round trips to memory and little else
+    float b[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) b[u] = 0.f;
+    int s = q;
+    for (; s + 120 < S; s += 128) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) b[u] += in[(size_t)(s + 8 * u) * n + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (s + 8 * u < S) b[u] += in[(size_t)(s + 8 * u) * n + i];
+    return (((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]))) +
+           (((b[8] + b[9]) + (b[10] + b[11])) + ((b[12] + b[13]) + (b[14] + b[15])));
+  }
   float a[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) a[u] = 0.f;
