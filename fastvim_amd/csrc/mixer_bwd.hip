@@ -471,9 +471,28 @@ __device__ __forceinline__ float column_sum(const float* __restrict__ in, int S,
   return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
+constexpr int FLAT_S = 8;      // at most this many partials: one column per thread (see flat_sum)
+
+// Few partials (split-K weight gradients: 7): one column per thread, every partial and the old value in flight at once,
+// no LDS stage.  A 32-column block would move 32 x 7 floats behind two dependent memory round trips; at FastVim-T
+// that was 31 872 such blocks per launch, 37 us for 26 MB.
+__device__ __forceinline__ void flat_sum(const float* __restrict__ in, float* __restrict__ out, int S, size_t n, size_t i,
+                                         int accumulate) {
+  if (i >= n) return;
+  float v[FLAT_S];
+#pragma unroll
+  for (int u = 0; u < FLAT_S; ++u) v[u] = u < S ? in[(size_t)u * n + i] : 0.f;
+  const float o = accumulate ? out[i] : 0.f;
+  out[i] = o + (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               int S, size_t n, int accumulate) {
   __shared__ float s_acc[8][33];
+  if (S <= FLAT_S) {
+    flat_sum(in, out, S, n, (size_t)blockIdx.x * 256 + threadIdx.x, accumulate);
+    return;
+  }
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
   const size_t i = (size_t)blockIdx.x * 32 + c;
   s_acc[q][c] = i < n ? column_sum(in, S, n, i, q) : 0.f;
@@ -655,7 +674,6 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
 // Several independent fixed-order reductions in ONE launch (gradient partials of different kernels /
 // layers whose sums are only needed before the optimizer step).
 constexpr int MAXJOBS = 16;
-constexpr int FLAT_S = 8;      // reduce_partials_multi: jobs with at most this many partials take one column per thread
 struct ReduceJobs {
   const float* in[MAXJOBS];
   float* out[MAXJOBS];
@@ -674,18 +692,7 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J
   const int S = J.S[job];
   const size_t n = (size_t)J.n[job];
   if (S <= FLAT_S) {
-    // few partials (split-K weight gradients: 7): one column per thread, every partial and the old value in flight
-    // at once, no LDS stage.  A 32-column block would move 32 x 7 floats behind two dependent memory round trips;
-    // at FastVim-T that was 31 872 such blocks per launch, 37 us for 26 MB.
-    const size_t i = (size_t)blk * 256 + threadIdx.x;
-    if (i < n) {
-      float v[FLAT_S];
-#pragma unroll
-      for (int u = 0; u < FLAT_S; ++u) v[u] = u < S ? in[(size_t)u * n + i] : 0.f;
-      float* out = J.out[job];
-      const float o = J.accumulate ? out[i] : 0.f;
-      out[i] = o + (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
-    }
+    flat_sum(in, J.out[job], S, n, (size_t)blk * 256 + threadIdx.x, J.accumulate);
     return;
   }
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
@@ -724,7 +731,7 @@ extern "C" int fv_reduce_partials(const float* partials, float* out, int n_parti
                                   fv_stream_t stream) {
   FV_CHECK(partials && out && n_partials > 0, "reduce_partials: bad arguments");
   if (n == 0) return FV_OK;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(fv_cdiv((long)n, 32)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(fv_cdiv((long)n, n_partials <= FLAT_S ? 256 : 32)), dim3(256), 0, (hipStream_t)stream,
                      partials, out, n_partials, n, accumulate);
   FV_LAUNCH_CHECK();
   return FV_OK;

@@ -158,7 +158,8 @@ class PatchEmbed(nn.Module):
         if self.dynamic_img_pad:
             pad_h = (self.patch_size[0] - H % self.patch_size[0]) % self.patch_size[0]
             pad_w = (self.patch_size[1] - W % self.patch_size[1]) % self.patch_size[1]
-            x = F.pad(x, (0, pad_w, 0, pad_h))
+            if pad_h or pad_w:          # F.pad with zero pads still clones the batch (77 MB at 128 x 3 x 224 x 224 fp32)
+                x = F.pad(x, (0, pad_w, 0, pad_h))
         # k == stride conv == one GEMM over non-overlapping patches: (B*gh*gw, C*ph*pw) x (C*ph*pw, D).
         # (MIOpen resolves this bf16 conv to naive kernels on gfx950; the GEMM form is also what the
         # patch-embed MFMA kernel consumes.)
@@ -379,7 +380,12 @@ class VisionMamba(nn.Module):
         x = self.forward_features(x, inference_params)
         if return_features:
             return x
-        x = self.head(x)
+        if isinstance(self.head, nn.Linear) and x.is_cuda:
+            # F.linear(x, head.weight, head.bias) (models/fastvim.py:541) through the MFMA GEMM: at batch 128 the
+            # library picks a one-workgroup kernel for this 128 x 1000 x 192 problem (25 us)
+            x = LinearFn.apply(x, self.head.weight, _compute_dtype(x), self.head.bias)
+        else:
+            x = self.head(x)
         if self.final_pool_type == "max":
             x = x.max(dim=1)[0]
         return x

@@ -61,7 +61,7 @@ def _mfma_ok(*ts):
 
 def linear_fwd(a2, w_c, bias=None):
     """a2 (M, K) x w_c (N, K)^T (+ bias) in the compute dtype: hand-written MFMA GEMM for bf16, rocBLAS for fp32."""
-    if _mfma_ok(a2, w_c) and a2.shape[1] % 8 == 0:
+    if _mfma_ok(a2, w_c) and a2.shape[1] % 8 == 0 and w_c.shape[0] % 8 == 0:      # 16-byte rows of A, W and C
         return gemm_nt(a2, w_c, bias=None if bias is None else bias.float())
     return F.linear(a2, w_c, None if bias is None else bias.to(a2.dtype))
 
@@ -148,18 +148,20 @@ def linear_wgrad(g2, a2, W=None, splits=None):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = a @ W^T (no bias) through the MFMA GEMMs, with the deterministic split-K weight gradient
-    (and direct accumulation into a flat .grad).  Used for the patch-embed projection."""
+    """y = a @ W^T (+ bias, added in the GEMM epilogue) through the MFMA GEMMs, with the deterministic split-K
+    weight gradient (and direct accumulation into a flat .grad).  Used for the patch-embed projection and the
+    classification head."""
 
     @staticmethod
-    def forward(ctx, a, W, cdt):
+    def forward(ctx, a, W, cdt, bias=None):
         with torch.autocast("cuda", enabled=False):
             a2 = a.reshape(-1, a.shape[-1]).to(cdt).contiguous()
             W2 = W.reshape(W.shape[0], -1)
-            y = linear_fwd(a2, _shadow(W, cdt).reshape(W2.shape))
+            y = linear_fwd(a2, _shadow(W, cdt).reshape(W2.shape), bias)
         ctx.save_for_backward(a2, W)
         ctx.a_shape, ctx.a_dtype, ctx.cdt = a.shape, a.dtype, cdt
         ctx.need_da = a.requires_grad
+        ctx.has_bias = bias is not None
         return y.view(*a.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -173,7 +175,8 @@ class LinearFn(torch.autograd.Function):
             dW = linear_wgrad(g2, a2, W)
             if dW is not None:
                 dW = dW.view(W.shape)
-        return da, dW, None
+            db = g2.float().sum(0) if ctx.has_bias else None
+        return da, dW, None, db
 
 
 def _compute_dtype(t):
