@@ -188,7 +188,16 @@ __global__ __launch_bounds__(64 * NW) void combine_bwd_wave_kernel(BwdParams p) 
       }
     };
     fetch(0);
+    // LayerNorm statistics of the group's tokens: lane l holds token j0 + l of the current 64-token chunk, loaded
+    // with the group's first fetch and handed out by v_readlane -- a per-token load inside the loop is a memory
+    // round trip in front of every iteration's arithmetic
+    float mu_l = 0.f, rs_l = 1.f;
     for (int j0 = 0; j0 < pcols; j0 += TT) {       // pcols % TT == 0
+      if (p.use_norm && (j0 & 63) == 0 && j0 + lane < pcols) {
+        const size_t sm = (size_t)b * g.L + base + (j0 + lane) * step;
+        mu_l = p.mean[sm];
+        rs_l = p.rstd[sm];
+      }
       f2 xh[TT][NCK][NP], dxh[TT][NCK][NP];
       float c1[TT], c2[TT], rs[TT];
       {
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(64 * NW) void combine_bwd_wave_kernel(BwdParams p) 
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
           const int m = base + (j0 + t) * step;
-          rs[t] = p.use_norm ? p.rstd[(size_t)b * g.L + m] : 1.f;
-          const float mu = p.use_norm ? p.mean[(size_t)b * g.L + m] : 0.f;
+          rs[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs_l), (j0 + t) & 63));
+          const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu_l), (j0 + t) & 63));
           const float hr = 0.5f * rs[t], mr = -mu * rs[t];
           f2 s1 = splat(0.f), s2 = splat(0.f);
 #pragma unroll
