@@ -280,11 +280,13 @@ __global__ __launch_bounds__(256) void add_norm_fwd3_kernel(NormParams p) {
     if (p.b) VecIO<float, 4>::load(p.b + (k * LPR + lr) * 4, bb[k]);
   }
   for (int row0 = wave * RPW * RU; row0 < p.M; row0 += nwaves * RPW * RU) {
-    float v[RU][3][4], r[RU][3][4];
+    float v[RU][3][4], r[RU][3][4], sc_u[RU];
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const int row = row0 + u * RPW + gr;
-      const size_t base = (size_t)(row < p.M ? row : p.M - 1) * N;
+      const int rowc = row < p.M ? row : p.M - 1;
+      const size_t base = (size_t)rowc * N;
+      sc_u[u] = p.row_scale ? p.row_scale[rowc / p.rows_per_scale] : 1.f;    // DropPath scale: rides with the row's loads
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = (k * LPR + lr) * 4;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void add_norm_fwd3_kernel(NormParams p) {
       const int row = row0 + u * RPW + gr;
       const bool live = row < p.M;
       const size_t base = (size_t)(live ? row : p.M - 1) * N;
-      const float sc = p.row_scale ? p.row_scale[(live ? row : p.M - 1) / p.rows_per_scale] : 1.f;
+      const float sc = sc_u[u];
       float s = 0.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -358,10 +360,17 @@ __global__ __launch_bounds__(256) void add_norm_bwd3_kernel(NormParams p) {
   }
   for (int row0 = wave * RPW * RU; row0 < p.M; row0 += nwaves * RPW * RU) {
     float rr[RU][3][4], dyv[RU][3][4], gg[RU][3][4];
+    float rstd_u[RU], mu_u[RU], sc_u[RU];
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const int row = row0 + u * RPW + gr;
-      const size_t base = (size_t)(row < p.M ? row : p.M - 1) * N;
+      const int rowc = row < p.M ? row : p.M - 1;
+      const size_t base = (size_t)rowc * N;
+      // the per-row statistics ride with the row's loads: read where they are used, the second row's would wait
+      // behind the first row's stores (no aliasing guarantee) -- one more memory round trip in a one-pass kernel
+      rstd_u[u] = p.rstd_in[rowc];
+      mu_u[u] = p.is_rms ? 0.f : p.mean_in[rowc];
+      sc_u[u] = p.row_scale ? p.row_scale[rowc / p.rows_per_scale] : 1.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = (k * LPR + lr) * 4;
@@ -376,8 +385,8 @@ __global__ __launch_bounds__(256) void add_norm_bwd3_kernel(NormParams p) {
       const bool live = row < p.M;
       const int rowc = live ? row : p.M - 1;
       const size_t base = (size_t)rowc * N;
-      const float rstd = p.rstd_in[rowc];
-      const float mu = p.is_rms ? 0.f : p.mean_in[rowc];
+      const float rstd = rstd_u[u];
+      const float mu = mu_u[u];
       const float lv = live ? 1.f : 0.f;                 // a clamped (repeated) row adds nothing
       float xh[3][4], dxh[3][4];
       float c1 = 0.f, c2 = 0.f;
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(256) void add_norm_bwd3_kernel(NormParams p) {
         }
       c2 = group_sum<LPR>(c2) * inv_n;
       c1 = p.is_rms ? 0.f : group_sum<LPR>(c1) * inv_n;
-      const float sc = p.row_scale ? p.row_scale[rowc / p.rows_per_scale] : 1.f;
+      const float sc = sc_u[u];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = (k * LPR + lr) * 4;
