@@ -32,12 +32,34 @@ __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
   const int dd = act ? d : 0;
   const int m0 = slice * p.rows_per_block;
   const int nr = min(p.rows_per_block, p.M - m0);
-  // stage the slice's dx_dbl rows, summing the channel-chunk partials in fixed order
-  for (int e = threadIdx.x; e < nr * W; e += blockDim.x) {
-    float t = 0.f;
-    for (int c = 0; c < p.nchunks; ++c)
-      t += p.dxdbl_part[(((size_t)c * 2 + dir) * p.M + m0) * W + e];
-    s_dx[e] = t;
+  // this lane's column of W_x: needed after the barrier, requested before the staging loop so that it arrives under it
+  float wcol[W], acc[W];
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    wcol[c] = p.Wx[dir][(size_t)c * p.d_in + dd];
+    acc[c] = 0.f;
+  }
+  // stage the slice's dx_dbl rows, summing the channel-chunk partials in fixed order.  The block is short-lived and
+  // all latency: six partials of two elements are in flight per lane (a chunk loop with a run-time bound issues one
+  // load, waits, adds, and repeats)
+  for (int e = threadIdx.x; e < nr * W; e += 2 * blockDim.x) {
+    const int e1 = e + blockDim.x;
+    const bool two = e1 < nr * W;
+    float t0 = 0.f, t1 = 0.f;
+    for (int c0 = 0; c0 < p.nchunks; c0 += 6) {
+      float v0[6], v1[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const bool on = c0 + u < p.nchunks;
+        const size_t o = (((size_t)(on ? c0 + u : 0) * 2 + dir) * p.M + m0) * W;
+        v0[u] = on ? p.dxdbl_part[o + e] : 0.f;
+        v1[u] = on && two ? p.dxdbl_part[o + e1] : 0.f;
+      }
+      t0 += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + (v0[4] + v0[5]);
+      t1 += ((v1[0] + v1[1]) + (v1[2] + v1[3])) + (v1[4] + v1[5]);
+    }
+    s_dx[e] = t0;
+    if (two) s_dx[e1] = t1;
   }
   __syncthreads();
   if (p.dxdbl_out && blockIdx.x == 0) {      // one channel block publishes the summed rows (bf16, padded row stride)
@@ -47,12 +69,6 @@ __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
       const int r = e / WP, c = e - r * WP;
       o[e] = __float2bfloat16(c < W ? s_dx[r * W + c] : 0.f);
     }
-  }
-  float wcol[W], acc[W];
-#pragma unroll
-  for (int c = 0; c < W; ++c) {
-    wcol[c] = p.Wx[dir][(size_t)c * p.d_in + dd];
-    acc[c] = 0.f;
   }
   const T* xc = (const T*)p.xc + ((size_t)dir * p.M + m0) * p.d_in + dd;
   float* dxc = p.dxc + ((size_t)dir * p.M + m0) * p.d_in + dd;
