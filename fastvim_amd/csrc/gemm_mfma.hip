@@ -199,7 +199,7 @@ struct KsFrags {
 // MB = 8 (128-row wave tiles, 256-row block tiles) is for the compute-bound FastVim-S/B widths: a k-step of a
 // 64x64 wave tile reads 8 KiB of fragments for 16 MFMAs -- at the full MFMA rate that is exactly the 128 B/clk the
 // LDS delivers -- while a 128x64 wave tile reads 12 KiB for 32.
-template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4, bool XREMAP = true>
 __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id, int split) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN, WNC = 16 * NB, WMR = 16 * MB;
@@ -213,7 +213,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int nblk = tiles_m * tiles_n;
   int bid = block_id;
-  {
+  if constexpr (XREMAP) {      // block_id is the hardware block index (XCD = block_id % 8); the grouped kernel remaps itself
     const int q8 = nblk / 8, r8 = nblk % 8, xcd = bid % 8, j = bid / 8;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;   // bijective remap
   }
@@ -384,15 +384,24 @@ struct GroupedParams {
 };
 
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_grouped_kernel(GroupedParams G) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_grouped_kernel(GroupedParams G, int xcd_order) {
+  // Hardware block g runs on XCD g % 8.  The workgroups of one (problem, K slice) read the same token range of both
+  // operands: in the logical order [problem][slice][tile] they are neighbours, so XCD x takes the x-th eighth of that
+  // order (neighbours share an XCD and its L2, and start together) instead of every eighth workgroup -- with the
+  // round-robin order the 12 tiles of an in_proj slice sat on 8 XCDs and each fetched its operands over the fabric
+  int g = blockIdx.x;
+  if (xcd_order) {
+    const int n = gridDim.x, q8 = n / 8, r8 = n % 8, xcd = g % 8, k = g / 8;
+    g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
   int j = 0;
-  while (j + 1 < G.count && (int)blockIdx.x >= G.blk_end[j]) ++j;
+  while (j + 1 < G.count && g >= G.blk_end[j]) ++j;
   const GemmParams& p = G.p[j];
-  const int local = blockIdx.x - (j ? G.blk_end[j - 1] : 0);
+  const int local = g - (j ? G.blk_end[j - 1] : 0);
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int split = local / tiles;
-  gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB>(p, local - split * tiles, split);
+  gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB, false>(p, local - split * tiles, split);
 }
 
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
@@ -737,6 +746,7 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
     }
     G.count = n;
     static const int tile = getenv("FASTVIM_WGRAD_GROUP_TILE") ? atoi(getenv("FASTVIM_WGRAD_GROUP_TILE")) : 0;   // tuning hook
+    static const int xcd_order = getenv("FASTVIM_WGRAD_GROUP_XCD") ? atoi(getenv("FASTVIM_WGRAD_GROUP_XCD")) : 1;   // tuning hook
     if (tile == 7) {          // 8 waves, 256x192 tiles (every N = 192 problem reads its wide operand once)
       int b2 = 0;
       for (int i = 0; i < n; ++i) {
@@ -750,10 +760,10 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
         attr = true;
       }
       hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 4, 2, false, 6, 4>), dim3(b2), dim3(512),
-                         (size_t)2 * (256 + 192) * BK * 2, st, G);
+                         (size_t)2 * (256 + 192) * BK * 2, st, G, xcd_order);
     } else {
       hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256),
-                         (size_t)2 * (128 + 128) * BK * 2, st, G);
+                         (size_t)2 * (128 + 128) * BK * 2, st, G, xcd_order);
     }
     FV_LAUNCH_CHECK();
   }
