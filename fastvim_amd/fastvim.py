@@ -166,8 +166,10 @@ class PatchEmbed(nn.Module):
         ph, pw = self.patch_size
         gh, gw = x.shape[2] // ph, x.shape[3] // pw
         cdt = _compute_dtype(x)
-        # cast first: the unfold copy then moves half the bytes and the GEMM needs no second pass over the patches
-        patches = x.to(cdt).reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
+        # unfold and cast in ONE strided copy (fp32 image read once, compute-dtype patches written once); the GEMM then
+        # needs no second pass over the patches
+        patches = torch.empty(B, gh * gw, C * ph * pw, device=x.device, dtype=cdt)
+        patches.view(B, gh, gw, C, ph, pw).copy_(x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5))
         x = LinearFn.apply(patches, self.proj.weight, cdt)          # (B, gh*gw, D), weight viewed (D, C*ph*pw)
         if self.scanpath_type == "colwise":
             x = x.reshape(B, gh, gw, -1).transpose(1, 2).reshape(B, gh * gw, -1)
