@@ -673,7 +673,7 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
 
 // Several independent fixed-order reductions in ONE launch (gradient partials of different kernels /
 // layers whose sums are only needed before the optimizer step).
-constexpr int MAXJOBS = 16;
+constexpr int MAXJOBS = 96;      // 96 x 32 bytes of job table + prefix stay under the 4 KiB kernel-argument limit
 struct ReduceJobs {
   const float* in[MAXJOBS];
   float* out[MAXJOBS];
@@ -685,8 +685,12 @@ struct ReduceJobs {
 
 __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J) {
   __shared__ float s_acc[8][33];
-  int job = 0;
-  while (job + 1 < J.njobs && (int)blockIdx.x >= J.blk_end[job]) ++job;
+  int lo = 0, hi = J.njobs - 1;         // first job whose block range ends beyond this block (binary search, uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= J.blk_end[mid]) lo = mid + 1; else hi = mid;
+  }
+  const int job = lo;
   const int blk = blockIdx.x - (job ? J.blk_end[job - 1] : 0);
   const float* __restrict__ in = J.in[job];
   const int S = J.S[job];

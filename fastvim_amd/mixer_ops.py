@@ -69,11 +69,12 @@ def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1):
 
 class _Deferred:
     """Gradient-partial reductions whose results are only needed before the optimizer step are queued
-    (flat training state only) and issued 16 at a time by ONE launch (fv_reduce_partials_multi).
+    (flat training state only) and issued up to 96 at a time by ONE launch (fv_reduce_partials_multi).
     FASTVIM_REDUCE_STREAM=1 issues them on a second HIP stream (forked after the producers, joined in
     ``flush_reductions``; partial buffers stay referenced until the join): measured 3 % SLOWER under graph
     replay on MI355X (9.54 vs 9.28 ms/step), like the weight-gradient side stream, so it is off by default."""
     enabled = False
+    max_jobs = int(os.environ.get("FASTVIM_REDUCE_JOBS", "96"))      # per launch (<= 96, the C side's table); tuning hook
     side = os.environ.get("FASTVIM_REDUCE_STREAM", "0") == "1"
     jobs = []
     stream = None
@@ -82,7 +83,7 @@ class _Deferred:
     @classmethod
     def add(cls, part, out, n_partials):
         cls.jobs.append((part, out, n_partials))
-        if len(cls.jobs) >= 16:
+        if len(cls.jobs) >= cls.max_jobs:
             cls.flush()
 
     @classmethod

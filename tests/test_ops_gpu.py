@@ -171,7 +171,7 @@ def test_xproj_fwd_kernel_vs_torch(Mrows, d_in, W):
 
 
 def test_deferred_partial_reductions_match_single_launches():
-    """fv_reduce_partials_multi (up to 16 queued gradient-partial reductions in one launch) against fp64 and against
+    """fv_reduce_partials_multi (up to 96 queued gradient-partial reductions in one launch) against fp64 and against
     the one-job kernel, which shares its summation code (bitwise equal: an eager model and one on the flat training
     state stay in lock-step); a repeat is bitwise identical."""
     from fastvim_amd import mixer_ops as M
