@@ -368,6 +368,9 @@ def main():
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(5678 + rank)             # per-rank DropPath streams
 
+    from fastvim_amd.losses import SoftTargetCrossEntropy
+    criterion = SoftTargetCrossEntropy()
+
     def fwd_bwd():
         flat.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
@@ -376,7 +379,7 @@ def main():
             else:
                 logits = model(x)
         if args.model != "M":
-            loss = torch.sum(-tgt * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()   # SoftTargetCrossEntropy
+            loss = criterion(logits, tgt)      # SoftTargetCrossEntropy (supervised_imagenet.py:83), fused value + gradient
         loss.backward()
         flat.finish_backward()
         return loss.detach()

@@ -291,6 +291,14 @@ int fv_mixer_xproj_bwd2(const float* dx_dbl_partials, int nchunks, const void* x
                         const float* x_proj_w_b, float* dxc, float* dW_partials, void* dx_dbl_bf16, int M, int d_inner,
                         int width, int dtype, fv_stream_t stream);
 
+/* Soft-target cross-entropy, value and gradient in one call (replaces timm.loss.SoftTargetCrossEntropy as the
+ * reference trainer uses it, imagenet_classification/supervised_imagenet.py:83, 109-115, and its autograd):
+ *   loss_rows[b] = sum_c -target[b][c] * log_softmax(logits[b])[c];  loss[0] = mean_b loss_rows[b];
+ *   dlogits[b][c] = (softmax(logits[b])[c] * sum_c' target[b][c'] - target[b][c]) / batch      (fp32)
+ * logits (batch, classes) fp32 or bf16, target fp32; classes <= 2048.  Deterministic (fixed summation order). */
+int fv_soft_target_ce(const void* logits, int logits_dtype, const float* target, float* loss_rows, float* loss,
+                      float* dlogits, int batch, int classes, fv_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Fused AdamW (decoupled weight decay, bias correction; torch.optim.AdamW semantics) over a flat fp32
  * parameter buffer, optionally updating an EMA copy (timm ModelEmaV2: ema = d*ema + (1-d)*p) and the

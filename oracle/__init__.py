@@ -23,6 +23,7 @@ reference root).
 from .scan import selective_scan_oracle, selective_scan_ref_port  # noqa: F401
 from .conv import causal_conv1d_oracle  # noqa: F401
 from .norm import fused_add_norm_oracle  # noqa: F401
+from .losses import soft_target_ce_oracle  # noqa: F401
 from .mixer import fastvim_mixer_oracle, masked_mixer_oracle  # noqa: F401
 from .model import (fastvim_block_oracle, fastvim_forward_oracle, make_state_dict,  # noqa: F401
                     channel_forward_oracle, channel_block_oracle, make_channel_state_dict,

@@ -204,3 +204,32 @@ def test_deferred_partial_reductions_match_single_launches():
         finally:
             M.defer_reductions(False)
         assert all(torch.equal(a_, m_) for a_, m_ in zip(again, multi))
+
+
+@pytest.mark.parametrize("B,C,dtype", [(128, 1000, torch.bfloat16), (128, 1000, torch.float32), (5, 10, torch.float32),
+                                       (3, 2048, torch.bfloat16)])
+def test_soft_target_cross_entropy_vs_oracle(B, C, dtype):
+    """fastvim_amd.losses.SoftTargetCrossEntropy (fv_soft_target_ce: value + gradient in one launch) against the fp64
+    restatement of timm's formula, mixup-style soft targets (rows sum to 1) and un-normalised ones; upstream gradient
+    scale honoured; repeat bitwise identical."""
+    from fastvim_amd.losses import SoftTargetCrossEntropy
+    from oracle import soft_target_ce_oracle
+    torch.manual_seed(B + C)
+    x = (torch.randn(B, C, device="cuda") * 3).to(dtype).requires_grad_(True)
+    for normalised in (True, False):
+        t = torch.rand(B, C, device="cuda")
+        if normalised:
+            t = t / t.sum(-1, keepdim=True)
+        ref, gref = soft_target_ce_oracle(x, t)
+        x.grad = None
+        loss = SoftTargetCrossEntropy()(x, t)
+        (loss * 2.5).backward()
+        assert loss.dtype == torch.float32 and loss.dim() == 0
+        assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item()))
+        tol = (1e-6 if dtype == torch.float32 else 2e-2) * gref.abs().max().item() * 2.5
+        assert (x.grad.double().cpu() - 2.5 * gref).abs().max().item() <= tol
+        g1 = x.grad.clone()
+        x.grad = None
+        loss2 = SoftTargetCrossEntropy()(x, t)
+        (loss2 * 2.5).backward()
+        assert torch.equal(loss, loss2) and torch.equal(g1, x.grad)
