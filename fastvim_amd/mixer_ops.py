@@ -242,6 +242,9 @@ def xproj_fwd(xc, Wx2_c):
     return out
 
 
+_XPROJ_PRESUM = int(os.environ.get("FASTVIM_XPROJ_PRESUM", "16"))      # tuning hook: chunk count from which dx_dbl is summed first
+
+
 def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True):
     """dxc (2, B, Lc, d_in) fp32 += dx_dbl @ Wx (in place); returns d x_proj weights (2, W, d_in) fp32, or
     accumulates them into ``grad_out`` (flat view of that shape) and returns None.  ``dw=False``: the weight gradient
@@ -250,6 +253,12 @@ def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True):
     nchunks, _, Mrows, W = dx_dbl_chunks.shape
     d_in = xc.shape[-1]
     lib = L.lib()
+    # every 128-channel block of the adjoint kernel re-sums the chunk partials of its rows: nchunks x d_in / 128 reads
+    # of each row (24 x 12 at FastVim-B, 330 MB).  From 16 chunks up (d_inner >= 1024) they are summed once, by the reduction
+    # kernel: FastVim-B 37.2 -> 36.6 ms per step; neutral to slightly worse at 12 chunks (FastVim-S), so not there.
+    if nchunks >= _XPROJ_PRESUM:
+        dx_dbl_chunks = reduce_partials(dx_dbl_chunks, nchunks, defer=False).view(1, 2, Mrows, W)
+        nchunks = 1
     if not dw:
         WP = (W + 7) // 8 * 8
         dxb = torch.empty(2, Mrows, WP, device=xc.device, dtype=torch.bfloat16)
