@@ -54,6 +54,12 @@ def test_gemm_streaming_form(M, N, K):
     c32 = gemm_nt(a, w, out_dtype=torch.float32)
     assert torch.equal(c32.bfloat16(), c)
     assert torch.equal(gemm_nn(a, b, out_dtype=torch.float32).bfloat16(), c2)
+    # A as a column slice of a wider buffer (row stride > K), B as a row slice of a taller one
+    wide = torch.randn(M, K + 64, device="cuda").bfloat16()
+    wide[:, :K] = a
+    tall = torch.randn(K + 16, N, device="cuda").bfloat16()
+    tall[:K] = b
+    assert torch.equal(gemm_nn(wide[:, :K], tall[:K]), c2)
 
 
 @pytest.mark.parametrize("Kd,M,N,splits", [(64, 128, 128, 1), (1024, 192, 384, 4), (25088, 768, 192, 16),
