@@ -33,12 +33,12 @@ class _EmbedEpilogueFn(torch.autograd.Function):
     def forward(ctx, lin, bias, pos):
         ctx.lin_dtype = lin.dtype
         ctx.has = (bias is not None, pos is not None)
-        out = lin.float()
-        if bias is not None:
-            out = out + bias.float()
+        pb = bias.float() if bias is not None else None
         if pos is not None:
-            out = out + pos.float()
-        return out
+            pb = pos.float() if pb is None else pos.float() + pb          # (1, L, D): tiny
+        if pb is None:
+            return lin.float()
+        return torch.add(pb, lin)          # ONE full-length pass: fp32 (1, L, D) + bf16 (B, L, D) promotes to fp32
 
     @staticmethod
     def backward(ctx, g):

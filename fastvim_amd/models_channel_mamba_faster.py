@@ -35,12 +35,12 @@ class _ChannelEmbedEpilogueFn(torch.autograd.Function):
         ctx.lin_dtype = lin.dtype
         ctx.has = (bias is not None, pos is not None)
         ctx.chan_batched = chan.shape[0] != 1
-        out = lin.float() + chan.float()[:, None]
+        add = chan.float()[:, None]                                   # (Bc, 1, C, D)
         if bias is not None:
-            out = out + bias.float()
+            add = add + bias.float()
         if pos is not None:
-            out = out + pos.float()[:, :, None]
-        return out
+            add = add + pos.float()[:, :, None]                       # (Bc, P, C, D): per-sample only under channel sampling
+        return torch.add(add, lin)       # one full-length pass; fp32 + bf16 promotes to fp32
 
     @staticmethod
     def backward(ctx, g):
