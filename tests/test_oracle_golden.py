@@ -220,3 +220,22 @@ def test_mae_oracle_matches_reference(case):
     assert torch.equal(mask.float(), c["mask"].float())
     for k, g in c["grads"].items():
         assert (sd[k].grad - g).abs().max().item() <= 1e-5 * max(1.0, g.abs().max().item()), k
+
+
+def test_soft_target_ce_oracle_known_answers():
+    """oracle.soft_target_ce_oracle (timm.loss.SoftTargetCrossEntropy's published formula; timm is not vendored in the
+    reference) on cases with closed-form answers: uniform logits give log C for any target summing to 1; a one-hot
+    target reduces to ordinary cross-entropy, whose gradient is (softmax - onehot) / B."""
+    import math
+    import torch.nn.functional as F
+    from oracle import soft_target_ce_oracle
+    t = torch.tensor([[0.2, 0.3, 0.5], [1.0, 0.0, 0.0]])
+    loss, g = soft_target_ce_oracle(torch.zeros(2, 3), t)
+    assert abs(loss.item() - math.log(3.0)) < 1e-12
+    assert torch.allclose(g, (torch.full((2, 3), 1.0 / 3.0).double() - t.double()) / 2)
+    torch.manual_seed(0)
+    x = torch.randn(4, 7)
+    y = torch.tensor([1, 0, 6, 3])
+    loss, g = soft_target_ce_oracle(x, F.one_hot(y, 7).float())
+    assert abs(loss.item() - F.cross_entropy(x.double(), y).item()) < 1e-12
+    assert torch.allclose(g, (F.softmax(x.double(), -1) - F.one_hot(y, 7).double()) / 4)
