@@ -229,7 +229,7 @@ def test_soft_target_ce_oracle_known_answers():
     import math
     import torch.nn.functional as F
     from oracle import soft_target_ce_oracle
-    t = torch.tensor([[0.2, 0.3, 0.5], [1.0, 0.0, 0.0]])
+    t = torch.tensor([[0.25, 0.25, 0.5], [1.0, 0.0, 0.0]])          # exactly representable, rows sum to 1
     loss, g = soft_target_ce_oracle(torch.zeros(2, 3), t)
     assert abs(loss.item() - math.log(3.0)) < 1e-12
     assert torch.allclose(g, (torch.full((2, 3), 1.0 / 3.0).double() - t.double()) / 2)
