@@ -143,12 +143,19 @@ def fastvim_block_oracle(sd_layer, hidden, residual, layer_idx, token_size, *, n
 
 def fastvim_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, rotate_every_block=True,
                            final_pool_type="mean", row_scales=None, compute_dtype=torch.float64,
-                           return_features=False, return_hidden=False, mixer_kwargs=None):
+                           return_features=False, return_hidden=False, mixer_kwargs=None,
+                           scanpath_type="rowwise"):
     """models/fastvim.py:484-557 (if_abs_pos_embed=True, fused_add_norm, rms_norm,
     residual_in_fp32).  ``row_scales``: optional list of depth+1 per-sample DropPath scales
-    ((B,) tensors or None); entry i is applied inside block i, entry ``depth`` before norm_f."""
+    ((B,) tensors or None); entry i is applied inside block i, entry ``depth`` before norm_f.
+    ``scanpath_type="colwise"`` (Pool_row): the patch grid is transposed before it is flattened and
+    the token grid is (gw, gh) (models/fastvim.py:45-51, 97-98)."""
     cd = compute_dtype
     h, token_size = patch_embed_oracle(sd, x, patch_size, cd)
+    if scanpath_type == "colwise":
+        gh, gw = token_size
+        h = h.reshape(h.shape[0], gh, gw, -1).transpose(1, 2).reshape(h.shape[0], gh * gw, -1)
+        token_size = (gw, gh)
     h = h + sd["pos_embed"].to(cd)                                        # :500
     h = h.to(cd if cd == torch.float64 else torch.float32)
     residual = None

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# before the HIP runtime initialises (same switch fastvim_amd/__init__.py and bench.py set)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import pytest
 import torch
 

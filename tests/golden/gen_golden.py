@@ -436,7 +436,51 @@ def gen_mae():
     save("mae.pt", cases)
 
 
+def gen_config34():
+    """BASELINE config 3 (FastVim-B): the whole FastVim-B model at bs = 2 with parameters from the seeded recipe
+    (re-derivable on the GPU box, not stored), and a colwise (Pool_row) tiny model.  The FastVim-B mixer on the 14x14
+    and 128-column grids is compared with the (golden-pinned) fp64 oracle directly in tests/test_config34_gpu.py."""
+    fv = ref.fastvim
+    sd = make_state_dict(seed=9, embed_dim=768, depth=24)
+    model = fv.vim_base_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2(drop_path_rate=0.0)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(223))
+    logits = model(x)
+    g = torch.randn(logits.shape, generator=torch.Generator().manual_seed(224))
+    logits.backward(g)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()
+             if n in ("head.bias", "norm_f.weight", "layers.0.norm.weight", "layers.23.mixer.D_b",
+                      "layers.12.mixer.A_log", "layers.5.mixer.dt_proj.bias", "patch_embed.proj.bias",
+                      "layers.7.mixer.conv1d_b.weight", "layers.0.mixer.x_proj.weight", "layers.11.mixer.layernorm.weight")}
+    save("model_fastvim_b.pt", dict(param_seed=9, x_seed=223, g_seed=224, x_probe=x[0, 0, :2, :8].clone(),
+                                     logits=logits.detach(), grads=grads))
+
+    # colwise scan path (models/fastvim.py:45-51, 97-98): patch grid transposed before flattening
+    torch.manual_seed(16)
+    img = (64, 64)      # square: the reference's pos-embed resize call is broken when the transposed grid differs (SURVEY section 9)
+    model = fv.VisionMamba(img_size=img, patch_size=16, depth=4, embed_dim=32, channels=3, num_classes=10,
+                           rms_norm=True, residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean",
+                           if_abs_pos_embed=True, drop_path_rate=0.0, scanpath_type="colwise")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(("D", "D_b", "norm.weight", "layernorm.weight", "norm_f.weight")):
+                p.add_(0.2 * torch.randn_like(p))
+            elif n.endswith(("layernorm.bias", "head.bias", "patch_embed.proj.bias")):
+                p.add_(0.1 * torch.randn_like(p))
+    model.eval()
+    x = torch.randn(2, 3, *img)
+    logits = model(x)
+    g = torch.randn_like(logits)
+    logits.backward(g)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()
+             if n in ("pos_embed", "head.weight", "layers.0.mixer.in_proj.weight", "layers.1.mixer.A_b_log",
+                      "layers.3.mixer.x_proj_b.weight", "patch_embed.proj.weight", "layers.1.mixer.conv1d.weight")}
+    save("model_colwise.pt", dict(img=img, state_dict={k: v.clone() for k, v in model.state_dict().items()}, x=x,
+                                   logits=logits.detach(), g=g, grads=grads))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked", "mae"]
+    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked", "mae", "config34"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,0 +1,303 @@
+"""GPU parity and full-size properties for BASELINE configs 3 and 4 (FastVim-B 224 px bs=128 bf16; FastVim-B
+2048 px bs=8: 128x128 token grid, pooled scan length 128) and the full-size graph-replay check of configs 2-4.
+
+* FastVim-B model, bs=2, fp32 and bf16, against the golden captured from the imported reference
+  (tests/golden/model_fastvim_b.pt, seeded parameter recipe);
+* FastVim-B mixer (d_model 768, d_inner 1536, dt_rank 48) on the 14x14 grid, fp32 AND bf16, forward and every
+  gradient against the fp64 oracle (the channel-split whole-row conv kernels, the generic x_proj path);
+* the same mixer on the 128x128 grid at bs=1 (cell-walking conv kernels, pooled scan with global checkpoints);
+* the hot-path pooled scan kernels (csrc/scan_cl.hip: fv_mixer_scan_fwd / fv_mixer_scan_bwd) at Lc = 128 and
+  Lc = 14 directly against selective_scan_oracle, both directions, fp32 and bf16 I/O;
+* configs 2, 3, 4 at FULL size: finite, bitwise deterministic, and the HIP-graph replay of the whole training
+  step (fwd + loss + bwd + AdamW + EMA) bitwise equal to the eager trajectory for 10 replays, under the same
+  DEBUG_CLR_GRAPH_PACKET_CAPTURE setting bench.py runs with.
+"""
+import os
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _err(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+# --------------------------------------------------------------------------- FastVim-B model vs the reference golden
+def _fastvim_b():
+    from fastvim_amd.fastvim import FastVimB
+    from oracle import make_state_dict
+    c = load_golden("model_fastvim_b.pt")
+    m = FastVimB(drop_path_rate=0.0).cuda().eval()
+    m.load_state_dict(make_state_dict(seed=c["param_seed"], embed_dim=768, depth=24), strict=True)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(c["x_seed"]))
+    assert torch.equal(x[0, 0, :2, :8], c["x_probe"])
+    return c, m, x
+
+
+def test_fastvim_b_vs_reference_golden_fp32():
+    """BASELINE config 3 model at bs=2 (seeded weights), fp32: logits within 1e-4, sampled gradients within 1e-3
+    of the reference's own autograd."""
+    c, m, x = _fastvim_b()
+    logits = m(x.cuda())
+    s = max(1.0, c["logits"].abs().max().item())
+    assert _err(logits, c["logits"]) <= 1e-4 * s, (_err(logits, c["logits"]), s)
+    g = torch.randn(logits.shape, generator=torch.Generator().manual_seed(c["g_seed"]))
+    logits.backward(g.cuda())
+    params = dict(m.named_parameters())
+    for k, gref in c["grads"].items():
+        e = _err(params[k].grad, gref)
+        assert e <= 1e-3 * max(1.0, gref.abs().max().item()), (k, e, gref.abs().max().item())
+
+
+def test_fastvim_b_bf16_autocast_close_to_fp32_reference():
+    c, m, x = _fastvim_b()
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        logits = m(x.cuda())
+    assert _rel(logits.float(), c["logits"]) <= 3e-2
+
+
+# --------------------------------------------------------------------------- FastVim-B mixer vs the fp64 oracle
+def _b_mixer(grid, seed=0):
+    from fastvim_amd.mamba_simple_faster import Mamba
+    torch.manual_seed(seed)
+    m = Mamba(768, token_size=list(grid)).cuda()
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if n in ("D", "D_b", "layernorm.weight") or n.endswith("bias"):
+                p_.add_(0.1 * torch.randn_like(p_))
+    return m, {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+def _oracle_mixer(sd, h, g, grid, round_bf16=False):
+    from oracle import fastvim_mixer_oracle
+    p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    hc = (h.bfloat16().float() if round_bf16 else h).clone().requires_grad_()
+    y = fastvim_mixer_oracle(p, hc, grid, compute_dtype=F64, out_dtype=F64)
+    y.backward((g.bfloat16().float() if round_bf16 else g).double())
+    return y.detach(), hc.grad, {k: v.grad for k, v in p.items()}
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_mixer_b_14x14_fp32_vs_oracle(transposed):
+    grid = (14, 14)
+    rows, cols = grid
+    m, sd = _b_mixer(grid, seed=1)
+    Bsz, Ltok = 2, rows * cols
+    h, g = torch.randn(Bsz, Ltok, 768), torch.randn(Bsz, Ltok, 768)
+    perm = (lambda t: t.reshape(Bsz, rows, cols, -1).transpose(1, 2).reshape(Bsz, Ltok, -1)) if transposed else (lambda t: t)
+    hg = perm(h).contiguous().cuda().requires_grad_()
+    y = m(hg, transposed_grid=transposed)
+    y.backward(perm(g).contiguous().cuda())
+    yr, dhr, gr = _oracle_mixer(sd, h, g, grid)
+    assert _err(y, perm(yr)) <= 2e-5 * max(1.0, yr.abs().max().item()), _err(y, perm(yr))
+    assert _err(hg.grad, perm(dhr)) <= 5e-5 * max(1.0, dhr.abs().max().item())
+    for n, q in m.named_parameters():
+        e = _err(q.grad, gr[n])
+        assert e <= 2e-4 * max(1.0, gr[n].abs().max().item()), (n, e, gr[n].abs().max().item())
+
+
+def test_mixer_b_14x14_bf16_vs_oracle():
+    """bf16 storage under autocast (the benchmarked mode of config 3).  The oracle runs in fp64 on the bf16-rounded
+    input and output gradient; what remains is the rounding of the bf16 activations the kernels store (xz, skip, g,
+    xc, x_dbl) and of the bf16 weights in the GEMMs: relative L2 error <= 1e-2 on the output, 2e-2 on the
+    gradients (max-norm bounds next to them)."""
+    grid = (14, 14)
+    m, sd = _b_mixer(grid, seed=2)
+    Bsz, Ltok = 2, 196
+    h, g = torch.randn(Bsz, Ltok, 768), torch.randn(Bsz, Ltok, 768)
+    hg = h.cuda().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(hg)
+    assert y.dtype == torch.bfloat16
+    y.backward(g.cuda().bfloat16())
+    yr, dhr, gr = _oracle_mixer(sd, h, g, grid, round_bf16=True)
+    assert _rel(y, yr) <= 1e-2, _rel(y, yr)
+    assert _err(y, yr) <= 2e-2 * max(1.0, yr.abs().max().item())
+    assert _rel(hg.grad, dhr) <= 2e-2, _rel(hg.grad, dhr)
+    for n, q in m.named_parameters():
+        r = _rel(q.grad, gr[n])
+        assert r <= 3e-2, (n, r)
+        assert _err(q.grad, gr[n]) <= 4e-2 * max(1.0, gr[n].abs().max().item()), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mixer_b_128x128_vs_oracle(dtype):
+    """BASELINE config 4 geometry: d_model 768 on the 128 x 128 token grid (16 384 tokens, pooled scan length 128),
+    bs = 1, even-layer and odd-layer (transposed) orientation, against the fp64 oracle."""
+    grid = (128, 128)
+    m, sd = _b_mixer(grid, seed=3)
+    Ltok = 128 * 128
+    g0 = torch.Generator().manual_seed(5)
+    h, g = torch.randn(1, Ltok, 768, generator=g0), torch.randn(1, Ltok, 768, generator=g0)
+    lo = dtype == torch.bfloat16
+    yr, dhr, gr = _oracle_mixer(sd, h, g, grid, round_bf16=lo)
+    for transposed in (False, True):
+        m.zero_grad(set_to_none=True)
+        perm = (lambda t: t.reshape(1, 128, 128, -1).transpose(1, 2).reshape(1, Ltok, -1)) if transposed else (lambda t: t)
+        hg = perm(h).contiguous().cuda().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=lo):
+            y = m(hg, transposed_grid=transposed)
+        y.backward(perm(g).contiguous().cuda().to(y.dtype))
+        if lo:
+            assert _rel(y, perm(yr)) <= 1e-2 and _rel(hg.grad, perm(dhr)) <= 2e-2
+            for n, q in m.named_parameters():
+                assert _rel(q.grad, gr[n]) <= 3e-2, (n, _rel(q.grad, gr[n]))
+        else:
+            assert _err(y, perm(yr)) <= 2e-5 * max(1.0, yr.abs().max().item()), _err(y, perm(yr))
+            assert _err(hg.grad, perm(dhr)) <= 5e-5 * max(1.0, dhr.abs().max().item())
+            for n, q in m.named_parameters():
+                e = _err(q.grad, gr[n])
+                # parameter gradients sum 16 384 tokens: fp32 accumulation error grows with sqrt(count)
+                assert e <= 5e-4 * max(1.0, gr[n].abs().max().item()), (n, transposed, e, gr[n].abs().max().item())
+
+
+# --------------------------------------------------------------------------- the hot-path pooled scan kernels, directly
+def _scan_cl_case(Bsz, Lc, d_in, R, dtype, seed):
+    N = 16
+    g = torch.Generator().manual_seed(seed)
+    xc = torch.randn(2, Bsz, Lc, d_in, generator=g)
+    x_dbl = torch.randn(2, Bsz * Lc, R + 2 * N, generator=g)
+    x_dbl[..., :R] *= 0.5
+    Wdt = [torch.randn(d_in, R, generator=g) * R ** -0.5 for _ in range(2)]
+    bdt = [torch.rand(d_in, generator=g) - 3.0 for _ in range(2)]
+    A_log = [torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(d_in, 1) + 0.1 * torch.randn(d_in, N, generator=g)
+             for _ in range(2)]
+    dyc = torch.randn(Bsz, Lc, d_in, generator=g)
+    if dtype == torch.bfloat16:
+        xc, x_dbl = xc.bfloat16().float(), x_dbl.bfloat16().float()
+    return xc, x_dbl, Wdt, bdt, A_log, dyc
+
+
+@pytest.mark.parametrize("Bsz,Lc,d_in,R", [(2, 128, 1536, 48),      # config 4: global-checkpoint branch, 24 channel chunks
+                                           (3, 128, 384, 12),       # long scan at the FastVim-T width
+                                           (4, 14, 1536, 48),       # config 3
+                                           (5, 14, 384, 12),        # config 2
+                                           (2, 112, 768, 24),       # config 5 (pooled length rows * channels)
+                                           (2, 37, 192, 6)])        # ragged: Lc not a multiple of the 4-step segment
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_cl_kernels_vs_selective_scan_oracle(Bsz, Lc, d_in, R, dtype):
+    """fv_mixer_scan_fwd / fv_mixer_scan_bwd (dt_proj + softplus + scan over the pooled rows, channel-last, both
+    directions in one launch) == selective_scan_ref semantics: delta = softplus(dt_low @ Wdt^T + bias), forward
+    direction in ascending and backward direction in descending row order; all gradients (u, x_dbl = [dt_low|B|C],
+    A_log, dt_proj weight and bias) against fp64 autograd of the oracle."""
+    from fastvim_amd import mixer_ops as M
+    from oracle import selective_scan_oracle
+    N = 16
+    xc, x_dbl, Wdt, bdt, A_log, dyc = _scan_cl_case(Bsz, Lc, d_in, R, dtype, seed=Lc + d_in)
+    dev = "cuda"
+    yc = M.scan_fwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
+                    Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev))
+    dxc, dx_dbl, pr = M.scan_bwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
+                                 Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev), dyc.to(dev))
+    dxc2, dx_dbl2, pr2 = M.scan_bwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
+                                    Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev), dyc.to(dev))
+    assert torch.equal(dxc, dxc2) and torch.equal(dx_dbl, dx_dbl2) and torch.equal(pr, pr2)     # no atomics: bitwise
+    for k in range(2):
+        u = xc[k].double().requires_grad_()                                      # (B, Lc, d_in)
+        xd = x_dbl[k].view(Bsz, Lc, R + 2 * N).double().requires_grad_()
+        W_, b_, Al = Wdt[k].double().requires_grad_(), bdt[k].double().requires_grad_(), A_log[k].double().requires_grad_()
+        delta = xd[..., :R] @ W_.t()                                             # (B, Lc, d_in)
+        y = selective_scan_oracle(u.transpose(1, 2), delta.transpose(1, 2), -torch.exp(Al), xd[..., R:R + N].transpose(1, 2),
+                                  xd[..., R + N:].transpose(1, 2), None, None, b_, True, compute_dtype=F64, out_dtype=F64,
+                                  reverse=bool(k)).transpose(1, 2)
+        y.backward(dyc.double())
+        s = max(1.0, y.abs().max().item())
+        assert _err(yc[k], y) <= 1e-5 * s, ("y", k, _err(yc[k], y), s)
+        assert _err(dxc[k], u.grad) <= 2e-5 * max(1.0, u.grad.abs().max().item()), ("du", k)
+        e = _err(dx_dbl[k].view(Bsz, Lc, -1), xd.grad)
+        # d x_dbl sums d_in channels in fp32
+        assert e <= 5e-5 * max(1.0, xd.grad.abs().max().item()), ("dx_dbl", k, e, xd.grad.abs().max().item())
+        prk = pr[k]
+        gA, gW, gb = prk[:d_in * N].view(d_in, N), prk[d_in * N:d_in * (N + R)].view(d_in, R), prk[d_in * (N + R):]
+        for name, a, b in (("dA_log", gA, Al.grad), ("dWdt", gW, W_.grad), ("dbias", gb, b_.grad)):
+            e = _err(a, b)
+            assert e <= 1e-4 * max(1.0, b.abs().max().item()), (name, k, e, b.abs().max().item())
+
+
+# --------------------------------------------------------------------------- full-size configs: properties + graph replay
+_FULL = {        # BASELINE configs -> (factory name, image size, per-GPU batch, drop_path)
+    "cfg2_FastVimT_224_bs128": ("FastVimT", 224, 128, 0.05),
+    "cfg3_FastVimB_224_bs128": ("FastVimB", 224, 128, 0.4),
+    "cfg4_FastVimB_2048_bs8": ("FastVimB", 2048, 8, 0.4),
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(_FULL))
+def test_full_size_step_graph_replay_equals_eager(cfg):
+    """The benchmarked training step at the FULL size of BASELINE configs 2, 3 and 4 (bf16 autocast, train mode with
+    the config's DropPath rate, soft-target cross-entropy, backward, fused AdamW + EMA on the flat training state):
+    finite, bitwise reproducible run to run, and 10 HIP-graph replays bitwise equal to 12 eager steps (2 warm-up +
+    10) of an identically initialised copy -- under DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, the setting fastvim_amd applies
+    on import and bench.py runs with."""
+    import fastvim_amd
+    from fastvim_amd import fastvim as fv
+    from fastvim_amd.flat import FlatAdamW, FlatTrainingState
+    from fastvim_amd.losses import SoftTargetCrossEntropy
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and fastvim_amd.graph_capture_safe()
+    name, img, bs, dpr = _FULL[cfg]
+    n_replay = 10
+    crit = SoftTargetCrossEntropy()
+    x = torch.randn(bs, 3, img, img, generator=torch.Generator().manual_seed(1)).cuda()
+    tgt = torch.softmax(torch.randn(bs, 1000, generator=torch.Generator().manual_seed(2)), -1).cuda()
+
+    def make():
+        torch.manual_seed(1234)
+        m = getattr(fv, name)(img_size=img, drop_path_rate=dpr).cuda().train()
+        flat = FlatTrainingState(m)
+        nd = {n for n, p in m.named_parameters() if p.ndim <= 1 or n.endswith(".bias") or n in m.no_weight_decay()
+              or getattr(p, "_no_weight_decay", False)}
+        opt = FlatAdamW(flat, m, lr=1e-4, weight_decay=0.05, no_decay=nd, ema_decay=0.9999)
+        return m, flat, opt
+
+    def one_step(m, flat, opt):
+        flat.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = m(x)
+        loss = crit(logits, tgt)
+        loss.backward()
+        flat.finish_backward()
+        opt.step()
+        return loss.detach()
+
+    # DropPath draws from torch's CUDA generator: the eager run and the captured run see the same stream when
+    # both start from the same seed and the captured graph registers the generator (torch.cuda.graph does)
+    def run_eager():
+        m, flat, opt = make()
+        torch.manual_seed(99)
+        losses = [one_step(m, flat, opt).item() for _ in range(2 + n_replay)]
+        return losses, flat.param_flat.clone()
+
+    e1, p1 = run_eager()
+    assert all(l == l and abs(l) < 1e4 for l in e1), e1
+    e2, p2 = run_eager()
+    assert e1 == e2 and torch.equal(p1, p2), "eager step is not bitwise reproducible"
+    del p2
+    m, flat, opt = make()
+    torch.manual_seed(99)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        warm = [one_step(m, flat, opt).item() for _ in range(2)]
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lbuf = one_step(m, flat, opt)
+    replayed = []
+    for _ in range(n_replay):
+        graph.replay()
+        replayed.append(lbuf.item())
+    assert warm + replayed == e1, (warm + replayed, e1)
+    torch.cuda.synchronize()
+    assert torch.equal(flat.param_flat, p1)
+    assert torch.isfinite(flat.param_flat).all() and torch.isfinite(opt.ema).all()

@@ -40,6 +40,21 @@ def test_tiny_model_vs_reference_golden(case):
         assert e <= 2e-4 * max(1.0, gref.abs().max().item()), (k, e, gref.abs().max().item())
 
 
+def test_colwise_model_vs_reference_golden():
+    """scanpath_type="colwise" (Pool_row in the paper, models/fastvim.py:45-51, 97-98): the patch grid is transposed
+    before flattening; logits and gradients against the golden captured from the reference."""
+    c = load_golden("model_colwise.pt")
+    m = _tiny(c["img"], drop_path_rate=0.0, scanpath_type="colwise").cuda().eval()
+    m.load_state_dict(c["state_dict"], strict=True)
+    logits = m(c["x"].cuda())
+    assert _err(logits, c["logits"]) <= 2e-5 * max(1.0, c["logits"].abs().max().item()), _err(logits, c["logits"])
+    logits.backward(c["g"].cuda())
+    params = dict(m.named_parameters())
+    for k, gref in c["grads"].items():
+        e = _err(params[k].grad, gref)
+        assert e <= 2e-4 * max(1.0, gref.abs().max().item()), (k, e, gref.abs().max().item())
+
+
 def test_fastvim_t_vs_reference_golden_fp32():
     """BASELINE config 1 input (FastVim-T 224x224 bs=2, seeded weights) on the GPU, fp32."""
     from fastvim_amd.fastvim import FastVimT

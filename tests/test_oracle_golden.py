@@ -135,6 +135,32 @@ def test_model_oracle_fastvim_t_logits():
     close(logits, c["logits"], 0, 2e-3 * max(1.0, c["logits"].abs().max().item()))
 
 
+def test_model_oracle_fastvim_b_logits():
+    """BASELINE config 3 model (FastVim-B 224x224) at bs=2 through the pure-PyTorch path on CPU, fp32."""
+    c = load_golden("model_fastvim_b.pt")
+    sd = make_state_dict(seed=c["param_seed"], embed_dim=768, depth=24)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(c["x_seed"]))
+    assert torch.equal(x[0, 0, :2, :8], c["x_probe"]), "seeded input recipe drifted"
+    with torch.no_grad():
+        logits = fastvim_forward_oracle(sd, x, compute_dtype=torch.float32)
+    close(logits, c["logits"], 0, 2e-3 * max(1.0, c["logits"].abs().max().item()))
+
+
+def test_model_oracle_colwise():
+    """scanpath_type="colwise" (Pool_row, models/fastvim.py:45-51, 97-98): logits and gradients."""
+    c = load_golden("model_colwise.pt")
+    sd = {k: v.clone().requires_grad_() for k, v in c["state_dict"].items()}
+    logits = fastvim_forward_oracle(sd, c["x"], patch_size=16, depth=4, compute_dtype=F64, scanpath_type="colwise")
+    close(logits, c["logits"], 0, 5e-5 * max(1.0, c["logits"].abs().max().item()))
+    logits.backward(c["g"].double())
+    for k, gref in c["grads"].items():
+        close(sd[k].grad, gref, 0, 5e-4 * max(1.0, gref.abs().max().item()))
+    # and the path is not the rowwise one
+    with torch.no_grad():
+        rw = fastvim_forward_oracle({k: v.detach() for k, v in sd.items()}, c["x"], patch_size=16, depth=4, compute_dtype=F64)
+    assert (rw - c["logits"]).abs().max().item() > 1e-3
+
+
 # ---- FastChannelVim (channel-wise tokenization, Channel-First): oracle vs the imported reference
 @pytest.mark.parametrize("case", ["mixer_d32_4x4_t3", "mixer_d32_2x6_t5", "mixer_d64_4x2_t8"])
 def test_channel_mixer_oracle(case):
