@@ -308,83 +308,45 @@ def scan_op_table(cpu=True):
     return out
 
 
-# --------------------------------------------------------------------------- main
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C", "V", "M"],
-                    help="FastVim-T/S/B, C = FastChannelVim-S/16 (use --batch 64 for BASELINE configs[4]), V = Vim-T baseline")
-    ap.add_argument("--channels", type=int, default=8, help="input channels of the channel model (--model C)")
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--img", type=int, default=224)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernels", action="store_true")
-    ap.add_argument("--no-scan-op", action="store_true",
-                    help="skip timing the reference-layout op selective_scan_fn at every config's (B, d_in, Lc, N)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # test hook: FASTVIM_BENCH_ONE_GPU=1 puts every rank on GPU 0 and exchanges gradients through gloo, so the
-    # multi-rank code path (graph replay -> all-reduce -> optimizer) can be exercised on a one-GPU box
-    one_gpu = os.environ.get("FASTVIM_BENCH_ONE_GPU") == "1"
-    if one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
-
+def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, rank, world, dev, use_graph=True,
+                       trace=False):
+    """Build the model + flat training state + fused optimizer, capture the whole step (fwd + loss + bwd + AdamW + EMA;
+    the gradient exchange sits between graph replay and optimizer when world > 1) and time exactly ``steps`` steps
+    after ``warmup`` untimed ones, bracketed by barrier + synchronize.  Returns (seconds, final loss, extras)."""
     from fastvim_amd.flat import FlatAdamW, FlatTrainingState
+    from fastvim_amd.losses import SoftTargetCrossEntropy
 
     torch.manual_seed(1234)                    # identical init on every rank (DDP broadcast equivalent)
-    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1, "V": 0.05, "M": 0.0}[args.model]   # imagenet_classification/config/FastVim*.yaml:15
-    model = build_model(args.model, args.img, drop_path, args.channels).to(dev).train()
+    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1, "V": 0.05, "M": 0.0}[model_name]   # imagenet_classification/config/FastVim*.yaml:15
+    model = build_model(model_name, img, drop_path, channels).to(dev).train()
     gen = torch.Generator().manual_seed(100 + rank)
-    in_ch = args.channels if args.model == "C" else 3
-    x = torch.randn(args.batch, in_ch, args.img, args.img, generator=gen).to(dev)
-    tgt = soft_targets(args.batch, 1000, gen, dev)
+    in_ch = channels if model_name == "C" else 3
+    x = torch.randn(batch, in_ch, img, img, generator=gen).to(dev)
+    tgt = soft_targets(batch, 1000, gen, dev)
     flat = FlatTrainingState(model)      # flat fp32 params / grads + bf16 shadow weights
     no_decay = {n for n, p in model.named_parameters()
                 if p.ndim <= 1 or n.endswith(".bias") or n in model.no_weight_decay() or getattr(p, "_no_weight_decay", False)}
     # one fused kernel: AdamW (the reference recipe's two param groups) + ModelEmaV2 lerp + bf16 shadow refresh
     # MAE pre-training recipe: lr = blr * batch / 256 with blr 1.5e-4, betas (0.9, 0.95) (mae/config/pretrain_FastVimB.yaml:20,
     # mae/mae_imagenet.py); the classification recipe's 1e-3 without warm-up diverges on it within ~10 steps
-    lr, betas = (1.5e-4 * args.batch * world / 256, (0.9, 0.95)) if args.model == "M" else (1e-3, (0.9, 0.999))
+    lr, betas = (1.5e-4 * batch * world / 256, (0.9, 0.95)) if model_name == "M" else (1e-3, (0.9, 0.999))
     opt = FlatAdamW(flat, model, lr=lr, betas=betas, weight_decay=0.05, no_decay=no_decay, ema_decay=0.9999)
-    amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(5678 + rank)             # per-rank DropPath streams
-
-    from fastvim_amd.losses import SoftTargetCrossEntropy
     criterion = SoftTargetCrossEntropy()
 
     def fwd_bwd():
         flat.zero_grad()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
-            if args.model == "M":
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == "bf16"):
+            if model_name == "M":
                 loss = model(x, mask_ratio=0.75)[0]      # norm-pix MSE on the 75 % removed patches (mae_imagenet.py SSLModule)
             else:
                 logits = model(x)
-        if args.model != "M":
+        if model_name != "M":
             loss = criterion(logits, tgt)      # SoftTargetCrossEntropy (supervised_imagenet.py:83), fused value + gradient
         loss.backward()
         flat.finish_backward()
         return loss.detach()
 
-    use_graph = not args.no_graph
     if use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -414,8 +376,7 @@ def main():
             opt.step()
             return l
 
-    trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)
-    for i in range(args.warmup):
+    for i in range(warmup):
         loss = step()
         if trace and rank == 0:
             print(f"warmup {i} loss {float(loss):.5f}", file=sys.stderr, flush=True)
@@ -424,7 +385,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -436,6 +397,96 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     loss_val = float(loss)
+    n_params = sum(p.numel() for p in model.parameters())
+    flat.close()
+    return elapsed, loss_val, {"params": n_params}
+
+
+OTHER_CONFIGS = (      # BASELINE configs[2..4] (per-GPU shape) + the paper's comparison point; model, img, batch, channels
+    ("cfg3_FastVimB_224_bs128", "B", 224, 128, 3),
+    ("cfg4_FastVimB_2048_bs8", "B", 2048, 8, 3),
+    ("cfg5_FastChannelVimS16_8ch_224_bs64", "C", 224, 64, 8),
+    ("f2_VimT_224_bs128_unpooled_baseline", "V", 224, 128, 3),
+)
+
+
+def other_configs_block(dtype, rank, dev, steps=5, warmup=2):
+    """The other BASELINE configurations at their per-GPU shape on this one GPU, a few steps each, with the kernel table of
+    the FastVim-B shapes (dominant kernel and its roofline fraction, MFMA fraction of in_proj / out_proj)."""
+    import gc
+    out = {}
+    for key, mname, img, batch, ch in OTHER_CONFIGS:
+        try:
+            el, lv, ex = run_training_steps(mname, img, batch, ch, dtype, steps, warmup, rank, 1, dev)
+        except Exception as e:      # a failing side configuration must not lose the headline line
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            continue
+        row = {"ms_per_step": round(el / steps * 1e3, 3), "images_per_sec": round(batch * steps / el, 1), "steps": steps,
+               "warmup": warmup, "final_loss": round(lv, 4), "finite": lv == lv, "params_M": round(ex["params"] / 1e6, 2)}
+        if mname in ("T", "S", "B"):
+            gs = img // 16
+            d = {"T": 192, "S": 384, "B": 768}[mname]
+            kt = kernel_table(batch, gs, gs, d, 24, torch.bfloat16 if dtype == "bf16" else torch.float32)
+            dom = max(kt, key=lambda k: kt[k]["us_per_step"])
+            row["dominant_kernel"] = {"kernel": dom, "avg_us": kt[dom]["us"], "us_per_step": kt[dom]["us_per_step"],
+                                      "GBps": kt[dom]["GBps"], "hbm_frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
+                                      **({"TFLOPs": kt[dom]["TFLOPs"], "mfma_frac": kt[dom]["mfma_frac"]} if "TFLOPs" in kt[dom] else {})}
+            row["mfma_frac"] = {k[5:]: kt[k]["mfma_frac"] for k in kt if k.startswith("gemm_") and "mfma_frac" in kt[k]}
+            row["kernel_us"] = {k: kt[k]["us"] for k in kt}
+            del kt
+        out[key] = row
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+# --------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C", "V", "M"],
+                    help="FastVim-T/S/B, C = FastChannelVim-S/16 (use --batch 64 for BASELINE configs[4]), V = Vim-T baseline")
+    ap.add_argument("--channels", type=int, default=8, help="input channels of the channel model (--model C)")
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
+    ap.add_argument("--no-scan-op", action="store_true",
+                    help="skip timing the reference-layout op selective_scan_fn at every config's (B, d_in, Lc, N)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hook: FASTVIM_BENCH_ONE_GPU=1 puts every rank on GPU 0 and exchanges gradients through gloo, so the
+    # multi-rank code path (graph replay -> all-reduce -> optimizer) can be exercised on a one-GPU box
+    one_gpu = os.environ.get("FASTVIM_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    use_graph = not args.no_graph
+    amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)
+    elapsed, loss_val, _ = run_training_steps(args.model, args.img, args.batch, args.channels, args.dtype, args.steps,
+                                              args.warmup, rank, world, dev, use_graph=use_graph, trace=trace)
     if not (loss_val == loss_val):
         raise SystemExit("non-finite loss in the timed region")
 
@@ -495,6 +546,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         if not args.no_scan_op and not args.no_kernels and world == 1 and args.model == "T":
             out["scan_op"] = scan_op_table(cpu=not args.no_cpu_baseline)
+        if (not args.no_other_configs and world == 1 and use_graph
+                and (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16")):
+            out["other_configs"] = other_configs_block(args.dtype, rank, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

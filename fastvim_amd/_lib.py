@@ -27,6 +27,35 @@ C_ABI_SYMBOLS = (
 )
 
 
+_launch_dev = None      # device index of the tensor the last ``stream_of`` was asked about
+
+
+class _DeviceGuarded:
+    """The CDLL with every entry point wrapped in a device guard: a kernel is launched with the device of the
+    tensor whose stream it was given (``stream_of``) current, like the reference's ops do with
+    ``at::cuda::CUDAGuard`` (selective_scan.cpp:326-327) -- costs one ``current_device()`` query per launch, and a
+    ``torch.cuda.device`` switch only when the tensors live on another GPU than the current one."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._wrapped = {}
+
+    def __getattr__(self, name):
+        w = self._wrapped.get(name)
+        if w is None:
+            fn = getattr(self._cdll, name)
+
+            def call(*args, _fn=fn):
+                dev = _launch_dev
+                if dev is None or dev == torch.cuda.current_device():
+                    return _fn(*args)
+                with torch.cuda.device(dev):
+                    return _fn(*args)
+
+            w = self._wrapped[name] = call
+        return w
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -34,10 +63,11 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m fastvim_amd.build` "
                 "(or __graft_entry__.build()). fastvim_amd has no CPU / eager fallback.")
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.fv_last_error.restype = ctypes.c_char_p
-        _lib.fv_selective_scan_bwd_workspace.restype = ctypes.c_size_t
-        _lib.fv_mixer_scan_bwd_ckpt_floats.restype = ctypes.c_size_t
+        cdll = ctypes.CDLL(LIB_PATH)
+        cdll.fv_last_error.restype = ctypes.c_char_p
+        cdll.fv_selective_scan_bwd_workspace.restype = ctypes.c_size_t
+        cdll.fv_mixer_scan_bwd_ckpt_floats.restype = ctypes.c_size_t
+        _lib = _DeviceGuarded(cdll)
     return _lib
 
 
@@ -54,6 +84,8 @@ def ptr(t):
 
 
 def stream_of(t):
+    global _launch_dev
+    _launch_dev = t.device.index
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

@@ -14,14 +14,15 @@ buckets + autocast casts + AccumulateGrad nodes, imagenet_classification/train.p
 """
 import ctypes
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
 
 from . import _lib as L
 from .layernorm import RMSNorm
-from .mamba_simple_faster import Mamba, _SideStream, flush_wgrads, group_wgrads
-from .mixer_ops import defer_reductions, flush_reductions
+from .mamba_simple_faster import Mamba, _GroupedWgrad, _SideStream, flush_wgrads, group_wgrads
+from .mixer_ops import defer_reductions, drop_reductions, flush_reductions, pending_reductions
 
 # per-mixer parameter order; each group is one contiguous region matching a kernel's partial layout
 _MIXER_GROUPS = (
@@ -73,6 +74,8 @@ class FlatTrainingState:
                 p.data = self.param_flat[o:o + k].view_as(p)
                 p.grad = self.grad_flat[o:o + k].view_as(p)
                 p._fv_shadow = self.shadow_flat[o:o + k].view_as(p)
+                p._fv_shadow_version = -1
+        self._params = params
         for mod, gname, full in regions:
             lo = self.offsets[full[0]]
             last = named[full[-1]]
@@ -93,17 +96,53 @@ class FlatTrainingState:
                 if mod.weight.requires_grad:
                     mod.weight._fv_direct = True     # my backward kernels may accumulate into .grad directly
         self.refresh_shadow()
+        # ``model.load_state_dict`` writes the fp32 masters in place: re-cast the shadow right away (the version check in
+        # ``_shadow`` would also catch it at the next forward, but a captured HIP graph never runs that check again)
+        self._hook = model.register_load_state_dict_post_hook(lambda module, incompatible: self.refresh_shadow())
+        # queued gradient work (deferred partial sums, grouped weight-gradient GEMMs) is process-wide state of the
+        # kernels' wrappers: remember what it was so ``close()`` can put it back
+        from .mixer_ops import _Deferred
+        self._saved_switches = (_Deferred.enabled, _GroupedWgrad.enabled, _SideStream.enabled)
         defer_reductions(True)
         group_wgrads(True)
         # weight-gradient GEMMs on a second stream (joined in finish_backward): measured neutral-to-slower
         # on MI355X under graph replay (12.35 vs 12.04 ms/step), so opt-in only
         _SideStream.enabled = os.environ.get("FASTVIM_WGRAD_STREAM", "0") == "1"
 
+    def close(self):
+        """Issue whatever is queued and restore the wrappers' process-wide switches (deferred reductions, grouped weight
+        gradients, side stream) to what they were before this training state was attached.  Also the exit of
+        ``with FlatTrainingState(model) as flat:``."""
+        if self._saved_switches is None:
+            return
+        self.finish_backward()
+        d, g, s_ = self._saved_switches
+        defer_reductions(d)
+        group_wgrads(g)
+        _SideStream.enabled = s_
+        self._hook.remove()
+        self._saved_switches = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     # ------------------------------------------------------------------ per-step operations
     def zero_grad(self):
+        """Zero the flat gradient.  Gradient work still queued from a backward pass that was never finished
+        (``finish_backward`` / ``allreduce_mean_`` / ``FlatAdamW.step`` all finish it) would be computed only to be
+        zeroed: it is dropped instead, with a warning."""
         _SideStream.join()
-        flush_wgrads()
-        flush_reductions()
+        n = len(_GroupedWgrad.jobs) + pending_reductions()
+        if n:
+            _GroupedWgrad.jobs = []
+            drop_reductions()
+            warnings.warn(f"FlatTrainingState.zero_grad(): {n} queued gradient jobs of an unfinished backward pass "
+                          "were discarded -- call finish_backward() (or allreduce_mean_() / optimizer.step()) after "
+                          "loss.backward()", RuntimeWarning, stacklevel=2)
         self.grad_flat.zero_()
 
     def finish_backward(self):
@@ -114,16 +153,22 @@ class FlatTrainingState:
         flush_reductions()        # ... which are issued here
 
     def refresh_shadow(self):
+        """Re-cast every bf16 shadow weight from its fp32 master.  Needed only after writing ``param_flat`` directly
+        (in-place writes through the parameters -- load_state_dict, copy_, a torch optimizer -- are detected by
+        version counter; the fused optimizer kernel refreshes the shadow itself)."""
         self.shadow_flat.copy_(self.param_flat)
+        for p in self._params:
+            p._fv_shadow_version = p._version
 
     @property
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def allreduce_mean_(self):
-        """Sum the flat gradient across ranks (RCCL) and divide by the world size (torch DDP semantics)."""
-        _SideStream.join()
-        flush_reductions()
+        """Sum the flat gradient across ranks (RCCL) and divide by the world size (torch DDP semantics).  Finishes
+        the backward pass first (queued weight-gradient GEMMs and partial sums), so ``backward -> allreduce_mean_ ->
+        step`` is a complete sequence."""
+        self.finish_backward()
         ws = self.world_size
         if ws == 1:
             return
@@ -170,8 +215,48 @@ class FlatAdamW:
     def set_lr(self, lr):
         self.lr.fill_(float(lr))
 
+    # ------------------------------------------------------------------ checkpoint I/O
+    def _named_slices(self, buf):
+        f = self.flat
+        named = dict(zip(f.names, f._params))
+        return {n: buf[o:o + named[n].numel()].view_as(named[n]) for n, o in f.offsets.items()}
+
+    def state_dict(self):
+        """Portable optimizer state: per-parameter NAMED tensors (no flat offsets / padding), the step count and the
+        hyper-parameters -- the information of ``torch.optim.AdamW.state_dict()`` keyed by parameter name."""
+        ea, es = self._named_slices(self.exp_avg), self._named_slices(self.exp_avg_sq)
+        return {"state": {n: {"exp_avg": ea[n].detach().clone(), "exp_avg_sq": es[n].detach().clone()} for n in ea},
+                "step": float(self.step_t.item()), "lr": float(self.lr.item()), "betas": tuple(self.betas),
+                "eps": self.eps, "weight_decay": self.weight_decay, "ema_decay": self.ema_decay,
+                "ema": None if self.ema is None else {n: v.detach().clone() for n, v in self._named_slices(self.ema).items()}}
+
+    def load_state_dict(self, sd):
+        ea, es = self._named_slices(self.exp_avg), self._named_slices(self.exp_avg_sq)
+        missing = set(ea) - set(sd["state"])
+        if missing:
+            raise KeyError(f"FlatAdamW.load_state_dict: no state for {sorted(missing)[:4]} ...")
+        with torch.no_grad():
+            for n in ea:
+                ea[n].copy_(sd["state"][n]["exp_avg"])
+                es[n].copy_(sd["state"][n]["exp_avg_sq"])
+            self.step_t.fill_(float(sd["step"]))
+            self.lr.fill_(float(sd["lr"]))
+            if self.ema is not None and sd.get("ema") is not None:
+                for n, v in self._named_slices(self.ema).items():
+                    v.copy_(sd["ema"][n])
+        self.betas, self.eps, self.weight_decay = tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+
+    def ema_state_dict(self, prefix=""):
+        """The EMA weights under the model's own ``state_dict`` key names (``prefix`` + name): the
+        ``state_dict_ema`` entry of the reference's Lightning checkpoints (supervised_imagenet.py:107-110) with
+        ``prefix="backbone."`` -- what ``MM_FastVim.load_pretrained`` prefers when present."""
+        if self.ema is None:
+            raise RuntimeError("FlatAdamW was built without ema_decay")
+        return {prefix + n: v.detach().clone() for n, v in self._named_slices(self.ema).items()}
+
     def step(self):
         f = self.flat
+        f.finish_backward()         # idempotent: nothing queued in the steady state of a captured step
         rc = L.lib().fv_adamw_flat(
             L.ptr(f.param_flat), L.ptr(f.grad_flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(self.ema),
             L.ptr(f.shadow_flat), L.ptr(self.decay_mask), L.ptr(self.lr), L.ptr(self.step_t),
@@ -179,3 +264,26 @@ class FlatAdamW:
             ctypes.c_float(self.weight_decay), ctypes.c_float(self.ema_decay), ctypes.c_size_t(f.param_flat.numel()),
             L.stream_of(f.param_flat))
         L.check(rc, "adamw_flat")
+
+
+def save_checkpoint(path, model, opt, prefix="backbone.", **extra):
+    """Write a checkpoint in the layout of the reference's Lightning checkpoints: ``state_dict`` (model keys behind
+    ``prefix``), ``state_dict_ema`` (when the optimizer tracks an EMA) and the optimizer state -- loadable by
+    ``MM_FastVim.load_pretrained`` / ``load_checkpoint``."""
+    ck = {"state_dict": {prefix + k: v.detach().clone() for k, v in model.state_dict().items()},
+          "optimizer_states": [opt.state_dict()], **extra}
+    if opt.ema is not None:
+        ck["state_dict_ema"] = opt.ema_state_dict(prefix)
+    torch.save(ck, path)
+    return ck
+
+
+def load_checkpoint(path_or_dict, model, opt=None, prefix="backbone.", use_ema=False):
+    """Resume: model weights (or the EMA weights) and, when ``opt`` is given, the optimizer state.  The flat training
+    state's bf16 shadow follows through the load_state_dict hook."""
+    ck = torch.load(path_or_dict, map_location="cpu", weights_only=False) if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
+    sd = ck["state_dict_ema"] if (use_ema and "state_dict_ema" in ck) else ck["state_dict"]
+    model.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, strict=True)
+    if opt is not None:
+        opt.load_state_dict(ck["optimizer_states"][0])
+    return ck

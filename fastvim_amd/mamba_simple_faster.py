@@ -21,9 +21,15 @@ from .gemm import gemm_nn, gemm_nt, gemm_tn
 
 
 def _shadow(w, cdt):
-    """bf16 shadow copy kept by FlatTrainingState, else a cast."""
+    """bf16 shadow copy kept by FlatTrainingState, else a cast.  The shadow is refreshed by the fused optimizer
+    kernel; any OTHER in-place write to the parameter (``load_state_dict``, an EMA copy-in, a torch optimizer) bumps
+    the tensor's version counter, which is compared here, so a stale shadow is re-cast before it is used."""
     sh = getattr(w, "_fv_shadow", None)
     if sh is not None and sh.dtype == cdt:
+        if w._version != w._fv_shadow_version:
+            with torch.no_grad():
+                sh.copy_(w)
+            w._fv_shadow_version = w._version
         return sh
     return w.to(cdt)
 
@@ -114,6 +120,11 @@ class _GroupedWgrad:
     @classmethod
     def add(cls, g2, a2, out):
         from .gemm import grouped_splits
+        if any(j[2].data_ptr() == out.data_ptr() for j in cls.jobs):
+            # a second gradient for the same weight (gradient accumulation: two backward passes before one
+            # finish_backward): problems of one grouped launch are summed into ``out`` concurrently, so the
+            # earlier one is issued first -- same-destination sums stay ordered, i.e. deterministic
+            cls.flush()
         cls.jobs.append((g2, a2, out, grouped_splits(g2.shape[0])))
 
     @classmethod
@@ -212,7 +223,11 @@ class FastVimMixerFn(torch.autograd.Function):
                                            D=D, D_b=D_b)
             if fv is not None and "Wx2" in fv:          # x_proj / x_proj_b adjacent in the flat buffers
                 Wx2 = fv["Wx2"]
-                Wx2_c = fv["Wx2_shadow"] if fv["Wx2_shadow"].dtype == cdt else Wx2.to(cdt)
+                if fv["Wx2_shadow"].dtype == cdt:
+                    _shadow(Wx, cdt), _shadow(Wx_b, cdt)       # version check of the two halves of Wx2_shadow
+                    Wx2_c = fv["Wx2_shadow"]
+                else:
+                    Wx2_c = Wx2.to(cdt)
             else:
                 Wx2 = torch.stack([Wx, Wx_b])                                           # (2, R+2N, d_in) fp32
                 Wx2_c = Wx2.to(cdt)

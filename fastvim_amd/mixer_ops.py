@@ -82,6 +82,11 @@ class _Deferred:
 
     @classmethod
     def add(cls, part, out, n_partials):
+        lo, hi = out.data_ptr(), out.data_ptr() + out.numel() * 4
+        if any(j[1].data_ptr() < hi and lo < j[1].data_ptr() + j[1].numel() * 4 for j in cls.jobs):
+            # jobs of one launch read-modify-write their destinations concurrently: a second sum into the same
+            # gradient (gradient accumulation) must wait for the first, or updates are lost nondeterministically
+            cls.flush()
         cls.jobs.append((part, out, n_partials))
         if len(cls.jobs) >= cls.max_jobs:
             cls.flush()
@@ -122,6 +127,17 @@ class _Deferred:
 def defer_reductions(on):
     flush_reductions()
     _Deferred.enabled = bool(on)
+
+
+def pending_reductions():
+    return len(_Deferred.jobs)
+
+
+def drop_reductions():
+    """Forget queued (not yet issued) reductions; returns how many were dropped."""
+    n = len(_Deferred.jobs)
+    _Deferred.jobs = []
+    return n
 
 
 def flush_reductions():
