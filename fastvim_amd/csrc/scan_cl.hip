@@ -317,6 +317,226 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward for SHORT pooled lengths (Lc <= 16: the 224 / 256 px grids, BASELINE configs 2 and 3).
+// Everything of a (batch element, direction, 192-channel chunk) lives in registers: the forward recurrence is run
+// ONCE and its 14 x 4 states per lane are kept (no checkpoint sweep, no segment recompute, no barrier inside the
+// time loop); the decay factors are re-derived in the adjoint sweep (one v_exp_f32 each) because keeping them too
+// would cost a wave of occupancy.  Per-channel values are spread over the four state-quad lanes of a channel IN TIME:
+// lane q holds u, dy, delta and sigmoid(delta_raw) of the steps s = q (mod 4) and the others read them as DPP
+// quad-broadcast operands, so the loads, the softplus and the sigmoid of a step are done once per channel, not four
+// times.  One 768-thread workgroup (12 waves, 3 per SIMD, one workgroup per CU) walks NBB batch elements of its
+// chunk: 256 workgroups at FastVim-T bs 128 -- exactly one round -- and the parameter-gradient partials shrink by
+// NBB.  d x_dbl needs a sum over channels: in-wave reduce-scatter as in the long kernel, then ONE fixed-order sum of
+// the 12 waves through LDS per batch element (two barriers per element in all).
+constexpr int SH_CH = 192, SH_THREADS = 768, SH_NWV = 12;
+
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {      // value of quad lane K, in all four lanes (DPP quad_perm)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_pick(float v, int k) {  // k is a compile-time constant after unrolling
+  switch (k & 3) {
+    case 0: return quad_bcast<0>(v);
+    case 1: return quad_bcast<1>(v);
+    case 2: return quad_bcast<2>(v);
+    default: return quad_bcast<3>(v);
+  }
+}
+
+template <typename T, int RQ, int PV, int LCT, bool EXACT>      // EXACT: Lc == LCT (the 14- and 16-row grids)
+__global__ __launch_bounds__(SH_THREADS) void scan_cl_bwd_short_kernel(ScanClParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int RQP = (RQ + 3) / 4 * 4;     // dt_low part of a staged row: [q][RQP] (zero padded), 16-byte groups
+  constexpr int WP = 4 * RQP + 2 * N;       // staged row: [dt_low by quad | B | C]
+  constexpr int NG = (LCT + 3) / 4;         // step groups of 4 (one step per quad lane)
+  constexpr int Q = PV / 16;
+  float* s_dbl = smem;                      // LCT * WP, rows in SCAN order (row s = step s): compile-time LDS offsets
+  float* s_part = smem + LCT * WP;          // LCT * SH_NWV * 4 * PV   [step][wave][q][value]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = tid & 3;
+  const int dir = blockIdx.z;
+  const int d = blockIdx.x * SH_CH + (tid >> 2);
+  const bool act = d < p.d_in;
+  const int dd = act ? d : 0;
+  const int W = p.R + 2 * N;
+  const int Lc = EXACT ? LCT : p.Lc;
+  float A2[4], Araw[4], wdt[RQ];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    Araw[j] = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + j]);
+    A2[j] = Araw[j] * FV_LOG2E;
+  }
+#pragma unroll
+  for (int i = 0; i < RQ; ++i) {
+    const int r = q + 4 * i;
+    wdt[i] = (r < p.R) ? p.Wdt[dir][(size_t)dd * p.R + r] : 0.f;
+  }
+  const float bias = p.dtb[dir][dd];
+  float dA[4] = {0.f, 0.f, 0.f, 0.f}, dW[RQ], dbias = 0.f;
+#pragma unroll
+  for (int i = 0; i < RQ; ++i) dW[i] = 0.f;
+  const float* my_dl = s_dbl + q * RQP;                 // this quad lane's dt_low group of row 0
+  const float* my_bc = s_dbl + 4 * RQP + q * 4;         // this quad lane's B states of row 0 (C: + N)
+  float* my_part = s_part + (wv * 4 + q) * PV + (lane >> 2) * Q;
+
+  for (int bi = 0; bi < p.NBB; ++bi) {
+    const int b = blockIdx.y * p.NBB + bi;
+    const size_t bd = ((size_t)dir * p.B + b) * Lc;
+    const T* u = (const T*)p.xc + bd * p.d_in + dd;
+    const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + dd;
+    // this lane's share of the per-channel inputs: steps s = 4i + q (requested before the staging barrier)
+    float ur[NG], gr[NG];
+    int roff[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int s = 4 * i + q, sc = min(s, Lc - 1), l = dir ? Lc - 1 - sc : sc;
+      roff[i] = l * p.d_in;
+      ur[i] = io<T>::ld(u + roff[i]);
+      const float gv = gy[roff[i]];
+      gr[i] = (act && s < Lc) ? gv : 0.f;
+    }
+    // stage the x_dbl rows of (dir, b) in scan order: fp32, dt_low regrouped by quad lane, rows past Lc zero
+    {
+      const T* dbl = (const T*)p.xdbl + bd * W;
+      for (int e = tid; e < LCT * WP; e += SH_THREADS) {
+        const int srow = e / WP, c = e - srow * WP;
+        const int l = dir ? Lc - 1 - srow : srow;
+        float v = 0.f;
+        if (EXACT || srow < Lc) {
+          if (c < 4 * RQP) {
+            const int qq = c / RQP, i = c - qq * RQP, r = qq + 4 * i;
+            if (i < RQ && r < p.R) v = io<T>::ld(dbl + (size_t)l * W + r);
+          } else {
+            v = io<T>::ld(dbl + (size_t)l * W + p.R + (c - 4 * RQP));
+          }
+        }
+        s_dbl[e] = v;
+      }
+    }
+    __syncthreads();      // rows staged; the previous element's readers of s_part are done as well
+
+    // ---- delta = softplus(dt_proj(dt_low) + bias) and its derivative, one step per quad lane and group
+    float dtr[NG], sgr[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      float mine = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (4 * i + k < LCT) {
+          const float* row = my_dl + (4 * i + k) * WP;
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < RQ; ++j) acc = fmaf(wdt[j], row[j], acc);
+          acc = quad_sum(acc);
+          mine = (q == k) ? acc : mine;
+        }
+      }
+      const bool on = act && (4 * i + q < Lc);
+      const float dtq = on ? fv_softplus(mine + bias) : 0.f;     // delta = 0: identity step (a = 1, b = 0)
+      dtr[i] = dtq;
+      sgr[i] = 1.f - __expf(-dtq);                                // sigmoid(raw) = 1 - exp(-softplus(raw)); 0 when off
+    }
+
+    // ---- forward recurrence, states kept
+    float xs[LCT][4];
+    {
+      float st[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < LCT; ++s) {
+        const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+        const float Bn[4] = {Bv.x, Bv.y, Bv.z, Bv.w};
+        const float dt = quad_pick(dtr[s >> 2], s), uu = quad_pick(ur[s >> 2], s);
+        const float dtu = dt * uu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], dtu * Bn[j]);
+          xs[s][j] = st[j];
+        }
+      }
+    }
+
+    // ---- adjoint sweep, high to low
+    float dxa[4] = {0.f, 0.f, 0.f, 0.f};
+    float dxr[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) dxr[i] = 0.f;
+#pragma unroll
+    for (int s = LCT - 1; s >= 0; --s) {
+      if (s < p.Lc) {         // uniform; a real branch also in the EXACT build: one basic block per step keeps the
+                              // scheduler from hoisting every step's LDS reads to the top (it spilled 145 VGPRs)
+        const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+        const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
+        const float Bn[4] = {Bv.x, Bv.y, Bv.z, Bv.w}, Cn[4] = {Cv.x, Cv.y, Cv.z, Cv.w};
+        const float dt = quad_pick(dtr[s >> 2], s), uu = quad_pick(ur[s >> 2], s);
+        const float g = quad_pick(gr[s >> 2], s), sg = quad_pick(sgr[s >> 2], s);
+        const float dtu = dt * uu;
+        float vals[PV];
+#pragma unroll
+        for (int e = 0; e < PV; ++e) vals[e] = 0.f;
+        float du_acc = 0.f, dd_acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = fv_exp2(dt * A2[j]);
+          const float dx = fmaf(g, Cn[j], dxa[j]);
+          const float pj = s > 0 ? dx * (a * xs[s > 0 ? s - 1 : 0][j]) : 0.f;     // dx * a_t * x_{t-1}
+          du_acc = fmaf(dx, Bn[j], du_acc);
+          dd_acc = fmaf(Araw[j], pj, dd_acc);
+          dA[j] = fmaf(dt, pj, dA[j]);
+          vals[j] = dx * dtu;                                   // dB[4q+j]
+          vals[4 + j] = g * xs[s][j];                           // dC[4q+j]
+          dxa[j] = a * dx;
+        }
+        du_acc = quad_sum(du_acc);
+        dd_acc = quad_sum(dd_acc);
+        // d delta = sum_n dx (B u + A a x_prev) = u * sum_n dx B + sum_n A dx a x_prev;  through the softplus: * sigmoid
+        const float ddraw = fmaf(uu, du_acc, dd_acc) * sg;
+        dbias += ddraw;
+        const float* dl = my_dl + s * WP;
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) {
+          dW[i] = fmaf(ddraw, dl[i], dW[i]);
+          vals[8 + i] = ddraw * wdt[i];                         // d dt_low[q + 4i]
+        }
+        dxr[s >> 2] = (q == (s & 3)) ? dt * du_acc : dxr[s >> 2];      // d u of step s: kept by the lane that loaded u_s
+        chan_reduce_scatter<PV>(vals, lane);
+#pragma unroll
+        for (int e = 0; e < Q; ++e) my_part[s * (SH_NWV * 4 * PV) + e] = vals[e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+      if (act && 4 * i + q < Lc) p.dxc[bd * p.d_in + roff[i] + d] = dxr[i];
+    __syncthreads();
+    // sum the 12 waves in fixed order and scatter to the x_dbl column layout [dt_low | B | C]
+    for (int e = tid; e < Lc * 4 * PV; e += SH_THREADS) {
+      const int s = e / (4 * PV), rem = e - s * 4 * PV;
+      const int qq = rem / PV, v = rem - qq * PV;
+      int col = -1;
+      if (v < 4) col = p.R + qq * 4 + v;
+      else if (v < 8) col = p.R + N + qq * 4 + (v - 4);
+      else if (v < 8 + RQ && qq + 4 * (v - 8) < p.R) col = qq + 4 * (v - 8);
+      if (col >= 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SH_NWV; ++w) t += s_part[((s * SH_NWV + w) * 4 + qq) * PV + v];
+        const int l = dir ? Lc - 1 - s : s;
+        p.dxdbl[(((size_t)blockIdx.x * 2 + dir) * p.B + b) * Lc * W + (size_t)l * W + col] = t;
+      }
+    }
+  }   // batch elements of this block
+  if (act) {
+    const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
+    float* base = p.pP + ((size_t)blockIdx.y * 2 + dir) * per_dir;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) base[(size_t)d * N + q * 4 + j] = dA[j] * Araw[j];            // dA_log = dA * A
+#pragma unroll
+    for (int i = 0; i < RQ; ++i)
+      if (q + 4 * i < p.R) base[(size_t)p.d_in * N + (size_t)d * p.R + q + 4 * i] = dW[i];
+    if (q == 0) base[(size_t)p.d_in * (N + p.R) + d] = dbias;           // identical in the four lanes of a channel
+  }
+}
+
 int rq_of(int R) { return (R + 3) / 4; }
 
 }  // namespace
@@ -356,21 +576,26 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
   return FV_OK;
 }
 
-extern "C" int fv_mixer_scan_bwd_chunks(int d_inner) { return fv_cdiv(d_inner, CPB); }
+// pooled lengths up to 16 take the register-resident kernel (192-channel workgroups)
+static bool bwd_short(int Lc) {
+  static const int off = getenv("FASTVIM_SCAN_SHORT") ? atoi(getenv("FASTVIM_SCAN_SHORT")) == 0 : 0;   // A/B hook
+  return Lc <= 16 && !off;
+}
+extern "C" int fv_mixer_scan_bwd_chunks(int d_inner, int Lc) { return fv_cdiv(d_inner, bwd_short(Lc) ? SH_CH : CPB); }
 
 // A block can walk several batch elements (fewer, longer blocks; parameter-gradient partials shrink by the same
 // factor).  Measured on FastVim-T: 2 per block 49.0 us vs 47-48 us, 4 per block 65 us -- so one, unless forced.
 static int scan_bwd_nbb(int batch, int Lc) {
   static const int force = getenv("FASTVIM_SCAN_NBB") ? atoi(getenv("FASTVIM_SCAN_NBB")) : 0;   // tuning hook
-  (void)Lc;
-  return (force > 0 && batch % force == 0) ? force : 1;
+  if (force > 0 && batch % force == 0) return force;
+  return (bwd_short(Lc) && batch % 2 == 0) ? 2 : 1;
 }
 extern "C" int fv_mixer_scan_bwd_partials(int batch, int Lc) { return batch / scan_bwd_nbb(batch, Lc); }
 
 static bool ck_in_lds(int Lc) { return ((Lc + 3) / 4) * 4096 + Lc * CPB * 4 <= 32 * 1024; }
 
 extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state) {
-  if (ck_in_lds(Lc)) return 0;
+  if (bwd_short(Lc) || ck_in_lds(Lc)) return 0;
   return (size_t)2 * batch * ((Lc + 3) / 4) * d_inner * d_state;
 }
 
@@ -403,8 +628,39 @@ extern "C" int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const fl
   const int RQ = rq_of(dt_rank);
   const bool ckl = ck_in_lds(Lc);
   p.NBB = scan_bwd_nbb(batch, Lc);
-  dim3 grid(fv_cdiv(d_inner, CPB), batch / p.NBB, 2), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (bwd_short(Lc)) {
+    dim3 sgrid(fv_cdiv(d_inner, SH_CH), batch / p.NBB, 2), sblock(SH_THREADS);
+#define FV_S(TT, RQQ, PVV, LCC, EXX)                                                            \
+  do {                                                                                       \
+    constexpr int RQP_ = (RQQ + 3) / 4 * 4;                                                  \
+    size_t smem = ((size_t)LCC * (4 * RQP_ + 2 * N) + (size_t)LCC * SH_NWV * 4 * PVV) * 4;   \
+    static bool done = false;                                                                \
+    if (!done && smem > 64 * 1024) {                                                         \
+      (void)hipFuncSetAttribute((const void*)scan_cl_bwd_short_kernel<TT, RQQ, PVV, LCC, EXX>, \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      done = true;                                                                           \
+    }                                                                                        \
+    hipLaunchKernelGGL((scan_cl_bwd_short_kernel<TT, RQQ, PVV, LCC, EXX>), sgrid, sblock, smem, st, p); \
+  } while (0)
+#define FV_SL(TT, RQQ, PVV)                                                                  \
+  do {                                                                                       \
+    if (Lc == 14) FV_S(TT, RQQ, PVV, 14, true); else if (Lc < 14) FV_S(TT, RQQ, PVV, 14, false); \
+    else if (Lc == 16) FV_S(TT, RQQ, PVV, 16, true); else FV_S(TT, RQQ, PVV, 16, false);     \
+  } while (0)
+#define FV_SD(TT)                                                                            \
+  do {                                                                                       \
+    if (RQ <= 3) FV_SL(TT, 3, 16); else if (RQ <= 6) FV_SL(TT, 6, 16);                       \
+    else if (RQ <= 12) FV_SL(TT, 12, 32); else FV_SL(TT, 24, 32);                            \
+  } while (0)
+    if (dtype == FV_F32) FV_SD(float); else FV_SD(bf16_t);
+#undef FV_SD
+#undef FV_SL
+#undef FV_S
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
+  dim3 grid(fv_cdiv(d_inner, CPB), batch / p.NBB, 2), block(256);
 #define FV_B(TT, RQQ, PVV, CKK, DTT)                                                         \
   do {                                                                                       \
     size_t smem = ((size_t)Lc * (4 * RQQ + 2 * N) + (size_t)4 * 4 * 4 * PVV + (DTT ? (size_t)Lc * CPB : 0) + \

@@ -51,7 +51,7 @@ def test_load_state_dict_after_flat_attach_gives_fresh_model_logits():
 def test_checkpoint_resume_gives_identical_next_steps(tmp_path):
     from fastvim_amd.flat import FlatAdamW, FlatTrainingState, load_checkpoint, save_checkpoint
     torch.manual_seed(0)
-    base = _model()
+    m1 = _model()       # (not a deepcopy: copy.deepcopy drops the parameters' _no_weight_decay attribute)
     x = torch.randn(8, 3, 224, 224, device="cuda")
     g = torch.randn(8, 50, device="cuda")
 
@@ -62,7 +62,6 @@ def test_checkpoint_resume_gives_identical_next_steps(tmp_path):
         (y.float() * g).sum().backward()
         opt.step()                            # finishes the backward pass itself
 
-    m1 = copy.deepcopy(base)
     f1 = FlatTrainingState(m1)
     o1 = FlatAdamW(f1, m1, lr=1e-3, weight_decay=0.05, no_decay=_nd(m1), ema_decay=0.99)
     for _ in range(3):
