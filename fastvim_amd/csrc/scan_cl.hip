@@ -320,81 +320,101 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
 
 // ------------------------------------------------------------------------------------------------------------
 // Backward for SHORT pooled lengths (Lc <= 16: the 224 / 256 px grids, BASELINE configs 2 and 3).
-// Everything of a (batch element, direction, 192-channel chunk) lives in registers: the forward recurrence is run
-// ONCE and its 14 x 4 states per lane are kept (no checkpoint sweep, no segment recompute, no barrier inside the
-// time loop); the decay factors are re-derived in the adjoint sweep (one v_exp_f32 each) because keeping them too
-// would cost a wave of occupancy.  Per-channel values are spread over the four state-quad lanes of a channel IN TIME:
-// lane q holds u, dy, delta and sigmoid(delta_raw) of the steps s = q (mod 4) and the others read them as DPP
-// quad-broadcast operands, so the loads, the softplus and the sigmoid of a step are done once per channel, not four
-// times.  One 768-thread workgroup (12 waves, 3 per SIMD, one workgroup per CU) walks NBB batch elements of its
-// chunk: 256 workgroups at FastVim-T bs 128 -- exactly one round -- and the parameter-gradient partials shrink by
-// NBB.  d x_dbl needs a sum over channels: in-wave reduce-scatter as in the long kernel, then ONE fixed-order sum of
-// the 12 waves through LDS per batch element (two barriers per element in all).
-constexpr int SH_CH = 192, SH_THREADS = 768, SH_NWV = 12;
+//
+// One 768-thread workgroup (12 waves, 3 per SIMD, one workgroup per CU) owns a 192-channel chunk of one direction and
+// walks NBB batch elements: 256 workgroups at FastVim-T bs 128 -- exactly one round -- and the parameter-gradient
+// partials shrink by NBB.  Per batch element:
+//   * the forward recurrence runs ONCE and its Lc x 4 states per lane stay in registers (no checkpoint sweep, no
+//     segment recompute, no barrier inside the time loop); the decay factors are re-derived in the adjoint sweep (one
+//     v_exp_f32 each) because keeping them too would cost a wave of occupancy;
+//   * dt_proj runs on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32 = an fp32 FMA chain), in all three of its
+//     roles: delta_raw[t][ch] = dt_low[t][:] . Wdt[ch][:] (forward), d dt_low[t][r] = sum_ch ddelta_raw[t][ch] Wdt[ch][r]
+//     and d Wdt[ch][r] += sum_t ddelta_raw[t][ch] dt_low[t][r] (adjoint; the accumulator tile lives across the batch
+//     elements).  The MFMA result layout (lane = channel x 4-step group) is also where softplus / sigmoid are
+//     evaluated -- once per (step, channel), not once per state-quad lane -- and where u, dy are loaded and d u stored;
+//   * the scan lanes (channel x state quad) read {delta, u, dy, sigmoid} of a step as ONE 16-byte LDS word per
+//     (step, channel) and publish {d delta_raw, d u} through LDS the same way;
+//   * dB / dC (8 values per lane and step) are summed over the 16 channel lanes of a wave by a reduce-scatter
+//     (v_permlane32_swap, v_permlane16_swap, DPP row rotates), then over the 12 waves through LDS in fixed order.
+// Two workgroup barriers per batch element; deterministic (no atomics).
+#ifndef SH_WAVES
+#define SH_WAVES 12
+#endif
+constexpr int SH_NWV = SH_WAVES, SH_CH = 16 * SH_NWV, SH_THREADS = 64 * SH_NWV;
+constexpr int SH_DRS = SH_CH + 2;      // row stride of the d delta_raw table: = 2 (mod 32), MFMA operand reads conflict-free
 
-template <int K>
-__device__ __forceinline__ float quad_bcast(float v) {      // value of quad lane K, in all four lanes (DPP quad_perm)
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float quad_pick(float v, int k) {  // k is a compile-time constant after unrolling
-  switch (k & 3) {
-    case 0: return quad_bcast<0>(v);
-    case 1: return quad_bcast<1>(v);
-    case 2: return quad_bcast<2>(v);
-    default: return quad_bcast<3>(v);
-  }
-}
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <typename T, int RQ, int PV, int LCT, bool EXACT>      // EXACT: Lc == LCT (the 14- and 16-row grids)
-__global__ __launch_bounds__(SH_THREADS) void scan_cl_bwd_short_kernel(ScanClParams p) {
+template <int RQ, int LCT>
+struct ShortLds {
+  static constexpr int RQP = (RQ + 3) / 4 * 4;     // dt_low part of a staged row: [q][RQP] (zero padded)
+  static constexpr int RT = RQP / 4;               // 16-wide r tiles of the dt_proj MFMAs
+  static constexpr int WP = 4 * RQP + 2 * N;       // staged row: [dt_low by quad | B | C]
+  static constexpr int o_dbl = 0;                                  // LCT * WP
+  static constexpr int o_ch = o_dbl + LCT * WP;                    // LCT * 192 * 4   {delta, u, dy, sigmoid}
+  static constexpr int o_dr = o_ch + LCT * SH_CH * 4;              // 16 * SH_DRS     d delta_raw (rows >= Lc zero)
+  static constexpr int o_du = o_dr + 16 * SH_DRS;                  // LCT * 192       d u
+  static constexpr int o_part = o_du + LCT * SH_CH;                // LCT * 12 * 4 * 8   dB / dC wave partials
+  static constexpr int o_pd = o_part + LCT * SH_NWV * 4 * 8;       // 12 * 16 * 16 * RT  d dt_low wave partials
+  static constexpr int floats = o_pd + SH_NWV * 16 * 16 * RT;
+};
+
+template <typename T, int RQ, int LCT, bool EXACT>      // EXACT: Lc == LCT (the 14- and 16-row grids)
+__global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int RQP = (RQ + 3) / 4 * 4;     // dt_low part of a staged row: [q][RQP] (zero padded), 16-byte groups
-  constexpr int WP = 4 * RQP + 2 * N;       // staged row: [dt_low by quad | B | C]
-  constexpr int NG = (LCT + 3) / 4;         // step groups of 4 (one step per quad lane)
-  constexpr int Q = PV / 16;
-  float* s_dbl = smem;                      // LCT * WP, rows in SCAN order (row s = step s): compile-time LDS offsets
-  float* s_part = smem + LCT * WP;          // LCT * SH_NWV * 4 * PV   [step][wave][q][value]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = tid & 3;
-  const int dir = blockIdx.z;
-  const int d = blockIdx.x * SH_CH + (tid >> 2);
-  const bool act = d < p.d_in;
-  const int dd = act ? d : 0;
+  typedef ShortLds<RQ, LCT> LD;
+  constexpr int RQP = LD::RQP, RT = LD::RT, WP = LD::WP;
+  float* s_dbl = smem + LD::o_dbl;
+  float* s_ch = smem + LD::o_ch;
+  float* s_dr = smem + LD::o_dr;
+  float* s_du = smem + LD::o_du;
+  float* s_part = smem + LD::o_part;
+  float* s_pd = smem + LD::o_pd;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dir = blockIdx.z, ch0 = blockIdx.x * SH_CH;
   const int W = p.R + 2 * N;
   const int Lc = EXACT ? LCT : p.Lc;
-  float A2[4], Araw[4], wdt[RQ];
+  // ---- scan role: lane = (channel c of the wave, state quad q)
+  const int q = lane & 3, ch = wv * 16 + (lane >> 2);
+  const int d = ch0 + ch;
+  const bool act = d < p.d_in;
+  const int dd = act ? d : 0;
+  float A2[4], Araw[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     Araw[j] = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + j]);
     A2[j] = Araw[j] * FV_LOG2E;
   }
+  float dA[4] = {0.f, 0.f, 0.f, 0.f}, dbias = 0.f;
+  // ---- matrix role: lane = (channel cm = lane & 15 of the wave, step group tg = lane >> 4: steps 4 tg .. 4 tg + 3)
+  const int cm = lane & 15, tg = lane >> 4;
+  const int dm = ch0 + wv * 16 + cm;
+  const bool actm = dm < p.d_in;
+  const int ddm = actm ? dm : 0;
+  const float bias_m = p.dtb[dir][ddm];
+  f32x4_t accW[RT];                      // d Wdt tile: rows = channel 16 wv + 4 tg + reg, cols = r = 16 rt + cm
 #pragma unroll
-  for (int i = 0; i < RQ; ++i) {
-    const int r = q + 4 * i;
-    wdt[i] = (r < p.R) ? p.Wdt[dir][(size_t)dd * p.R + r] : 0.f;
-  }
-  const float bias = p.dtb[dir][dd];
-  float dA[4] = {0.f, 0.f, 0.f, 0.f}, dW[RQ], dbias = 0.f;
-#pragma unroll
-  for (int i = 0; i < RQ; ++i) dW[i] = 0.f;
-  const float* my_dl = s_dbl + q * RQP;                 // this quad lane's dt_low group of row 0
-  const float* my_bc = s_dbl + 4 * RQP + q * 4;         // this quad lane's B states of row 0 (C: + N)
-  float* my_part = s_part + (wv * 4 + q) * PV + (lane >> 2) * Q;
+  for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // the d delta_raw table's rows past Lc feed the K / M padding of the MFMAs: zero once
+  for (int e = tid; e < 16 * SH_DRS; e += SH_THREADS) s_dr[e] = 0.f;
 
   for (int bi = 0; bi < p.NBB; ++bi) {
     const int b = blockIdx.y * p.NBB + bi;
     const size_t bd = ((size_t)dir * p.B + b) * Lc;
-    const T* u = (const T*)p.xc + bd * p.d_in + dd;
-    const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + dd;
-    // this lane's share of the per-channel inputs: steps s = 4i + q (requested before the staging barrier)
-    float ur[NG], gr[NG];
-    int roff[NG];
+    // matrix role: u and dy of this lane's 4 steps (requested before the staging barrier)
+    float um[4], gm[4];
+    int roff[4];
+    {
+      const T* u = (const T*)p.xc + bd * p.d_in + ddm;
+      const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + ddm;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const int s = 4 * i + q, sc = min(s, Lc - 1), l = dir ? Lc - 1 - sc : sc;
-      roff[i] = l * p.d_in;
-      ur[i] = io<T>::ld(u + roff[i]);
-      const float gv = gy[roff[i]];
-      gr[i] = (act && s < Lc) ? gv : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const int s = 4 * tg + r, sc = min(s, Lc - 1), l = dir ? Lc - 1 - sc : sc;
+        roff[r] = l * p.d_in;
+        um[r] = io<T>::ld(u + roff[r]);
+        const float gv = gy[roff[r]];
+        gm[r] = (actm && s < Lc) ? gv : 0.f;
+      }
     }
     // stage the x_dbl rows of (dir, b) in scan order: fp32, dt_low regrouped by quad lane, rows past Lc zero
     {
@@ -414,66 +434,75 @@ __global__ __launch_bounds__(SH_THREADS) void scan_cl_bwd_short_kernel(ScanClPar
         s_dbl[e] = v;
       }
     }
-    __syncthreads();      // rows staged; the previous element's readers of s_part are done as well
+    __syncthreads();      // rows staged; the previous element's readers of s_part / s_pd are done as well
 
-    // ---- delta = softplus(dt_proj(dt_low) + bias) and its derivative, one step per quad lane and group
-    float dtr[NG], sgr[NG];
+    // ---- delta_raw[t][ch] = sum_r dt_low[t][r] Wdt[ch][r] on the matrix cores (A: t x r, B: r x ch), then
+    //      softplus / sigmoid once per (step, channel); the table row {delta, u, dy, sigmoid} goes to LDS
+    {
+      f32x4_t D = {0.f, 0.f, 0.f, 0.f};
+      const int ta = min(cm, LCT - 1);            // A operand row of this lane: step cm
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      float mine = 0.f;
+      for (int kg = 0; kg < RQP; ++kg) {           // r = 4 kg + (lane >> 4): stored at [q = r & 3][i = r >> 2]
+        const float a = s_dbl[ta * WP + tg * RQP + kg];
+        const int r = 4 * kg + tg;
+        const float w = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, D, 0, 0, 0);
+      }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (4 * i + k < LCT) {
-          const float* row = my_dl + (4 * i + k) * WP;
-          float acc = 0.f;
-#pragma unroll
-          for (int j = 0; j < RQ; ++j) acc = fmaf(wdt[j], row[j], acc);
-          acc = quad_sum(acc);
-          mine = (q == k) ? acc : mine;
+      for (int r = 0; r < 4; ++r) {
+        const int s = 4 * tg + r;
+        if (s < LCT) {
+          const bool on = actm && s < Lc;
+          const float dt = on ? fv_softplus(D[r] + bias_m) : 0.f;     // delta = 0: identity step (a = 1, b = 0)
+          const float sg = 1.f - __expf(-dt);                         // sigmoid(raw) = 1 - exp(-softplus(raw))
+          *reinterpret_cast<float4*>(s_ch + ((size_t)s * SH_CH + wv * 16 + cm) * 4) = make_float4(dt, um[r], gm[r], sg);
         }
       }
-      const bool on = act && (4 * i + q < Lc);
-      const float dtq = on ? fv_softplus(mine + bias) : 0.f;     // delta = 0: identity step (a = 1, b = 0)
-      dtr[i] = dtq;
-      sgr[i] = 1.f - __expf(-dtq);                                // sigmoid(raw) = 1 - exp(-softplus(raw)); 0 when off
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();       // the table rows of this wave's 16 channels are read by this wave only
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- forward recurrence, states kept
+    const float* my_bc = s_dbl + 4 * RQP + q * 4;                   // this quad lane's B states of row 0 (C: + N)
+    const float* my_ch = s_ch + (size_t)ch * 4;
     float xs[LCT][4];
     {
       float st[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < LCT; ++s) {
-        const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
-        const float Bn[4] = {Bv.x, Bv.y, Bv.z, Bv.w};
-        const float dt = quad_pick(dtr[s >> 2], s), uu = quad_pick(ur[s >> 2], s);
-        const float dtu = dt * uu;
+        // a compiler memory barrier per step keeps the scheduler from hoisting every step's LDS reads to the top of the
+        // unrolled loop (it spilled 145 VGPRs)
+        asm volatile("" ::: "memory");
+        if (EXACT || s < Lc) {
+          const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+          const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (SH_CH * 4));
+          const float Bn[4] = {Bv.x, Bv.y, Bv.z, Bv.w};
+          const float dt = cv.x, dtu = cv.x * cv.y;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], dtu * Bn[j]);
-          xs[s][j] = st[j];
+          for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], dtu * Bn[j]);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[s][j] = st[j];
       }
     }
 
     // ---- adjoint sweep, high to low
     float dxa[4] = {0.f, 0.f, 0.f, 0.f};
-    float dxr[NG];
-#pragma unroll
-    for (int i = 0; i < NG; ++i) dxr[i] = 0.f;
+    float* my_part = s_part + (wv * 4 + q) * 8 + (lane >> 3);
+    float* my_dr = s_dr + ch;
+    float* my_du = s_du + ch;
 #pragma unroll
     for (int s = LCT - 1; s >= 0; --s) {
-      if (s < p.Lc) {         // uniform; a real branch also in the EXACT build: one basic block per step keeps the
-                              // scheduler from hoisting every step's LDS reads to the top (it spilled 145 VGPRs)
+      asm volatile("" ::: "memory");
+      if (EXACT || s < Lc) {         // uniform
         const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
         const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
+        const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (SH_CH * 4));
         const float Bn[4] = {Bv.x, Bv.y, Bv.z, Bv.w}, Cn[4] = {Cv.x, Cv.y, Cv.z, Cv.w};
-        const float dt = quad_pick(dtr[s >> 2], s), uu = quad_pick(ur[s >> 2], s);
-        const float g = quad_pick(gr[s >> 2], s), sg = quad_pick(sgr[s >> 2], s);
+        const float dt = cv.x, uu = cv.y, g = cv.z, sg = cv.w;
         const float dtu = dt * uu;
-        float vals[PV];
-#pragma unroll
-        for (int e = 0; e < PV; ++e) vals[e] = 0.f;
+        float vals[8];
         float du_acc = 0.f, dd_acc = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -492,49 +521,101 @@ __global__ __launch_bounds__(SH_THREADS) void scan_cl_bwd_short_kernel(ScanClPar
         // d delta = sum_n dx (B u + A a x_prev) = u * sum_n dx B + sum_n A dx a x_prev;  through the softplus: * sigmoid
         const float ddraw = fmaf(uu, du_acc, dd_acc) * sg;
         dbias += ddraw;
-        const float* dl = my_dl + s * WP;
-#pragma unroll
-        for (int i = 0; i < RQ; ++i) {
-          dW[i] = fmaf(ddraw, dl[i], dW[i]);
-          vals[8 + i] = ddraw * wdt[i];                         // d dt_low[q + 4i]
+        if (q == 0) {
+          my_dr[s * SH_DRS] = ddraw;
+          my_du[s * SH_CH] = dt * du_acc;
         }
-        dxr[s >> 2] = (q == (s & 3)) ? dt * du_acc : dxr[s >> 2];      // d u of step s: kept by the lane that loaded u_s
-        chan_reduce_scatter<PV>(vals, lane);
-#pragma unroll
-        for (int e = 0; e < Q; ++e) my_part[s * (SH_NWV * 4 * PV) + e] = vals[e];
+        // sum over the wave's 16 channels: three reduce-scatter levels leave value (lane >> 3) & 7, the last level adds
+        rs_swap32<4, 8>(vals);
+        rs_swap16<2, 8>(vals);
+        rs_row8<1, 8>(vals, lane);
+        const float tot = add_dpp<0x12C>(vals[0]);             // + lane i + 4 (the channel with bit 0 set)
+        if ((lane & 4) == 0) my_part[s * (SH_NWV * 4 * 8)] = tot;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- dt_proj adjoint on the matrix cores, from this wave's 16 columns of the d delta_raw table
+    {
+      // d dt_low[t][r] partial over the wave's channels: A[t][k = channel], B[k = channel][r]
+      f32x4_t Dl[RT];
 #pragma unroll
-    for (int i = 0; i < NG; ++i)
-      if (act && 4 * i + q < Lc) p.dxc[bd * p.d_in + roff[i] + d] = dxr[i];
+      for (int rt = 0; rt < RT; ++rt) Dl[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        const int chk = wv * 16 + 4 * kg + tg;                  // channel of this lane's k
+        const float a = s_dr[cm * SH_DRS + chk];                // step cm
+        const int dk = ch0 + chk;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int r = 16 * rt + cm;
+          const float w = (dk < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dk * p.R + r] : 0.f;
+          Dl[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, Dl[rt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_pd[((size_t)wv * 16 + 4 * tg + r) * (16 * RT) + 16 * rt + cm] = Dl[rt][r];
+      // d Wdt[ch][r] += sum_t ddelta_raw[t][ch] dt_low[t][r]: A[ch][k = t], B[k = t][r]
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        const int t = 4 * kg + tg;
+        const float a = s_dr[t * SH_DRS + wv * 16 + cm];
+        const int tc = min(t, LCT - 1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int r = 16 * rt + cm;                           // stored at [q = r & 3][i = r >> 2]; r < 4 RQP always
+          const float bq = s_dbl[tc * WP + (r & 3) * RQP + (r >> 2)];
+          accW[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, accW[rt], 0, 0, 0);
+        }
+      }
+      // d u of this lane's 4 steps
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s = 4 * tg + r;
+        if (actm && s < Lc) p.dxc[bd * p.d_in + roff[r] + dm] = s_du[s * SH_CH + wv * 16 + cm];
+      }
+    }
     __syncthreads();
-    // sum the 12 waves in fixed order and scatter to the x_dbl column layout [dt_low | B | C]
-    for (int e = tid; e < Lc * 4 * PV; e += SH_THREADS) {
-      const int s = e / (4 * PV), rem = e - s * 4 * PV;
-      const int qq = rem / PV, v = rem - qq * PV;
-      int col = -1;
-      if (v < 4) col = p.R + qq * 4 + v;
-      else if (v < 8) col = p.R + N + qq * 4 + (v - 4);
-      else if (v < 8 + RQ && qq + 4 * (v - 8) < p.R) col = qq + 4 * (v - 8);
-      if (col >= 0) {
+    // ---- sum the 12 waves in fixed order and scatter to the x_dbl column layout [dt_low | B | C]
+    {
+      float* out = p.dxdbl + (((size_t)blockIdx.x * 2 + dir) * p.B + b) * Lc * W;
+      for (int e = tid; e < Lc * 32; e += SH_THREADS) {
+        const int s = e >> 5, rem = e & 31, qq = rem >> 3, v = rem & 7;
+        const int col = v < 4 ? p.R + qq * 4 + v : p.R + N + qq * 4 + (v - 4);
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < SH_NWV; ++w) t += s_part[((s * SH_NWV + w) * 4 + qq) * PV + v];
+        for (int w = 0; w < SH_NWV; ++w) t += s_part[((s * SH_NWV + w) * 4 + qq) * 8 + v];
         const int l = dir ? Lc - 1 - s : s;
-        p.dxdbl[(((size_t)blockIdx.x * 2 + dir) * p.B + b) * Lc * W + (size_t)l * W + col] = t;
+        out[(size_t)l * W + col] = t;
+      }
+      for (int e = tid; e < Lc * p.R; e += SH_THREADS) {
+        const int s = e / p.R, r = e - s * p.R;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SH_NWV; ++w) t += s_pd[((size_t)w * 16 + s) * (16 * RT) + r];
+        const int l = dir ? Lc - 1 - s : s;
+        out[(size_t)l * W + r] = t;
       }
     }
   }   // batch elements of this block
+  const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
+  float* base = p.pP + ((size_t)blockIdx.y * 2 + dir) * per_dir;
   if (act) {
-    const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
-    float* base = p.pP + ((size_t)blockIdx.y * 2 + dir) * per_dir;
 #pragma unroll
     for (int j = 0; j < 4; ++j) base[(size_t)d * N + q * 4 + j] = dA[j] * Araw[j];            // dA_log = dA * A
-#pragma unroll
-    for (int i = 0; i < RQ; ++i)
-      if (q + 4 * i < p.R) base[(size_t)p.d_in * N + (size_t)d * p.R + q + 4 * i] = dW[i];
     if (q == 0) base[(size_t)p.d_in * (N + p.R) + d] = dbias;           // identical in the four lanes of a channel
   }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dw = ch0 + wv * 16 + 4 * tg + r, rr = 16 * rt + cm;
+      if (dw < p.d_in && rr < p.R) base[(size_t)p.d_in * N + (size_t)dw * p.R + rr] = accW[rt][r];
+    }
 }
 
 int rq_of(int R) { return (R + 3) / 4; }
@@ -577,25 +658,27 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
 }
 
 // pooled lengths up to 16 take the register-resident kernel (192-channel workgroups)
-static bool bwd_short(int Lc) {
+static bool bwd_short(int Lc, int dt_rank) {
   static const int off = getenv("FASTVIM_SCAN_SHORT") ? atoi(getenv("FASTVIM_SCAN_SHORT")) == 0 : 0;   // A/B hook
-  return Lc <= 16 && !off;
+  return Lc <= 16 && dt_rank <= 48 && !off;
 }
-extern "C" int fv_mixer_scan_bwd_chunks(int d_inner, int Lc) { return fv_cdiv(d_inner, bwd_short(Lc) ? SH_CH : CPB); }
+extern "C" int fv_mixer_scan_bwd_chunks(int d_inner, int Lc, int dt_rank) {
+  return fv_cdiv(d_inner, bwd_short(Lc, dt_rank) ? SH_CH : CPB);
+}
 
 // A block can walk several batch elements (fewer, longer blocks; parameter-gradient partials shrink by the same
 // factor).  Measured on FastVim-T: 2 per block 49.0 us vs 47-48 us, 4 per block 65 us -- so one, unless forced.
-static int scan_bwd_nbb(int batch, int Lc) {
+static int scan_bwd_nbb(int batch, int Lc, int dt_rank) {
   static const int force = getenv("FASTVIM_SCAN_NBB") ? atoi(getenv("FASTVIM_SCAN_NBB")) : 0;   // tuning hook
   if (force > 0 && batch % force == 0) return force;
-  return (bwd_short(Lc) && batch % 2 == 0) ? 2 : 1;
+  return (bwd_short(Lc, dt_rank) && batch % 2 == 0) ? 2 : 1;
 }
-extern "C" int fv_mixer_scan_bwd_partials(int batch, int Lc) { return batch / scan_bwd_nbb(batch, Lc); }
+extern "C" int fv_mixer_scan_bwd_partials(int batch, int Lc, int dt_rank) { return batch / scan_bwd_nbb(batch, Lc, dt_rank); }
 
 static bool ck_in_lds(int Lc) { return ((Lc + 3) / 4) * 4096 + Lc * CPB * 4 <= 32 * 1024; }
 
-extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state) {
-  if (bwd_short(Lc) || ck_in_lds(Lc)) return 0;
+extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank) {
+  if (bwd_short(Lc, dt_rank) || ck_in_lds(Lc)) return 0;
   return (size_t)2 * batch * ((Lc + 3) / 4) * d_inner * d_state;
 }
 
@@ -618,7 +701,7 @@ extern "C" int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const fl
   FV_CHECK(d_state == N, "mixer_scan_bwd: only d_state == 16 is built (got %d)", d_state);
   FV_CHECK(dt_rank <= 96, "mixer_scan_bwd: dt_rank %d > 96", dt_rank);
   FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && dyc && dxc && dx_dbl &&
-               partials && (ckpt || ck_in_lds(Lc)), "mixer_scan_bwd: null pointer");
+               partials && (ckpt || ck_in_lds(Lc) || bwd_short(Lc, dt_rank)), "mixer_scan_bwd: null pointer");
   ScanClParams p{};
   p.xc = xc; p.xdbl = x_dbl; p.dyc = dyc; p.dxc = dxc; p.dxdbl = dx_dbl; p.ckpt = ckpt; p.pP = partials;
   p.dyc_dir = dyc_per_direction ? (size_t)batch * Lc * d_inner : 0;
@@ -627,31 +710,29 @@ extern "C" int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const fl
   p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
   const int RQ = rq_of(dt_rank);
   const bool ckl = ck_in_lds(Lc);
-  p.NBB = scan_bwd_nbb(batch, Lc);
+  p.NBB = scan_bwd_nbb(batch, Lc, dt_rank);
   hipStream_t st = (hipStream_t)stream;
-  if (bwd_short(Lc)) {
+  if (bwd_short(Lc, dt_rank)) {
     dim3 sgrid(fv_cdiv(d_inner, SH_CH), batch / p.NBB, 2), sblock(SH_THREADS);
-#define FV_S(TT, RQQ, PVV, LCC, EXX)                                                            \
+#define FV_S(TT, RQQ, LCC, EXX)                                                              \
   do {                                                                                       \
-    constexpr int RQP_ = (RQQ + 3) / 4 * 4;                                                  \
-    size_t smem = ((size_t)LCC * (4 * RQP_ + 2 * N) + (size_t)LCC * SH_NWV * 4 * PVV) * 4;   \
+    size_t smem = (size_t)ShortLds<RQQ, LCC>::floats * 4;                                    \
     static bool done = false;                                                                \
     if (!done && smem > 64 * 1024) {                                                         \
-      (void)hipFuncSetAttribute((const void*)scan_cl_bwd_short_kernel<TT, RQQ, PVV, LCC, EXX>, \
+      (void)hipFuncSetAttribute((const void*)scan_cl_bwd_short_kernel<TT, RQQ, LCC, EXX>,    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       done = true;                                                                           \
     }                                                                                        \
-    hipLaunchKernelGGL((scan_cl_bwd_short_kernel<TT, RQQ, PVV, LCC, EXX>), sgrid, sblock, smem, st, p); \
+    hipLaunchKernelGGL((scan_cl_bwd_short_kernel<TT, RQQ, LCC, EXX>), sgrid, sblock, smem, st, p); \
   } while (0)
-#define FV_SL(TT, RQQ, PVV)                                                                  \
+#define FV_SL(TT, RQQ)                                                                       \
   do {                                                                                       \
-    if (Lc == 14) FV_S(TT, RQQ, PVV, 14, true); else if (Lc < 14) FV_S(TT, RQQ, PVV, 14, false); \
-    else if (Lc == 16) FV_S(TT, RQQ, PVV, 16, true); else FV_S(TT, RQQ, PVV, 16, false);     \
+    if (Lc == 14) FV_S(TT, RQQ, 14, true); else if (Lc < 14) FV_S(TT, RQQ, 14, false);       \
+    else if (Lc == 16) FV_S(TT, RQQ, 16, true); else FV_S(TT, RQQ, 16, false);               \
   } while (0)
 #define FV_SD(TT)                                                                            \
   do {                                                                                       \
-    if (RQ <= 3) FV_SL(TT, 3, 16); else if (RQ <= 6) FV_SL(TT, 6, 16);                       \
-    else if (RQ <= 12) FV_SL(TT, 12, 32); else FV_SL(TT, 24, 32);                            \
+    if (RQ <= 3) FV_SL(TT, 3); else if (RQ <= 6) FV_SL(TT, 6); else FV_SL(TT, 12);           \
   } while (0)
     if (dtype == FV_F32) FV_SD(float); else FV_SD(bf16_t);
 #undef FV_SD

@@ -196,13 +196,13 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     W = R + 2 * N
     dev = xc.device
     lib = L.lib()
-    nchunks = lib.fv_mixer_scan_bwd_chunks(L.i32(d_in), L.i32(Lc))
+    nchunks = lib.fv_mixer_scan_bwd_chunks(L.i32(d_in), L.i32(Lc), L.i32(R))
     f32o = dict(device=dev, dtype=torch.float32)
     dxc = torch.empty(2, B, Lc, d_in, **f32o)
     dx_dbl = torch.empty(nchunks, 2, B * Lc, W, **f32o)
-    nck = lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N))
+    nck = lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R))
     ckpt = torch.empty(nck, **f32o) if nck else None
-    nprt = lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc))
+    nprt = lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc), L.i32(R))
     part = torch.empty(nprt, 2 * d_in * (N + R + 1), **f32o)
     rc = lib.fv_mixer_scan_bwd_dir(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),

@@ -168,10 +168,10 @@ int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* skip, const
  *   partials (batch, 2, d_inner*(d_state + dt_rank + 1)): per-batch partials, per direction the
  *          segments [dA_log (d_inner*d_state) | d dt_proj.weight (d_inner*dt_rank) | d dt_proj.bias (d_inner)]
  *          (sum over batch with fv_reduce_partials). */
-int fv_mixer_scan_bwd_chunks(int d_inner, int Lc);
+int fv_mixer_scan_bwd_chunks(int d_inner, int Lc, int dt_rank);
 /* rows of the `partials` buffer of fv_mixer_scan_bwd: (rows, 2, d_inner*(d_state + dt_rank + 1)) fp32 */
-int fv_mixer_scan_bwd_partials(int batch, int Lc);
-size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state);
+int fv_mixer_scan_bwd_partials(int batch, int Lc, int dt_rank);
+size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank);
 int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
                       const float* A_log, const float* dt_w_b, const float* dt_bias_b, const float* A_log_b,
                       const float* dyc, float* dxc, float* dx_dbl, float* ckpt, float* partials, int batch,
