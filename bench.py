@@ -309,7 +309,7 @@ def scan_op_table(cpu=True):
 
 
 def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, rank, world, dev, use_graph=True,
-                       trace=False):
+                       trace=False, buckets=4, comm_dtype=None):
     """Build the model + flat training state + fused optimizer, capture the whole step (fwd + loss + bwd + AdamW + EMA;
     the gradient exchange sits between graph replay and optimizer when world > 1) and time exactly ``steps`` steps
     after ``warmup`` untimed ones, bracketed by barrier + synchronize.  Returns (seconds, final loss, extras)."""
@@ -323,7 +323,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     in_ch = channels if model_name == "C" else 3
     x = torch.randn(batch, in_ch, img, img, generator=gen).to(dev)
     tgt = soft_targets(batch, 1000, gen, dev)
-    flat = FlatTrainingState(model)      # flat fp32 params / grads + bf16 shadow weights
+    flat = FlatTrainingState(model, comm_dtype=comm_dtype)      # flat fp32 params / grads + bf16 shadow weights
     no_decay = {n for n, p in model.named_parameters()
                 if p.ndim <= 1 or n.endswith(".bias") or n in model.no_weight_decay() or getattr(p, "_no_weight_decay", False)}
     # one fused kernel: AdamW (the reference recipe's two param groups) + ModelEmaV2 lerp + bf16 shadow refresh
@@ -347,7 +347,18 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
         flat.finish_backward()
         return loss.detach()
 
-    if use_graph:
+    seg = None
+    if use_graph and world > 1 and model_name in ("T", "S", "B") and buckets > 0:
+        # N > 1: the step is a chain of graphs (forward | backward of K runs of blocks | optimizer) with the bucketed
+        # gradient all-reduce launched between them, so that it overlaps the remaining backward (fastvim_amd/pipeline.py)
+        from fastvim_amd.pipeline import SegmentedTrainStep
+        seg = SegmentedTrainStep(model, flat, opt, criterion, x, tgt, n_segments=buckets,
+                                 amp_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+        timing = {"on": False}
+
+        def step():
+            return seg.step(time_exposed=timing["on"])
+    elif use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -384,6 +395,8 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if seg is not None:
+        timing["on"] = True
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
@@ -398,8 +411,17 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
         elapsed = tt.item()
     loss_val = float(loss)
     n_params = sum(p.numel() for p in model.parameters())
+    extras = {"params": n_params}
+    if world > 1:
+        ex = getattr(flat, "exchange", None)
+        extras["ddp"] = {
+            "backend": dist.get_backend(), "ranks": dist.get_world_size(), "overlapped": seg is not None,
+            "buckets": len(ex.bounds) if ex is not None else 1,
+            "bucket_MB": [round((b - a) * 4 / 1e6, 2) for a, b in ex.bounds] if ex is not None else None,
+            "wire_dtype": str(comm_dtype or torch.float32).replace("torch.", ""),
+            "allreduce_exposed_ms": None if seg is None else round(seg.exposed_ms(), 3)}
     flat.close()
-    return elapsed, loss_val, {"params": n_params}
+    return elapsed, loss_val, extras
 
 
 OTHER_CONFIGS = (      # BASELINE configs[2..4] (per-GPU shape) + the paper's comparison point; model, img, batch, channels
@@ -455,6 +477,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--buckets", type=int, default=4,
+                    help="N > 1: gradient buckets = backward graph segments the all-reduce overlaps with (0: one all-reduce after backward)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
     ap.add_argument("--no-scan-op", action="store_true",
@@ -485,8 +510,10 @@ def main():
     use_graph = not args.no_graph
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)
-    elapsed, loss_val, _ = run_training_steps(args.model, args.img, args.batch, args.channels, args.dtype, args.steps,
-                                              args.warmup, rank, world, dev, use_graph=use_graph, trace=trace)
+    comm_dtype = {"fp32": None, "bf16": torch.bfloat16}[args.comm_dtype]
+    elapsed, loss_val, extras = run_training_steps(args.model, args.img, args.batch, args.channels, args.dtype, args.steps,
+                                                   args.warmup, rank, world, dev, use_graph=use_graph, trace=trace,
+                                                   buckets=args.buckets, comm_dtype=comm_dtype)
     if not (loss_val == loss_val):
         raise SystemExit("non-finite loss in the timed region")
 
@@ -511,6 +538,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "hip_graph": use_graph, "optimizer_in_step": True, "final_loss": round(loss_val, 4)},
         }
+        if "ddp" in extras:
+            out["ddp"] = extras["ddp"]
         if not args.no_kernels and args.model not in ("C", "V", "M"):
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
             dom = max(kt, key=lambda k: kt[k]["us_per_step"])     # the kernel that costs the most time per step

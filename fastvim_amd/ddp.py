@@ -1,54 +1,122 @@
-"""Data-parallel gradient exchange for the FastVim training step (SURVEY.md section 8e, C1).
+"""Data-parallel gradient exchange for the FastVim training step (SURVEY.md section 8e, row a17 / C1).
 
-The reference has no communication code of its own: Lightning wraps the model in torch DDP over
-NCCL (imagenet_classification/train.py:34-43).  Here it is explicit and minimal: one process per
-GPU, gradients live in ONE flat fp32 buffer (``p.grad`` are views), and after backward the buffer
-is summed across ranks with RCCL (``torch.distributed`` backend "nccl" on ROCm) in a few large
-chunks -- xGMI rings are per-link bound, so few large messages beat torch DDP's 25 MB bucket
-default for a 28.7 MB (FastVim-T) .. 391 MB (FastVim-B) gradient -- and averaged.
-No BatchNorm exists in FastVim, so nothing else is exchanged.
+The reference has no communication code of its own: Lightning wraps the model in torch DDP over NCCL
+(imagenet_classification/train.py:34-43), which all-reduces 25 MB buckets in reverse layer order while
+backward is still running.  Here it is explicit: one process per GPU, gradients live in ONE flat fp32
+buffer laid out layer by layer (``p.grad`` are views, fastvim_amd/flat.py), and ``GradExchange`` sums
+contiguous BUCKETS of that buffer across ranks with RCCL (``torch.distributed`` backend "nccl" on ROCm):
+
+* ``launch(k)`` enqueues the all-reduce of bucket k asynchronously: the collective waits (by event) for the
+  work already queued on the current stream -- the backward segment that produced the bucket -- and runs on the
+  process group's own stream, so the next backward segment overlaps it;
+* ``finish()`` makes the current stream wait for every outstanding bucket and divides by the world size
+  (torch DDP's mean semantics) -- the optimizer goes after it.
+
+xGMI is point-to-point (7 links per GPU), so ring collectives are per-link bound: a few LARGE buckets (default:
+4 per step, 7 MB each at FastVim-T, 98 MB at FastVim-B) instead of torch DDP's 25 MB default, and an optional
+bf16 wire format (``comm_dtype``) that halves the bytes per link.  No BatchNorm exists in FastVim, so nothing
+else is exchanged.  The same class is the whole-buffer exchange (one bucket) used by
+``FlatTrainingState.allreduce_mean_`` and by the CPU (gloo) tests.
 """
 import torch
 import torch.distributed as dist
 
 
-class FlatGradAllReduce:
-    def __init__(self, params, process_group=None, chunk_bytes=256 << 20, comm_dtype=None):
-        self.params = [p for p in params if p.requires_grad]
+class GradExchange:
+    """All-reduce (mean) of contiguous buckets of one flat fp32 gradient buffer.
+
+    ``bounds``: list of (lo, hi) element ranges, in the order the backward pass completes them; default one bucket
+    covering the buffer.  ``chunk_bytes`` caps the size of a single collective call (very large buckets are sent
+    as several calls).  ``comm_dtype``: wire dtype (e.g. torch.bfloat16); None = fp32."""
+
+    def __init__(self, flat_grad, bounds=None, process_group=None, comm_dtype=None, chunk_bytes=256 << 20):
+        assert flat_grad.dtype == torch.float32 and flat_grad.is_contiguous() and flat_grad.dim() == 1
+        self.flat = flat_grad
         self.group = process_group
-        self.comm_dtype = comm_dtype                     # e.g. torch.bfloat16 to halve xGMI bytes
+        self.comm_dtype = None if comm_dtype in (None, torch.float32) else comm_dtype
+        self.chunk = max(1, chunk_bytes // 4)
+        self.bounds = [(0, flat_grad.numel())] if bounds is None else [(int(a), int(b)) for a, b in bounds]
+        covered = sorted(self.bounds)
+        assert covered[0][0] == 0 and covered[-1][1] == flat_grad.numel() and \
+            all(a[1] == b[0] for a, b in zip(covered[:-1], covered[1:])), "buckets must tile the gradient buffer"
+        self._pending = []          # (work handle, view, wire buffer or None)
+        self._wire = {}             # persistent wire buffers (graph-safe addresses, no per-step allocation)
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def launch(self, k):
+        """Start summing bucket k across ranks (asynchronous; returns immediately)."""
+        if self.world_size == 1:
+            return
+        lo, hi = self.bounds[k]
+        for s in range(lo, hi, self.chunk):
+            e = min(hi, s + self.chunk)
+            view = self.flat[s:e]
+            if self.comm_dtype is not None:
+                buf = self._wire.get((s, e))
+                if buf is None:
+                    buf = self._wire[(s, e)] = torch.empty(e - s, device=view.device, dtype=self.comm_dtype)
+                buf.copy_(view)
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending.append((work, view, buf))
+            else:
+                work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending.append((work, view, None))
+
+    def finish(self):
+        """Wait (stream-wise on GPUs) for every launched bucket and turn the sums into means."""
+        ws = self.world_size
+        if ws == 1:
+            return
+        pending, self._pending = self._pending, []
+        for work, view, buf in pending:
+            work.wait()
+            if buf is not None:
+                view.copy_(buf)
+        self.flat.div_(ws)
+
+    def allreduce_mean_(self):
+        """Whole buffer in one go: every bucket launched, then finished."""
+        for k in range(len(self.bounds)):
+            self.launch(k)
+        self.finish()
+
+
+class FlatGradAllReduce:
+    """Flat gradient buffer for an arbitrary parameter list (``p.grad`` become views of ``flat``) plus its mean
+    all-reduce: the stand-alone form of what ``FlatTrainingState`` does for a whole model."""
+
+    def __init__(self, params, process_group=None, chunk_bytes=256 << 20, comm_dtype=None, n_buckets=1):
+        self.params = [p for p in params if p.requires_grad]
         numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(numel, device=dev, dtype=torch.float32)
-        off = 0
+        off, offs = 0, []
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)   # autograd accumulates in place into the view
+            offs.append(off)
             off += n
-        self.chunk = max(1, chunk_bytes // 4)
+        # buckets of whole parameters, last parameters first (the order backward produces them)
+        bounds = None
+        if n_buckets > 1:
+            cuts = sorted({offs[min(len(offs) - 1, round(i * len(offs) / n_buckets))] for i in range(1, n_buckets)} - {0})
+            edges = [0] + cuts + [numel]
+            bounds = list(reversed(list(zip(edges[:-1], edges[1:]))))
+        self.exchange = GradExchange(self.flat, bounds, process_group, comm_dtype, chunk_bytes)
 
     def zero_(self):
         self.flat.zero_()
 
     @property
     def world_size(self):
-        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+        return self.exchange.world_size
 
     def allreduce_mean_(self):
         """Sum the flat gradient across ranks and divide by the world size (torch DDP semantics)."""
-        ws = self.world_size
-        if ws == 1:
-            return
-        n = self.flat.numel()
-        for s in range(0, n, self.chunk):
-            view = self.flat[s:min(n, s + self.chunk)]
-            if self.comm_dtype is not None and self.comm_dtype != torch.float32:
-                buf = view.to(self.comm_dtype)
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-                view.copy_(buf)
-            else:
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(ws)
+        self.exchange.allreduce_mean_()
 
 
 def shard_batch(global_batch, rank, world_size):

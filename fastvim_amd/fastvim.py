@@ -334,7 +334,9 @@ class VisionMamba(nn.Module):
     def no_weight_decay(self):
         return {"pos_embed"}
 
-    def forward_features(self, x, inference_params=None, out_indices=None):
+    # forward_features (models/fastvim.py:484-546) in three pieces, so that a training step can be cut into segments of
+    # layers (fastvim_amd/pipeline.py: gradient buckets exchanged while the next segment's backward runs)
+    def _embed(self, x):
         B, _, H, W = x.shape
         if self.if_abs_pos_embed:
             H, W = math.ceil(H / self.patch_size), math.ceil(W / self.patch_size)
@@ -347,19 +349,20 @@ class VisionMamba(nn.Module):
             x = self.patch_embed(x, pos_embed=self.pos_embed)     # x + pos_embed (:500) in the epilogue
             x = self.pos_drop(x)
         else:
+            H, W = math.ceil(H / self.patch_size), math.ceil(W / self.patch_size)
             x = self.patch_embed(x)
-        outs = []
-        residual = None
-        hidden_states = x
         if self.training:
             DropPath.predraw([l.drop_path for l in self.layers] + [self.drop_path], x.shape[0], x.device)
-        for layer_idx, layer in enumerate(self.layers):
-            hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
+        return x, (H, W)
+
+    def _run_layers(self, hidden_states, residual, lo, hi, inference_params=None, out_indices=None, outs=None):
+        for layer_idx in range(lo, hi):
+            hidden_states, residual = self.layers[layer_idx](hidden_states, residual, inference_params=inference_params)
             if out_indices is not None and layer_idx in out_indices:
                 outs.append(hidden_states)
-        if out_indices is not None:
-            assert len(outs) == len(out_indices)
-            return outs, (H, W)
+        return hidden_states, residual
+
+    def _final(self, hidden_states, residual):
         is_rms = isinstance(self.norm_f, RMSNorm)
         if not self.fused_add_norm:
             residual = hidden_states if residual is None else residual + self.drop_path(hidden_states)
@@ -378,10 +381,7 @@ class VisionMamba(nn.Module):
             return hidden_states
         raise NotImplementedError
 
-    def forward(self, x, return_features=False, inference_params=None):
-        x = self.forward_features(x, inference_params)
-        if return_features:
-            return x
+    def _head(self, x):
         if isinstance(self.head, nn.Linear) and x.is_cuda:
             # F.linear(x, head.weight, head.bias) (models/fastvim.py:541) through the MFMA GEMM: at batch 128 the
             # library picks a one-workgroup kernel for this 128 x 1000 x 192 problem (25 us)
@@ -391,6 +391,22 @@ class VisionMamba(nn.Module):
         if self.final_pool_type == "max":
             x = x.max(dim=1)[0]
         return x
+
+    def forward_features(self, x, inference_params=None, out_indices=None):
+        hidden_states, (H, W) = self._embed(x)
+        outs = []
+        hidden_states, residual = self._run_layers(hidden_states, None, 0, len(self.layers), inference_params,
+                                                   out_indices, outs)
+        if out_indices is not None:
+            assert len(outs) == len(out_indices)
+            return outs, (H, W)
+        return self._final(hidden_states, residual)
+
+    def forward(self, x, return_features=False, inference_params=None):
+        x = self.forward_features(x, inference_params)
+        if return_features:
+            return x
+        return self._head(x)
 
 
 class MM_FastVim(VisionMamba):

@@ -14,6 +14,7 @@ buckets + autocast casts + AccumulateGrad nodes, imagenet_classification/train.p
 """
 import ctypes
 import os
+import re
 import warnings
 
 import torch
@@ -23,6 +24,8 @@ from . import _lib as L
 from .layernorm import RMSNorm
 from .mamba_simple_faster import Mamba, _GroupedWgrad, _SideStream, flush_wgrads, group_wgrads
 from .mixer_ops import defer_reductions, drop_reductions, flush_reductions, pending_reductions
+
+_LAYER_RE = re.compile(r"^((?:.*\.)?[A-Za-z_]*layers\.\d+)\.")      # "layers.3.mixer.A_log" -> "layers.3"
 
 # per-mixer parameter order; each group is one contiguous region matching a kernel's partial layout
 _MIXER_GROUPS = (
@@ -40,21 +43,48 @@ class FlatTrainingState:
         self.comm_dtype = comm_dtype
         self.chunk = max(1, chunk_bytes // 4)
         named = dict(model.named_parameters())
-        order, seen = [], set()
-        regions = []      # (mixer, group name, [param names])
-        for mname, mod in model.named_modules():
-            if not isinstance(mod, Mamba):
-                continue
-            for gname, keys in _MIXER_GROUPS:
-                full = [f"{mname}.{k}" if mname else k for k in keys]
-                if all(f in named and named[f].requires_grad for f in full):
-                    regions.append((mod, gname, full))
-                    for f in full:
-                        order.append(f)
-                        seen.add(f)
+        # Layer-major layout: [parameters before the block stack | block 0 | block 1 | ... | parameters after it], so
+        # that the gradient of a run of blocks is ONE contiguous slice -- a bucket of the overlapped gradient exchange
+        # (fastvim_amd/ddp.py).  Inside a block the groups of _MIXER_GROUPS come first, each contiguous.
+        mixers = {mname: mod for mname, mod in model.named_modules() if isinstance(mod, Mamba)}
+        units, unit_of = [], {}          # unit = (key, [names]); key = "<prefix>layers.<i>" for block parameters, else None
         for n, p in named.items():
-            if n not in seen and p.requires_grad:
-                order.append(n)
+            if not p.requires_grad:
+                continue
+            m_ = _LAYER_RE.match(n)
+            key = m_.group(1) if m_ else None
+            if key is None:
+                if not units or units[-1][0] is not None:
+                    units.append((None, []))
+                units[-1][1].append(n)
+            else:
+                if key not in unit_of:
+                    unit_of[key] = len(units)
+                    units.append((key, []))
+                units[unit_of[key]][1].append(n)
+        order, regions = [], []      # regions: (mixer, group name, [param names])
+        self.units = []              # (key, first name, last name) -> element ranges are filled in below
+        for key, names in units:
+            front = []
+            for mname, mod in mixers.items():
+                if key is not None and (mname + ".").startswith(key + "."):
+                    for gname, keys in _MIXER_GROUPS:
+                        full = [f"{mname}.{k}" if mname else k for k in keys]
+                        if all(f in named and named[f].requires_grad for f in full):
+                            regions.append((mod, gname, full))
+                            front += full
+            rest = [n for n in names if n not in set(front)]
+            self.units.append((key, len(order), len(order) + len(front) + len(rest)))
+            order += front + rest
+        if not any(k is not None for k, _ in units):      # no block stack found: mixers anywhere in the model
+            for mname, mod in mixers.items():
+                for gname, keys in _MIXER_GROUPS:
+                    full = [f"{mname}.{k}" if mname else k for k in keys]
+                    if all(f in named and named[f].requires_grad for f in full):
+                        regions.append((mod, gname, full))
+            front = [f for _, _, full in regions for f in full]
+            order = front + [n for n in order if n not in set(front)]
+            self.units = [(None, 0, len(order))]
         self.names = order
         params = [named[n] for n in order]
         dev = params[0].device
@@ -67,6 +97,10 @@ class FlatTrainingState:
         self.grad_flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self.shadow_flat = torch.zeros(off, device=dev, dtype=shadow_dtype)
         self.offsets = dict(zip(order, offs))
+        total = off
+        # element range of every unit (block / run of non-block parameters), in layout order
+        self.unit_ranges = [(key, offs[i0] if i0 < len(offs) else total, offs[i1] if i1 < len(offs) else total)
+                            for key, i0, i1 in self.units if i1 > i0]
         with torch.no_grad():
             for n, p, o in zip(order, params, offs):
                 k = p.numel()
@@ -164,24 +198,51 @@ class FlatTrainingState:
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def buckets(self, n_buckets):
+        """Cut the block stack into ``n_buckets`` runs of whole blocks of about equal gradient size.  Returns them in
+        the order BACKWARD completes them (last blocks first): a list of dicts with ``bounds`` (element range of the
+        flat gradient: the run's blocks plus, for the first / last run, the parameters after / before the stack) and
+        ``layers`` ((lo, hi) block indices of the run, in forward order)."""
+        blocks = [(i, u) for i, u in enumerate(self.unit_ranges) if u[0] is not None]
+        if not blocks:
+            return [{"bounds": (0, self.grad_flat.numel()), "layers": (0, 0)}]
+        first_u, last_u = blocks[0][0], blocks[-1][0]
+        nb = len(blocks)
+        n_buckets = max(1, min(n_buckets, nb))
+        sizes = [u[2] - u[1] for _, u in blocks]
+        target, runs, acc, lo = sum(sizes) / n_buckets, [], 0, 0
+        for j, sz in enumerate(sizes):
+            acc += sz
+            left = nb - 1 - j
+            if (acc >= target * (len(runs) + 1) - 1e-9 and len(runs) < n_buckets - 1 and left >= n_buckets - 1 - len(runs)) \
+                    or j == nb - 1:
+                runs.append((lo, j + 1))
+                lo = j + 1
+        out = []
+        for k, (a, b) in enumerate(runs):
+            e0 = self.unit_ranges[first_u + a][1] if k > 0 else 0
+            e1 = self.unit_ranges[first_u + b - 1][2] if k < len(runs) - 1 else self.grad_flat.numel()
+            out.append({"bounds": (e0, e1), "layers": (a, b)})
+        return out[::-1]
+
+    def make_exchange(self, n_buckets=1):
+        """The gradient exchange over this state's flat gradient, cut into ``n_buckets`` (fastvim_amd/ddp.py)."""
+        from .ddp import GradExchange
+        bk = self.buckets(n_buckets)
+        self.exchange = GradExchange(self.grad_flat, [b["bounds"] for b in bk], self.group, self.comm_dtype, self.chunk * 4)
+        self.exchange.layers = [b["layers"] for b in bk]
+        return self.exchange
+
     def allreduce_mean_(self):
         """Sum the flat gradient across ranks (RCCL) and divide by the world size (torch DDP semantics).  Finishes
         the backward pass first (queued weight-gradient GEMMs and partial sums), so ``backward -> allreduce_mean_ ->
         step`` is a complete sequence."""
         self.finish_backward()
-        ws = self.world_size
-        if ws == 1:
+        if self.world_size == 1:
             return
-        n = self.grad_flat.numel()
-        for s in range(0, n, self.chunk):
-            view = self.grad_flat[s:min(n, s + self.chunk)]
-            if self.comm_dtype is not None and self.comm_dtype != torch.float32:
-                buf = view.to(self.comm_dtype)
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-                view.copy_(buf)
-            else:
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-        self.grad_flat.div_(ws)
+        if getattr(self, "exchange", None) is None:
+            self.make_exchange(1)
+        self.exchange.allreduce_mean_()
 
 
 class FlatAdamW:

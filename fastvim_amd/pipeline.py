@@ -1,0 +1,139 @@
+"""The data-parallel training step as a chain of HIP graphs with the gradient exchange between them.
+
+torch DDP (what the reference trains with, imagenet_classification/train.py:34-43) overlaps its bucketed all-reduce
+with backward through autograd hooks.  Here the step is captured into HIP graphs, so the overlap is made explicit
+(SURVEY.md section 8e): the block stack is cut into K runs of blocks; ONE graph holds the forward pass, K graphs hold
+the backward pass of one run each (last run first), one graph holds the fused optimizer.  The flat gradient is laid
+out block by block (fastvim_amd/flat.py), so the gradient of run k is one contiguous bucket: as soon as backward graph
+k has been enqueued, bucket k's all-reduce is launched asynchronously (RCCL, on the process group's stream, ordered
+behind graph k by an event) and runs under backward graphs k+1 .. K-1:
+
+    replay(fwd) -> replay(bwd 0), launch(bucket 0) -> replay(bwd 1), launch(bucket 1) -> ... -> finish() -> replay(opt)
+
+Only the last bucket (the first blocks + patch embedding) is exposed.  Cutting backward needs the activations at the
+cuts to be graph leaves: each run's input (hidden, residual) is a detached view of the previous run's output, and
+backward of run k is ``torch.autograd.backward(outputs_k, grads of run k+1's inputs)``.  With one rank nothing is
+exchanged and the chain computes, bit for bit, what the single-graph step computes
+(tests/test_pipeline_gpu.py).
+"""
+import torch
+
+
+class SegmentedTrainStep:
+    """``model`` must expose ``_embed / _run_layers / _final / _head`` (fastvim_amd.fastvim.VisionMamba).
+    ``loss_fn(logits, target) -> scalar``.  ``x`` / ``target`` are the static input buffers the graphs read; copy
+    new batches into them between steps."""
+
+    def __init__(self, model, flat, opt, loss_fn, x, target, n_segments=4, amp_dtype=torch.bfloat16, use_graph=True,
+                 warmup=2):
+        self.model, self.flat, self.opt, self.loss_fn = model, flat, opt, loss_fn
+        self.x, self.target, self.amp_dtype = x, target, amp_dtype
+        self.exchange = flat.make_exchange(n_segments)
+        self.runs = self.exchange.layers                 # (lo, hi) block ranges in BACKWARD order
+        self.K = len(self.runs)
+        self.use_graph = use_graph
+        self.loss = None
+        self._cuts = None
+        self._exposed = []                               # (event before finish, event after) of the timed steps
+        self.graphs = None
+        if use_graph:
+            self._capture(warmup)
+
+    # ------------------------------------------------------------------ the pieces
+    def _forward(self):
+        m = self.model
+        self.flat.zero_grad()
+        cuts = []              # per run in FORWARD order: (inputs (leaves) or None, outputs)
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype != torch.float32):
+            h, _ = m._embed(self.x)
+            res = None
+            fwd_runs = self.runs[::-1]
+            for i, (lo, hi) in enumerate(fwd_runs):
+                if i > 0:          # cut: this run's inputs are leaves that alias the previous run's outputs
+                    h = h.detach().requires_grad_()
+                    res = res.detach().requires_grad_()
+                    ins = (h, res)
+                else:
+                    ins = None
+                h, res = m._run_layers(h, res, lo, hi)
+                cuts.append([ins, (h, res)])
+            logits = m._head(m._final(h, res))
+        loss = self.loss_fn(logits, self.target)
+        cuts[-1][1] = (loss,)
+        self._cuts = cuts
+        return loss.detach()
+
+    def _backward(self, k):
+        """Backward of run k (backward order: k = 0 is the last run of blocks + head + loss)."""
+        i = self.K - 1 - k                      # forward index
+        outs = self._cuts[i][1]
+        if k == 0:
+            torch.autograd.backward(outs[0])
+        else:
+            nxt = self._cuts[i + 1][0]
+            torch.autograd.backward(list(outs), [t.grad for t in nxt])
+        self.flat.finish_backward()             # this run's queued weight-gradient GEMMs and partial sums
+        self._cuts[i][1] = None                 # free the run's autograd graph
+
+    # ------------------------------------------------------------------ capture / run
+    def _eager_step(self):
+        loss = self._forward()
+        for k in range(self.K):
+            self._backward(k)
+            self.exchange.launch(k)
+        self.exchange.finish()
+        self.opt.step()
+        return loss
+
+    def _capture(self, warmup):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fwd, pool=pool):
+            self.loss = self._forward()
+        g_bwd = []
+        for k in range(self.K):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self._backward(k)
+            g_bwd.append(g)
+        g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_opt, pool=pool):
+            self.opt.step()
+        self.graphs = (g_fwd, g_bwd, g_opt)
+
+    def step(self, time_exposed=False):
+        """One training step; returns the (device) loss tensor.  ``time_exposed`` brackets the wait for the gradient
+        exchange with events (read them with ``exposed_ms()`` after a synchronize)."""
+        if not self.use_graph:
+            self.loss = self._eager_step()
+            return self.loss
+        g_fwd, g_bwd, g_opt = self.graphs
+        g_fwd.replay()
+        for k in range(self.K):
+            g_bwd[k].replay()
+            self.exchange.launch(k)
+        if time_exposed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.exchange.finish()
+        if time_exposed:
+            e1.record()
+            self._exposed.append((e0, e1))
+        g_opt.replay()
+        return self.loss
+
+    def exposed_ms(self):
+        """Mean time the compute stream waited for the gradient exchange after the last backward graph (call after a
+        device synchronize)."""
+        if not self._exposed:
+            return None
+        t = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return sum(t) / len(t)

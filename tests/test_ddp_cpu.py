@@ -55,3 +55,59 @@ def test_flat_grad_allreduce_matches_full_batch(tmp_path, chunk_bytes, comm_dtyp
     ((m(x) - y) ** 2).mean().backward()
     ref = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
     assert (got - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastvim_amd.ddp import GradExchange
+    g = torch.Generator().manual_seed(10 + rank)
+    base = torch.randn(1000, generator=g)
+    res = {}
+    for name, bounds, order in (("one", None, [0]), ("four", [(700, 1000), (400, 700), (96, 400), (0, 96)], [0, 1, 2, 3]),
+                                ("chunked", [(512, 1000), (0, 512)], [0, 1])):
+        flat = base.clone()
+        ex = GradExchange(flat, bounds, chunk_bytes=(1 << 30) if name != "chunked" else 400)
+        for k in order:             # buckets launched one by one (as backward segments complete), finished once
+            ex.launch(k)
+        ex.finish()
+        res[name] = flat
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_bitwise_equals_single_allreduce(tmp_path):
+    """The bucketed, asynchronously launched exchange computes exactly the single all-reduce's mean."""
+    out = str(tmp_path / "b.pt")
+    mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    ref = (torch.randn(1000, generator=torch.Generator().manual_seed(10))
+           + torch.randn(1000, generator=torch.Generator().manual_seed(11))) / 2
+    assert torch.equal(res["one"], ref)
+    assert torch.equal(res["four"], res["one"]) and torch.equal(res["chunked"], res["one"])
+
+
+def test_layer_major_buckets_tile_the_flat_gradient():
+    """FlatTrainingState lays the gradient out block by block; buckets() cuts it into runs of whole blocks, last
+    blocks first, that tile the buffer (CPU: no kernels involved)."""
+    from fastvim_amd.fastvim import VisionMamba
+    from fastvim_amd.flat import FlatTrainingState
+    m = VisionMamba(img_size=32, depth=7, embed_dim=32, num_classes=5, rms_norm=True, fused_add_norm=True, residual_in_fp32=True)
+    with FlatTrainingState(m) as flat:
+        named = dict(m.named_parameters())
+        for n in (1, 2, 3, 4, 7, 12):
+            bk = flat.buckets(n)
+            assert len(bk) == min(n, 7)
+            assert bk[0]["bounds"][1] == flat.grad_flat.numel() and bk[-1]["bounds"][0] == 0
+            assert all(a["bounds"][0] == b["bounds"][1] for a, b in zip(bk[:-1], bk[1:]))
+            assert bk[0]["layers"][1] == 7 and bk[-1]["layers"][0] == 0
+            for b in bk:                                   # every block's parameters sit inside its bucket
+                for i in range(*b["layers"]):
+                    for pn, p in named.items():
+                        if pn.startswith(f"layers.{i}."):
+                            assert b["bounds"][0] <= flat.offsets[pn] and flat.offsets[pn] + p.numel() <= b["bounds"][1]
+            assert bk[0]["bounds"][0] <= flat.offsets["norm_f.weight"]                 # after the stack: first bucket
+            assert flat.offsets["patch_embed.proj.weight"] < bk[-1]["bounds"][1]       # before it: last bucket

@@ -1,0 +1,72 @@
+"""The segmented training step (fastvim_amd/pipeline.py: forward graph | K backward graphs | optimizer graph, gradient
+buckets exchanged between them) against the single-graph step: with one rank it must produce the same parameters bit
+for bit; with two ranks sharing the GPU over gloo it must run end to end and report its exchange."""
+import copy
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n_seg,graph", [(3, True), (6, True), (2, False)])
+def test_segmented_step_equals_single_step(n_seg, graph):
+    from fastvim_amd.fastvim import VisionMamba
+    from fastvim_amd.flat import FlatAdamW, FlatTrainingState
+    from fastvim_amd.losses import SoftTargetCrossEntropy
+    from fastvim_amd.pipeline import SegmentedTrainStep
+
+    def make():
+        torch.manual_seed(0)
+        m = VisionMamba(img_size=224, depth=6, embed_dim=192, num_classes=100, rms_norm=True, residual_in_fp32=True,
+                        fused_add_norm=True, final_pool_type="mean", if_abs_pos_embed=True, drop_path_rate=0.1).cuda().train()
+        flat = FlatTrainingState(m)
+        nd = {n for n, p in m.named_parameters() if p.ndim <= 1 or n.endswith(".bias") or n in m.no_weight_decay()
+              or getattr(p, "_no_weight_decay", False)}
+        return m, flat, FlatAdamW(flat, m, lr=1e-3, weight_decay=0.05, no_decay=nd, ema_decay=0.999)
+
+    x = torch.randn(16, 3, 224, 224, device="cuda")
+    tgt = torch.softmax(torch.randn(16, 100, device="cuda"), -1)
+    crit = SoftTargetCrossEntropy()
+    m1, f1, o1 = make()
+    torch.manual_seed(7)
+    ref = []
+    for _ in range(5):
+        f1.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = crit(m1(x), tgt)
+        loss.backward()
+        o1.step()
+        ref.append(loss.item())
+    m2, f2, o2 = make()
+    torch.manual_seed(7)
+    seg = SegmentedTrainStep(m2, f2, o2, crit, x, tgt, n_segments=n_seg, use_graph=graph, warmup=2)
+    assert seg.K == n_seg and sorted(sum(([a, b] for a, b in seg.runs), [])) == sorted(
+        [0, 6] + 2 * [r[0] for r in seg.runs if r[0] != 0])
+    got = []
+    for _ in range(5 - (2 if graph else 0)):
+        got.append(seg.step().item())
+    assert got == ref[2 if graph else 0:], (got, ref)
+    torch.cuda.synchronize()
+    assert torch.equal(f1.param_flat, f2.param_flat)
+    f1.close(); f2.close()
+
+
+def test_two_rank_segmented_bench_line():
+    """Two ranks on GPU 0 over gloo (FASTVIM_BENCH_ONE_GPU=1): the N > 1 bench path = segmented step with bucketed,
+    asynchronously launched all-reduces; the line reports the exchange."""
+    env = dict(os.environ, FASTVIM_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--batch", "16", "--buckets", "3", "--no-cpu-baseline", "--no-kernels", "--no-scan-op"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["ddp"]["overlapped"] and out["ddp"]["buckets"] == 3 and out["ddp"]["ranks"] == 2
+    assert abs(sum(out["ddp"]["bucket_MB"]) - 28.7) < 0.5            # FastVim-T: 7.17 M fp32 gradients
+    assert out["ddp"]["allreduce_exposed_ms"] is not None and out["config"]["final_loss"] == out["config"]["final_loss"]
