@@ -309,7 +309,7 @@ def scan_op_table(cpu=True):
 
 
 def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, rank, world, dev, use_graph=True,
-                       trace=False, buckets=4, comm_dtype=None):
+                       trace=False, buckets=4, comm_dtype=None, force_segmented=False):
     """Build the model + flat training state + fused optimizer, capture the whole step (fwd + loss + bwd + AdamW + EMA;
     the gradient exchange sits between graph replay and optimizer when world > 1) and time exactly ``steps`` steps
     after ``warmup`` untimed ones, bracketed by barrier + synchronize.  Returns (seconds, final loss, extras)."""
@@ -348,7 +348,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
         return loss.detach()
 
     seg = None
-    if use_graph and world > 1 and model_name in ("T", "S", "B") and buckets > 0:
+    if use_graph and (world > 1 or force_segmented) and model_name in ("T", "S", "B") and buckets > 0:
         # N > 1: the step is a chain of graphs (forward | backward of K runs of blocks | optimizer) with the bucketed
         # gradient all-reduce launched between them, so that it overlaps the remaining backward (fastvim_amd/pipeline.py)
         from fastvim_amd.pipeline import SegmentedTrainStep
@@ -479,6 +479,8 @@ def main():
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--buckets", type=int, default=4,
                     help="N > 1: gradient buckets = backward graph segments the all-reduce overlaps with (0: one all-reduce after backward)")
+    ap.add_argument("--segmented", action="store_true",
+                    help="use the segmented (N > 1) step also on one GPU: measures what the chain of graphs costs by itself")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
@@ -513,7 +515,8 @@ def main():
     comm_dtype = {"fp32": None, "bf16": torch.bfloat16}[args.comm_dtype]
     elapsed, loss_val, extras = run_training_steps(args.model, args.img, args.batch, args.channels, args.dtype, args.steps,
                                                    args.warmup, rank, world, dev, use_graph=use_graph, trace=trace,
-                                                   buckets=args.buckets, comm_dtype=comm_dtype)
+                                                   buckets=args.buckets, comm_dtype=comm_dtype,
+                                                   force_segmented=args.segmented)
     if not (loss_val == loss_val):
         raise SystemExit("non-finite loss in the timed region")
 
@@ -540,6 +543,8 @@ def main():
         }
         if "ddp" in extras:
             out["ddp"] = extras["ddp"]
+        if args.segmented:
+            out["config"]["segmented_step"] = args.buckets
         if not args.no_kernels and args.model not in ("C", "V", "M"):
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
             dom = max(kt, key=lambda k: kt[k]["us_per_step"])     # the kernel that costs the most time per step

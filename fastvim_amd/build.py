@@ -45,8 +45,19 @@ def _compile(src, obj, verbose):
     return obj
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, tuning=False):
+    """``tuning=True`` (``python -m fastvim_amd.build --tuning``): compile the kernel dispatchers' A/B hooks in
+    (FASTVIM_* environment variables, tools/README.md); the default library reads no environment variable."""
     os.makedirs(OBJ, exist_ok=True)
+    stamp = os.path.join(OBJ, ".tuning")
+    was = os.path.exists(stamp)
+    if was != tuning:
+        force = True
+        (open(stamp, "w").close() if tuning else os.remove(stamp))
+    if tuning and "-DFASTVIM_TUNING_HOOKS" not in FLAGS:
+        FLAGS.append("-DFASTVIM_TUNING_HOOKS")
+    if not tuning and "-DFASTVIM_TUNING_HOOKS" in FLAGS:
+        FLAGS.remove("-DFASTVIM_TUNING_HOOKS")
     hdr_m = _deps_mtime()
     jobs, objs = [], []
     for src in _sources():
@@ -66,4 +77,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))

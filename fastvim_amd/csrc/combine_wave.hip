@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void combine_bwd_wave_kernel(BwdParams p) 
 }
 
 int mode() {   // tuning hook: 0 = generic kernels only, 1 = wave kernels where a token spans more than one 384-chunk, 2 = wherever they apply
-  static const int m = getenv("FASTVIM_COMBINE_WAVE") ? atoi(getenv("FASTVIM_COMBINE_WAVE")) : 2;
+  static const int m = fv_tune("FASTVIM_COMBINE_WAVE", 2);
   return m;
 }
 
@@ -307,14 +307,14 @@ int chunks(int d_in) {
 }  // namespace
 
 static bool wide_bwd(int d_in) {
-  static const bool on = !(getenv("FASTVIM_COMBINE_WAVE_B") && atoi(getenv("FASTVIM_COMBINE_WAVE_B")) == 0);   // tuning hook
+  static const bool on = (fv_tune("FASTVIM_COMBINE_WAVE_B", 1) != 0);   // tuning hook
   return on && d_in == 4 * 384 && mode() >= 1;
 }
 
 int fvi::combine_wave_blocks(int B, int rows, int tpp, int d_in) {
   if (!chunks(d_in) && !wide_bwd(d_in)) return 0;
   const long groups = ((long)B * rows * tpp + NW - 1) / NW;
-  static const int cap = getenv("FASTVIM_COMBINE_GRID") ? atoi(getenv("FASTVIM_COMBINE_GRID")) : 0;   // tuning hook
+  static const int cap = fv_tune("FASTVIM_COMBINE_GRID", 0);   // tuning hook
   if (cap) return (int)(groups < cap ? groups : cap);
   const long per = (groups + 511) / 512;
   return (int)((groups + per - 1) / per);

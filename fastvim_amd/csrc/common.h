@@ -33,6 +33,16 @@ void fv_set_error(const char* fmt, ...);
 
 static inline int fv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// A/B hooks of the kernel dispatchers.  The shipped library takes the measured default of every choice and reads NO
+// environment variable; a build with -DFASTVIM_TUNING_HOOKS (python -m fastvim_amd.build --tuning) reads FASTVIM_<NAME>
+// once per process so that an experiment can be repeated on one box in one call (tools/README.md lists them).
+#ifdef FASTVIM_TUNING_HOOKS
+#include <stdlib.h>
+static inline int fv_tune(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static inline int fv_tune(const char*, int dflt) { return dflt; }
+#endif
+
 // ---------------------------------------------------------------- scalar type traits
 template <typename T> struct io;
 template <> struct io<float> {

@@ -405,7 +405,7 @@ int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t
   const int cap = 8 / nchg < 1 ? 1 : 8 / nchg;
   const int rgr = rg < cap ? rg : cap;
   if (chan8 || dense8) {
-    static const bool chan = !(getenv("FASTVIM_BWD_CHAN") && atoi(getenv("FASTVIM_BWD_CHAN")) == 0);   // tuning hook
+    static const bool chan = (fv_tune("FASTVIM_BWD_CHAN", 1) != 0);   // tuning hook
     if (!chan) return FV_ERR_UNSUPPORTED;
 #define FV_CH(TT, CC) launch_chan<TT, 8, CC>(p, nchg, rgr, grid, groups, smem, st)
     if (dtype == FV_F32) return chan8 ? FV_CH(float, true) : FV_CH(float, false);
@@ -413,7 +413,7 @@ int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t
 #undef FV_CH
   }
   if (p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16)) return FV_ERR_UNSUPPORTED;
-  static const bool wide = !(getenv("FASTVIM_BWD_ROWK_WIDE") && atoi(getenv("FASTVIM_BWD_ROWK_WIDE")) == 0);   // tuning hook
+  static const bool wide = (fv_tune("FASTVIM_BWD_ROWK_WIDE", 1) != 0);   // tuning hook
   if (groups > 1 && !wide) return FV_ERR_UNSUPPORTED;
   if (dtype == FV_F32)
     return p.geo.cols == 14 ? launch_row<float, 14>(p, nchg, rgr, grid, groups, smem, st)

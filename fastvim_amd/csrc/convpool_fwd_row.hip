@@ -235,7 +235,7 @@ int launch_row(const FwdParams& p, int pool_max, hipStream_t st) {
 
 template <typename T, int NT>
 int pick_np(const FwdParams& p, int pool_max, hipStream_t st) {
-  static const int force = getenv("FASTVIM_FWD_NP") ? atoi(getenv("FASTVIM_FWD_NP")) : 0;   // tuning hook
+  static const int force = fv_tune("FASTVIM_FWD_NP", 0);   // tuning hook
   // one channel pair per lane measured fastest (12.8 vs 16.5 us with three pairs on FastVim-T): more, shorter waves
   if ((force == 0 || force == 1) && p.d_in % 128 == 0 && p.d_in <= 16 * 128) return launch_row<T, NT, 1>(p, pool_max, st);
   if ((force == 0 || force == 3) && p.d_in % 384 == 0 && p.d_in <= 8 * 384) return launch_row<T, NT, 3>(p, pool_max, st);
@@ -247,7 +247,7 @@ int pick_np(const FwdParams& p, int pool_max, hipStream_t st) {
 
 int fvi::conv_pool_fwd_row(const FwdParams& p, int pool_max, int dtype, hipStream_t st) {
   const bool fits = p.d_in % 128 == 0 && (size_t)p.geo.L * 2 * p.d_in * 4 <= 0xfffff000ull;   // one batch element per descriptor
-  static const bool chan = !(getenv("FASTVIM_FWD_CHAN") && atoi(getenv("FASTVIM_FWD_CHAN")) == 0);   // tuning hook
+  static const bool chan = (fv_tune("FASTVIM_FWD_CHAN", 1) != 0);   // tuning hook
   if (chan && fits && !pool_max && p.geo.tpp == 8 && p.geo.pcols >= 2 && p.d_in <= 8 * 128)
     return dtype == FV_F32 ? launch_chan<float, 8, true>(p, pool_max, st) : launch_chan<bf16_t, 8, true>(p, pool_max, st);
   // long rows of the dense path (cols = 32 / 64 / 128: the 512 / 1024 / 2048 px grids)

@@ -423,7 +423,7 @@ int launch_k(const GemmParams& p, int splits, hipStream_t st) {
 template <int AMODE, int BMODE, int WM, int WN>
 int launch(const GemmParams& p, int splits, hipStream_t st) {
   // LDS-DMA staging needs whole 64-deep K tiles in every split and >= 8 columns in K-slow operands
-  static const bool allow = !(getenv("FASTVIM_GEMM_GLDS") && atoi(getenv("FASTVIM_GEMM_GLDS")) == 0);   // tuning hook
+  static const bool allow = (fv_tune("FASTVIM_GEMM_GLDS", 1) != 0);   // tuning hook
   // (measured: a win for K-contiguous A -- forward and data-gradient GEMMs, -8..-20 % -- and a loss for the
   //  K-slow x K-slow weight-gradient form, +10 %, which keeps register staging)
   const bool whole = AMODE == KC && p.K % BK == 0 && p.k_per_split % BK == 0 && (BMODE == KC || p.N >= 8);
@@ -608,8 +608,8 @@ int launch_stream(const GemmParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<BMODE, WM, WN, NB, MB, S>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
-  static const int per_cu_env = getenv("FASTVIM_GEMM_STREAM_WG") ? atoi(getenv("FASTVIM_GEMM_STREAM_WG")) : 0;   // tuning hook
-  static const bool balance = !(getenv("FASTVIM_GEMM_STREAM_BAL") && atoi(getenv("FASTVIM_GEMM_STREAM_BAL")) == 0);   // tuning hook
+  static const int per_cu_env = fv_tune("FASTVIM_GEMM_STREAM_WG", 0);   // tuning hook
+  static const bool balance = (fv_tune("FASTVIM_GEMM_STREAM_BAL", 1) != 0);   // tuning hook
   const int fit = (int)((160 * 1024) / smem);
   const int per_cu = per_cu_env > 0 ? (per_cu_env < fit ? per_cu_env : fit) : fit;
   int G = cus * (per_cu < 1 ? 1 : per_cu);
@@ -635,12 +635,12 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   // N a multiple of 192 (FastVim-T/S/B: d, 2*d_in): 128x192 tiles, the A panel is read N/192 times instead of
   // N/128.  Measured on MI355X: N = 384 -9 %, FastVim-S/B steps -3 %; N = 192 neutral (K-contiguous B) or +12 %
   // (K-slow B, 4-way swizzle), N = 768 with K = 192 +3 % -- those keep the 128-wide tiles.
-  static const int tall = getenv("FASTVIM_GEMM_TALL") ? atoi(getenv("FASTVIM_GEMM_TALL")) : 0;   // tuning hook: 1 = 256x128, 2 = 256x192, 3 = 256x256 tiles
+  static const int tall = fv_tune("FASTVIM_GEMM_TALL", 0);   // tuning hook: 1 = 256x128, 2 = 256x192, 3 = 256x256 tiles
   const bool whole_k = p.K % BK == 0 && p.k_per_split % BK == 0;
   // streaming form (gemm_stream_kernel): K-contiguous activations, bf16 output, no split-K, the FastVim-T weight
   // sizes it was measured on (HBM-cold, M = 25088: in_proj forward 24.3 -> 23.0 us, in_proj data gradient
   // 20.4 -> 18.3; whole step 7.635 -> 7.59 ms)
-  static const bool stream = !(getenv("FASTVIM_GEMM_STREAM") && atoi(getenv("FASTVIM_GEMM_STREAM")) == 0);   // tuning hook
+  static const bool stream = (fv_tune("FASTVIM_GEMM_STREAM", 1) != 0);   // tuning hook
   if constexpr (AMODE == KC) {
     // (K-slow B only: inside the training step, where A was written by the previous kernel, the <KC, KC> forward
     //  GEMMs measured 21.1 -> 22.4 ms per 27 steps with it, the <KC, KS> data gradients 23.8 -> 20.1 ms)
@@ -660,21 +660,21 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   }
   // FastVim-B in_proj forward (N = 3072, K = 768): eight waves of 128x64 on a 256x256 tile, -10 % (161 -> 144 us);
   // measured slower at every FastVim-T/S shape and for the data-gradient forms, which keep the 4-wave tiles
-  static const bool big = !(getenv("FASTVIM_GEMM_BIG") && atoi(getenv("FASTVIM_GEMM_BIG")) == 0);   // tuning hook
+  static const bool big = (fv_tune("FASTVIM_GEMM_BIG", 1) != 0);   // tuning hook
   if (big && !tall && AMODE == KC && BMODE == KC && p.N % 256 == 0 && p.N >= 2048 && p.K >= 512 && p.M >= 4096 && whole_k)
     return launch_k<AMODE, BMODE, 2, 4, true, 4, 8>(p, splits, st);
   // N = 192 (FastVim-T: out_proj forward, in_proj data gradient, patch embed): two 96-wide tiles cover it exactly,
   // two 128-wide ones compute and load a quarter too much
-  static const int n96 = getenv("FASTVIM_GEMM_N96") ? atoi(getenv("FASTVIM_GEMM_N96")) : 1;   // tuning hook (out_proj forward 11.2 -> 10.1 us, in_proj dgrad 18.0 -> 16.9)
+  static const int n96 = fv_tune("FASTVIM_GEMM_N96", 1);   // tuning hook (out_proj forward 11.2 -> 10.1 us, in_proj dgrad 18.0 -> 16.9)
   if (n96 && !tall && AMODE == KC && p.N % 96 == 0 && p.N < 384 && whole_k)
     return launch_k<AMODE, BMODE, 2, 2, true, 3>(p, splits, st);
-  static const bool wide = !(getenv("FASTVIM_GEMM_N192") && atoi(getenv("FASTVIM_GEMM_N192")) == 0);   // tuning hook
+  static const bool wide = (fv_tune("FASTVIM_GEMM_N192", 1) != 0);   // tuning hook
   if (wide && AMODE == KC && p.N % 192 == 0 && p.N >= 384 && !(p.N == 768 && p.K <= 192) && p.K % BK == 0 &&
       p.k_per_split % BK == 0)
     return launch_k<AMODE, BMODE, 2, 2, true, 6>(p, splits, st);
   // 128x128 everywhere else: with LDS-DMA staging the 256x64 shape no longer pays at N = 192 (measured equal or
   // up to 8 % slower); it stays available for tuning
-  static const int force = getenv("FASTVIM_GEMM_TILE") ? atoi(getenv("FASTVIM_GEMM_TILE")) : 0;   // 41 = 256x64
+  static const int force = fv_tune("FASTVIM_GEMM_TILE", 0);   // 41 = 256x64
   if (force == 41 && p.M >= 256) return launch<AMODE, BMODE, 4, 1>(p, splits, st);
   return launch<AMODE, BMODE, 2, 2>(p, splits, st);
 }
@@ -745,8 +745,8 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
       G.blk_end[i] = blocks;
     }
     G.count = n;
-    static const int tile = getenv("FASTVIM_WGRAD_GROUP_TILE") ? atoi(getenv("FASTVIM_WGRAD_GROUP_TILE")) : 0;   // tuning hook
-    static const int xcd_order = getenv("FASTVIM_WGRAD_GROUP_XCD") ? atoi(getenv("FASTVIM_WGRAD_GROUP_XCD")) : 1;   // tuning hook
+    static const int tile = fv_tune("FASTVIM_WGRAD_GROUP_TILE", 0);   // tuning hook
+    static const int xcd_order = fv_tune("FASTVIM_WGRAD_GROUP_XCD", 1);   // tuning hook
     if (tile == 7) {          // 8 waves, 256x192 tiles (every N = 192 problem reads its wide operand once)
       int b2 = 0;
       for (int i = 0; i < n; ++i) {

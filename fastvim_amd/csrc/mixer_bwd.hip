@@ -518,7 +518,7 @@ int persistent_blocks(long nrows, int rg) {
   // one block per CU: measured best for the persistent backward kernels (conv_pool_bwd at FastVim-T 32.6 us with 256
   // blocks vs 37.8 with 448, 36.9 with 384, 33.3 with 224, 46.0 with 299) -- no CU carries two blocks while others
   // carry one, and the per-block gradient partials halve
-  static const int cap = getenv("FASTVIM_BWD_GRID") ? atoi(getenv("FASTVIM_BWD_GRID")) : 256;   // tuning hook
+  static const int cap = fv_tune("FASTVIM_BWD_GRID", 256);   // tuning hook
   return (int)(groups < cap ? groups : cap);
 }
 
@@ -562,7 +562,7 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
     }
   }
   // short rows: the whole-row kernel (convpool_bwd_row.hip) over the same persistent grid / partial layout
-  static const bool rowk = !(getenv("FASTVIM_BWD_ROWK") && atoi(getenv("FASTVIM_BWD_ROWK")) == 0);   // tuning hook
+  static const bool rowk = (fv_tune("FASTVIM_BWD_ROWK", 1) != 0);   // tuning hook
   if (rowk && VEC == 2 && !p.amax) {
     int rc = fvi::conv_pool_bwd_row(p, nch, rg, (int)grid.x, smem, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
     if (rc != FV_ERR_UNSUPPORTED) return rc;

@@ -351,7 +351,7 @@ int launch_conv_pool(const FwdParams& p, int pool_max, hipStream_t st) {
     if (pool_max) hipLaunchKernelGGL((K<__VA_ARGS__, true>), grid, block, smem, st, p);      \
     else hipLaunchKernelGGL((K<__VA_ARGS__, false>), grid, block, smem, st, p);              \
   } while (0)
-  static const bool rowk = !(getenv("FASTVIM_FWD_ROWK") && atoi(getenv("FASTVIM_FWD_ROWK")) == 0);   // tuning hook
+  static const bool rowk = (fv_tune("FASTVIM_FWD_ROWK", 1) != 0);   // tuning hook
   if (rowk && !pool_max) {     // short rows / 8-token cells, mean pooling: the packed-math kernels (convpool_fwd_row.hip): the whole-row packed-math kernel (convpool_fwd_row.hip)
     int rc = fvi::conv_pool_fwd_row(p, pool_max, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
     if (rc != FV_ERR_UNSUPPORTED) return rc;
@@ -398,7 +398,7 @@ int dispatch_fwd(int which, const FwdParams& p, int pool_max, hipStream_t st) {
     if (v == 2) return launch_combine<T, 2>(p, st);
     return launch_combine<T, 1>(p, st);
   }
-  static const int force = getenv("FASTVIM_FWD_VEC") ? atoi(getenv("FASTVIM_FWD_VEC")) : 0;   // tuning hook
+  static const int force = fv_tune("FASTVIM_FWD_VEC", 0);   // tuning hook
   if ((force == 2 || p.geo.tpp > 1) && p.d_in % 128 == 0 && p.d_in <= 8 * 128) return launch_conv_pool<T, 2>(p, pool_max, st);
   if (p.geo.tpp > 1 && p.d_in % 256 == 0 && p.d_in <= 8 * 256) return launch_conv_pool<T, 4>(p, pool_max, st);
   if (p.geo.tpp > 1) return launch_conv_pool<T, 1>(p, pool_max, st);

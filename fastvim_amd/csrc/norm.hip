@@ -443,7 +443,7 @@ int dt_ok(int dt) { return dt == FV_F32 || dt == FV_BF16; }
 }  // namespace
 
 extern "C" int fv_add_norm_blocks(int M) {
-  static const int cap = getenv("FASTVIM_NORM_WAVES") ? atoi(getenv("FASTVIM_NORM_WAVES")) : 4096;   // tuning hook
+  static const int cap = fv_tune("FASTVIM_NORM_WAVES", 4096);   // tuning hook
   long waves = M < cap ? M : cap;   // persistent: at most 1024 blocks of 4 waves
   return (int)((waves + 3) / 4);
 }
@@ -467,7 +467,7 @@ extern "C" int fv_add_norm_fwd(const void* x, int x_dtype, const void* residual,
   p.M = M; p.N = N; p.rows_per_scale = rows_per_scale; p.is_rms = is_rms_norm; p.eps = eps;
   const dim3 grid(fv_add_norm_blocks(M)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  static const bool k3 = !(getenv("FASTVIM_NORM3") && atoi(getenv("FASTVIM_NORM3")) == 0);   // tuning hook
+  static const bool k3 = (fv_tune("FASTVIM_NORM3", 1) != 0);   // tuning hook
   if (k3 && N == 192) hipLaunchKernelGGL(add_norm_fwd3_kernel<16>, grid, block, 0, st, p);
   else if (k3 && N == 384) hipLaunchKernelGGL(add_norm_fwd3_kernel<32>, grid, block, 0, st, p);
   else if (k3 && N == 768) hipLaunchKernelGGL(add_norm_fwd3_kernel<64>, grid, block, 0, st, p);
@@ -498,7 +498,7 @@ extern "C" int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidu
   p.M = M; p.N = N; p.rows_per_scale = rows_per_scale; p.is_rms = is_rms_norm;
   const dim3 grid(fv_add_norm_blocks(M)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  static const bool k3 = !(getenv("FASTVIM_NORM3") && atoi(getenv("FASTVIM_NORM3")) == 0);   // tuning hook
+  static const bool k3 = (fv_tune("FASTVIM_NORM3", 1) != 0);   // tuning hook
   if (k3 && N == 192) hipLaunchKernelGGL(add_norm_bwd3_kernel<16>, grid, block, 0, st, p);
   else if (k3 && N == 384) hipLaunchKernelGGL(add_norm_bwd3_kernel<32>, grid, block, 0, st, p);
   else if (k3 && N == 768) hipLaunchKernelGGL(add_norm_bwd3_kernel<64>, grid, block, 0, st, p);

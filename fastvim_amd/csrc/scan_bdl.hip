@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64) void scan_bdl_bwd_kernel(ScanParams p, int ntil
 // Requires d_state == 16, variable B and C, and whole 64-channel chunks per group.
 constexpr int SN = 16, SCPB = 64, SKS = 4;
 
-static const bool g_short_on = !(getenv("FASTVIM_SCAN_SHORT") && atoi(getenv("FASTVIM_SCAN_SHORT")) == 0);   // tuning hook
+static const bool g_short_on = (fv_tune("FASTVIM_SCAN_SHORT", 1) != 0);   // tuning hook
 inline bool short_path(int L, int N, int dim, int G, int Bv, int Cv) {
   return g_short_on && L <= 128 && N == SN && Bv && Cv && (dim / G) % SCPB == 0;
 }

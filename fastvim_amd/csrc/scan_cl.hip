@@ -659,7 +659,7 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
 
 // pooled lengths up to 16 take the register-resident kernel (192-channel workgroups)
 static bool bwd_short(int Lc, int dt_rank) {
-  static const int off = getenv("FASTVIM_SCAN_SHORT") ? atoi(getenv("FASTVIM_SCAN_SHORT")) == 0 : 0;   // A/B hook
+  static const int off = (fv_tune("FASTVIM_SCAN_SHORT", 1) == 0);   // A/B hook
   return Lc <= 16 && dt_rank <= 48 && !off;
 }
 extern "C" int fv_mixer_scan_bwd_chunks(int d_inner, int Lc, int dt_rank) {
@@ -669,7 +669,7 @@ extern "C" int fv_mixer_scan_bwd_chunks(int d_inner, int Lc, int dt_rank) {
 // A block can walk several batch elements (fewer, longer blocks; parameter-gradient partials shrink by the same
 // factor).  Measured on FastVim-T: 2 per block 49.0 us vs 47-48 us, 4 per block 65 us -- so one, unless forced.
 static int scan_bwd_nbb(int batch, int Lc, int dt_rank) {
-  static const int force = getenv("FASTVIM_SCAN_NBB") ? atoi(getenv("FASTVIM_SCAN_NBB")) : 0;   // tuning hook
+  static const int force = fv_tune("FASTVIM_SCAN_NBB", 0);   // tuning hook
   if (force > 0 && batch % force == 0) return force;
   return (bwd_short(Lc, dt_rank) && batch % 2 == 0) ? 2 : 1;
 }

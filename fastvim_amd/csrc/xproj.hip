@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * NWV) void xproj_fwd_kernel(const bf16_t* __res
 }  // namespace
 
 static int xproj_rows() {
-  static const int r = getenv("FASTVIM_XPROJ_ROWS") ? atoi(getenv("FASTVIM_XPROJ_ROWS")) : 16;   // tuning hook
+  static const int r = fv_tune("FASTVIM_XPROJ_ROWS", 16);   // tuning hook
   return r;
 }
 extern "C" int fv_mixer_xproj_bwd_slices(int M) { return fv_cdiv(M, xproj_rows()); }
@@ -182,7 +182,7 @@ extern "C" int fv_mixer_xproj_bwd2(const float* dx_dbl_partials, int nchunks, co
   p.dxdbl_part = dx_dbl_partials; p.xc = xc; p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.dxc = dxc;
   p.dW_part = dW_partials; p.dxdbl_out = dx_dbl_bf16; p.nchunks = nchunks; p.M = M; p.d_in = d_inner; p.rows_per_block = xproj_rows();
   const int bs = d_inner >= 256 ? 128 : 64;
-  static const int rb = getenv("FASTVIM_XPROJ_RB") ? atoi(getenv("FASTVIM_XPROJ_RB")) : 8;   // tuning hook (rows of loads in flight; 8: 25.7 vs 26.8 us)
+  static const int rb = fv_tune("FASTVIM_XPROJ_RB", 8);   // tuning hook (rows of loads in flight; 8: 25.7 vs 26.8 us)
   dim3 grid(fv_cdiv(d_inner, bs), fv_mixer_xproj_bwd_slices(M), 2), block(bs);
   hipStream_t st = (hipStream_t)stream;
 #define FV_XPK(TT, WW, RR)                                                                                     \

@@ -139,9 +139,9 @@ class FlatTrainingState:
         self._saved_switches = (_Deferred.enabled, _GroupedWgrad.enabled, _SideStream.enabled)
         defer_reductions(True)
         group_wgrads(True)
-        # weight-gradient GEMMs on a second stream (joined in finish_backward): measured neutral-to-slower
-        # on MI355X under graph replay (12.35 vs 12.04 ms/step), so opt-in only
-        _SideStream.enabled = os.environ.get("FASTVIM_WGRAD_STREAM", "0") == "1"
+        # (weight-gradient GEMMs on a second stream, joined in finish_backward, measured neutral-to-slower on MI355X under
+        # graph replay -- 12.35 vs 12.04 ms/step: _SideStream stays off unless a caller switches it on)
+        _SideStream.enabled = False
 
     def close(self):
         """Issue whatever is queued and restore the wrappers' process-wide switches (deferred reductions, grouped weight

@@ -1,6 +1,5 @@
 """Host wrappers of the bf16 MFMA GEMM (csrc/gemm_mfma.hip, C ABI fv_gemm_bf16)."""
 import ctypes
-import os
 
 import torch
 
@@ -75,9 +74,9 @@ def gemm_tn(x, y, splits=1, out=None, accumulate=False, defer=True):
 def grouped_splits(Kd, target=None):
     """Split-K factor inside a grouped launch: the queue of workgroups is long whatever the factor, so it only trades
     the length of one workgroup's K loop against the fp32 partial traffic -- the largest divisor of the K tiles not
-    above ``target`` (default 7, FASTVIM_WGRAD_GROUP_SPLITS overrides)."""
+    above ``target`` (default 7)."""
     if target is None:
-        target = int(os.environ.get("FASTVIM_WGRAD_GROUP_SPLITS", "7"))
+        target = 7
     if Kd % 64:
         return 1
     kt = Kd // 64

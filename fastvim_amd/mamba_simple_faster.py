@@ -9,7 +9,6 @@ backward; activations stay token-major so in_proj/out_proj are plain row-major G
 odd-layer grid transpose of ``Block`` is a stride pair, not a copy (``transposed_grid``).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -113,7 +112,7 @@ class _GroupedWgrad:
     (operands kept alive) and computed by grouped launches (fv_gemm_bf16_tn_grouped, up to 40 problems each) at the end of
     the backward pass: one weight-gradient GEMM at FastVim-T is 168-336 workgroups, a fraction of what the chip holds
     at once, so each separate launch pays a tail; the grouped queue does not, and with the tail gone a smaller
-    split-K factor (less fp32 partial traffic) is affordable.  FASTVIM_WGRAD_GROUP=0 turns it off."""
+    split-K factor (less fp32 partial traffic) is affordable."""
     enabled = False
     jobs = []
 
@@ -137,7 +136,7 @@ class _GroupedWgrad:
 
 def group_wgrads(on):
     _GroupedWgrad.flush()
-    _GroupedWgrad.enabled = bool(on) and os.environ.get("FASTVIM_WGRAD_GROUP", "1") != "0"
+    _GroupedWgrad.enabled = bool(on)
 
 
 def flush_wgrads():

@@ -1,7 +1,6 @@
 """Thin typed wrappers over the fused-mixer C-ABI entry points (include/fastvim_hip.h).
 No arithmetic happens here: allocate outputs with torch, pass pointers + sizes + stream."""
 import ctypes
-import os
 
 import torch
 
@@ -70,12 +69,12 @@ def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1):
 class _Deferred:
     """Gradient-partial reductions whose results are only needed before the optimizer step are queued
     (flat training state only) and issued up to 96 at a time by ONE launch (fv_reduce_partials_multi).
-    FASTVIM_REDUCE_STREAM=1 issues them on a second HIP stream (forked after the producers, joined in
+    ``side = True`` issues them on a second HIP stream (forked after the producers, joined in
     ``flush_reductions``; partial buffers stay referenced until the join): measured 3 % SLOWER under graph
     replay on MI355X (9.54 vs 9.28 ms/step), like the weight-gradient side stream, so it is off by default."""
     enabled = False
-    max_jobs = int(os.environ.get("FASTVIM_REDUCE_JOBS", "96"))      # per launch (<= 96, the C side's table); tuning hook
-    side = os.environ.get("FASTVIM_REDUCE_STREAM", "0") == "1"
+    max_jobs = 96        # per launch (the C side's table size)
+    side = False         # second-stream issue: measured slower (see above)
     jobs = []
     stream = None
     pending = []
@@ -258,7 +257,7 @@ def xproj_fwd(xc, Wx2_c):
     return out
 
 
-_XPROJ_PRESUM = int(os.environ.get("FASTVIM_XPROJ_PRESUM", "16"))      # tuning hook: chunk count from which dx_dbl is summed first
+_XPROJ_PRESUM = 16      # chunk count from which dx_dbl is summed by the reduction kernel first
 
 
 def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True):
