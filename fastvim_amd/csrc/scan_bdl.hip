@@ -481,6 +481,28 @@ __device__ __forceinline__ void stage_bc(const ScanParams& p, int b, int g, floa
   }
 }
 
+// The (B, D, L) operands of a block -- 64 consecutive channels of one batch element -- are one contiguous span when
+// the whole sequence fits a window (L <= 32: 64 * L elements), and 64 row segments of 32 steps otherwise.  A lane owns a
+// channel, so loading / storing them per lane would be 2-byte accesses at a stride of L: they go through LDS tiles
+// [channel][33] instead, filled and drained by element-coalesced block-wide copies (backward: 7 operands; the forward
+// kernel, with 3, measured faster with its per-lane loads -- 8.5 vs 10.7 us at (128, 384, 14, 16) -- and keeps them).
+constexpr int SWL = 32, SWLP = 33;
+
+template <typename T>
+__device__ __forceinline__ void tile_ld(const T* __restrict__ src, int L, int w0, int wl, float* __restrict__ s) {
+  for (int e = threadIdx.x; e < SCPB * wl; e += blockDim.x) {
+    const int c = e / wl, l = e - c * wl;
+    s[c * SWLP + l] = io<T>::ld(src + (size_t)c * L + w0 + l);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void tile_st(T* __restrict__ dst, int L, int w0, int wl, const float* __restrict__ s) {
+  for (int e = threadIdx.x; e < SCPB * wl; e += blockDim.x) {
+    const int c = e / wl, l = e - c * wl;
+    io<T>::st(dst + (size_t)c * L + w0 + l, s[c * SWLP + l]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scan_short_fwd_kernel(ScanParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [L][B(16) | C(16)]
@@ -536,16 +558,22 @@ __global__ __launch_bounds__(256) void scan_short_fwd_kernel(ScanParams p) {
 template <typename T>
 __global__ __launch_bounds__(256) void scan_short_bwd_kernel(ScanParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int PV = 16, NWV = 4;
+  constexpr int PV = 16, NWV = 4, TILE = SCPB * SWLP;
   float* s_bc = smem;                              // L * 32
   float* s_part = s_bc + p.L * 2 * SN;             // SKS * NWV * 4 * PV
-  const int tid = threadIdx.x, q = tid & 3, lane = tid & 63, wv = tid >> 6;
+  float* s_u = s_part + SKS * NWV * 4 * PV;        // input tiles u, delta, dout, z; output tiles du, ddelta, dz
+  float* s_d = s_u + TILE;
+  float* s_g = s_d + TILE;
+  float* s_z = s_g + TILE;
+  float* s_du = s_z + TILE;
+  float* s_dd = s_du + TILE;
+  float* s_dz = s_dd + TILE;
+  const int tid = threadIdx.x, q = tid & 3, lane = tid & 63, wv = tid >> 6, cl = tid >> 2;
   const int cpg = p.dim / p.G, chunks = cpg / SCPB;
   const int g = blockIdx.x / chunks, cx = blockIdx.x - g * chunks, b = blockIdx.y;
-  const int d = g * cpg + cx * SCPB + (tid >> 2);
+  const int d0 = g * cpg + cx * SCPB, d = d0 + cl;
   const int nseg = (p.L + SKS - 1) / SKS;
   stage_bc<T>(p, b, g, s_bc);
-  __syncthreads();
   float A2[4], Ar[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -553,135 +581,151 @@ __global__ __launch_bounds__(256) void scan_short_bwd_kernel(ScanParams p) {
     A2[j] = Ar[j] * FV_LOG2E;
   }
   const float Dd = p.D ? p.D[d] : 0.f, bias = p.delta_bias ? p.delta_bias[d] : 0.f;
-  const size_t row = ((size_t)b * p.dim + d) * p.L;
-  const T* u = (const T*)p.u + row;
-  const T* dl = (const T*)p.delta + row;
-  const T* z = p.z ? (const T*)p.z + row : nullptr;
-  const T* go = (const T*)p.dout + row;
-  T* du_o = (T*)p.du + row;
-  T* dd_o = (T*)p.ddelta + row;
-  T* dz_o = p.dz ? (T*)p.dz + row : nullptr;
+  const size_t row0 = ((size_t)b * p.dim + d0) * p.L;
+  const bool has_z = p.z != nullptr;
   float* ck = p.ckpt + (((size_t)b * nseg) * p.dim + d) * SN + q * 4;
   const size_t ck_seg = (size_t)p.dim * SN;
+  const int nwin = (p.L + SWL - 1) / SWL;
 
-  {  // forward sweep: state entering every segment but the first
+  {  // forward sweep: state entering every segment but the first (windows ascending; a single window stays staged)
     float st[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int seg = 0; seg + 1 < nseg; ++seg) {
-      float uv[SKS], dv[SKS];
-#pragma unroll
-      for (int k = 0; k < SKS; ++k) {
-        uv[k] = io<T>::ld(u + seg * SKS + k);
-        dv[k] = io<T>::ld(dl + seg * SKS + k);
+    for (int w = 0; w < nwin; ++w) {
+      const int w0 = w * SWL, wl = min(SWL, p.L - w0);
+      if (w) __syncthreads();
+      tile_ld<T>((const T*)p.u + row0, p.L, w0, wl, s_u);
+      tile_ld<T>((const T*)p.delta + row0, p.L, w0, wl, s_d);
+      if (nwin == 1) {
+        tile_ld<T>((const T*)p.dout + row0, p.L, w0, wl, s_g);
+        if (has_z) tile_ld<T>((const T*)p.z + row0, p.L, w0, wl, s_z);
       }
-#pragma unroll
-      for (int k = 0; k < SKS; ++k) {
-        const float* r = s_bc + (seg * SKS + k) * 2 * SN;
-        float dt = dv[k] + bias;
+      __syncthreads();
+      for (int l = 0; l < wl; ++l) {
+        const int gl = w0 + l;
+        if (gl % SKS == 0 && gl > 0)
+          *reinterpret_cast<float4*>(ck + (size_t)(gl / SKS) * ck_seg) = make_float4(st[0], st[1], st[2], st[3]);
+        if (gl >= (nseg - 1) * SKS) break;       // the last segment's states are recomputed, not checkpointed
+        const float* r = s_bc + gl * 2 * SN;
+        float dt = s_d[cl * SWLP + l] + bias;
         if (p.softplus) dt = fv_softplus(dt);
-        const float dub = dt * uv[k];
+        const float dub = dt * s_u[cl * SWLP + l];
 #pragma unroll
         for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], dub * r[q * 4 + j]);
       }
-      *reinterpret_cast<float4*>(ck + (size_t)(seg + 1) * ck_seg) = make_float4(st[0], st[1], st[2], st[3]);
     }
   }
   float dxa[4] = {0.f, 0.f, 0.f, 0.f}, dA[4] = {0.f, 0.f, 0.f, 0.f}, dD_acc = 0.f, dbias_acc = 0.f;
   const int s_chunk = cx;                           // split index of the dB / dC partials
-  for (int seg = nseg - 1; seg >= 0; --seg) {
-    const int s0 = seg * SKS, ns = min(SKS, p.L - s0);
-    float uv[SKS], dv[SKS], gq[SKS], zv[SKS];
-#pragma unroll
-    for (int k = 0; k < SKS; ++k) {
-      const int l = min(s0 + k, p.L - 1);
-      uv[k] = io<T>::ld(u + l);
-      dv[k] = io<T>::ld(dl + l);
-      gq[k] = io<T>::ld(go + l);
-      zv[k] = z ? io<T>::ld(z + l) : 0.f;
+  for (int w = nwin - 1; w >= 0; --w) {
+    const int w0 = w * SWL, wl = min(SWL, p.L - w0);
+    if (nwin > 1) {
+      __syncthreads();                              // the previous window's output tiles are out
+      tile_ld<T>((const T*)p.u + row0, p.L, w0, wl, s_u);
+      tile_ld<T>((const T*)p.delta + row0, p.L, w0, wl, s_d);
+      tile_ld<T>((const T*)p.dout + row0, p.L, w0, wl, s_g);
+      if (has_z) tile_ld<T>((const T*)p.z + row0, p.L, w0, wl, s_z);
+      __syncthreads();
     }
-    float cur[4] = {0.f, 0.f, 0.f, 0.f};
-    if (seg > 0) {
-      const float4 c4 = *reinterpret_cast<const float4*>(ck + (size_t)seg * ck_seg);
-      cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
-    }
-    float xs[SKS][4], aq[SKS][4], dtv[SKS], raw[SKS];
+    for (int seg = (w0 + wl - 1) / SKS; seg * SKS >= w0; --seg) {      // SWL is a multiple of SKS: segments do not straddle windows
+      const int s0 = seg * SKS, ns = min(SKS, p.L - s0);
+      float uv[SKS], dv[SKS], gq[SKS], zv[SKS];
 #pragma unroll
-    for (int k = 0; k < SKS; ++k) {
-      const float* r = s_bc + min(s0 + k, p.L - 1) * 2 * SN;
-      const bool on = k < ns;
-      raw[k] = dv[k] + bias;
-      float dt = p.softplus ? fv_softplus(raw[k]) : raw[k];
-      dtv[k] = on ? dt : 0.f;                      // delta = 0: the step is an identity
-      if (!on) gq[k] = 0.f;
-      const float dub = dtv[k] * uv[k];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        aq[k][j] = fv_exp2(dtv[k] * A2[j]);
-        cur[j] = fmaf(aq[k][j], cur[j], dub * r[q * 4 + j]);
-        xs[k][j] = cur[j];
+      for (int k = 0; k < SKS; ++k) {
+        const int l = min(s0 + k, p.L - 1) - w0;
+        uv[k] = s_u[cl * SWLP + l];
+        dv[k] = s_d[cl * SWLP + l];
+        gq[k] = s_g[cl * SWLP + l];
+        zv[k] = has_z ? s_z[cl * SWLP + l] : 0.f;
       }
-    }
+      float cur[4] = {0.f, 0.f, 0.f, 0.f};
+      if (seg > 0) {
+        const float4 c4 = *reinterpret_cast<const float4*>(ck + (size_t)seg * ck_seg);
+        cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
+      }
+      float xs[SKS][4], aq[SKS][4], dtv[SKS];
 #pragma unroll
-    for (int k = SKS - 1; k >= 0; --k) {
-      if (k < ns) {          // uniform across the block
-        const int l = s0 + k;
-        const float* r = s_bc + l * 2 * SN;
-        float gk = gq[k];
-        if (z) {             // out = y * silu(z): gradient wrt y and wrt z
-          float ypre = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) ypre = fmaf(r[SN + q * 4 + j], xs[k][j], ypre);
-          ypre = quad_sum(ypre) + Dd * uv[k];
-          const float sg = fv_sigmoid(zv[k]);
-          if (q == 0 && dz_o) io<T>::st(dz_o + l, gq[k] * ypre * sg * (1.f + zv[k] * (1.f - sg)));
-          gk = gq[k] * zv[k] * sg;
-        }
-        float vals[PV];
-#pragma unroll
-        for (int e = 0; e < PV; ++e) vals[e] = 0.f;
-        float du_acc = 0.f, ddt_acc = 0.f;
-        const float dtu = dtv[k] * uv[k];
+      for (int k = 0; k < SKS; ++k) {
+        const float* r = s_bc + min(s0 + k, p.L - 1) * 2 * SN;
+        const bool on = k < ns;
+        const float raw = dv[k] + bias;
+        const float dt = p.softplus ? fv_softplus(raw) : raw;
+        dtv[k] = on ? dt : 0.f;                      // delta = 0: the step is an identity
+        if (!on) gq[k] = 0.f;
+        const float dub = dtv[k] * uv[k];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float Bn = r[q * 4 + j], Cn = r[SN + q * 4 + j];
-          const float dx = fmaf(gk, Cn, dxa[j]);
-          const float ax = xs[k][j] - dtu * Bn;               // a_t * x_{t-1}
-          du_acc = fmaf(dx, Bn, du_acc);
-          ddt_acc += dx * fmaf(Ar[j], ax, Bn * uv[k]);
-          dA[j] = fmaf(dx * dtv[k], ax, dA[j]);
-          vals[j] = dx * dtu;                                  // dB[4q+j]
-          vals[4 + j] = gk * xs[k][j];                         // dC[4q+j]
-          dxa[j] = aq[k][j] * dx;
+          aq[k][j] = fv_exp2(dtv[k] * A2[j]);
+          cur[j] = fmaf(aq[k][j], cur[j], dub * r[q * 4 + j]);
+          xs[k][j] = cur[j];
         }
-        du_acc = quad_sum(du_acc);
-        ddt_acc = quad_sum(ddt_acc);
-        // d softplus: sigmoid(raw) = 1 - exp(-softplus(raw))
-        const float ddraw = p.softplus ? ddt_acc * (1.f - __expf(-dtv[k])) : ddt_acc;
-        if (q == 0) {
-          dbias_acc += ddraw;
-          dD_acc = fmaf(gk, uv[k], dD_acc);
-          io<T>::st(du_o + l, fmaf(dtv[k], du_acc, Dd * gk));
-          io<T>::st(dd_o + l, ddraw);
-        }
-        chan_reduce_scatter<PV>(vals, lane);
-        s_part[((k * NWV + wv) * 4 + q) * PV + (lane >> 2)] = vals[0];
       }
-    }
-    __syncthreads();
-    // the 4 waves in fixed order -> this chunk's partial of dB / dC, layout (split, batch, G, N, L)
-    for (int e = tid; e < ns * 4 * PV; e += blockDim.x) {
-      const int k = e / (4 * PV), rem = e - k * 4 * PV;
-      const int qq = rem / PV, v = rem - qq * PV;
-      if (v < 8) {
-        float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) t += s_part[((k * NWV + w) * 4 + qq) * PV + v];
-        const int n = qq * 4 + (v & 3);
-        float* dst = (v < 4 ? p.dB_part : p.dC_part) + ((((size_t)s_chunk * p.batch + b) * p.G + g) * SN + n) * p.L;
-        dst[s0 + k] = t;
+      for (int k = SKS - 1; k >= 0; --k) {
+        if (k < ns) {          // uniform across the block
+          const int l = s0 + k, lw = l - w0;
+          const float* r = s_bc + l * 2 * SN;
+          float gk = gq[k];
+          if (has_z) {         // out = y * silu(z): gradient wrt y and wrt z
+            float ypre = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ypre = fmaf(r[SN + q * 4 + j], xs[k][j], ypre);
+            ypre = quad_sum(ypre) + Dd * uv[k];
+            const float sg = fv_sigmoid(zv[k]);
+            if (q == 0) s_dz[cl * SWLP + lw] = gq[k] * ypre * sg * (1.f + zv[k] * (1.f - sg));
+            gk = gq[k] * zv[k] * sg;
+          }
+          float vals[PV];
+#pragma unroll
+          for (int e = 0; e < PV; ++e) vals[e] = 0.f;
+          float du_acc = 0.f, ddt_acc = 0.f;
+          const float dtu = dtv[k] * uv[k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float Bn = r[q * 4 + j], Cn = r[SN + q * 4 + j];
+            const float dx = fmaf(gk, Cn, dxa[j]);
+            const float ax = xs[k][j] - dtu * Bn;               // a_t * x_{t-1}
+            du_acc = fmaf(dx, Bn, du_acc);
+            ddt_acc += dx * fmaf(Ar[j], ax, Bn * uv[k]);
+            dA[j] = fmaf(dx * dtv[k], ax, dA[j]);
+            vals[j] = dx * dtu;                                  // dB[4q+j]
+            vals[4 + j] = gk * xs[k][j];                         // dC[4q+j]
+            dxa[j] = aq[k][j] * dx;
+          }
+          du_acc = quad_sum(du_acc);
+          ddt_acc = quad_sum(ddt_acc);
+          // d softplus: sigmoid(raw) = 1 - exp(-softplus(raw))
+          const float ddraw = p.softplus ? ddt_acc * (1.f - __expf(-dtv[k])) : ddt_acc;
+          if (q == 0) {
+            dbias_acc += ddraw;
+            dD_acc = fmaf(gk, uv[k], dD_acc);
+            s_du[cl * SWLP + lw] = fmaf(dtv[k], du_acc, Dd * gk);
+            s_dd[cl * SWLP + lw] = ddraw;
+          }
+          chan_reduce_scatter<PV>(vals, lane);
+          s_part[((k * NWV + wv) * 4 + q) * PV + (lane >> 2)] = vals[0];
+        }
       }
+      __syncthreads();
+      // the 4 waves in fixed order -> this chunk's partial of dB / dC, layout (split, batch, G, N, L)
+      for (int e = tid; e < ns * 4 * PV; e += blockDim.x) {
+        const int k = e / (4 * PV), rem = e - k * 4 * PV;
+        const int qq = rem / PV, v = rem - qq * PV;
+        if (v < 8) {
+          float t = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < NWV; ++ww) t += s_part[((k * NWV + ww) * 4 + qq) * PV + v];
+          const int n = qq * 4 + (v & 3);
+          float* dst = (v < 4 ? p.dB_part : p.dC_part) + ((((size_t)s_chunk * p.batch + b) * p.G + g) * SN + n) * p.L;
+          dst[s0 + k] = t;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    // (the loop's last barrier also orders the output tiles' writes before the copies below)
+    tile_st<T>((T*)p.du + row0, p.L, w0, wl, s_du);
+    tile_st<T>((T*)p.ddelta + row0, p.L, w0, wl, s_dd);
+    if (has_z && p.dz) tile_st<T>((T*)p.dz + row0, p.L, w0, wl, s_dz);
   }
+  // per-(batch, channel) partials, one row per batch element: [dA (dim*N) | dD (dim) | d delta_bias (dim)]
   const size_t bd = (size_t)b * p.dim + d;
 #pragma unroll
   for (int j = 0; j < 4; ++j) p.pA[bd * SN + q * 4 + j] = dA[j];
@@ -777,7 +821,12 @@ int launch_short(const ScanParams& p, int bwd, hipStream_t st) {
   if (!bwd) {
     hipLaunchKernelGGL((scan_short_fwd_kernel<T>), grid, block, (size_t)p.L * 2 * SN * 4, st, p);
   } else {
-    const size_t smem = ((size_t)p.L * 2 * SN + SKS * 4 * 4 * 16) * 4;
+    const size_t smem = ((size_t)p.L * 2 * SN + SKS * 4 * 4 * 16 + 7 * SCPB * SWLP) * 4;
+    static bool done = false;
+    if (!done && smem > 64 * 1024) {
+      (void)hipFuncSetAttribute((const void*)scan_short_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
     hipLaunchKernelGGL((scan_short_bwd_kernel<T>), grid, block, smem, st, p);
   }
   FV_LAUNCH_CHECK();
@@ -868,14 +917,22 @@ extern "C" int fv_selective_scan_bwd(const void* u, const void* delta, const flo
   else if (dtype == FV_BF16) rc = launch_bwd<bf16_t>(p, st);
   else rc = launch_bwd<__half>(p, st);
   if (rc) return rc;
-  const size_t dn = (size_t)dim * dstate;
-  if ((rc = reduce_leading(p.pA, dA, batch, dn, st))) return rc;
-  if (dD && (rc = reduce_leading(p.pD, dD, batch, dim, st))) return rc;
-  if (ddelta_bias && (rc = reduce_leading(p.pbias, ddelta_bias, batch, dim, st))) return rc;
-  if (!B_variable && (rc = reduce_leading(p.pBc, dB, batch, dn, st))) return rc;
-  if (!C_variable && (rc = reduce_leading(p.pCc, dC, batch, dn, st))) return rc;
-  const size_t bn = (size_t)batch * n_groups * dstate * seqlen;
-  if (B_variable && p.S > 1 && (rc = reduce_leading(p.dB_part, dB, p.S, bn, st))) return rc;
-  if (C_variable && p.S > 1 && (rc = reduce_leading(p.dC_part, dC, p.S, bn, st))) return rc;
-  return FV_OK;
+  // every fixed-order partial sum of this call in ONE launch (fv_reduce_partials_multi: many loads in flight per
+  // thread): per-batch partials of dA / dD / d delta_bias (/ constant dB, dC) and the per-split partials of the
+  // variable dB / dC.  As separate one-thread-per-output launches they cost more than the scan kernel itself
+  // (126 us of reductions around a 30 us kernel at (128, 384, 14, 16)).
+  const size_t dn = (size_t)dim * dstate, bn = (size_t)batch * n_groups * dstate * seqlen;
+  const float* ins[8];
+  float* outs[8];
+  int Ss[8], nj = 0;
+  size_t ns[8];
+  auto job = [&](const float* in, float* out, int S_, size_t n_) { ins[nj] = in; outs[nj] = out; Ss[nj] = S_; ns[nj] = n_; ++nj; };
+  job(p.pA, dA, batch, dn);
+  if (dD) job(p.pD, dD, batch, dim);
+  if (ddelta_bias) job(p.pbias, ddelta_bias, batch, dim);
+  if (!B_variable) job(p.pBc, dB, batch, dn);
+  if (!C_variable) job(p.pCc, dC, batch, dn);
+  if (B_variable && p.S > 1) job(p.dB_part, dB, p.S, bn);
+  if (C_variable && p.S > 1) job(p.dC_part, dC, p.S, bn);
+  return fv_reduce_partials_multi(ins, outs, Ss, ns, nj, 0, stream);
 }
