@@ -230,8 +230,12 @@ class FastVimMixerFn(torch.autograd.Function):
             else:
                 Wx2 = torch.stack([Wx, Wx_b])                                           # (2, R+2N, d_in) fp32
                 Wx2_c = Wx2.to(cdt)
-            x_dbl = M.xproj_fwd(xc, Wx2_c)                                               # (2, B*Lc, R+2N)
-            yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
+            fused = M.xproj_scan_fwd(xc, Wx2_c, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)      # short pooled lengths, bf16
+            if fused is not None:
+                x_dbl, yc = fused
+            else:
+                x_dbl = M.xproj_fwd(xc, Wx2_c)                                           # (2, B*Lc, R+2N)
+                yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
             g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
             out = linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
         ctx.save_for_backward(h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b,

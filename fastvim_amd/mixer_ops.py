@@ -47,6 +47,27 @@ def scan_fwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
     return yc
 
 
+def xproj_scan_fwd(xc, Wx2_c, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
+    """x_proj + dt_proj + scan in one launch (short pooled lengths, bf16): returns (x_dbl (2, B*Lc, W) bf16, yc fp32),
+    or None when the shape is not covered (the caller then runs xproj_fwd + scan_fwd)."""
+    _, B, Lc, d_in = xc.shape
+    R, N = dt_w.shape[1], A_log.shape[1]
+    W = Wx2_c.shape[1]
+    lib = L.lib()
+    if (xc.dtype != torch.bfloat16 or Wx2_c.dtype != torch.bfloat16 or N != 16 or W != R + 2 * N
+            or not xc.is_contiguous() or not Wx2_c.is_contiguous() or xc.data_ptr() % 16 or Wx2_c.data_ptr() % 16
+            or not lib.fv_mixer_xproj_scan_fwd_ok(L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(L.dtype_code(xc.dtype)))):
+        return None
+    x_dbl = torch.empty(2, B * Lc, W, device=xc.device, dtype=xc.dtype)
+    yc = torch.empty(2, B, Lc, d_in, device=xc.device, dtype=torch.float32)
+    rc = lib.fv_mixer_xproj_scan_fwd(
+        L.ptr(xc), L.ptr(Wx2_c), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b), L.ptr(A_log_b),
+        L.ptr(x_dbl), L.ptr(yc), L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)),
+        L.stream_of(xc))
+    L.check(rc, "mixer_xproj_scan_fwd")
+    return x_dbl, yc
+
+
 def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1):
     """g (B, L, d_in) = LayerNorm((yc_f + yc_b + skip) / 2) * silu(z); also returns mean, rstd (B*L) fp32."""
     B, Ltok, two_d = xz.shape
@@ -248,7 +269,7 @@ def xproj_fwd(xc, Wx2_c):
     d_in = xc.shape[-1]
     Mrows = xc.numel() // (2 * d_in)
     W = Wx2_c.shape[1]
-    if (xc.dtype != torch.bfloat16 or Wx2_c.dtype != torch.bfloat16 or d_in % 32 or W > 112 or d_in > 512
+    if (xc.dtype != torch.bfloat16 or Wx2_c.dtype != torch.bfloat16 or d_in % 32 or W > 112
             or not xc.is_contiguous() or not Wx2_c.is_contiguous() or xc.data_ptr() % 16 or Wx2_c.data_ptr() % 16):
         return torch.bmm(xc.view(2, Mrows, d_in), Wx2_c.transpose(1, 2))
     out = torch.empty(2, Mrows, W, device=xc.device, dtype=xc.dtype)

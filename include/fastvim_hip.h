@@ -135,6 +135,17 @@ int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, cons
                       const float* A_log_b, float* yc, int batch, int Lc, int d_inner, int dt_rank,
                       int d_state, int dtype, fv_stream_t stream);
 
+/* x_proj + dt_proj + softplus + selective scan in ONE launch for short pooled lengths (Lc <= 16, bf16, dt_rank <= 48:
+ * the 224 / 256 px grids): x_dbl (2, batch*Lc, dt_rank + 2*d_state) = xc @ x_proj_w2[dir]^T is computed on the matrix
+ * cores inside the scan kernel (mamba_simple_faster.py:321-327 + 328-354), written out in bf16 for the backward pass and
+ * consumed from LDS.  x_proj_w2: (2, dt_rank + 2*d_state, d_inner) bf16, both directions.  fv_mixer_xproj_scan_fwd_ok
+ * tells whether a shape is covered (else: fv_mixer_xproj_fwd + fv_mixer_scan_fwd). */
+int fv_mixer_xproj_scan_fwd_ok(int Lc, int d_inner, int dt_rank, int dtype);
+int fv_mixer_xproj_scan_fwd(const void* xc, const void* x_proj_w2, const float* dt_w, const float* dt_bias,
+                            const float* A_log, const float* dt_w_b, const float* dt_bias_b, const float* A_log_b,
+                            void* x_dbl, float* yc, int batch, int Lc, int d_inner, int dt_rank, int d_state,
+                            int dtype, fv_stream_t stream);
+
 /* g = LayerNorm((yc_f + yc_b + skip) / 2) * silu(z), the scan outputs expanded over `cols`; ln_w == NULL
  * skips the norm (use_norm_after_ssm=False).  mean/rstd (batch*L) fp32 are saved for backward, which
  * rebuilds the normalised value from skip, yc, mean, rstd. */

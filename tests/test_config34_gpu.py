@@ -224,6 +224,41 @@ def test_scan_cl_kernels_vs_selective_scan_oracle(Bsz, Lc, d_in, R, dtype):
             assert e <= 1e-4 * max(1.0, b.abs().max().item()), (name, k, e, b.abs().max().item())
 
 
+@pytest.mark.parametrize("Bsz,Lc,d_in,R", [(5, 14, 384, 12), (3, 14, 768, 24), (2, 16, 768, 24), (2, 9, 384, 12),
+                                           (2, 14, 64, 2), (2, 15, 224, 7)])
+def test_fused_xproj_scan_fwd_short(Bsz, Lc, d_in, R):
+    """fv_mixer_xproj_scan_fwd (x_proj on the bf16 matrix cores + dt_proj on the fp32 ones + scan, one launch, Lc <= 16):
+    x_dbl within one bf16 rounding of the fp64 product, y == selective_scan_ref evaluated on the kernel's own x_dbl."""
+    from fastvim_amd import mixer_ops as M
+    from oracle import selective_scan_oracle
+    N = 16
+    W = R + 2 * N
+    xc, _, Wdt, bdt, A_log, _ = _scan_cl_case(Bsz, Lc, d_in, R, torch.bfloat16, seed=7 + d_in)
+    g = torch.Generator().manual_seed(d_in)
+    Wx = (torch.randn(2, W, d_in, generator=g) * d_in ** -0.5).bfloat16()
+    dev = "cuda"
+    out = M.xproj_scan_fwd(xc.to(dev, torch.bfloat16), Wx.to(dev), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
+                           Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev))
+    assert out is not None, "shape should take the fused kernel"
+    x_dbl, yc = out
+    assert x_dbl.dtype == torch.bfloat16 and x_dbl.shape == (2, Bsz * Lc, W)
+    ref = torch.einsum("kbld,kwd->kblw", xc.double(), Wx.double()).reshape(2, Bsz * Lc, W)
+    assert _err(x_dbl, ref) <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+    # the unfused pair computes the same function
+    x2 = M.xproj_fwd(xc.to(dev, torch.bfloat16), Wx.to(dev))
+    y2 = M.scan_fwd(xc.to(dev, torch.bfloat16), x_dbl, Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
+                    Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev))
+    assert _err(x2, x_dbl) <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
+    assert _err(yc, y2) <= 2e-5 * max(1.0, y2.abs().max().item())
+    for k in range(2):
+        xd = x_dbl[k].view(Bsz, Lc, W).double().cpu()
+        delta = xd[..., :R] @ Wdt[k].double().t()
+        y = selective_scan_oracle(xc[k].double().transpose(1, 2), delta.transpose(1, 2), -torch.exp(A_log[k].double()),
+                                  xd[..., R:R + N].transpose(1, 2), xd[..., R + N:].transpose(1, 2), None, None,
+                                  bdt[k].double(), True, compute_dtype=F64, out_dtype=F64, reverse=bool(k)).transpose(1, 2)
+        assert _err(yc[k], y) <= 1e-5 * max(1.0, y.abs().max().item()), (k, _err(yc[k], y))
+
+
 # --------------------------------------------------------------------------- full-size configs: properties + graph replay
 _FULL = {        # BASELINE configs -> (factory name, image size, per-GPU batch, drop_path)
     "cfg2_FastVimT_224_bs128": ("FastVimT", 224, 128, 0.05),

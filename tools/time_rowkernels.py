@@ -31,6 +31,10 @@ dxc, dxd, _ = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc)
 out = {}
 out["conv_pool_fwd"] = time_kernel(lambda: M.conv_pool_fwd(xz, cw, cb, cwb, cbb, rows, cols, False, 0, 1.0, tpp, D=D, D_b=Db))
 out["scan_fwd"] = time_kernel(lambda: M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log))
+Wx2 = (torch.randn(2, R_ + 2 * N, d_in, device=dev, generator=g) * d_in ** -0.5).to(dtype)
+out["xproj_fwd"] = time_kernel(lambda: M.xproj_fwd(xc, Wx2))
+if M.xproj_scan_fwd(xc, Wx2, Wdt, bdt, A_log, Wdt, bdt, A_log) is not None:
+    out["xproj_scan_fwd"] = time_kernel(lambda: M.xproj_scan_fwd(xc, Wx2, Wdt, bdt, A_log, Wdt, bdt, A_log))
 out["combine_fwd"] = time_kernel(lambda: M.combine_fwd(xz, skip, yc, lnw, lnb, 1e-5, rows, cols, False, tpp=tpp))
 out["combine_bwd"] = time_kernel(lambda: M.combine_bwd(dg, xz, skip, yc, lnw, lnb, mean, rstd, dxz, rows, cols, False, tpp=tpp))
 out["scan_bwd"] = time_kernel(lambda: M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc))
