@@ -3,11 +3,15 @@ mamba-1p1p1/mamba_ssm/modules/mamba_simple_channel_faster.py:25-481 -- same cons
 (adds ``scan_order``), same parameter names/shapes/initialisation, same
 ``forward(hidden_states (B, L, D), tokens_per_patch) -> (B, L, D)``.
 
-Channel-First order only (the default and what the FastChannelVim-S/16 entry point uses): the
+Channel-First order (the default and what the FastChannelVim-S/16 entry point uses): the
 sequence position of a token is ``(row*cols + col)*tokens_per_patch + channel`` and the pooling
 group of a token is ``(row, channel)`` (:242-256), so the pooled scan runs over
 ``rows*tokens_per_patch`` steps.  The same fused HIP kernels as the FastVim mixer run it, with the
 ``tokens_per_patch`` argument of the C ABI (include/fastvim_hip.h).
+
+Spatial-First order (:226-241, 259-274, 325-331, 376-382): position ``(channel*rows + row)*cols + col``, pooling
+group ``(channel, row)`` -- exactly the FastVim mixer on a ``(tokens_per_patch*rows) x cols`` grid, which is how it
+runs here (no ``tokens_per_patch`` in the kernels; the channel ``Block`` transposes rotated layers physically).
 """
 from .mamba_simple_faster import FastVimMixerFn, Mamba as _FastVimMamba, _compute_dtype
 
@@ -18,9 +22,8 @@ class Mamba(_FastVimMamba):
                  use_fast_path=False, layer_idx=None, device=None, dtype=None, init_layer_scale=None,
                  scanpath_type="rowwise", token_size=None, use_norm_after_ssm=True,
                  use_our_selective_scan=False, scan_order="Channel-First", collapse_method="mean"):
-        if scan_order != "Channel-First":
-            raise NotImplementedError("fastvim_amd channel mixer: scan_order='Channel-First' only "
-                                      "(Spatial-First is an ablation, SURVEY.md section 8 row f3)")
+        if scan_order not in ("Channel-First", "Spatial-First"):
+            raise ValueError(scan_order)
         # the reference asserts even grids (:68-73)
         assert token_size[0] % 2 == 0, "num_of_rows needs to be even for this implementation since we do compress and expand"
         assert token_size[1] % 2 == 0, "num_of_col needs to be even for this implementation since we do compress and expand"
@@ -47,6 +50,9 @@ class Mamba(_FastVimMamba):
         ln_w = self.layernorm.weight if self.use_norm_after_ssm else None
         ln_b = self.layernorm.bias if self.use_norm_after_ssm else None
         ln_eps = self.layernorm.eps if self.use_norm_after_ssm else 0.0
+        rows, cols, tpp = self._geometry(int(tokens_per_patch))
+        if self.scan_order == "Spatial-First" and transposed_grid:
+            raise RuntimeError("Spatial-First mixers take physically transposed tokens (the channel Block does that)")
         out = FastVimMixerFn.apply(
             hidden_states, self.in_proj.weight, self.in_proj.bias,
             self.conv1d.weight, self.conv1d.bias, self.conv1d_b.weight, self.conv1d_b.bias,
@@ -54,8 +60,14 @@ class Mamba(_FastVimMamba):
             self.dt_proj.weight, self.dt_proj.bias, self.dt_proj_b.weight, self.dt_proj_b.bias,
             self.A_log, self.A_b_log, self.D, self.D_b, ln_w, ln_b,
             self.out_proj.weight, self.out_proj.bias,
-            self.num_of_rows, self.num_of_col, bool(transposed_grid), self.collapse_method == "max",
-            1.0, float(ln_eps), cdt, self.__dict__.get("_fv"), int(tokens_per_patch))
+            rows, cols, bool(transposed_grid), self.collapse_method == "max",
+            1.0, float(ln_eps), cdt, self.__dict__.get("_fv"), tpp)
         if self.init_layer_scale is not None:
             out = out * self.gamma
         return out
+
+    def _geometry(self, tokens_per_patch):
+        """(rows, cols, tokens per cell) of the pooling grid the kernels see."""
+        if self.scan_order == "Spatial-First":
+            return tokens_per_patch * self.num_of_rows, self.num_of_col, 1
+        return self.num_of_rows, self.num_of_col, tokens_per_patch

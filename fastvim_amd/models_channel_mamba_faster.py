@@ -1,7 +1,9 @@
 """FastChannelVim backbone: mirror of models/channel_wise_tokenization/models_channel_mamba_faster.py
 (``PatchEmbedPerChannel`` :22-203, ``Block`` :206-336, ``create_block`` :339-408, ``VisionMamba``
 :458-682, factory :685-706).  Same constructor kwargs, attribute names, ``state_dict`` keys and entry
-point; Channel-First scan order (the default, and the only one the S/16 entry point uses).
+point.  ``scan_order="Channel-First"`` (the default, what the S/16 entry point uses) runs without any token copy;
+``"Spatial-First"`` (the reference's ablation: tokens ordered (channel, row, col)) permutes the embedded tokens once and
+transposes rotated layers physically, as the reference does.
 
 Internals follow fastvim_amd/fastvim.py: the shared Conv3d(1, d, (1, p, p)) is one MFMA GEMM over
 per-channel patches written directly in (row, col, channel) token order; bias + channel embedding +
@@ -69,8 +71,8 @@ class PatchEmbedPerChannel(nn.Module):
                  embed_dim: int = 768, hcs: bool = True, scan_order: str = "Channel-First", sort_channels=True,
                  scanpath_type="rowwise", flatten=True):
         super().__init__()
-        if scan_order != "Channel-First":
-            raise NotImplementedError("fastvim_amd channel model: scan_order='Channel-First' only")
+        if scan_order not in ("Channel-First", "Spatial-First"):
+            raise ValueError(scan_order)
         if stride != patch_size:
             raise NotImplementedError("PatchEmbedPerChannel: stride == patch_size (non-overlapping patches)")
         self.img_size = to_2tuple(img_size)
@@ -127,7 +129,14 @@ class PatchEmbedPerChannel(nn.Module):
         lin = LinearFn.apply(patches, self.proj.weight, cdt)                     # weight viewed (D, ph*pw)
         D = lin.shape[-1]
         out = _ChannelEmbedEpilogueFn.apply(lin.view(B, g0 * g1, C, D), self.proj.bias, chan, pos_embed)
-        if self.flatten:
+        if self.scan_order == "Spatial-First":                                   # tokens ordered (channel, row, col)
+            out = out.transpose(1, 2)                                            # (B, C, P, D); pos_embed[p] per (c, p) (:620-623)
+            if self.flatten:
+                out = out.reshape(B, C * g0 * g1, D)
+            else:
+                assert pos_embed is None
+                out = out.reshape(B, C, g0, g1, D).permute(0, 4, 1, 2, 3)        # B D C H' W'
+        elif self.flatten:
             out = out.view(B, g0 * g1 * C, D)
         else:
             assert pos_embed is None
@@ -173,10 +182,29 @@ class Block(nn.Module):
                                           eps=self.norm.eps, is_rms_norm=is_rms, out_dtype=cdt)
             if self.residual_in_fp32:
                 residual = residual.to(torch.float32)
-        rot = self.rotate_every_block is True and self.layer_idx % 2 != 0       # :298-329 without the copies
-        hidden_states = self.mixer(hidden_states, tokens_per_patch, inference_params=inference_params,
-                                   transposed_grid=rot)
+        rot = self._rotated()
+        if rot and self._physical_transpose():                                   # :298-329 as written: two copies
+            B, M, _ = hidden_states.shape
+            T0, T1 = self.token_size
+            if self.scan_order == "Spatial-First":
+                hidden_states = hidden_states.reshape(B, tokens_per_patch, T0, T1, -1).transpose(2, 3).reshape(B, M, -1)
+            else:
+                hidden_states = hidden_states.reshape(B, T0, T1, tokens_per_patch, -1).transpose(1, 2).reshape(B, M, -1)
+            hidden_states = self.mixer(hidden_states, tokens_per_patch, inference_params=inference_params)
+            if self.scan_order == "Spatial-First":
+                hidden_states = hidden_states.reshape(B, tokens_per_patch, T1, T0, -1).transpose(2, 3).reshape(B, M, -1)
+            else:
+                hidden_states = hidden_states.reshape(B, T1, T0, tokens_per_patch, -1).transpose(1, 2).reshape(B, M, -1)
+        else:                                                                    # Channel-First: swapped cell strides, no copy
+            hidden_states = self.mixer(hidden_states, tokens_per_patch, inference_params=inference_params,
+                                       transposed_grid=rot)
         return hidden_states, residual
+
+    def _rotated(self):
+        return self.rotate_every_block is True and self.layer_idx % 2 != 0
+
+    def _physical_transpose(self):
+        return self.scan_order == "Spatial-First"
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         raise NotImplementedError("FastVim mixers have no inference cache")
@@ -185,18 +213,21 @@ class Block(nn.Module):
 def create_block(d_model, ssm_cfg=None, norm_epsilon=1e-5, drop_path=0.0, rms_norm=False, residual_in_fp32=False,
                  fused_add_norm=False, layer_idx=None, device=None, dtype=None, init_layer_scale=None,
                  scanpath_type="rowwise", use_norm_after_ssm=True, rotate_every_block=True,
-                 collapse_method="mean", token_size=None, scan_order=None, max_tokens_per_patch=None):
+                 collapse_method="mean", token_size=None, scan_order=None, max_tokens_per_patch=None,
+                 mixer_type=Mamba, block_type=None, rotated=None):
+    """``mixer_type`` / ``block_type`` / ``rotated(layer_idx)``: hooks of the 2-D compress variant (its own mixer class,
+    Block subclass and three-layer rotation cycle)."""
     if ssm_cfg is None:
         ssm_cfg = {}
     factory_kwargs = {"device": device, "dtype": dtype}
-    rot = rotate_every_block is True and layer_idx % 2 != 0
+    rot = rotate_every_block is True and (layer_idx % 2 != 0 if rotated is None else rotated(layer_idx))
     mixer_cls = partial(
-        Mamba, layer_idx=layer_idx, init_layer_scale=init_layer_scale, scanpath_type=scanpath_type,
+        mixer_type, layer_idx=layer_idx, init_layer_scale=init_layer_scale, scanpath_type=scanpath_type,
         use_norm_after_ssm=use_norm_after_ssm,
         token_size=[token_size[1], token_size[0]] if rot else list(token_size),   # :363-388
         collapse_method=collapse_method, scan_order=scan_order, **ssm_cfg, **factory_kwargs)
     norm_cls = partial(nn.LayerNorm if not rms_norm else RMSNorm, eps=norm_epsilon, **factory_kwargs)
-    block = Block(d_model, mixer_cls, norm_cls=norm_cls, drop_path=drop_path, fused_add_norm=fused_add_norm,
+    block = (block_type or Block)(d_model, mixer_cls, norm_cls=norm_cls, drop_path=drop_path, fused_add_norm=fused_add_norm,
                   residual_in_fp32=residual_in_fp32, rotate_every_block=rotate_every_block, layer_idx=layer_idx,
                   token_size=token_size, scan_order=scan_order, max_tokens_per_patch=max_tokens_per_patch)
     block.layer_idx = layer_idx
@@ -210,6 +241,8 @@ def segm_init_weights(m):
 
 
 class VisionMamba(nn.Module):
+    _create_block = staticmethod(create_block)
+
     def __init__(self, img_size=224, patch_size=16, stride=16, depth=24, embed_dim=192, channels=3,
                  num_classes=1000, ssm_cfg=None, drop_rate=0.0, drop_path_rate=0.1, norm_epsilon: float = 1e-5,
                  rms_norm: bool = False, initializer_cfg=None, fused_add_norm=False, residual_in_fp32=False,
@@ -243,7 +276,7 @@ class VisionMamba(nn.Module):
         inter_dpr = [0.0] + dpr
         self.drop_path = DropPath(drop_path_rate) if drop_path_rate > 0.0 else nn.Identity()
         self.layers = nn.ModuleList([
-            create_block(embed_dim, ssm_cfg=ssm_cfg, norm_epsilon=norm_epsilon, rms_norm=rms_norm,
+            self._create_block(embed_dim, ssm_cfg=ssm_cfg, norm_epsilon=norm_epsilon, rms_norm=rms_norm,
                          residual_in_fp32=residual_in_fp32, fused_add_norm=fused_add_norm, layer_idx=i,
                          drop_path=inter_dpr[i], init_layer_scale=init_layer_scale, scanpath_type=scanpath_type,
                          use_norm_after_ssm=use_norm_after_ssm, rotate_every_block=rotate_every_block,

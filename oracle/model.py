@@ -222,8 +222,14 @@ def channel_patch_embed_oracle(sd, x, patch_size, cd, channels=None):
 
 def channel_block_oracle(sd_layer, hidden, residual, layer_idx, token_size, tokens_per_patch, *,
                          norm_eps=1e-5, rotate_every_block=True, row_scale=None,
-                         compute_dtype=torch.float64, mixer_kwargs=None):
-    """Block.forward of the channel model (models_channel_mamba_faster.py:249-331), Channel-First."""
+                         compute_dtype=torch.float64, mixer_kwargs=None, scan_order="Channel-First", compress2d=False):
+    """Block.forward of the channel model (models_channel_mamba_faster.py:249-331).
+    ``scan_order="Spatial-First"``: tokens ordered (channel, row, col), pooling groups (channel, row)
+    (mamba_simple_channel_faster.py:226-241) = the FastVim mixer on a (t*rows, cols) grid; rotated layers transpose
+    each channel's grid (:300-305).  ``compress2d``: the 2-D compress variant
+    (models_channel_mamba_faster_2dcompress.py:265-300, mamba_simple_channel_faster_2dcompress.py:226-249): layers cycle
+    row scan / column scan (cells transposed) / channel scan; the row and column scans pool cols AND channels, the
+    channel scan pools every cell."""
     cd = compute_dtype
     h, res = fused_add_norm_oracle(hidden, sd_layer["norm.weight"], None, residual, norm_eps,
                                    prenorm=True, residual_in_fp32=True, is_rms_norm=True,
@@ -232,33 +238,54 @@ def channel_block_oracle(sd_layer, hidden, residual, layer_idx, token_size, toke
     T0, T1 = token_size
     Bsz, M, d = h.shape
     t = tokens_per_patch
-    rot = rotate_every_block and layer_idx % 2 != 0
+    rot = rotate_every_block and ((layer_idx + 2) % 3 == 0 if compress2d else layer_idx % 2 != 0)
     ts = token_size
+    spatial = scan_order == "Spatial-First"
     if rot:                                                               # :307-311
-        h = h.reshape(Bsz, T0, T1, t, d).transpose(1, 2).reshape(Bsz, M, d)
+        if spatial:
+            h = h.reshape(Bsz, t, T0, T1, d).transpose(2, 3).reshape(Bsz, M, d)
+        else:
+            h = h.reshape(Bsz, T0, T1, t, d).transpose(1, 2).reshape(Bsz, M, d)
         ts = (T1, T0)                                                     # create_block :363-374
-    h = fastvim_mixer_oracle(_sub(sd_layer, "mixer."), h, ts, tokens_per_patch=t, compute_dtype=cd,
+    if compress2d and (layer_idx + 1) % 3 == 0:       # channel-wise scan: one pooling group per channel slot
+        grid, tpp = (1, ts[0] * ts[1]), t
+    elif compress2d:                                  # row / column scan over cells AND channels
+        grid, tpp = (ts[0], ts[1] * t), 1
+    elif spatial:
+        grid, tpp = (t * ts[0], ts[1]), 1
+    else:
+        grid, tpp = ts, t
+    h = fastvim_mixer_oracle(_sub(sd_layer, "mixer."), h, grid, tokens_per_patch=tpp, compute_dtype=cd,
                              **(mixer_kwargs or {}))
     if rot:                                                               # :325-329
-        h = h.reshape(Bsz, T1, T0, t, d).transpose(1, 2).reshape(Bsz, M, d)
+        if spatial:
+            h = h.reshape(Bsz, t, T1, T0, d).transpose(2, 3).reshape(Bsz, M, d)
+        else:
+            h = h.reshape(Bsz, T1, T0, t, d).transpose(1, 2).reshape(Bsz, M, d)
     return h, res
 
 
 def channel_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, rotate_every_block=True,
                            final_pool_type="mean", channels=None, row_scales=None,
-                           compute_dtype=torch.float64, return_features=False, mixer_kwargs=None):
+                           compute_dtype=torch.float64, return_features=False, mixer_kwargs=None,
+                           scan_order="Channel-First", compress2d=False):
     """VisionMamba.forward_features / forward of the channel model
     (models_channel_mamba_faster.py:614-682), Channel-First, fused_add_norm + rms_norm + fp32 residual."""
     cd = compute_dtype
     h, token_size, t = channel_patch_embed_oracle(sd, x, patch_size, cd, channels)
-    h = h + torch.repeat_interleave(sd["pos_embed"].to(cd), t, 1)          # :626-627
+    if "pos_embed" in sd:                                                  # if_abs_pos_embed (:617-627)
+        h = h + torch.repeat_interleave(sd["pos_embed"].to(cd), t, 1)      # :626-627
+    if scan_order == "Spatial-First":                                      # (row, col, channel) -> (channel, row, col)
+        Bsz = h.shape[0]
+        h = h.reshape(Bsz, token_size[0] * token_size[1], t, -1).transpose(1, 2).reshape(Bsz, -1, h.shape[-1])
     h = h.to(cd if cd == torch.float64 else torch.float32)
     residual = None
     for i in range(depth):
         rs = row_scales[i] if row_scales is not None else None
         h, residual = channel_block_oracle(_sub(sd, f"layers.{i}."), h, residual, i, token_size, t,
                                            norm_eps=norm_eps, rotate_every_block=rotate_every_block,
-                                           row_scale=rs, compute_dtype=cd, mixer_kwargs=mixer_kwargs)
+                                           row_scale=rs, compute_dtype=cd, mixer_kwargs=mixer_kwargs,
+                                           scan_order=scan_order, compress2d=compress2d)
     rs = row_scales[depth] if row_scales is not None else None
     h = fused_add_norm_oracle(h, sd["norm_f.weight"], None, residual, norm_eps, prenorm=False,
                               residual_in_fp32=True, is_rms_norm=True, row_scale=rs, compute_dtype=cd)

@@ -29,3 +29,19 @@ def golden():
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+@pytest.fixture(autouse=True)
+def _reset_flat_training_switches():
+    """FlatTrainingState switches the kernels' wrappers to deferred reductions / grouped weight gradients process-wide
+    until its close(); a test that forgets to close one must not change what the next test measures."""
+    yield
+    import sys
+    mo, mf = sys.modules.get("fastvim_amd.mixer_ops"), sys.modules.get("fastvim_amd.mamba_simple_faster")
+    if mo is not None:
+        mo._Deferred.jobs = []
+        mo._Deferred.enabled = False
+    if mf is not None:
+        mf._GroupedWgrad.jobs = []
+        mf._GroupedWgrad.enabled = False
+        mf._SideStream.enabled = False

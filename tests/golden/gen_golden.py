@@ -436,6 +436,50 @@ def gen_mae():
     save("mae.pt", cases)
 
 
+def gen_channel_variants():
+    """Remaining channel-model variants: scan_order="Spatial-First" of the channel model and the
+    "2-D compress" model (row-wise -> column-wise -> channel-wise scan cycle).  Tiny backbones, eval mode (HCS off)."""
+    cases = {}
+    # reference quirk: models_channel_mamba_faster_2dcompress.create_block passes max_tokens_per_patch to a Block whose
+    # __init__ does not take it (:363-375 vs :175-190), so the model cannot be constructed as shipped; the keyword is
+    # dropped here (it is unused in the sibling model's Block as well)
+    _orig_init = ref.chan2.Block.__init__
+    if not getattr(_orig_init, "_patched", False):
+        def _init(self, *a, max_tokens_per_patch=None, **k):
+            _orig_init(self, *a, **k)
+        _init._patched = True
+        ref.chan2.Block.__init__ = _init
+    for name, mod, kw, img, chans, depth in (
+            ("spatial_first_64x96_c3", ref.chan, dict(scan_order="Spatial-First", if_abs_pos_embed=True), (64, 96), 3, 4),
+            ("compress2d_64x96_c4", ref.chan2, dict(if_abs_pos_embed=True), (64, 96), 4, 6),
+            ("compress2d_64x64_c3_nopos", ref.chan2, dict(), (64, 64), 3, 3)):
+        torch.manual_seed(41)
+        model = mod.VisionMamba(img_size=img, patch_size=16, depth=depth, embed_dim=32, channels=chans, num_classes=10,
+                                rms_norm=True, residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean",
+                                drop_path_rate=0.0, **kw)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith(("D", "D_b", "norm.weight", "layernorm.weight", "norm_f.weight")):
+                    p.add_(0.2 * torch.randn_like(p))
+                elif n.endswith(("layernorm.bias", "head.bias", "patch_embed.proj.bias")):
+                    p.add_(0.1 * torch.randn_like(p))
+        model.eval()
+        x = torch.randn(2, chans, *img)
+        logits = model(x)
+        g = torch.randn_like(logits)
+        logits.backward(g)
+        keep = ("pos_embed", "head.weight", "layers.0.mixer.in_proj.weight", "layers.1.mixer.A_b_log",
+                "layers.2.mixer.x_proj_b.weight", "layers.2.norm.weight", "patch_embed.proj.bias",
+                "patch_embed.proj.weight", "patch_embed.channel_embed.weight", "norm_f.weight",
+                "layers.1.mixer.conv1d.weight", "layers.2.mixer.dt_proj.bias", "layers.2.mixer.out_proj.weight",
+                "layers.5.mixer.A_log")
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if n in keep and p.grad is not None}
+        cases[name] = dict(img=img, channels=chans, depth=depth, kw=kw,
+                           state_dict={k: v.clone() for k, v in model.state_dict().items()},
+                           x=x, logits=logits.detach(), g=g, grads=grads)
+    save("channel_variants.pt", cases)
+
+
 def gen_config34():
     """BASELINE config 3 (FastVim-B): the whole FastVim-B model at bs = 2 with parameters from the seeded recipe
     (re-derivable on the GPU box, not stored), and a colwise (Pool_row) tiny model.  The FastVim-B mixer on the 14x14
@@ -481,6 +525,6 @@ def gen_config34():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked", "mae", "config34"]
+    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked", "mae", "config34", "channel_variants"]
     for w in which:
         globals()["gen_" + w]()

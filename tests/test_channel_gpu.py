@@ -163,3 +163,46 @@ def test_channel_mixer_max_pool_vs_oracle():
     for n, q in m.named_parameters():
         e = _err(q.grad, p[n].grad)
         assert e <= 2e-4 * max(1.0, p[n].grad.abs().max().item()), (n, e)
+
+
+@pytest.mark.parametrize("case", ["spatial_first_64x96_c3", "compress2d_64x96_c4", "compress2d_64x64_c3_nopos"])
+def test_channel_variants_vs_reference_golden(case):
+    """SURVEY section 8 row f3 remainder: scan_order="Spatial-First" of the channel model and the 2-D compress model
+    (row scan -> column scan -> channel scan), logits and gradients against goldens captured from the imported
+    reference (tests/golden/gen_golden.py: gen_channel_variants)."""
+    c = load_golden("channel_variants.pt")[case]
+    if case.startswith("compress2d"):
+        from fastvim_amd.models_channel_mamba_faster_2dcompress import VisionMamba
+    else:
+        from fastvim_amd.models_channel_mamba_faster import VisionMamba
+    m = VisionMamba(img_size=c["img"], patch_size=16, depth=c["depth"], embed_dim=32, channels=c["channels"],
+                    num_classes=10, rms_norm=True, residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean",
+                    drop_path_rate=0.0, **c["kw"]).cuda().eval()
+    m.load_state_dict(c["state_dict"], strict=True)
+    logits = m(c["x"].cuda())
+    assert _err(logits, c["logits"]) <= 2e-5 * max(1.0, c["logits"].abs().max().item()), _err(logits, c["logits"])
+    logits.backward(c["g"].cuda())
+    params = dict(m.named_parameters())
+    for k, gref in c["grads"].items():
+        e = _err(params[k].grad, gref)
+        assert e <= 2e-4 * max(1.0, gref.abs().max().item()), (k, e, gref.abs().max().item())
+
+
+def test_compress2d_small_entry_point_bf16_step():
+    """FastChannelVim-S/16 2-D compress entry point at the config-5 input shape (8 channels, 224 px), reduced depth:
+    one bf16 training step runs on the fused kernels (channel-scan layers: 1 x 196 cells of 8 tokens, scan length 8;
+    row / column layers: 14 x 112 grid) and matches the fp64 oracle."""
+    from fastvim_amd.models_channel_mamba_faster_2dcompress import VisionMamba
+    from oracle import channel_forward_oracle
+    torch.manual_seed(0)
+    m = VisionMamba(img_size=224, patch_size=16, depth=3, embed_dim=384, channels=8, num_classes=20, rms_norm=True,
+                    residual_in_fp32=True, fused_add_norm=True, hcs=False, drop_path_rate=0.0, if_abs_pos_embed=True).cuda().train()
+    x = torch.randn(2, 8, 224, 224)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = m(x.cuda())
+    logits.float().square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = channel_forward_oracle(sd, x, patch_size=16, depth=3, compute_dtype=F64, compress2d=True)
+    rel = (logits.float().cpu().double() - ref).norm() / ref.norm()
+    assert rel <= 3e-2, rel

@@ -4,7 +4,7 @@ import torch
 import pytest
 
 from conftest import load_golden
-from oracle import (causal_conv1d_oracle, fastvim_forward_oracle, fastvim_mixer_oracle,
+from oracle import (causal_conv1d_oracle, channel_forward_oracle, fastvim_forward_oracle, fastvim_mixer_oracle,
                     fused_add_norm_oracle, make_state_dict, selective_scan_oracle,
                     selective_scan_ref_port)
 from oracle.scan import compressed_scan_oracle
@@ -182,6 +182,20 @@ def test_channel_model_oracle(case):
     c = load_golden("channel.pt")[case]
     sd = {k: v.clone().requires_grad_() for k, v in c["state_dict"].items()}
     logits = channel_forward_oracle(sd, c["x"], patch_size=16, depth=4, channels=c["subset"], compute_dtype=F64)
+    close(logits, c["logits"], 0, 5e-5 * max(1.0, c["logits"].abs().max().item()))
+    logits.backward(c["g"].double())
+    for k, gref in c["grads"].items():
+        close(sd[k].grad, gref, 0, 5e-4 * max(1.0, gref.abs().max().item()))
+
+
+@pytest.mark.parametrize("case", ["spatial_first_64x96_c3", "compress2d_64x96_c4", "compress2d_64x64_c3_nopos"])
+def test_channel_variant_oracle(case):
+    """scan_order="Spatial-First" and the 2-D compress model against the imported reference."""
+    c = load_golden("channel_variants.pt")[case]
+    sd = {k: v.clone().requires_grad_() for k, v in c["state_dict"].items()}
+    logits = channel_forward_oracle(sd, c["x"], patch_size=16, depth=c["depth"], compute_dtype=F64,
+                                    scan_order=c["kw"].get("scan_order", "Channel-First"),
+                                    compress2d=case.startswith("compress2d"))
     close(logits, c["logits"], 0, 5e-5 * max(1.0, c["logits"].abs().max().item()))
     logits.backward(c["g"].double())
     for k, gref in c["grads"].items():
