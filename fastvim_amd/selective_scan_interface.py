@@ -197,6 +197,45 @@ def FastVim_mamba_inner_fn_no_out_proj_withoutZ(
     return out
 
 
+def mamba_inner_fn_no_out_proj_withoutZ(x, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None,
+                                        C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                                        delta_softplus=True):
+    """One direction of the Vim baseline mixer in the reference op layout (the op ``mamba_simple.Mamba`` calls with
+    ``use_norm_after_ssm=True``, mamba_simple.py:226-255): x (batch, dim, seqlen) -> conv1d + SiLU -> x_proj / dt_proj ->
+    selective scan over ALL seqlen steps with the D skip inside the scan, no gate; returns (batch, dim, seqlen)
+    (selective_scan_interface.py:779-1016 ``MambaInnerFnNoOutProj_withoutZ``, wrapper :1684-1713; same argument list).
+
+    Like its FastVim sibling above it is the compatibility surface, composed of the HIP ops ``causal_conv1d_fn`` and
+    ``selective_scan_fn`` (autograd chains their hand-written backwards); the ``fastvim_amd.mamba_simple.Mamba`` module
+    runs both directions on the fused channel-last kernels instead."""
+    import torch.nn.functional as F
+    from .causal_conv1d import causal_conv1d_fn
+    if A.is_complex():
+        raise NotImplementedError("complex A is not supported")
+    delta_rank = delta_proj_weight.shape[1]
+    d_state = A.shape[-1]
+    if torch.is_autocast_enabled():
+        adt = torch.get_autocast_dtype("cuda")
+        x_proj_weight, delta_proj_weight = x_proj_weight.to(adt), delta_proj_weight.to(adt)
+        x = x.to(adt)
+    with torch.autocast("cuda", enabled=False):
+        conv_out = causal_conv1d_fn(x, conv1d_weight.reshape(conv1d_weight.shape[0], -1), conv1d_bias, activation="silu")
+        Bsz, dim, L = conv_out.shape
+        x_dbl = F.linear(conv_out.transpose(1, 2).reshape(Bsz * L, dim), x_proj_weight.to(conv_out.dtype))   # (b l) d
+        delta = (delta_proj_weight.to(conv_out.dtype) @ x_dbl[:, :delta_rank].t()).view(dim, Bsz, L).transpose(0, 1)
+        if B is None:                      # variable B (:826-838)
+            B = x_dbl[:, delta_rank:delta_rank + d_state]
+            if B_proj_bias is not None:
+                B = B + B_proj_bias.to(B.dtype)
+            B = B.view(Bsz, L, d_state).transpose(1, 2).unsqueeze(1)
+        if C is None:                      # variable C (:842-854)
+            C = x_dbl[:, -d_state:]
+            if C_proj_bias is not None:
+                C = C + C_proj_bias.to(C.dtype)
+            C = C.view(Bsz, L, d_state).transpose(1, 2).unsqueeze(1)
+        return selective_scan_fn(conv_out, delta, A, B, C, D, None, delta_bias, delta_softplus)
+
+
 # ------------------------------------------------------------------------------------------------
 # "Compressed scan" of the FastVim kernel fork (experimental in the reference; forward only there)
 # ------------------------------------------------------------------------------------------------

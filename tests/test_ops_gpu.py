@@ -152,6 +152,46 @@ def test_fused_inner_fn_vs_mixer_oracle_direction(dtype):
         assert e <= (5e-2 if lo else 2e-4) * max(1.0, r[k].grad.abs().max().item()), (k, e, r[k].grad.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype,L", [(torch.float32, 197), (torch.bfloat16, 197), (torch.float32, 24)])
+def test_vim_inner_fn_vs_oracle(dtype, L):
+    """mamba_inner_fn_no_out_proj_withoutZ (the Vim baseline's fused op, selective_scan_interface.py:779-1016,
+    1684-1713): conv + SiLU -> x_proj / dt_proj -> scan over all L tokens with D inside, against the fp64 oracle
+    (197 = 196 patches + the class token of Vim-T at 224 px)."""
+    from fastvim_amd.selective_scan_interface import mamba_inner_fn_no_out_proj_withoutZ as fused
+    from oracle import causal_conv1d_oracle, selective_scan_oracle
+    g = torch.Generator().manual_seed(13)
+    Bsz, d_in, N, R = 2, 64, 16, 4
+    x = torch.randn(Bsz, d_in, L, generator=g).to(dtype).float()
+    cw = 0.5 * torch.randn(d_in, 1, 4, generator=g)
+    cb = 0.1 * torch.randn(d_in, generator=g)
+    Wx = torch.randn(R + 2 * N, d_in, generator=g) * d_in ** -0.5
+    Wdt = torch.randn(d_in, R, generator=g) * R ** -0.5
+    A = -torch.exp(torch.log(torch.arange(1, N + 1).float())[None].repeat(d_in, 1))
+    Dp = 1 + 0.1 * torch.randn(d_in, generator=g)
+    bias = torch.rand(d_in, generator=g) * 0.1 - 3.0
+    go = torch.randn(Bsz, d_in, L, generator=g).to(dtype).float()
+    leaves = dict(x=x, cw=cw, cb=cb, Wx=Wx, Wdt=Wdt, A=A, D=Dp, bias=bias)
+    r = {k: v.double().requires_grad_() for k, v in leaves.items()}
+    conv = causal_conv1d_oracle(r["x"], r["cw"].reshape(d_in, 4), r["cb"], "silu", compute_dtype=F64, out_dtype=F64)
+    x_dbl = conv.transpose(1, 2).reshape(Bsz * L, d_in) @ r["Wx"].t()
+    delta = (r["Wdt"] @ x_dbl[:, :R].t()).view(d_in, Bsz, L).transpose(0, 1)
+    Bm = x_dbl[:, R:R + N].view(Bsz, L, N).transpose(1, 2)
+    Cm = x_dbl[:, -N:].view(Bsz, L, N).transpose(1, 2)
+    yr = selective_scan_oracle(conv, delta, r["A"], Bm, Cm, r["D"], None, r["bias"], True, False, F64, F64)
+    yr.backward(go.double())
+    q = {k: v.cuda().requires_grad_() for k, v in leaves.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        y = fused(q["x"].to(dtype) if dtype != torch.float32 else q["x"], q["cw"], q["cb"], q["Wx"], q["Wdt"], q["A"],
+                  None, None, q["D"], q["bias"], None, None, True)
+    lo = dtype != torch.float32
+    assert y.shape == (Bsz, d_in, L)
+    assert _err(y, yr) <= (3e-2 if lo else 2e-5) * max(1.0, yr.abs().max().item()), _err(y, yr)
+    y.backward(go.cuda().to(y.dtype))
+    for k in leaves:
+        e = _err(q[k].grad, r[k].grad)
+        assert e <= (5e-2 if lo else 2e-4) * max(1.0, r[k].grad.abs().max().item()), (k, e, r[k].grad.abs().max().item())
+
+
 @pytest.mark.parametrize("Mrows,d_in,W", [(1792, 384, 44), (37, 768, 56), (256, 1536, 80), (16, 64, 34), (100, 2560, 112)])
 def test_xproj_fwd_kernel_vs_torch(Mrows, d_in, W):
     """fv_mixer_xproj_fwd (both directions in one launch) against an fp64 product of the same bf16 operands."""
