@@ -202,7 +202,11 @@ class FastVimMixerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden, W_in, b_in, cw, cb, cw_b, cb_b, Wx, Wx_b, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log,
-                D, D_b, ln_w, ln_b, W_out, b_out, rows, cols, transposed, pool_max, scaling, ln_eps, cdt, fv, tpp=1):
+                D, D_b, ln_w, ln_b, W_out, b_out, rows, cols, transposed, pool_max, scaling, ln_eps, cdt, fv, tpp=1,
+                valid=None):
+        """``valid``: number of pooled positions that are real; the rest are zero-input padding at the END of the sequence
+        (the un-pooled Vim mixer pads 197 tokens to 25 rows of 8).  Their pooled conv output is zeroed, which makes them
+        inert in both scans (u = 0 => B = C = 0; the state they see first is zero), and nothing else has to know."""
         L.require_gpu(hidden)
         B, Ltok, d = hidden.shape
         if Ltok != rows * cols * tpp:
@@ -220,6 +224,8 @@ class FastVimMixerFn(torch.autograd.Function):
             else:
                 xc, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
                                            D=D, D_b=D_b)
+            if valid is not None and valid < rows * tpp:
+                xc[:, :, valid:].zero_()
             if fv is not None and "Wx2" in fv:          # x_proj / x_proj_b adjacent in the flat buffers
                 Wx2 = fv["Wx2"]
                 if fv["Wx2_shadow"].dtype == cdt:
@@ -320,7 +326,7 @@ class FastVimMixerFn(torch.autograd.Function):
         g_lb = p1[1] if (has_ln and p1 is not None) else None
         return (dhidden, dW_in, db_in, g_cw, g_cb, g_cwb, g_cbb,
                 dWx2[0], dWx2[1], g_Wdt[0], g_bdt[0], g_Wdt[1], g_bdt[1], g_A[0], g_A[1],
-                g_D, g_Db, g_lw, g_lb, dW_out, db_out, None, None, None, None, None, None, None, None, None)
+                g_D, g_Db, g_lw, g_lb, dW_out, db_out, None, None, None, None, None, None, None, None, None, None)
 
 
 class Mamba(nn.Module):
