@@ -14,6 +14,16 @@ import torch.nn.functional as F
 from .mamba_simple_faster import FastVimMixerFn, Mamba as _FastVimMamba, _compute_dtype
 
 
+def _split_rows_exact(L):
+    """rows * t == L with t >= 3 tokens per row (conv halo) and as many rows as possible (parallelism): the MAE masked
+    mixer's kept-token sequence (49 = 7 x 7 at mask ratio 0.75), which is not padded."""
+    best = 1
+    for r in range(1, L + 1):
+        if L % r == 0 and L // r >= 3:
+            best = r
+    return best
+
+
 def _split_rows(L):
     """(rows, tokens per row, padded length).  The row walkers parallelise over rows, and their fastest un-pooled form
     is the 8-token cell: the sequence is cut into rows of 8 tokens and padded at its END to a whole number of rows

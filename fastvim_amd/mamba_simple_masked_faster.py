@@ -21,7 +21,7 @@ import torch
 
 from . import _lib as L
 from . import mixer_ops as M
-from .mamba_simple import _split_rows
+from .mamba_simple import _split_rows_exact as _split_rows
 from .mamba_simple_faster import (Mamba as _FastVimMamba, _compute_dtype, _shadow, linear_dgrad, linear_fwd,
                                   linear_wgrad)
 
