@@ -359,6 +359,15 @@ struct ShortLds {
   static constexpr int floats = o_pd + SH_NWV * 16 * 16 * RT;
 };
 
+// An index the compiler cannot relate to earlier copies of itself: the address arithmetic of a late section (output
+// pointers of the epilogues) is then done where it is used, instead of at kernel entry and spilled across the time loops
+// (the spills, ~25 per batch element, were 40 MB of scratch traffic per launch).
+__device__ __forceinline__ int opaque_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 template <typename T, int RQ, int LCT, bool EXACT>      // EXACT: Lc == LCT (the 14- and 16-row grids)
 __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -386,12 +395,8 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     A2[j] = Araw[j] * FV_LOG2E;
   }
   float dA[4] = {0.f, 0.f, 0.f, 0.f}, dbias = 0.f;
-  // ---- matrix role: lane = (channel cm = lane & 15 of the wave, step group tg = lane >> 4: steps 4 tg .. 4 tg + 3)
-  const int cm = lane & 15, tg = lane >> 4;
-  const int dm = ch0 + wv * 16 + cm;
-  const bool actm = dm < p.d_in;
-  const int ddm = actm ? dm : 0;
-  const float bias_m = p.dtb[dir][ddm];
+  // ---- matrix role: lane = (channel cm = lane & 15 of the wave, step group tg = lane >> 4: steps 4 tg .. 4 tg + 3);
+  //      its indices are re-derived in every section that uses them (opaque_tid)
   f32x4_t accW[RT];                      // d Wdt tile: rows = channel 16 wv + 4 tg + reg, cols = r = 16 rt + cm
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -403,16 +408,19 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     const size_t bd = ((size_t)dir * p.B + b) * Lc;
     // matrix role: u and dy of this lane's 4 steps (requested before the staging barrier)
     float um[4], gm[4];
-    int roff[4];
+    float bias_m;
     {
+      const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + cm;
+      const bool actm = dm < p.d_in;
+      const int ddm = actm ? dm : 0;
+      bias_m = p.dtb[dir][ddm];
       const T* u = (const T*)p.xc + bd * p.d_in + ddm;
       const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + ddm;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s = 4 * tg + r, sc = min(s, Lc - 1), l = dir ? Lc - 1 - sc : sc;
-        roff[r] = l * p.d_in;
-        um[r] = io<T>::ld(u + roff[r]);
-        const float gv = gy[roff[r]];
+        um[r] = io<T>::ld(u + l * p.d_in);
+        const float gv = gy[l * p.d_in];
         gm[r] = (actm && s < Lc) ? gv : 0.f;
       }
     }
@@ -439,6 +447,9 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     // ---- delta_raw[t][ch] = sum_r dt_low[t][r] Wdt[ch][r] on the matrix cores (A: t x r, B: r x ch), then
     //      softplus / sigmoid once per (step, channel); the table row {delta, u, dy, sigmoid} goes to LDS
     {
+      const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + cm;
+      const bool actm = dm < p.d_in;
+      const int ddm = actm ? dm : 0;
       f32x4_t D = {0.f, 0.f, 0.f, 0.f};
       const int ta = min(cm, LCT - 1);            // A operand row of this lane: step cm
 #pragma unroll
@@ -539,6 +550,8 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
 
     // ---- dt_proj adjoint on the matrix cores, from this wave's 16 columns of the d delta_raw table
     {
+      const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv = t2 >> 6, dm = ch0 + wv * 16 + cm;
+      const bool actm = dm < p.d_in;
       // d dt_low[t][r] partial over the wave's channels: A[t][k = channel], B[k = channel][r]
       f32x4_t Dl[RT];
 #pragma unroll
@@ -576,12 +589,14 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s = 4 * tg + r;
-        if (actm && s < Lc) p.dxc[bd * p.d_in + roff[r] + dm] = s_du[s * SH_CH + wv * 16 + cm];
+        const int l = dir ? Lc - 1 - s : s;
+        if (actm && s < Lc) p.dxc[(bd + l) * p.d_in + dm] = s_du[s * SH_CH + wv * 16 + cm];
       }
     }
     __syncthreads();
     // ---- sum the 12 waves in fixed order and scatter to the x_dbl column layout [dt_low | B | C]
     {
+      const int tid = opaque_tid();
       float* out = p.dxdbl + (((size_t)blockIdx.x * 2 + dir) * p.B + b) * Lc * W;
       for (int e = tid; e < Lc * 32; e += SH_THREADS) {
         const int s = e >> 5, rem = e & 31, qq = rem >> 3, v = rem & 7;
@@ -604,6 +619,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   }   // batch elements of this block
   const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
   float* base = p.pP + ((size_t)blockIdx.y * 2 + dir) * per_dir;
+  const int t3 = opaque_tid(), cm = t3 & 15, tg = (t3 >> 4) & 3;
   if (act) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) base[(size_t)d * N + q * 4 + j] = dA[j] * Araw[j];            // dA_log = dA * A
