@@ -368,6 +368,11 @@ __device__ __forceinline__ int opaque_tid() {
   return t;
 }
 
+typedef float sf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sf2 ssplat(float a) { sf2 o; o.x = a; o.y = a; return o; }
+__device__ __forceinline__ sf2 sfma2(sf2 a, sf2 b, sf2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ sf2 sexp2_2(sf2 a) { sf2 o; o.x = fv_exp2(a.x); o.y = fv_exp2(a.y); return o; }
+
 template <typename T, int RQ, int LCT, bool EXACT>      // EXACT: Lc == LCT (the 14- and 16-row grids)
 __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -388,13 +393,16 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   const int d = ch0 + ch;
   const bool act = d < p.d_in;
   const int dd = act ? d : 0;
-  float A2[4], Araw[4];
+  // the 4 states of a lane are two packed pairs: v_pk_mul_f32 / v_pk_fma_f32 do both halves in one issue slot
+  sf2 A2[2], Araw[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    Araw[j] = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + j]);
-    A2[j] = Araw[j] * FV_LOG2E;
+  for (int h = 0; h < 2; ++h) {
+    Araw[h].x = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h]);
+    Araw[h].y = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h + 1]);
+    A2[h] = Araw[h] * FV_LOG2E;
   }
-  float dA[4] = {0.f, 0.f, 0.f, 0.f}, dbias = 0.f;
+  sf2 dA[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float dbias = 0.f;
   // ---- matrix role: lane = (channel cm = lane & 15 of the wave, step group tg = lane >> 4: steps 4 tg .. 4 tg + 3);
   //      its indices are re-derived in every section that uses them (opaque_tid)
   f32x4_t accW[RT];                      // d Wdt tile: rows = channel 16 wv + 4 tg + reg, cols = r = 16 rt + cm
@@ -477,9 +485,9 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     // ---- forward recurrence, states kept
     const float* my_bc = s_dbl + 4 * RQP + q * 4;                   // this quad lane's B states of row 0 (C: + N)
     const float* my_ch = s_ch + (size_t)ch * 4;
-    float xs[LCT][4];
+    sf2 xs[LCT][2];
     {
-      float st[4] = {0.f, 0.f, 0.f, 0.f};
+      sf2 st[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
       for (int s = 0; s < LCT; ++s) {
         // a compiler memory barrier per step keeps the scheduler from hoisting every step's LDS reads to the top of the
@@ -488,18 +496,18 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
         if (EXACT || s < Lc) {
           const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
           const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (SH_CH * 4));
-          const float Bn[4] = {Bv.x, Bv.y, Bv.z, Bv.w};
+          const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
           const float dt = cv.x, dtu = cv.x * cv.y;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], dtu * Bn[j]);
+          for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xs[s][j] = st[j];
+        for (int h = 0; h < 2; ++h) xs[s][h] = st[h];
       }
     }
 
     // ---- adjoint sweep, high to low
-    float dxa[4] = {0.f, 0.f, 0.f, 0.f};
+    sf2 dxa[2] = {{0.f, 0.f}, {0.f, 0.f}};
     float* my_part = s_part + (wv * 4 + q) * 8 + (lane >> 3);
     float* my_dr = s_dr + ch;
     float* my_du = s_du + ch;
@@ -510,25 +518,27 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
         const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
         const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
         const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (SH_CH * 4));
-        const float Bn[4] = {Bv.x, Bv.y, Bv.z, Bv.w}, Cn[4] = {Cv.x, Cv.y, Cv.z, Cv.w};
+        const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
         const float dt = cv.x, uu = cv.y, g = cv.z, sg = cv.w;
         const float dtu = dt * uu;
         float vals[8];
-        float du_acc = 0.f, dd_acc = 0.f;
+        sf2 du2 = {0.f, 0.f}, dd2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a = fv_exp2(dt * A2[j]);
-          const float dx = fmaf(g, Cn[j], dxa[j]);
-          const float pj = s > 0 ? dx * (a * xs[s > 0 ? s - 1 : 0][j]) : 0.f;     // dx * a_t * x_{t-1}
-          du_acc = fmaf(dx, Bn[j], du_acc);
-          dd_acc = fmaf(Araw[j], pj, dd_acc);
-          dA[j] = fmaf(dt, pj, dA[j]);
-          vals[j] = dx * dtu;                                   // dB[4q+j]
-          vals[4 + j] = g * xs[s][j];                           // dC[4q+j]
-          dxa[j] = a * dx;
+        for (int h = 0; h < 2; ++h) {
+          const sf2 a = sexp2_2(A2[h] * dt);
+          const sf2 dx = sfma2(Cn[h], ssplat(g), dxa[h]);
+          sf2 pj = {0.f, 0.f};
+          if (s > 0) pj = dx * (a * xs[s > 0 ? s - 1 : 0][h]);   // dx * a_t * x_{t-1}
+          du2 = sfma2(dx, Bn[h], du2);
+          dd2 = sfma2(Araw[h], pj, dd2);
+          dA[h] = sfma2(pj, ssplat(dt), dA[h]);
+          const sf2 vb = dx * dtu, vc = xs[s][h] * g;
+          vals[2 * h] = vb.x; vals[2 * h + 1] = vb.y;            // dB[4q + 2h ..]
+          vals[4 + 2 * h] = vc.x; vals[5 + 2 * h] = vc.y;        // dC[4q + 2h ..]
+          dxa[h] = a * dx;
         }
-        du_acc = quad_sum(du_acc);
-        dd_acc = quad_sum(dd_acc);
+        const float du_acc = quad_sum(du2.x + du2.y);
+        const float dd_acc = quad_sum(dd2.x + dd2.y);
         // d delta = sum_n dx (B u + A a x_prev) = u * sum_n dx B + sum_n A dx a x_prev;  through the softplus: * sigmoid
         const float ddraw = fmaf(uu, du_acc, dd_acc) * sg;
         dbias += ddraw;
@@ -605,15 +615,17 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
 #pragma unroll
         for (int w = 0; w < SH_NWV; ++w) t += s_part[((s * SH_NWV + w) * 4 + qq) * 8 + v];
         const int l = dir ? Lc - 1 - s : s;
-        out[(size_t)l * W + col] = t;
+        out[l * W + col] = t;
       }
-      for (int e = tid; e < Lc * p.R; e += SH_THREADS) {
-        const int s = e / p.R, r = e - s * p.R;
-        float t = 0.f;
+      for (int e = tid; e < Lc * (16 * RT); e += SH_THREADS) {       // (step, r) with r < 16 RT; no run-time division
+        const int s = e / (16 * RT), r = e - s * (16 * RT);
+        if (r < p.R) {
+          float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < SH_NWV; ++w) t += s_pd[((size_t)w * 16 + s) * (16 * RT) + r];
-        const int l = dir ? Lc - 1 - s : s;
-        out[(size_t)l * W + r] = t;
+          for (int w = 0; w < SH_NWV; ++w) t += s_pd[(w * 16 + s) * (16 * RT) + r];
+          const int l = dir ? Lc - 1 - s : s;
+          out[l * W + r] = t;
+        }
       }
     }
   }   // batch elements of this block
@@ -622,7 +634,11 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   const int t3 = opaque_tid(), cm = t3 & 15, tg = (t3 >> 4) & 3;
   if (act) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) base[(size_t)d * N + q * 4 + j] = dA[j] * Araw[j];            // dA_log = dA * A
+    for (int h = 0; h < 2; ++h) {                                                             // dA_log = dA * A
+      const sf2 v = dA[h] * Araw[h];
+      base[(size_t)d * N + q * 4 + 2 * h] = v.x;
+      base[(size_t)d * N + q * 4 + 2 * h + 1] = v.y;
+    }
     if (q == 0) base[(size_t)p.d_in * (N + p.R) + d] = dbias;           // identical in the four lanes of a channel
   }
 #pragma unroll
@@ -771,9 +787,12 @@ __global__ __launch_bounds__(SH_THREADS) void xproj_scan_fwd_short_kernel(ScanCl
       const int chl = wv * 16 + (lane >> 2), d = ch0 + chl;
       const bool act = d < d_in;
       const int dd = act ? d : 0;
-      float A2[4], st[4] = {0.f, 0.f, 0.f, 0.f};
+      sf2 A2[2], st[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) A2[j] = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + j]) * FV_LOG2E;
+      for (int h = 0; h < 2; ++h) {
+        A2[h].x = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h]) * FV_LOG2E;
+        A2[h].y = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h + 1]) * FV_LOG2E;
+      }
       const float* my_ch = s_ch + (size_t)chl * 2;
 #pragma unroll
       for (int s = 0; s < LCT; ++s) {
@@ -782,14 +801,14 @@ __global__ __launch_bounds__(SH_THREADS) void xproj_scan_fwd_short_kernel(ScanCl
           const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
           const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
           const float2 cv = *reinterpret_cast<const float2*>(my_ch + s * (SH_CH * 2));
-          const float Bn[4] = {Bv.x, Bv.y, Bv.z, Bv.w}, Cn[4] = {Cv.x, Cv.y, Cv.z, Cv.w};
-          float acc = 0.f;
+          const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
+          sf2 acc2 = {0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            st[j] = fmaf(fv_exp2(cv.x * A2[j]), st[j], cv.y * Bn[j]);
-            acc = fmaf(Cn[j], st[j], acc);
+          for (int h = 0; h < 2; ++h) {                 // two packed state pairs per lane
+            st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
+            acc2 = sfma2(Cn[h], st[h], acc2);
           }
-          acc = quad_sum(acc);
+          const float acc = quad_sum(acc2.x + acc2.y);
           if (q == 0) s_y[s * SH_CH + chl] = acc;
         }
       }
