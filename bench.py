@@ -551,7 +551,7 @@ def main():
             out["kernels"] = kt
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")))["kernels"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_v2_pmc_traffic.json")))["kernels"]
                 if (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16") and dom in pm:
                     traffic = pm[dom]["traffic_bytes"]
             except (OSError, KeyError, ValueError):

@@ -15,9 +15,11 @@ from .conv import causal_conv1d_oracle
 from .scan import selective_scan_oracle
 
 
-def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd):
+def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd, rq=None):
     """One scan direction.  x_bdl: (B, d_in, L) in compute dtype.
-    Returns out (B, d_in, L) = expand(scan(pool(conv(x)))) + D * conv(x)."""
+    Returns out (B, d_in, L) = expand(scan(pool(conv(x)))) + D * conv(x); with ``rq`` (a storage-rounding function,
+    see fastvim_mixer_oracle) the pair (expand(scan(...)), D * conv(x)) with the pooled tensor and x_dbl rounded where
+    the HIP path stores them."""
     Bsz, d_in, L = x_bdl.shape
     w = p[f"conv1d{sfx}.weight"].to(cd).reshape(d_in, -1)
     b = p.get(f"conv1d{sfx}.bias")
@@ -34,13 +36,19 @@ def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd):
     else:
         raise NotImplementedError(collapse)
     pooled = pooled.reshape(Bsz, d_in, rows * tpp)                       # (B, d_in, Lc)
+    if rq is not None:
+        pooled = rq(pooled)                                              # xc is stored in the compute dtype
     Lc = rows * tpp
     # :321-337 x_proj -> (dt, B, C); dt_proj without bias (bias goes into the scan)
     Wx = p[f"x_proj{sfx}.weight"].to(cd)
     Wdt = p[f"dt_proj{sfx}.weight"].to(cd)
     R = Wdt.shape[1]
     N = (Wx.shape[0] - R) // 2
+    if rq is not None:
+        Wx = rq(Wx)                                                      # bf16 shadow weight
     x_dbl = pooled.permute(0, 2, 1).reshape(Bsz * Lc, d_in) @ Wx.t()    # (B*Lc, R+2N)
+    if rq is not None:
+        x_dbl = rq(x_dbl)                                                # stored in the compute dtype
     dt = (x_dbl[:, :R] @ Wdt.t()).reshape(Bsz, Lc, d_in).permute(0, 2, 1)
     Bm = x_dbl[:, R:R + N].reshape(Bsz, Lc, N).permute(0, 2, 1)
     Cm = x_dbl[:, R + N:].reshape(Bsz, Lc, N).permute(0, 2, 1)
@@ -50,37 +58,56 @@ def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd):
                               True, False, compute_dtype=cd, out_dtype=cd, reverse=reverse)
     # :356-358 repeat_interleave(cols) + D * conv_out
     y = y.reshape(Bsz, d_in, rows, 1, tpp).expand(Bsz, d_in, rows, cols, tpp).reshape(Bsz, d_in, L)
+    if rq is not None:
+        return y, p[f"D{sfx}"].float().to(cd)[None, :, None] * xc
     return y + p[f"D{sfx}"].float().to(cd)[None, :, None] * xc
 
 
 def fastvim_mixer_oracle(p, hidden, token_size, tokens_per_patch=1, collapse_method="mean",
                          scaling_factor=1, use_norm_after_ssm=True, ln_eps=1e-5,
-                         compute_dtype=torch.float64, out_dtype=None):
+                         compute_dtype=torch.float64, out_dtype=None, storage_dtype=None):
     """p: dict of tensors keyed like the reference mixer's state_dict
     (``in_proj.weight``, ``conv1d.weight`` (d_in,1,W), ``conv1d.bias``, ``x_proj.weight``,
     ``dt_proj.weight``, ``dt_proj.bias``, ``A_log``, ``D``, the same with ``_b``,
     ``layernorm.weight/bias``, ``out_proj.weight``, optional ``gamma``).
-    hidden: (B, L, d_model) with L = rows*cols*tokens_per_patch.  Returns (B, L, d_model)."""
+    hidden: (B, L, d_model) with L = rows*cols*tokens_per_patch.  Returns (B, L, d_model).
+    ``storage_dtype`` (e.g. torch.bfloat16): emulate the autocast mode of the HIP path -- same math in
+    ``compute_dtype``, with a round trip through ``storage_dtype`` at every tensor the HIP path STORES in it: the
+    input, the projection weights (bf16 shadows), xz, the pooled conv output xc, x_dbl, the skip term
+    D*conv_f + D_b*conv_b (rounded once), the gated output g and the result.  Lets a bf16 parity test use a
+    tolerance of a few bf16 ulps instead of percent-level bounds."""
     cd = compute_dtype
     out_dtype = hidden.dtype if out_dtype is None else out_dtype
     rows, cols = token_size
     tpp = tokens_per_patch
     Bsz, L, d = hidden.shape
     assert L == rows * cols * tpp
+    rq = None if storage_dtype is None else (lambda t: t.to(storage_dtype).to(cd))
     W_in = p["in_proj.weight"].to(cd)
+    W_out = p["out_proj.weight"].to(cd)
+    hid = hidden.to(cd)
+    if rq is not None:
+        W_in, W_out, hid = rq(W_in), rq(W_out), rq(hid)
     d_in = W_in.shape[0] // 2
-    xz = hidden.to(cd) @ W_in.t()                                        # :189-193
+    xz = hid @ W_in.t()                                                  # :189-193
     if p.get("in_proj.bias") is not None:
         xz = xz + p["in_proj.bias"].to(cd)
+    if rq is not None:
+        xz = rq(xz)
     x = xz[..., :d_in].permute(0, 2, 1)                                  # (B, d_in, L)
     z = xz[..., d_in:]                                                   # (B, L, d_in)
-    out_f = _direction(x, p, "", rows, cols, tpp, collapse_method, scaling_factor, False, cd)
-    out_b = _direction(x, p, "_b", rows, cols, tpp, collapse_method, scaling_factor, True, cd)
-    o = ((out_f + out_b) / 2).permute(0, 2, 1)                           # :434-444
+    out_f = _direction(x, p, "", rows, cols, tpp, collapse_method, scaling_factor, False, cd, rq)
+    out_b = _direction(x, p, "_b", rows, cols, tpp, collapse_method, scaling_factor, True, cd, rq)
+    if rq is not None:                                                   # (y_f + y_b + round(D conv_f + D_b conv_b)) / 2
+        o = ((out_f[0] + out_b[0] + rq(out_f[1] + out_b[1])) / 2).permute(0, 2, 1)
+    else:
+        o = ((out_f + out_b) / 2).permute(0, 2, 1)                       # :434-444
     if use_norm_after_ssm:
         o = F.layer_norm(o, (d_in,), p["layernorm.weight"].to(cd), p["layernorm.bias"].to(cd), ln_eps)
     g = o * F.silu(z)
-    y = g @ p["out_proj.weight"].to(cd).t()
+    if rq is not None:
+        g = rq(g)
+    y = g @ W_out.t()
     if p.get("out_proj.bias") is not None:
         y = y + p["out_proj.bias"].to(cd)
     if p.get("gamma") is not None:                                       # :455-456
