@@ -61,8 +61,18 @@ __device__ __forceinline__ void flush_partials(const BwdParams& p, float* smem, 
   }
 }
 
+// Where a row lives: descriptors of its batch element and the token offsets of the row and of its two neighbours.
+// A row past the end gets zero-length descriptors: its (prefetch) loads return zeros and touch no memory.
+struct RowSrc {
+  __amdgpu_buffer_rsrc_t bx, bd;
+  int pooled_off;            // byte offset of row i's forward pooled gradient in dxc
+  int m_row, s_up, s_dn;
+  bool up, down;
+  int b;
+};
+
 template <typename T, int NT>
-__global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int nch, int RG) {
+__global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_pool_bwd_row_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
   typedef PairVec<T, 1> P;
   const int lane = threadIdx.x & 63;
@@ -71,13 +81,6 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
   const int c_lo = blockIdx.y * nch * 128;             // channels beyond 1024 are split over blockIdx.y
   const int c0 = c_lo + (cw * 64 + lane) * 2;          // first channel of this lane's pair
   const Geo g = p.geo;
-  f2 wf[CW], wb[CW], bf, bb, Dfh, Dbh;
-  load_taps2(p.wf, c0, wf);
-  load_taps2(p.wb, c0, wb);
-  bf = load_f2(p.bf, c0);
-  bb = load_f2(p.bb, c0);
-  Dfh = load_f2(p.Df, c0) * 0.5f;
-  Dbh = load_f2(p.Db, c0) * 0.5f;
   f2 a_wf[CW], a_wb[CW], a_bf = splat(0.f), a_bb = splat(0.f), a_Df = splat(0.f), a_Db = splat(0.f);
 #pragma unroll
   for (int k = 0; k < CW; ++k) a_wf[k] = a_wb[k] = splat(0.f);
@@ -86,86 +89,137 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_row_kernel(BwdParams p, int
   const int nit = (nrows + gridDim.x * RG - 1) / (gridDim.x * RG);
   const int tok_x = 2 * p.d_in * (int)sizeof(T), tok_d = p.d_in * (int)sizeof(T);   // bytes per token
   const int voff = c0 * (int)sizeof(T);
+  const __amdgpu_buffer_rsrc_t bp = fv_make_buf(p.dxc, 2 * dstride * 4);    // both directions' pooled gradients
+  auto locate = [&](int row) {
+    const bool ok = row < nrows;
+    const int r = ok ? row : 0;
+    const int b = r / g.rows, i = r - b * g.rows;
+    RowSrc s;
+    s.b = b;
+    s.bx = fv_make_buf((const T*)p.xz + (size_t)b * g.L * 2 * p.d_in, ok ? (size_t)g.L * tok_x : 0);
+    s.bd = fv_make_buf((const T*)p.dob_in + (size_t)b * g.L * p.d_in, ok ? (size_t)g.L * tok_d : 0);
+    s.up = i > 0;
+    s.down = i + 1 < g.rows;
+    s.m_row = i * g.s_i;
+    s.s_up = s.up ? -g.s_i : 0;            // a missing neighbour row reads this row (always mapped) and is masked
+    s.s_dn = s.down ? g.s_i : 0;
+    s.pooled_off = (b * g.rows + i) * p.d_in * 4;
+    return s;
+  };
+  // packed tokens, positions q = -3 .. NT+2 of a row (index q + 3).  The row being worked on was loaded while the
+  // previous one was: every register is refilled with the NEXT row's token as soon as this row has unpacked it, so a
+  // wave always has a whole row of loads in flight under its arithmetic.
+  P xr[NT + 6], dr[NT + 6];
+  auto fetch = [&](const RowSrc& s, int k) {
+    const int di = k < 3 ? -1 : (k >= NT + 3 ? 1 : 0);
+    const int j = k - 3 - di * NT;
+    const int m = s.m_row + (di < 0 ? s.s_up : di > 0 ? s.s_dn : 0) + j * g.s_j;
+    xr[k].load(s.bx, voff, m * tok_x);
+    dr[k].load(s.bd, voff, m * tok_d);
+  };
+  // pooled gradient of row i - 1 + r around row s (unscaled: the multiply by pool_scale, or by 0 for a missing row,
+  // waits for the load and is placed at the first use)
+  auto pooled = [&](const RowSrc& s, int r, bool backward) {
+    const bool ok = r == 1 || (r == 0 ? s.up : s.down);
+    uint32_t w[2];
+    fv_buf_load_words<2>(bp, c0 * 4, s.pooled_off + (ok ? (r - 1) * p.d_in * 4 : 0) + (backward ? (int)dstride * 4 : 0), w);
+    f2 o;
+    o.x = __uint_as_float(w[0]);
+    o.y = __uint_as_float(w[1]);
+    return o;
+  };
+  auto row_of = [&](int it) { return (it * gridDim.x + blockIdx.x) * RG + rg; };
+  RowSrc cur = locate(row_of(0));
+  // Pooled gradients: the forward conv needs rows i (positions of this row) and i+1 (the three halo positions
+  // behind it), the backward conv rows i-1 and i.  All are loaded unscaled, one row ahead, in the order of their
+  // first use -- here exactly as in the loop, so that the waits the compiler places at the top of the loop body (one
+  // count for both ways in) find them oldest: row i's pair at the top of the previous iteration, row i-1's after its
+  // last use (step -1), row i+1's at the end.
+  f2 cf_mid_raw = pooled(cur, 1, false), cb_mid_raw = pooled(cur, 1, true);
+  f2 cb_up = pooled(cur, 0, true);
+  __builtin_amdgcn_sched_barrier(0);      // (the scheduler would issue these last)
+#pragma unroll
+  for (int k = 0; k < NT + 6; ++k) fetch(cur, k);
+  __builtin_amdgcn_sched_barrier(0);
+  f2 cf_dn = pooled(cur, 2, false);
+  // the per-channel parameters go out behind the first row: one exposed round trip at the start of a wave, not two
+  // (an absent bias / D is read from the taps and multiplied by zero: no branch around the load, no wait inside it)
+  f2 wf[CW], wb[CW], bf, bb, Dfh, Dbh;
+  load_taps2(p.wf, c0, wf);
+  load_taps2(p.wb, c0, wb);
+  bf = load_f2(p.bf ? p.bf : p.wf, c0) * (p.bf ? 1.f : 0.f);
+  bb = load_f2(p.bb ? p.bb : p.wf, c0) * (p.bb ? 1.f : 0.f);
+  Dfh = load_f2(p.Df ? p.Df : p.wf, c0) * (p.Df ? 0.5f : 0.f);
+  Dbh = load_f2(p.Db ? p.Db : p.wf, c0) * (p.Db ? 0.5f : 0.f);
   for (int it = 0; it < nit; ++it) {
-    const int row = (it * gridDim.x + blockIdx.x) * RG + rg;
-    if (row < nrows) {          // uniform per wave; no block-level sync inside
-      const int b = row / g.rows, i = row - b * g.rows;
-      const __amdgpu_buffer_rsrc_t bx = fv_make_buf((const T*)p.xz + (size_t)b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
-      const __amdgpu_buffer_rsrc_t bd = fv_make_buf((const T*)p.dob_in + (size_t)b * g.L * p.d_in, (size_t)g.L * tok_d);
-      const __amdgpu_buffer_rsrc_t bo = fv_make_buf((T*)p.dxz + (size_t)b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
-      const int m_row = i * g.s_i;
-      const bool up = i > 0, down = i + 1 < g.rows;
-      const int s_up = up ? -g.s_i : 0, s_dn = down ? g.s_i : 0;
-      // positions q = -3 .. NT+2 of row i  (index q + 3)
-      P xr[NT + 6], dr[NT + 6];
+    if (row_of(it) >= nrows) break;          // uniform per wave; no block-level sync inside
+    const RowSrc nxt = locate(row_of(it + 1));
+    const __amdgpu_buffer_rsrc_t bo = fv_make_buf((T*)p.dxz + (size_t)cur.b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
+    const bool up = cur.up, down = cur.down;
+    const int m_row = cur.m_row;
+    const f2 cf_mid = cf_mid_raw * p.pool_scale, cb_mid = cb_mid_raw * p.pool_scale;
+    cf_mid_raw = pooled(nxt, 1, false);
+    cb_mid_raw = pooled(nxt, 1, true);
+    cb_up *= cur.up ? p.pool_scale : 0.f;
+    f2 x[NT + 6], dov[NT + 6], dpf[NT + 6], dpb[NT + 6];   // index q + 3; live ranges are 4 steps (full unroll)
+    const float m_up = up ? 1.f : 0.f, m_dn = down ? 1.f : 0.f;
 #pragma unroll
-      for (int k = 0; k < NT + 6; ++k) {
-        const int di = k < 3 ? -1 : (k >= NT + 3 ? 1 : 0);
-        const int j = k - 3 - di * NT;
-        const int m = m_row + (di < 0 ? s_up : di > 0 ? s_dn : 0) + j * g.s_j;
-        xr[k].load(bx, voff, m * tok_x);
-        dr[k].load(bd, voff, m * tok_d);
+    for (int k = 0; k < 3; ++k) {
+      x[k] = xr[k].get(0) * m_up;
+      dov[k] = dr[k].get(0);
+      dpf[k] = dpb[k] = splat(0.f);
+      fetch(nxt, k);
+    }
+#pragma unroll
+    for (int n = -3; n < NT; ++n) {
+      // step n: pre_f of position n+3 and pre_b of position n, both from x[n .. n+3]
+      const int q3 = n + 3, k0 = n + 3, k3 = n + 6;             // array indices of positions n and n+3
+      x[k3] = xr[k3].get(0);
+      if (q3 >= NT) x[k3] *= m_dn;
+      dov[k3] = dr[k3].get(0);
+      fetch(nxt, k3);
+      f2 pf = bf, pb = bb;
+#pragma unroll
+      for (int k = 0; k < CW; ++k) {
+        pf = fma2(wf[k], x[k0 + k], pf);             // pre_f[n+3] = b + sum_k w[k] x[n+k]
+        pb = fma2(wb[k], x[k3 - k], pb);             // pre_b[n]   = b + sum_k w[k] x[n+3-k]
       }
-      f2 dcf[3], dcb[3];   // pooled gradients of rows i-1, i, i+1 (x pool_scale; 0 for a missing row)
+      const f2 sgf = sigmoid2(pf), sgb = sigmoid2(pb);
+      const f2 dsf = sgf * fma2(pf, 1.f - sgf, splat(1.f)), dsb = sgb * fma2(pb, 1.f - sgb, splat(1.f));
+      // position n+3 / n missing (outside the sequence): its gradient is zero
+      const float e3 = q3 < NT ? 1.f : m_dn, e0 = n >= 0 ? 1.f : m_up;
+      if (q3 == NT) cf_dn *= cur.down ? p.pool_scale : 0.f;
+      const f2 nf = fma2(Dfh, dov[k3], q3 >= NT ? cf_dn : cf_mid) * dsf * e3;
+      const f2 nb = fma2(Dbh, dov[k0], n < 0 ? cb_up : cb_mid) * dsb * e0;
+      if (n == -1) cb_up = pooled(nxt, 0, true);
+      dpf[k3] = nf;
+      dpb[k0] = nb;
+      if (q3 < NT) {        // position n+3 belongs to this row: its parameter gradients are accumulated here
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const bool ok = r == 1 || (r == 0 ? up : down);
-        const float* dxc_r = p.dxc + ((size_t)b * g.rows + (ok ? i - 1 + r : i)) * p.d_in;
-        const float sc = ok ? p.pool_scale : 0.f;
-        dcf[r] = *reinterpret_cast<const f2*>(dxc_r + c0) * sc;
-        dcb[r] = *reinterpret_cast<const f2*>(dxc_r + dstride + c0) * sc;
+        for (int k = 0; k < CW; ++k) a_wf[k] = fma2(nf, x[k0 + k], a_wf[k]);
+        a_bf += nf;
+        a_Df = fma2(dov[k3] * 0.5f, pf * sgf, a_Df);
       }
-      f2 x[NT + 6], dov[NT + 6], dpf[NT + 6], dpb[NT + 6];   // index q + 3; live ranges are 4 steps (full unroll)
-      const float m_up = up ? 1.f : 0.f, m_dn = down ? 1.f : 0.f;
+      if (n >= 0) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        x[k] = xr[k].get(0) * m_up;
-        dov[k] = dr[k].get(0);
-        dpf[k] = dpb[k] = splat(0.f);
-      }
-#pragma unroll
-      for (int n = -3; n < NT; ++n) {
-        // step n: pre_f of position n+3 and pre_b of position n, both from x[n .. n+3]
-        const int q3 = n + 3, k0 = n + 3, k3 = n + 6;             // array indices of positions n and n+3
-        x[k3] = xr[k3].get(0);
-        if (q3 >= NT) x[k3] *= m_dn;
-        dov[k3] = dr[k3].get(0);
-        f2 pf = bf, pb = bb;
+        for (int k = 0; k < CW; ++k) a_wb[k] = fma2(nb, x[k3 - k], a_wb[k]);
+        a_bb += nb;
+        a_Db = fma2(dov[k0] * 0.5f, pb * sgb, a_Db);
+        // dx[n] = sum_k wf[k] dpre_f[n+3-k] + wb[k] dpre_b[n-3+k]
+        f2 dx = splat(0.f);
 #pragma unroll
         for (int k = 0; k < CW; ++k) {
-          pf = fma2(wf[k], x[k0 + k], pf);             // pre_f[n+3] = b + sum_k w[k] x[n+k]
-          pb = fma2(wb[k], x[k3 - k], pb);             // pre_b[n]   = b + sum_k w[k] x[n+3-k]
+          dx = fma2(wf[k], dpf[k3 - k], dx);
+          dx = fma2(wb[k], dpb[k0 - 3 + k], dx);
         }
-        const f2 sgf = sigmoid2(pf), sgb = sigmoid2(pb);
-        const f2 dsf = sgf * fma2(pf, 1.f - sgf, splat(1.f)), dsb = sgb * fma2(pb, 1.f - sgb, splat(1.f));
-        // position n+3 / n missing (outside the sequence): its gradient is zero
-        const float e3 = q3 < NT ? 1.f : m_dn, e0 = n >= 0 ? 1.f : m_up;
-        const f2 nf = fma2(Dfh, dov[k3], dcf[q3 >= NT ? 2 : 1]) * dsf * e3;
-        const f2 nb = fma2(Dbh, dov[k0], dcb[n < 0 ? 0 : 1]) * dsb * e0;
-        dpf[k3] = nf;
-        dpb[k0] = nb;
-        if (q3 < NT) {        // position n+3 belongs to this row: its parameter gradients are accumulated here
-#pragma unroll
-          for (int k = 0; k < CW; ++k) a_wf[k] = fma2(nf, x[k0 + k], a_wf[k]);
-          a_bf += nf;
-          a_Df = fma2(dov[k3] * 0.5f, pf * sgf, a_Df);
-        }
-        if (n >= 0) {
-#pragma unroll
-          for (int k = 0; k < CW; ++k) a_wb[k] = fma2(nb, x[k3 - k], a_wb[k]);
-          a_bb += nb;
-          a_Db = fma2(dov[k0] * 0.5f, pb * sgb, a_Db);
-          // dx[n] = sum_k wf[k] dpre_f[n+3-k] + wb[k] dpre_b[n-3+k]
-          f2 dx = splat(0.f);
-#pragma unroll
-          for (int k = 0; k < CW; ++k) {
-            dx = fma2(wf[k], dpf[k3 - k], dx);
-            dx = fma2(wb[k], dpb[k0 - 3 + k], dx);
-          }
-          { const f2 dxa[1] = {dx}; P::store(bo, voff, (m_row + n * g.s_j) * tok_x, dxa); }
-        }
+        { const f2 dxa[1] = {dx}; P::store(bo, voff, (m_row + n * g.s_j) * tok_x, dxa); }
       }
+      // the prefetch stays in the step that freed its registers: left alone, the scheduler sinks every load of the
+      // iteration to its end (shorter live ranges) and the next iteration starts by waiting for all of them
+      __builtin_amdgcn_sched_barrier(0);
     }
+    cf_dn = pooled(nxt, 2, false);
+    cur = nxt;
   }
   flush_partials(p, smem, c0, c_lo, nch * 128, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
 }
@@ -395,14 +449,18 @@ int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t
   // nch counts 128-channel waves (a lane owns a channel pair)
   if (p.d_in != nch * 128) return FV_ERR_UNSUPPORTED;
   if ((size_t)p.geo.L * 2 * p.d_in * 4 > 0xfffff000ull) return FV_ERR_UNSUPPORTED;   // one batch element per descriptor
+  if ((size_t)p.B * p.geo.rows * p.d_in * 8 > 0x7ffff000ull) return FV_ERR_UNSUPPORTED;   // pooled gradients: one descriptor, int offsets
   const bool chan8 = p.geo.tpp == 8 && p.geo.pcols >= 2;
   const bool dense8 = p.geo.tpp == 1 && p.geo.cols % 8 == 0 && p.geo.cols >= 24;      // 512 / 1024 / 2048 px grids
   int groups = (nch + 7) / 8;                   // channel groups of at most 8 waves over blockIdx.y
   while (nch % groups) ++groups;
   const int nchg = nch / groups;
-  // rows live in registers: blocks of <= 512 threads (256 VGPRs per wave), i.e. fewer row groups per block than the
-  // generic kernel, over the same persistent grid
-  const int cap = 8 / nchg < 1 ? 1 : 8 / nchg;
+  // rows live in registers: blocks of <= 512 threads (256 VGPRs per wave) for the long-row kernels and fp32 storage,
+  // <= 768 (168) for the bf16 14-token whole-row kernel, i.e. fewer row groups per block than the generic kernel, over
+  // the same persistent grid
+  const bool long_rows = chan8 || dense8;
+  const int wmax = (long_rows || dtype == FV_F32 || p.geo.cols > 14) ? 8 : 12;
+  const int cap = wmax / nchg < 1 ? 1 : wmax / nchg;
   const int rgr = rg < cap ? rg : cap;
   if (chan8 || dense8) {
     static const bool chan = (fv_tune("FASTVIM_BWD_CHAN", 1) != 0);   // tuning hook

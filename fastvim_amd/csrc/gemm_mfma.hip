@@ -18,6 +18,7 @@
 // roles swapped (weight-side operand in the A slot), which leaves each lane with 4 consecutive output
 // columns of one row: the epilogue stores 8-byte (bf16) / 16-byte (fp32) vectors.
 #include <stdlib.h>
+#include <utility>
 
 #include "common.h"
 
@@ -159,26 +160,49 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int blk, int ks, int lan
 // every <KC, KS> (data-gradient) GEMM.  As inline asm the reads carry no memory operand; the price is that their
 // completion is ours to wait for: all the reads of one staged tile (both 32-deep k steps) are issued, then one
 // s_waitcnt lgkmcnt(0), then empty asm statements that pin every consumer behind that wait.
+template <int OFF>
+__device__ __forceinline__ unsigned long long ds_read_tr16_b64(uint32_t a) {
+  unsigned long long v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// The swizzle code of a lane's k row does not change with the 32-deep k step nor between its low and high 4-row
+// halves (ks_swz reads bits 0, 1 and 3 of k; those offsets move bits 2 and 5), so a lane has ONE address per 16-wide
+// block and every read of a staged tile is that address plus an instruction immediate.
 template <int EXT, int NB>
 struct KsFrags {
   unsigned long long lo[BK / 32][NB], hi[BK / 32][NB];
-  __device__ __forceinline__ void read(const char* lds, int blk0, int lane) {
+  uint32_t addr[NB];
+  __device__ __forceinline__ void init(const char* lds, int blk0, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
     const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+    const int kl = g * 8 + q;
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      const int kl = ks * 32 + g * 8 + q, kh = kl + 4;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const uint32_t al = base + kl * (EXT * 2) + (((blk0 + b) ^ ks_swz<EXT>(kl)) << 5) + pp * 8;
-        const uint32_t ah = base + kh * (EXT * 2) + (((blk0 + b) ^ ks_swz<EXT>(kh)) << 5) + pp * 8;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[ks][b]) : "v"(al));
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[ks][b]) : "v"(ah));
-      }
-    }
+    for (int b = 0; b < NB; ++b) addr[b] = base + kl * (EXT * 2) + (((blk0 + b) ^ ks_swz<EXT>(kl)) << 5) + pp * 8;
+  }
+  // the tile staged `off` bytes behind the one init() was given
+  __device__ __forceinline__ void read(uint32_t off) {
+    static_for<BK / 32>([&](auto ks) {
+      static_for<NB>([&](auto b) {
+        const uint32_t a = addr[b] + off;
+        lo[ks][b] = ds_read_tr16_b64<ks * 32 * EXT * 2>(a);
+        hi[ks][b] = ds_read_tr16_b64<ks * 32 * EXT * 2 + 4 * EXT * 2>(a);
+      });
+    });
   }
   __device__ __forceinline__ void wait() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pin();
+  }
+  // every consumer of the fragments behind the s_waitcnt that precedes this in program order
+  __device__ __forceinline__ void pin() {
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks)
 #pragma unroll
@@ -229,22 +253,29 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
 #pragma unroll
     for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  constexpr bool OPA = GLDS && AMODE == KS, OPB = GLDS && BMODE == KS;
+  KsFrags<BM, OPA ? MB : 1> ka;
+  KsFrags<BN, OPB ? NB : 1> kb;
+  if constexpr (OPA) ka.init(sA(0), wm * MB, lane);
+  if constexpr (OPB) kb.init(sB(0), wn * NB, lane);
   auto compute = [&](int cur) {
-    // LDS-DMA staging with a K-slow B: opaque transposing reads (see KsFrags)
-    constexpr bool OPQ = GLDS && AMODE == KC && BMODE == KS;
-    KsFrags<BN, OPQ ? NB : 1> kb;
-    if constexpr (OPQ) {
-      kb.read(sB(cur), wn * NB, lane);
-      kb.wait();
-    }
+    // LDS-DMA staging with a K-slow operand: opaque transposing reads (see KsFrags)
+    if constexpr (OPA) ka.read(cur * (A_BYTES + B_BYTES));
+    if constexpr (OPB) kb.read(cur * (A_BYTES + B_BYTES));
+    if constexpr (OPA) ka.wait();
+    else if constexpr (OPB) kb.wait();
+    if constexpr (OPA && OPB) kb.pin();
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 fa[MB], fb[NB];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) fa[i] = frag<AMODE, BM>(sA(cur), wm * MB + i, ks, lane);
+      for (int i = 0; i < MB; ++i) {
+        if constexpr (OPA) fa[i] = ka.get(ks, i);
+        else fa[i] = frag<AMODE, BM>(sA(cur), wm * MB + i, ks, lane);
+      }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        if constexpr (OPQ) fb[i] = kb.get(ks, i);
+        if constexpr (OPB) fb[i] = kb.get(ks, i);
         else fb[i] = frag<BMODE, BN>(sB(cur), wn * NB + i, ks, lane);
       }
 #pragma unroll
@@ -369,7 +400,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
 }
 
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmParams p) {
   gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB>(p, blockIdx.x, blockIdx.z);
 }
 
@@ -384,7 +415,7 @@ struct GroupedParams {
 };
 
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_grouped_kernel(GroupedParams G, int xcd_order) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_grouped_kernel(GroupedParams G, int xcd_order) {
   // Hardware block g runs on XCD g % 8.  The workgroups of one (problem, K slice) read the same token range of both
   // operands: in the logical order [problem][slice][tile] they are neighbours, so XCD x takes the x-th eighth of that
   // order (neighbours share an XCD and its L2, and start together) instead of every eighth workgroup -- with the
@@ -426,7 +457,9 @@ int launch(const GemmParams& p, int splits, hipStream_t st) {
   static const bool allow = (fv_tune("FASTVIM_GEMM_GLDS", 1) != 0);   // tuning hook
   // (measured: a win for K-contiguous A -- forward and data-gradient GEMMs, -8..-20 % -- and a loss for the
   //  K-slow x K-slow weight-gradient form, +10 %, which keeps register staging)
-  const bool whole = AMODE == KC && p.K % BK == 0 && p.k_per_split % BK == 0 && (BMODE == KC || p.N >= 8);
+  static const bool ks_glds = (fv_tune("FASTVIM_WGRAD_GLDS", 1) != 0);   // tuning hook
+  const bool whole = (AMODE == KC || (ks_glds && p.M >= 8)) && p.K % BK == 0 && p.k_per_split % BK == 0 &&
+                     (BMODE == KC || p.N >= 8);
   if (allow && whole) return launch_k<AMODE, BMODE, WM, WN, true>(p, splits, st);
   return launch_k<AMODE, BMODE, WM, WN, false>(p, splits, st);
 }
@@ -507,6 +540,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_stream_kernel(GemmParams p,
 #pragma unroll
     for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  KsFrags<BN, BMODE == KS ? NB : 1> kb;
+  if constexpr (BMODE == KS) kb.init(smem + A_BYTES, wn * NB, lane);
 #pragma unroll
   for (int j = 0; j < S - 1; ++j) issue_next();
   int kt = 0, tile = 0, slot = 0;
@@ -521,9 +556,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_stream_kernel(GemmParams p,
     issue_next();                       // stage s + S - 1 -> the slot stage s - 1 was read from
     const char* sA = smem + slot * STAGE;
     const char* sB = sA + A_BYTES;
-    KsFrags<BN, BMODE == KS ? NB : 1> kb;
     if constexpr (BMODE == KS) {
-      kb.read(sB, wn * NB, lane);
+      kb.read(slot * STAGE);
       kb.wait();
     }
 #pragma unroll
@@ -648,6 +682,7 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
         p.N % 192 == 0 && (long)p.N * p.K <= 192 * 768)
       return launch_stream<BMODE, 2, 4, 3, 4, 3>(p, st);
   }
+#ifdef FASTVIM_TUNING_HOOKS      // tile-shape experiments that lost their A/B: tuning builds only
   if (tall && p.M >= 256 && p.N >= 128 && (AMODE != KC || whole_k)) {
     constexpr bool G = AMODE == KC;
     if (tall == 1) return launch_k<AMODE, BMODE, 2, 2, G, 4, 8>(p, splits, st);
@@ -658,6 +693,7 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
     if (tall == 6) return launch_k<AMODE, BMODE, 4, 2, G, 4, 4>(p, splits, st);     // 8 waves of 64x64: 256x128
     if (tall == 7 && p.N % 192 == 0) return launch_k<AMODE, BMODE, 4, 2, G, 6, 4>(p, splits, st);   // 8 waves of 64x96: 256x192
   }
+#endif
   // FastVim-B in_proj forward (N = 3072, K = 768): eight waves of 128x64 on a 256x256 tile, -10 % (161 -> 144 us);
   // measured slower at every FastVim-T/S shape and for the data-gradient forms, which keep the 4-wave tiles
   static const bool big = (fv_tune("FASTVIM_GEMM_BIG", 1) != 0);   // tuning hook
@@ -674,8 +710,10 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
     return launch_k<AMODE, BMODE, 2, 2, true, 6>(p, splits, st);
   // 128x128 everywhere else: with LDS-DMA staging the 256x64 shape no longer pays at N = 192 (measured equal or
   // up to 8 % slower); it stays available for tuning
+#ifdef FASTVIM_TUNING_HOOKS
   static const int force = fv_tune("FASTVIM_GEMM_TILE", 0);   // 41 = 256x64
   if (force == 41 && p.M >= 256) return launch<AMODE, BMODE, 4, 1>(p, splits, st);
+#endif
   return launch<AMODE, BMODE, 2, 2>(p, splits, st);
 }
 
@@ -747,6 +785,7 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
     G.count = n;
     static const int tile = fv_tune("FASTVIM_WGRAD_GROUP_TILE", 0);   // tuning hook
     static const int xcd_order = fv_tune("FASTVIM_WGRAD_GROUP_XCD", 1);   // tuning hook
+#ifdef FASTVIM_TUNING_HOOKS
     if (tile == 7) {          // 8 waves, 256x192 tiles (every N = 192 problem reads its wide operand once)
       int b2 = 0;
       for (int i = 0; i < n; ++i) {
@@ -761,9 +800,23 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
       }
       hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 4, 2, false, 6, 4>), dim3(b2), dim3(512),
                          (size_t)2 * (256 + 192) * BK * 2, st, G, xcd_order);
-    } else {
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256),
-                         (size_t)2 * (128 + 128) * BK * 2, st, G, xcd_order);
+    } else
+#endif
+    {
+      (void)tile;
+      // LDS-DMA staging needs whole 64-deep K tiles in every slice and whole 16-byte column groups
+      static const bool ks_glds = (fv_tune("FASTVIM_WGRAD_GLDS", 1) != 0);   // tuning hook
+      bool dma = ks_glds;
+      for (int i = 0; i < n; ++i) {
+        const GemmParams& q = G.p[i];
+        dma = dma && q.K % BK == 0 && q.k_per_split % BK == 0 && q.M % 8 == 0 && q.N % 8 == 0;
+      }
+      if (dma)
+        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 4>), dim3(blocks), dim3(256),
+                           (size_t)2 * (128 + 128) * BK * 2, st, G, xcd_order);
+      else
+        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256),
+                           (size_t)2 * (128 + 128) * BK * 2, st, G, xcd_order);
     }
     FV_LAUNCH_CHECK();
   }
