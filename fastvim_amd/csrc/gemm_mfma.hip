@@ -36,13 +36,15 @@ struct GemmParams {
   const bf16_t* A;
   const bf16_t* B;
   void* C;
-  const float* bias;     // (N) fp32, nullable, added in the epilogue
+  const float* bias;     // (N) fp32, nullable, added in the epilogue; with rb_period > 0 a (rb_period, N) table instead
   int M, N, K;
+  int rb_period;         // > 0: fp32 C only, C[m][n] = bf16_round(product) + bias[(m mod rb_period) * N + n]
   long lda, ldb, ldc;
   int k_per_split;       // K range of one grid.z slice (multiple of BK)
   int c_fp32;            // 1: C is fp32, else bf16
   long c_split_stride;   // elements between split-K partials
 };
+static_assert(sizeof(GemmParams) == 88, "40 of these plus the prefix table must fit the 4 KiB kernel-argument limit");
 
 // KS tiles: rows (k) are EXT*2 bytes = a multiple of the 256-byte bank row, and a transposing read
 // touches 8 different k rows at one column per 32-lane half -> 8-way conflict.  XOR the 32-byte
@@ -329,7 +331,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
   }
   // epilogue: acc[a][b][j] = C[m = m0 + wm*WMR + b*16 + (lane&15)][n = n0 + wn*WNC + a*16 + (lane>>4)*4 + j]
   const long zoff = (long)split * p.c_split_stride;
-  if (p.bias) {
+  if (p.bias && p.rb_period <= 0) {
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
       const int n = n0 + wn * WNC + a * 16 + (lane >> 4) * 4;
@@ -390,7 +392,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     for (int a = 0; a < NB; ++a) {
       const int n = n0 + wn * WNC + a * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
-      const f32x4 v = acc[a][b];
+      f32x4 v = acc[a][b];
+      if (p.rb_period > 0) {      // what a bf16 F.linear followed by an fp32 add of a per-token table returns (patch embed)
+        const float* t = p.bias + (long)(m % p.rb_period) * p.N + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < p.N) v[j] = bf16_bits_to_f32(f32_to_bf16_bits(v[j])) + t[j];
+      }
       float* dst = (float*)p.C + zoff + (long)m * p.ldc + n;
       if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
       else
@@ -719,9 +727,25 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
 
 }  // namespace
 
+static int gemm_entry(const void* A, const void* B, void* C, const float* bias, int rb_period, int M, int N, int K,
+                      long lda, long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits,
+                      fv_stream_t stream);
+
 extern "C" int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K,
                             long lda, long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits,
                             fv_stream_t stream) {
+  return gemm_entry(A, B, C, bias, 0, M, N, K, lda, ldb, ldc, a_k_slow, b_k_slow, c_fp32, splits, stream);
+}
+
+extern "C" int fv_gemm_bf16_rowbias(const void* A, const void* B, float* C, const float* table, int period, int M, int N,
+                                    int K, long lda, long ldb, long ldc, fv_stream_t stream) {
+  FV_CHECK(table && period > 0, "gemm_bf16_rowbias: needs a (period, N) table");
+  return gemm_entry(A, B, C, table, period, M, N, K, lda, ldb, ldc, 0, 0, 1, 1, stream);
+}
+
+static int gemm_entry(const void* A, const void* B, void* C, const float* bias, int rb_period, int M, int N, int K,
+                      long lda, long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits,
+                      fv_stream_t stream) {
   FV_CHECK(A && B && C, "gemm_bf16: null pointer");
   FV_CHECK(M > 0 && N > 0 && K > 0 && splits >= 1, "gemm_bf16: empty problem");
   FV_CHECK(lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16: leading dimensions must be multiples of 8 (16-byte rows)");
@@ -732,7 +756,7 @@ extern "C" int fv_gemm_bf16(const void* A, const void* B, void* C, const float* 
   FV_CHECK(b_k_slow ? N % 8 == 0 : K % 8 == 0, "gemm_bf16: B's contiguous extent must be a multiple of 8");
   GemmParams p{};
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.c_fp32 = c_fp32;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.c_fp32 = c_fp32; p.rb_period = rb_period;
   int kps = fv_cdiv(fv_cdiv(K, splits), BK) * BK;
   p.k_per_split = kps;
   p.c_split_stride = (long)M * ldc;

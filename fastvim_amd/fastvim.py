@@ -20,7 +20,8 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
-from .mamba_simple_faster import LinearFn, Mamba, _compute_dtype
+from . import glue_ops as G
+from .mamba_simple_faster import LinearFn, Mamba, _compute_dtype, _direct_grad, _shadow, linear_wgrad
 from .mixer_ops import reduce_partials
 
 
@@ -52,6 +53,56 @@ class _EmbedEpilogueFn(torch.autograd.Function):
             if ctx.has[0]:
                 dbias = reduce_partials(per_tok.view(Ltok, D), Ltok)                  # then over tokens
         return g.to(ctx.lin_dtype), dbias, dpos
+
+
+class _PatchProjFn(torch.autograd.Function):
+    """patches (B, L, K) bf16 -> fp32 (B, L, D) = bf16_round(patches @ W^T) + bias (D) + pos (1, L, D): the patch
+    projection (models/fastvim.py:95), the conv bias and the ``x + pos_embed`` of :500 in ONE GEMM whose epilogue adds a
+    per-token table -- bit for bit what ``LinearFn`` followed by ``_EmbedEpilogueFn`` returns, without their two
+    full-length passes.  Backward: the fixed-order batch / token sums go straight into the flat gradients when the
+    parameters have them."""
+
+    @staticmethod
+    def forward(ctx, patches, W, bias, pos, cdt):
+        B, Ltok, K = patches.shape
+        D = W.shape[0]
+        with torch.autocast("cuda", enabled=False):
+            if pos is not None:
+                table = pos.float().reshape(Ltok, D)
+                if bias is not None:
+                    table = table + bias.float()
+            else:
+                table = bias.float().reshape(1, D)
+            y = G.gemm_rowbias(patches.view(B * Ltok, K), _shadow(W, cdt).reshape(D, K), table.contiguous())
+        ctx.save_for_backward(patches, W, bias, pos)
+        ctx.cdt = cdt
+        return y.view(B, Ltok, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        patches, W, bias, pos = ctx.saved_tensors
+        B, Ltok, K = patches.shape
+        D = W.shape[0]
+        with torch.autocast("cuda", enabled=False):
+            g = g.contiguous()
+            dpos = dbias = None
+            per_tok = reduce_partials(g.view(B, Ltok * D), B)                               # sum over batch, (Ltok*D,)
+            if pos is not None and ctx.needs_input_grad[3]:
+                gd = _direct_grad(pos)
+                if gd is not None:
+                    reduce_partials(per_tok.view(1, Ltok * D), 1, out=gd.view(-1), accumulate=True)
+                else:
+                    dpos = per_tok.view(1, Ltok, D)
+            if bias is not None and ctx.needs_input_grad[2]:
+                gd = _direct_grad(bias)
+                if gd is not None:
+                    reduce_partials(per_tok.view(Ltok, D), Ltok, out=gd.view(-1), accumulate=True)
+                else:
+                    dbias = reduce_partials(per_tok.view(Ltok, D), Ltok)                    # then over tokens
+            dW = linear_wgrad(g.view(B * Ltok, D).to(ctx.cdt), patches.view(B * Ltok, K), W)
+            if dW is not None:
+                dW = dW.view(W.shape)
+        return None, dW, dbias, dpos, None
 
 
 def to_2tuple(v):
@@ -94,7 +145,11 @@ class DropPath(nn.Module):
                                 for m in mods], dtype=torch.float32, device=device)[:, None]
             cache[key] = (keep, inv)
         keep, inv = cache[key]
-        table = torch.rand(len(mods), batch, device=device, dtype=torch.float32).add_(keep).floor_().mul_(inv)
+        table = torch.rand(len(mods), batch, device=device, dtype=torch.float32)
+        if table.is_cuda:
+            G.droppath_table_(table, keep, inv)          # floor(keep + U) * inv in one launch
+        else:
+            table.add_(keep).floor_().mul_(inv)
         for i, m in enumerate(mods):
             m.__dict__["_pre"] = table[i]
 
@@ -168,8 +223,17 @@ class PatchEmbed(nn.Module):
         cdt = _compute_dtype(x)
         # unfold and cast in ONE strided copy (fp32 image read once, compute-dtype patches written once); the GEMM then
         # needs no second pass over the patches
-        patches = torch.empty(B, gh * gw, C * ph * pw, device=x.device, dtype=cdt)
-        patches.view(B, gh, gw, C, ph, pw).copy_(x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5))
+        if G.patch_unfold_ok(x, ph, pw) and cdt in (torch.float32, torch.bfloat16):
+            patches = G.patch_unfold(x, ph, pw, cdt)                # one HIP launch through LDS: 16-byte accesses both ways
+        else:
+            patches = torch.empty(B, gh * gw, C * ph * pw, device=x.device, dtype=cdt)
+            patches.view(B, gh, gw, C, ph, pw).copy_(x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5))
+        D = self.proj.weight.shape[0]
+        if (x.is_cuda and cdt == torch.bfloat16 and self.flatten and self.scanpath_type != "colwise"
+                and (pos_embed is not None or self.proj.bias is not None) and (C * ph * pw) % 8 == 0 and D % 8 == 0
+                and isinstance(self.norm, nn.Identity)):
+            # projection + conv bias + position embedding in one GEMM (row-periodic table in the epilogue)
+            return _PatchProjFn.apply(patches, self.proj.weight, self.proj.bias, pos_embed, cdt)
         x = LinearFn.apply(patches, self.proj.weight, cdt)          # (B, gh*gw, D), weight viewed (D, C*ph*pw)
         if self.scanpath_type == "colwise":
             x = x.reshape(B, gh, gw, -1).transpose(1, 2).reshape(B, gh * gw, -1)
@@ -376,6 +440,8 @@ class VisionMamba(nn.Module):
         if self.final_pool_type == "none":
             return hidden_states[:, -1, :]
         elif self.final_pool_type == "mean":
+            if G.mean_pool_ok(hidden_states):
+                return G.MeanPoolFn.apply(hidden_states)
             return hidden_states.mean(dim=1)
         elif self.final_pool_type in ("max", "all"):
             return hidden_states

@@ -129,6 +129,12 @@ class FlatTrainingState:
             if isinstance(mod, (RMSNorm, torch.nn.LayerNorm, torch.nn.Linear, torch.nn.Conv2d)) and getattr(mod, "weight", None) is not None:
                 if mod.weight.requires_grad:
                     mod.weight._fv_direct = True     # my backward kernels may accumulate into .grad directly
+                b = getattr(mod, "bias", None)
+                if isinstance(mod, (torch.nn.Linear, torch.nn.Conv2d)) and b is not None and b.requires_grad:
+                    b._fv_direct = True              # LinearFn / the patch projection sum their bias gradient in place
+        pe = getattr(model, "pos_embed", None)
+        if isinstance(pe, torch.nn.Parameter) and pe.requires_grad:
+            pe._fv_direct = True                     # (the patch projection's per-token table gradient)
         self.refresh_shadow()
         # ``model.load_state_dict`` writes the fp32 masters in place: re-cast the shadow right away (the version check in
         # ``_shadow`` would also catch it at the next forward, but a captured HIP graph never runs that check again)

@@ -36,6 +36,9 @@ class _SoftTargetCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
+        if ctx.x_dtype in (torch.float32, torch.bfloat16) and g.dtype == torch.float32 and g.numel() == 1:
+            from .glue_ops import scale_cast
+            return scale_cast(dx, g, ctx.x_dtype), None           # scale by the upstream scalar and cast, one launch
         return (dx * g).to(ctx.x_dtype), None
 
 

@@ -172,6 +172,7 @@ class LinearFn(torch.autograd.Function):
         ctx.a_shape, ctx.a_dtype, ctx.cdt = a.shape, a.dtype, cdt
         ctx.need_da = a.requires_grad
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         return y.view(*a.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -185,7 +186,18 @@ class LinearFn(torch.autograd.Function):
             dW = linear_wgrad(g2, a2, W)
             if dW is not None:
                 dW = dW.view(W.shape)
-            db = g2.float().sum(0) if ctx.has_bias else None
+            db = None
+            if ctx.has_bias:
+                bias = ctx.bias_ref
+                gd = _direct_grad(bias) if bias is not None else None
+                if g2.is_cuda and g2.dtype in (torch.float32, torch.bfloat16):
+                    from .glue_ops import column_sum
+                    if gd is not None:
+                        column_sum(g2, out=gd.view(-1), accumulate=True)     # straight into the flat gradient
+                    else:
+                        db = column_sum(g2)
+                else:
+                    db = g2.float().sum(0)
         return da, dW, None, db
 
 

@@ -311,6 +311,32 @@ int fv_soft_target_ce(const void* logits, int logits_dtype, const float* target,
                       float* dlogits, int batch, int classes, fv_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Small memory-bound ops around the backbone (csrc/glue.hip): each replaces a string of library elementwise /
+ * reduce launches of the reference step.
+ * ---------------------------------------------------------------------- */
+/* The k == stride patch-embed Conv2d (models/fastvim.py:95) as a GEMM: its A operand, unfolded and cast in one pass.
+ *   out[b][gi*gw + gj][(c*ph + pi)*pw + pj] = img[b][c][gi*ph + pi][gj*pw + pj]
+ * img (batch, chans, height, width), out (batch, gh*gw, chans*ph*pw); fp32 or bf16 each; pw % 8 == 0. */
+int fv_patch_unfold(const void* img, int img_dtype, void* out, int out_dtype, int batch, int chans, int height,
+                    int width, int ph, int pw, fv_stream_t stream);
+/* fv_gemm_bf16(a_k_slow = b_k_slow = 0) with fp32 C = bf16_round(A B^T) + table[(m mod period)][n]: the patch
+ * projection with conv bias and position embedding added in the epilogue (models/fastvim.py:95-101, 500) -- the
+ * value an autocast F.linear followed by the fp32 add returns.  table (period, N) fp32. */
+int fv_gemm_bf16_rowbias(const void* A, const void* B, float* C, const float* table, int period, int M, int N, int K,
+                         long lda, long ldb, long ldc, fv_stream_t stream);
+/* final_pool_type == "mean" (models/fastvim.py:529-531): out[b][d] = mean_l x[b][l][d] (fp32 sum, fixed order) and its
+ * adjoint dx[b][l][d] = g[b][d] / tokens.  x (batch, tokens, dim), dim % 4 == 0, one dtype throughout. */
+int fv_mean_pool_fwd(const void* x, void* out, int batch, int tokens, int dim, int dtype, fv_stream_t stream);
+int fv_mean_pool_bwd(const void* g, void* dx, int batch, int tokens, int dim, int dtype, fv_stream_t stream);
+/* Stochastic depth (timm DropPath, models/fastvim.py:175-178): table (mods, batch) holds U[0,1) draws on entry and
+ * floor(keep[m] + U) * inv_keep[m] on return -- one row of per-sample scales per DropPath module. */
+int fv_droppath_table(float* table, const float* keep, const float* inv_keep, int mods, int batch, fv_stream_t stream);
+/* y[i] = x[i] * scale[0] (device scalar), cast to y_dtype: the loss gradient handed to the head. */
+int fv_scale_cast(const float* x, const float* scale, void* y, int y_dtype, size_t n, fv_stream_t stream);
+/* out[c] (+)= sum_r x[r][c], x (rows, cols) fp32 or bf16, fixed order: a bias gradient. */
+int fv_column_sum(const void* x, int dtype, float* out, int rows, int cols, int accumulate, fv_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Fused AdamW (decoupled weight decay, bias correction; torch.optim.AdamW semantics) over a flat fp32
  * parameter buffer, optionally updating an EMA copy (timm ModelEmaV2: ema = d*ema + (1-d)*p) and the
  * bf16 shadow weights in the same pass.  Replaces the optimizer + EMA + autocast casts of the
