@@ -46,6 +46,19 @@ struct GemmParams {
 };
 static_assert(sizeof(GemmParams) == 88, "40 of these plus the prefix table must fit the 4 KiB kernel-argument limit");
 
+// Epilogue of the out_proj GEMM fused with the NEXT block's residual add + RMSNorm (fv_gemm_bf16_addnorm): one tile is
+// BN = N = 192 wide, so a workgroup owns whole rows.
+struct NormEpi {
+  const float* residual;   // (M, N) fp32
+  const float* w;          // (N) RMSNorm weight
+  const float* row_scale;  // per-sample DropPath scale of the GEMM output, nullable
+  float* res_out;          // (M, N) fp32: residual + scale * bf16_round(product)
+  bf16_t* y;               // (M, N) normalised rows
+  float* rstd;             // (M)
+  int rows_per_scale;
+  float eps;
+};
+
 // KS tiles: rows (k) are EXT*2 bytes = a multiple of the 256-byte bank row, and a transposing read
 // touches 8 different k rows at one column per 32-lane half -> 8-way conflict.  XOR the 32-byte
 // column chunk with a per-row code so those 8 rows land on 8 different chunks.
@@ -225,8 +238,8 @@ struct KsFrags {
 // MB = 8 (128-row wave tiles, 256-row block tiles) is for the compute-bound FastVim-S/B widths: a k-step of a
 // 64x64 wave tile reads 8 KiB of fragments for 16 MFMAs -- at the full MFMA rate that is exactly the 128 B/clk the
 // LDS delivers -- while a 128x64 wave tile reads 12 KiB for 32.
-template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4, bool XREMAP = true>
-__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id, int split) {
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4, bool XREMAP = true, bool NORM_EPI = false>
+__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id, int split, const NormEpi* ne = nullptr) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN, WNC = 16 * NB, WMR = 16 * MB;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -254,6 +267,21 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
   for (int a = 0; a < NB; ++a)
 #pragma unroll
     for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // add + norm epilogue: the residual rows this lane will add are requested now and arrive under the K loop
+  constexpr int NE_IT = NORM_EPI ? BM / 4 / 8 : 1;
+  float4 ne_r[NE_IT][2][3];
+  if constexpr (NORM_EPI) {
+    const int lr = lane % 16, gr = lane / 16;
+#pragma unroll
+    for (int it = 0; it < NE_IT; ++it)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row = m0 + wv * (BM / 4) + it * 8 + u * 4 + gr, rowc = row < p.M ? row : p.M - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          ne_r[it][u][k] = *reinterpret_cast<const float4*>(ne->residual + (size_t)rowc * BN + (k * 16 + lr) * 4);
+      }
+  }
 
   constexpr bool OPA = GLDS && AMODE == KS, OPB = GLDS && BMODE == KS;
   KsFrags<BM, OPA ? MB : 1> ka;
@@ -343,6 +371,94 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
       }
     }
   }
+  if constexpr (NORM_EPI) {
+    // ---- residual add + RMSNorm of the tile's rows (what fv_add_norm_fwd does to the bf16 GEMM output, same lane
+    //      mapping and operation order as add_norm_fwd3_kernel<16>): the product is rounded to bf16 into an LDS tile,
+    //      then a wave step takes 4 rows x 16 lanes x (3 x 4) channels.
+    static_assert(BN == 192 && WM * WN == 4 && BM % 32 == 0, "whole 192-wide rows, four waves");
+    constexpr int RSB = BN * 2 + 16, LPR = 16, RPW = 4, RU = 2, RW = BM / 4;   // RW rows per wave
+    __syncthreads();                                  // all waves are done reading the operand tiles
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        const f32x4 v = acc[a][b];
+        uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<uint2*>(smem + (wm * WMR + b * 16 + (lane & 15)) * RSB + (wn * WNC + a * 16 + (lane >> 4) * 4) * 2) = pk;
+      }
+    __syncthreads();
+    const int lr = lane % LPR, gr = lane / LPR;
+    const float inv_n = 1.f / (float)BN;
+    float w[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 t = *reinterpret_cast<const float4*>(ne->w + (k * LPR + lr) * 4);
+      w[k][0] = t.x; w[k][1] = t.y; w[k][2] = t.z; w[k][3] = t.w;
+    }
+#pragma unroll
+    for (int it = 0; it < RW / (RPW * RU); ++it) {
+      float v[RU][3][4], r[RU][3][4], sc_u[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int rl = wv * RW + it * (RPW * RU) + u * RPW + gr;       // row of the tile
+        const int row = m0 + rl, rowc = row < p.M ? row : p.M - 1;
+        sc_u[u] = ne->row_scale ? ne->row_scale[rowc / ne->rows_per_scale] : 1.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int c = (k * LPR + lr) * 4;
+          const uint2 xb = *reinterpret_cast<const uint2*>(smem + rl * RSB + c * 2);
+          v[u][k][0] = __uint_as_float(xb.x << 16); v[u][k][1] = __uint_as_float(xb.x & 0xffff0000u);
+          v[u][k][2] = __uint_as_float(xb.y << 16); v[u][k][3] = __uint_as_float(xb.y & 0xffff0000u);
+          const float4 t = ne_r[it][u][k];
+          r[u][k][0] = t.x; r[u][k][1] = t.y; r[u][k][2] = t.z; r[u][k][3] = t.w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int row = m0 + wv * RW + it * (RPW * RU) + u * RPW + gr;
+        const bool live = row < p.M;
+        const size_t base = (size_t)(live ? row : p.M - 1) * BN;
+        const float sc = sc_u[u];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int c = (k * LPR + lr) * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][k][e] = fmaf(v[u][k][e], sc, r[u][k][e]);
+          if (live) *reinterpret_cast<float4*>(ne->res_out + base + c) = make_float4(v[u][k][0], v[u][k][1], v[u][k][2], v[u][k][3]);
+        }
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q = fmaf(v[u][k][e], v[u][k][e], q);
+        // 16-lane row sum: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+#define FV_DPP_ADD(ctrl) q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), ctrl, 0xf, 0xf, true))
+        FV_DPP_ADD(0xB1);
+        FV_DPP_ADD(0x4E);
+        FV_DPP_ADD(0x141);
+        FV_DPP_ADD(0x140);
+#undef FV_DPP_ADD
+        const float rstd = rsqrtf(q * inv_n + ne->eps);
+        if (lr == 0 && live) ne->rstd[row] = rstd;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int c = (k * LPR + lr) * 4;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = v[u][k][e] * rstd;          // (r * rstd) * w, pinned: the order add_norm_fwd3_kernel uses
+            asm volatile("" : "+v"(t));
+            o[e] = t * w[k][e];
+          }
+          if (live) {
+            uint2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *reinterpret_cast<uint2*>(ne->y + base + c) = pk;
+          }
+        }
+      }
+    }
+    return;
+  }
   if (!p.c_fp32) {
     // bf16 C: the wave's WMR x WNC tile goes through LDS (32-row slabs, rows padded by 16 B) so that
     // every global store is 16 B per lane and a wave instruction writes whole 128-byte row segments
@@ -410,6 +526,11 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmParams p) {
   gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB>(p, blockIdx.x, blockIdx.z);
+}
+
+template <int BMROWS>
+__global__ __launch_bounds__(256, 2) void gemm_addnorm_kernel(GemmParams p, NormEpi ne) {
+  gemm_bf16_body<KC, KC, 2, 2, true, 6, BMROWS / 32, true, true>(p, blockIdx.x, 0, &ne);
 }
 
 // Several independent problems in ONE launch (the weight gradients of a whole backward pass, queued until its end):
@@ -768,6 +889,43 @@ static int gemm_entry(const void* A, const void* B, void* C, const float* bias, 
   if (a_k_slow && b_k_slow) return launch_shape<KS, KS>(p, splits, st);
   fv_set_error("gemm_bf16: A K-slow with B K-contiguous is not built");
   return FV_ERR_UNSUPPORTED;
+}
+
+extern "C" int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* residual, const float* norm_weight,
+                                    const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd,
+                                    int M, int N, int K, long lda, long ldw, float eps, fv_stream_t stream) {
+  FV_CHECK(A && W && residual && norm_weight && y && residual_out && rstd, "gemm_bf16_addnorm: null pointer");
+  FV_CHECK(M > 0 && K > 0, "gemm_bf16_addnorm: empty problem");
+  if (N != 192 || K % BK != 0) return FV_ERR_UNSUPPORTED;      // whole 192-wide rows per workgroup, LDS-DMA staging
+  FV_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
+               ((uintptr_t)residual & 15) == 0 && ((uintptr_t)residual_out & 15) == 0 && ((uintptr_t)y & 7) == 0,
+           "gemm_bf16_addnorm: operands must be 16-byte aligned with row strides multiples of 8");
+  FV_CHECK(!row_scale || rows_per_scale > 0, "gemm_bf16_addnorm: rows_per_scale must be positive");
+  GemmParams p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = y; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = N; p.c_fp32 = 0;
+  p.k_per_split = K;
+  NormEpi ne{residual, norm_weight, row_scale, residual_out, (bf16_t*)y, rstd, rows_per_scale > 0 ? rows_per_scale : 1, eps};
+  hipStream_t st = (hipStream_t)stream;
+  auto go = [&](auto bm) {
+    constexpr int BMR = decltype(bm)::value;
+    const size_t smem = (size_t)2 * (BMR + 192) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_addnorm_kernel<BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_addnorm_kernel<BMR>), dim3(fv_cdiv(M, BMR)), dim3(256), smem, st, p, ne);
+  };
+#ifdef FASTVIM_TUNING_HOOKS
+  static const int bm = fv_tune("FASTVIM_ADDNORM_BM", 64);
+  if (bm == 32) go(std::integral_constant<int, 32>{});
+  else if (bm == 128) go(std::integral_constant<int, 128>{});
+  else
+#endif
+  go(std::integral_constant<int, 64>{});
+  FV_LAUNCH_CHECK();
+  return FV_OK;
 }
 
 // Grouped weight gradients: problem i is x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32,

@@ -335,7 +335,13 @@ __global__ __launch_bounds__(256) void add_norm_fwd3_kernel(NormParams p) {
         const int c = (k * LPR + lr) * 4;
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[u][k][e] - mu) * rstd * w[k][e] + (p.b ? bb[k][e] : 0.f);
+        for (int e = 0; e < 4; ++e) {
+          // ((r - mu) * rstd) * w, in this order whatever -ffast-math would like: fv_gemm_bf16_addnorm's epilogue
+          // repeats it and must round the same way
+          float t = (v[u][k][e] - mu) * rstd;
+          asm volatile("" : "+v"(t));
+          o[e] = t * w[k][e] + (p.b ? bb[k][e] : 0.f);
+        }
         if (live) st4(p.y, p.y_dt, base + c, o);
       }
     }

@@ -21,7 +21,8 @@ from torch import Tensor
 
 from .layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
 from . import glue_ops as G
-from .mamba_simple_faster import LinearFn, Mamba, _compute_dtype, _direct_grad, _shadow, linear_wgrad
+from .mamba_simple_faster import (LinearFn, Mamba, OutProjAddNormFn, _compute_dtype, _direct_grad, _shadow, linear_wgrad,
+                                  out_proj_add_norm_ok)
 from .mixer_ops import reduce_partials
 
 
@@ -419,7 +420,47 @@ class VisionMamba(nn.Module):
             DropPath.predraw([l.drop_path for l in self.layers] + [self.drop_path], x.shape[0], x.device)
         return x, (H, W)
 
+    def _chainable(self, hidden_states, lo, hi, inference_params, out_indices):
+        """Blocks lo .. hi-1 can run with every interior ``out_proj`` fused into the next block's add + RMSNorm."""
+        if inference_params is not None or out_indices is not None or hi - lo < 2 or not hidden_states.is_cuda:
+            return False
+        if _compute_dtype(hidden_states) != torch.bfloat16 or self.embed_dim != 192:
+            return False
+        for blk in self.layers[lo:hi]:
+            mx = blk.mixer
+            if (type(blk) is not Block or type(mx) is not Mamba or not blk.fused_add_norm or not blk.residual_in_fp32
+                    or not isinstance(blk.norm, RMSNorm) or blk.norm.bias is not None or mx.init_layer_scale is not None
+                    or mx.out_proj.bias is not None or mx.out_proj.weight.shape[1] % 64):
+                return False
+        return True
+
+    def _run_layers_chained(self, hidden_states, residual, lo, hi):
+        """Same values as the plain loop: block i's mixer stops at its gated activations, and ``out_proj`` runs inside the
+        GEMM that also does block i+1's DropPath scale + residual add + RMSNorm (``OutProjAddNormFn``); the range is
+        closed by a plain ``out_proj``."""
+        cdt = _compute_dtype(hidden_states)
+        pend = None                               # (gated activations, out_proj weight) of the previous block
+        for layer_idx in range(lo, hi):
+            blk = self.layers[layer_idx]
+            scale = None
+            if residual is not None and isinstance(blk.drop_path, DropPath):
+                scale = blk.drop_path.row_scale(hidden_states if pend is None else pend[0])
+            if pend is not None and out_proj_add_norm_ok(pend[0], pend[1], residual, blk.norm.weight, cdt):
+                hidden_states, residual = OutProjAddNormFn.apply(pend[0], pend[1], residual, blk.norm.weight,
+                                                                 float(blk.norm.eps), scale, cdt)
+            else:
+                if pend is not None:
+                    hidden_states = LinearFn.apply(pend[0], pend[1], cdt)
+                hidden_states, residual = layer_norm_fn(
+                    hidden_states, blk.norm.weight, blk.norm.bias, residual=residual, eps=blk.norm.eps, prenorm=True,
+                    residual_in_fp32=blk.residual_in_fp32, is_rms_norm=True, row_scale=scale, out_dtype=cdt)
+            rot = blk.rotate_every_block is True and blk.layer_idx % 2 != 0
+            pend = (blk.mixer(hidden_states, transposed_grid=rot, defer_out_proj=True), blk.mixer.out_proj.weight)
+        return LinearFn.apply(pend[0], pend[1], cdt), residual
+
     def _run_layers(self, hidden_states, residual, lo, hi, inference_params=None, out_indices=None, outs=None):
+        if self._chainable(hidden_states, lo, hi, inference_params, out_indices):
+            return self._run_layers_chained(hidden_states, residual, lo, hi)
         for layer_idx in range(lo, hi):
             hidden_states, residual = self.layers[layer_idx](hidden_states, residual, inference_params=inference_params)
             if out_indices is not None and layer_idx in out_indices:

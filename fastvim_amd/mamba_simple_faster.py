@@ -8,6 +8,7 @@ channel-last HIP kernels (csrc/mixer_fwd.hip, csrc/mixer_bwd.hip) with a hand-wr
 backward; activations stay token-major so in_proj/out_proj are plain row-major GEMMs, and the
 odd-layer grid transpose of ``Block`` is a stride pair, not a copy (``transposed_grid``).
 """
+import ctypes
 import math
 
 import torch
@@ -201,6 +202,82 @@ class LinearFn(torch.autograd.Function):
         return da, dW, None, db
 
 
+class OutProjAddNormFn(torch.autograd.Function):
+    """(g (B, L, d_in) bf16, W_out (d, d_in), residual (B, L, d) fp32, norm weight (d)) -> (normed (B, L, d) bf16,
+    residual_out fp32): a mixer's ``out_proj`` (mamba_simple_faster.py:435-444) and the NEXT block's DropPath scale +
+    residual add + RMSNorm (models/fastvim.py:168-190) in one GEMM whose epilogue owns whole rows -- bit for bit
+    ``gemm_nt`` followed by ``fv_add_norm_fwd``, without the out_proj output ever reaching HBM.  Backward is the two
+    adjoints back to back (add + norm, then the data and weight gradients of out_proj)."""
+
+    @staticmethod
+    def forward(ctx, g, W_out, residual, norm_w, eps, row_scale, cdt):
+        L.require_gpu(g, W_out, residual, norm_w)
+        B, Ltok, d_in = g.shape
+        d = W_out.shape[0]
+        Mrows = B * Ltok
+        with torch.autocast("cuda", enabled=False):
+            g2 = g.view(Mrows, d_in)
+            res2 = residual.reshape(Mrows, d).contiguous()
+            w32 = norm_w.float().contiguous()
+            y = torch.empty(Mrows, d, device=g.device, dtype=cdt)
+            res_out = torch.empty(Mrows, d, device=g.device, dtype=torch.float32)
+            rstd = torch.empty(Mrows, device=g.device, dtype=torch.float32)
+            rows_per_scale = 1
+            if row_scale is not None:
+                row_scale = row_scale.float().contiguous()
+                rows_per_scale = Mrows // row_scale.numel()
+            rc = L.lib().fv_gemm_bf16_addnorm(
+                L.ptr(g2), L.ptr(_shadow(W_out, cdt)), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
+                L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
+                ctypes.c_long(d_in), ctypes.c_float(eps), L.stream_of(g2))
+            L.check(rc, "gemm_bf16_addnorm")
+        ctx.save_for_backward(g, W_out, res_out, w32, rstd, row_scale)
+        ctx.rows_per_scale = rows_per_scale
+        ctx.cdt = cdt
+        ctx.shape = (B, Ltok, d)
+        ctx.w_param = norm_w
+        return y.view(B, Ltok, d), res_out.view(B, Ltok, d)
+
+    @staticmethod
+    def backward(ctx, dy, dres_out):
+        g, W_out, r, w32, rstd, row_scale = ctx.saved_tensors
+        B, Ltok, d = ctx.shape
+        Mrows, d_in = B * Ltok, g.shape[2]
+        cdt, dev = ctx.cdt, g.device
+        with torch.autocast("cuda", enabled=False):
+            dy = dy.reshape(Mrows, d).contiguous()
+            dres_out = dres_out.reshape(Mrows, d).contiguous() if dres_out is not None else None
+            dx = torch.empty(Mrows, d, device=dev, dtype=cdt)            # gradient of the out_proj output
+            dres_in = torch.empty(Mrows, d, device=dev, dtype=torch.float32)
+            lib = L.lib()
+            nb = lib.fv_add_norm_blocks(L.i32(Mrows))
+            pw = torch.empty(nb, d, device=dev, dtype=torch.float32)
+            rc = lib.fv_add_norm_bwd(
+                L.ptr(dy), L.i32(L.dtype_code(dy.dtype)), L.ptr(dres_out),
+                L.i32(L.dtype_code(dres_out.dtype) if dres_out is not None else 0), L.ptr(r), L.i32(L.FV_F32),
+                L.ptr(w32), L.ptr(None), L.ptr(rstd), L.ptr(row_scale), L.i32(ctx.rows_per_scale), L.ptr(dx),
+                L.i32(L.dtype_code(cdt)), L.ptr(dres_in), L.i32(L.FV_F32), L.ptr(pw), L.ptr(None), L.i32(Mrows), L.i32(d),
+                L.i32(1), L.stream_of(r))
+            L.check(rc, "add_norm_bwd")
+            gd = _direct_grad(ctx.w_param)
+            if gd is not None:
+                M.reduce_partials(pw, nb, out=gd.view(-1), accumulate=True)
+                dw = None
+            else:
+                dw = M.reduce_partials(pw, nb).to(ctx.w_param.dtype)
+            g2 = g.view(Mrows, d_in)
+            dg = linear_dgrad(dx, _shadow(W_out, cdt)).view(B, Ltok, d_in)
+            dW_out = _SideStream.run(lambda: linear_wgrad(dx, g2, W_out), dx, g)
+        return dg, dW_out, dres_in.view(B, Ltok, d), dw, None, None, None
+
+
+def out_proj_add_norm_ok(g, W_out, residual, norm_w, cdt):
+    """The fused kernel owns whole 192-wide rows and stages through LDS-DMA (K % 64 == 0)."""
+    return (g.is_cuda and cdt == torch.bfloat16 and g.dtype == torch.bfloat16 and g.is_contiguous()
+            and W_out.shape[0] == 192 and W_out.shape[1] % 64 == 0 and residual is not None
+            and residual.dtype == torch.float32 and norm_w.dtype == torch.float32)
+
+
 def _compute_dtype(t):
     """bf16/fp16 under torch.autocast (reference: mamba_simple_faster.py:312-318), else the input dtype."""
     if torch.is_autocast_enabled():
@@ -226,7 +303,8 @@ class FastVimMixerFn(torch.autograd.Function):
         d_in = W_in.shape[0] // 2
         with torch.autocast("cuda", enabled=False):
             h_c = hidden.to(cdt).contiguous()
-            W_in_c, W_out_c = _shadow(W_in, cdt), _shadow(W_out, cdt)
+            W_in_c = _shadow(W_in, cdt)
+            W_out_c = _shadow(W_out, cdt) if W_out is not None else None
             xz = linear_fwd(h_c.view(B * Ltok, d), W_in_c, b_in).view(B, Ltok, 2 * d_in)  # (B, L, 2 d_in)
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             amax = None
@@ -255,7 +333,9 @@ class FastVimMixerFn(torch.autograd.Function):
                 x_dbl = M.xproj_fwd(xc, Wx2_c)                                           # (2, B*Lc, R+2N)
                 yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
             g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
-            out = linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
+            # W_out None: out_proj is the caller's (fused with the next block's add + norm, OutProjAddNormFn); the
+            # gated activations g (B, L, d_in) are returned and their gradient comes back as ``dout``
+            out = g if W_out is None else linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
         ctx.save_for_backward(h_c, W_in, cw, cb, cw_b, cb_b, Wx2, Wdt, bdt, Wdt_b, bdt_b, A_log, A_b_log, D, D_b,
                               ln_w, ln_b, W_out, xz, xc, x_dbl, g, skip, yc, mean, rstd, amax)
         ctx.geo = (rows, cols, transposed, pool_max, scaling, tpp)
@@ -276,10 +356,13 @@ class FastVimMixerFn(torch.autograd.Function):
         fv = ctx.fv or {}
         with torch.autocast("cuda", enabled=False):
             dout = dout.to(cdt).contiguous()
-            do2 = dout.view(B * Ltok, d)
-            dg = linear_dgrad(do2, _shadow(W_out, cdt))                                  # (B*L, d_in)
-            dW_out = _SideStream.run(lambda: linear_wgrad(do2, g.view(B * Ltok, d_in), W_out), do2, g)
-            db_out = do2.float().sum(0) if ctx.has_bias[1] else None
+            if W_out is None:
+                dg, dW_out, db_out = dout.view(B * Ltok, d_in), None, None
+            else:
+                do2 = dout.view(B * Ltok, d)
+                dg = linear_dgrad(do2, _shadow(W_out, cdt))                              # (B*L, d_in)
+                dW_out = _SideStream.run(lambda: linear_wgrad(do2, g.view(B * Ltok, d_in), W_out), do2, g)
+                db_out = do2.float().sum(0) if ctx.has_bias[1] else None
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             dxz = torch.empty_like(xz)
             d_o, dyc, p1 = M.combine_bwd(dg, xz, skip, yc, ln_w, ln_b, mean, rstd, dxz, rows, cols, transposed,
@@ -417,8 +500,9 @@ class Mamba(nn.Module):
         self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
         self.pre_x_shape = (-1, self.d_inner, self.num_of_rows, self.num_of_col)
 
-    def forward(self, hidden_states, inference_params=None, transposed_grid=False):
-        """hidden_states: (B, L, D) -> (B, L, D).
+    def forward(self, hidden_states, inference_params=None, transposed_grid=False, defer_out_proj=False):
+        """hidden_states: (B, L, D) -> (B, L, D).  ``defer_out_proj``: return the gated activations (B, L, d_inner)
+        instead -- ``out_proj`` is then applied by the caller (``OutProjAddNormFn``: fused with the next block's add + norm).
 
         ``transposed_grid=False``: tokens are in this mixer's own (rows, cols) sequence order, exactly
         the reference contract.  ``transposed_grid=True``: tokens are in the *transposed* (cols, rows)
@@ -438,9 +522,13 @@ class Mamba(nn.Module):
             self.x_proj.weight, self.x_proj_b.weight,
             self.dt_proj.weight, self.dt_proj.bias, self.dt_proj_b.weight, self.dt_proj_b.bias,
             self.A_log, self.A_b_log, self.D, self.D_b, ln_w, ln_b,
-            self.out_proj.weight, self.out_proj.bias,
+            None if defer_out_proj else self.out_proj.weight, None if defer_out_proj else self.out_proj.bias,
             self.num_of_rows, self.num_of_col, bool(transposed_grid), self.collapse_method == "max",
             float(self.scaling_factor), float(ln_eps), cdt, self.__dict__.get("_fv"))
+        if defer_out_proj:
+            if self.init_layer_scale is not None or self.out_proj.bias is not None:
+                raise RuntimeError("defer_out_proj: layer scale / out_proj bias are applied after out_proj")
+            return out
         if self.init_layer_scale is not None:
             out = out * self.gamma
         return out

@@ -267,6 +267,17 @@ int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidual_out, int
 int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                  long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits, fv_stream_t stream);
 
+/* out_proj fused with the NEXT block's residual add + RMSNorm (mamba_simple_faster.py:435-444 followed by
+ * models/fastvim.py:168-190 / layernorm.py:66-121):
+ *   h = bf16_round(A W^T);  r = residual + row_scale[row / rows_per_scale] * h;  residual_out = r (fp32);
+ *   rstd[row] = rsqrt(mean_n r^2 + eps);  y = bf16(r * rstd * norm_weight)
+ * -- bit for bit fv_gemm_bf16 (bf16 C) followed by fv_add_norm_fwd (is_rms_norm), without writing and re-reading h.
+ * A (M, K) bf16, W (N, K) bf16, residual / residual_out (M, N) fp32, row_scale nullable.  Built for N == 192 and
+ * K % 64 == 0 (a workgroup owns whole rows); returns FV_ERR_UNSUPPORTED otherwise and the caller runs the two calls. */
+int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* residual, const float* norm_weight,
+                         const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd, int M,
+                         int N, int K, long lda, long ldw, float eps, fv_stream_t stream);
+
 /* Several weight gradients in one launch (queued until the end of the backward pass): problem i is
  * x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32 partials (sum with fv_reduce_partials);
  * the same arithmetic, tiling and fixed split order as fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1). */

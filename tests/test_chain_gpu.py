@@ -1,0 +1,70 @@
+"""out_proj fused with the next block's add + RMSNorm (fv_gemm_bf16_addnorm, OutProjAddNormFn) against the two-kernel
+path it replaces: same bits, forward and backward (mamba_simple_faster.py:435-444 + models/fastvim.py:168-190)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("B,Ltok,d_in,with_scale", [(4, 196, 384, True), (3, 50, 384, False), (2, 196, 128, True)])
+def test_out_proj_add_norm_fn_bitwise(B, Ltok, d_in, with_scale):
+    from fastvim_amd.layernorm import layer_norm_fn
+    from fastvim_amd.mamba_simple_faster import LinearFn, OutProjAddNormFn, out_proj_add_norm_ok
+    d = 192
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device=_dev(), generator=gen)
+    g0 = rn(B, Ltok, d_in).bfloat16()
+    res0 = rn(B, Ltok, d)
+    scale = (torch.rand(B, device=_dev(), generator=gen) > 0.3).float() / 0.7 if with_scale else None
+    dy, dres = rn(B, Ltok, d).bfloat16(), rn(B, Ltok, d)
+    outs = []
+    for fused in (True, False):
+        g = g0.clone().requires_grad_()
+        res = res0.clone().requires_grad_()
+        W = (rn(d, d_in) * 0 + torch.sin(torch.arange(d * d_in, device=_dev()).float()).view(d, d_in) * d_in ** -0.5).requires_grad_()
+        nw = (1 + 0.1 * torch.cos(torch.arange(d, device=_dev()).float())).requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if fused:
+                assert out_proj_add_norm_ok(g, W, res, nw, torch.bfloat16)
+                y, ro = OutProjAddNormFn.apply(g, W, res, nw, 1e-5, scale, torch.bfloat16)
+            else:
+                h = LinearFn.apply(g, W, torch.bfloat16)
+                y, ro = layer_norm_fn(h, nw, None, residual=res, eps=1e-5, prenorm=True, residual_in_fp32=True,
+                                      is_rms_norm=True, row_scale=scale, out_dtype=torch.bfloat16)
+        torch.autograd.backward((y, ro), (dy, dres))
+        outs.append((y.detach(), ro.detach(), g.grad, res.grad, W.grad, nw.grad))
+    names = ("normed", "residual_out", "d g", "d residual", "d W_out", "d norm weight")
+    for n, a, b in zip(names, *outs):
+        assert a.dtype == b.dtype and torch.equal(a, b), f"{n}: max |diff| {(a.float() - b.float()).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("drop_path", [0.0, 0.1])
+def test_chained_backbone_equals_block_by_block(drop_path):
+    """FastVim-T forward + backward with the chain on and off: logits and every parameter gradient bit-identical."""
+    from fastvim_amd import fastvim as fv
+    x = torch.randn(4, 3, 224, 224, device=_dev(), generator=torch.Generator(device="cuda").manual_seed(5))
+    tgt = torch.softmax(torch.randn(4, 1000, device=_dev(), generator=torch.Generator(device="cuda").manual_seed(6)), -1)
+    res = []
+    for chain in (True, False):
+        torch.manual_seed(0)
+        m = fv.FastVimT(img_size=224, drop_path_rate=drop_path).to(_dev()).train()
+        if not chain:
+            m._chainable = lambda *a, **k: False
+        else:
+            assert m._chainable(x.new_zeros(1, 196, 192), 0, len(m.layers), None, None) is False      # fp32 input: not under autocast
+        torch.manual_seed(123)                    # same DropPath draws
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if chain:
+                assert m._chainable(x.new_zeros(1, 196, 192), 0, len(m.layers), None, None)
+            logits = m(x)
+        loss = torch.sum(-tgt * torch.log_softmax(logits.float(), -1), -1).mean()
+        loss.backward()
+        res.append((logits.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys()
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
