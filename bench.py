@@ -181,14 +181,23 @@ def kernel_table(B, rows, cols, d, depth, dtype):
             "gemm_in_proj_dgrad": (lambda: gemm_nn(xz2, W_in), Mt, d, 2 * d_in, 0),
         }
         # weight gradients run as grouped launches of 16 problems at the end of backward: one
-        # launch of 8 in_proj + 8 out_proj problems is timed here (reductions of the fp32 partials included)
+        # launch of 8 in_proj + 8 out_proj problems is timed here (reductions of the fp32 partials included).  As in the
+        # step, every problem has its OWN operands (8 blocks' activations and gradients, 0.6 GB at FastVim-T): re-using
+        # one set eight times would keep it in the 256 MB Infinity Cache and time a different kernel
         from fastvim_amd.gemm import gemm_tn_grouped, grouped_splits
         from fastvim_amd.mixer_ops import flush_reductions
         sp = grouped_splits(Mt)
-        gi, go = torch.zeros(2 * d_in * d, device=dev), torch.zeros(d * d_in, device=dev)
+        nset = 8 if Mt * (3 * d_in + 2 * d) * 2 * 8 <= (4 << 30) else 1
+        sets = [(xz2, h2, do2, g2)] + [(rn(Mt, 2 * d_in), rn(Mt, d), rn(Mt, d), rn(Mt, d_in)) for _ in range(nset - 1)]
+        gis = [torch.zeros(2 * d_in * d, device=dev) for _ in range(8)]
+        gos = [torch.zeros(d * d_in, device=dev) for _ in range(8)]
+        group = []
+        for i in range(8):
+            a, b_, c_, e_ = sets[i % nset]
+            group += [(a, b_, gis[i], sp), (c_, e_, gos[i], sp)]
 
         def wgrad_group():
-            gemm_tn_grouped([(xz2, h2, gi, sp), (do2, g2, go, sp)] * 8)
+            gemm_tn_grouped(group)
             flush_reductions()
         t = time_kernel(wgrad_group)
         fl = 8 * 2.0 * Mt * (2 * d_in * d + d * d_in)

@@ -132,7 +132,10 @@ struct GldsPlan {
       } else {
         const int kq = e / (EXT / 8), cbp = (e % (EXT / 8)) * 16;
         const int cbl = ((((cbp >> 5) ^ ks_swz<EXT>(kq)) << 5) | (cbp & 16));
-        const int gc = min(r0 + cbl / 2, rmax - 8);
+        // whole 16-byte column groups: an extent that is not a multiple of 8 is rounded up into the row padding (the
+        // launcher checks ld covers it); those columns only feed output rows / columns that are never stored
+        const int rm8 = min((rmax + 7) & ~7, (int)ld);
+        const int gc = min(r0 + cbl / 2, rm8 - 8);
         src[i] = base + (long)kq * ld + gc;
       }
     }
@@ -584,8 +587,9 @@ template <int AMODE, int BMODE, int WM, int WN>
 int launch(const GemmParams& p, int splits, hipStream_t st) {
   // LDS-DMA staging needs whole 64-deep K tiles in every split and >= 8 columns in K-slow operands
   static const bool allow = (fv_tune("FASTVIM_GEMM_GLDS", 1) != 0);   // tuning hook
-  // (measured: a win for K-contiguous A -- forward and data-gradient GEMMs, -8..-20 % -- and a loss for the
-  //  K-slow x K-slow weight-gradient form, +10 %, which keeps register staging)
+  // (measured: forward and data-gradient GEMMs -8..-20 %; the K-slow x K-slow weight-gradient form lost 10 % while its
+  //  transposing reads were compiler-visible -- every K step waited for all LDS-DMA loads -- and gains 15 % with the
+  //  opaque immediate-offset reads of KsFrags)
   static const bool ks_glds = (fv_tune("FASTVIM_WGRAD_GLDS", 1) != 0);   // tuning hook
   const bool whole = (AMODE == KC || (ks_glds && p.M >= 8)) && p.K % BK == 0 && p.k_per_split % BK == 0 &&
                      (BMODE == KC || p.N >= 8);
@@ -976,11 +980,11 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
       }
       static bool attr = false;
       if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 4, 2, false, 6, 4>,
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 4, 2, true, 6, 4>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * BK * 2);
         attr = true;
       }
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 4, 2, false, 6, 4>), dim3(b2), dim3(512),
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 4, 2, true, 6, 4>), dim3(b2), dim3(512),
                          (size_t)2 * (256 + 192) * BK * 2, st, G, xcd_order);
     } else
 #endif
@@ -991,8 +995,11 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
       bool dma = ks_glds;
       for (int i = 0; i < n; ++i) {
         const GemmParams& q = G.p[i];
-        dma = dma && q.K % BK == 0 && q.k_per_split % BK == 0 && q.M % 8 == 0 && q.N % 8 == 0;
+        dma = dma && q.K % BK == 0 && q.k_per_split % BK == 0 && ((q.M + 7) & ~7) <= q.lda && ((q.N + 7) & ~7) <= q.ldb &&
+              q.M >= 8 && q.N >= 8;
       }
+      // (a deeper LDS ring -- 3 or 4 K tiles in flight, 4 or 8 waves -- changes nothing: with every operand byte coming
+      //  from HBM the launch runs at 3.1 TB/s, and a plain read-only stream of the same size gets 3.7 on this GPU)
       if (dma)
         hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 4>), dim3(blocks), dim3(256),
                            (size_t)2 * (128 + 128) * BK * 2, st, G, xcd_order);

@@ -146,7 +146,10 @@ class FlatTrainingState:
         defer_reductions(True)
         group_wgrads(True)
         # (weight-gradient GEMMs on a second stream, joined in finish_backward, measured neutral-to-slower on MI355X under
-        # graph replay -- 12.35 vs 12.04 ms/step: _SideStream stays off unless a caller switches it on)
+        # graph replay -- per GEMM 12.35 vs 12.04 ms/step in round 1; as groups of 8 / 16 / 32 problems launched while
+        # backward is still running 6.54 / 6.52 / 6.37 vs 6.16 ms in round 2: the MFMA groups and the latency-bound row /
+        # scan kernels slow each other down by more than the serial tail costs.  _SideStream stays off and the groups run
+        # after the last block unless a caller switches them on)
         _SideStream.enabled = False
 
     def close(self):
@@ -176,9 +179,10 @@ class FlatTrainingState:
         (``finish_backward`` / ``allreduce_mean_`` / ``FlatAdamW.step`` all finish it) would be computed only to be
         zeroed: it is dropped instead, with a warning."""
         _SideStream.join()
-        n = len(_GroupedWgrad.jobs) + pending_reductions()
+        n = len(_GroupedWgrad.jobs) + len(_GroupedWgrad.sums) + pending_reductions()
         if n:
             _GroupedWgrad.jobs = []
+            _GroupedWgrad.sums = []
             drop_reductions()
             warnings.warn(f"FlatTrainingState.zero_grad(): {n} queued gradient jobs of an unfinished backward pass "
                           "were discarded -- call finish_backward() (or allreduce_mean_() / optimizer.step()) after "
@@ -188,9 +192,9 @@ class FlatTrainingState:
     def finish_backward(self):
         """Join the weight-gradient stream and issue the queued gradient reductions; call after
         loss.backward(), before reading any .grad."""
-        _SideStream.join()
-        flush_wgrads()            # grouped weight-gradient GEMMs queue their partial sums ...
-        flush_reductions()        # ... which are issued here
+        flush_wgrads()            # the last group of weight-gradient GEMMs (earlier ones went out during backward), the
+                                  # join of the weight-gradient stream, their partial sums queued ...
+        flush_reductions()        # ... and issued here
 
     def refresh_shadow(self):
         """Re-cast every bf16 shadow weight from its fp32 master.  Needed only after writing ``param_flat`` directly

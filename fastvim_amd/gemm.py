@@ -87,12 +87,13 @@ def grouped_splits(Kd, target=None):
     return best
 
 
-def gemm_tn_grouped(jobs):
-    """jobs: list of (x (Kd, M) bf16, y (Kd, N) bf16, out flat fp32 view of (M, N), splits).  ONE launch per 16
+def gemm_tn_grouped(jobs, reduce=True):
+    """jobs: list of (x (Kd, M) bf16, y (Kd, N) bf16, out flat fp32 view of (M, N), splits).  ONE launch per 40
     problems computes every problem's split-K partials; the partials are then summed (deferred, fixed order) into
-    ``out`` (accumulate)."""
+    ``out`` (accumulate).  ``reduce=False``: the sums are left to the caller -- returns [(partials, splits, out)] (a launch
+    on a second stream must be joined before anything reads the partials)."""
     if not jobs:
-        return
+        return []
     k = len(jobs)
     parts = []
     for x, y, out, sp in jobs:
@@ -114,5 +115,9 @@ def gemm_tn_grouped(jobs):
     ldy = (I * k)(*[j[1].stride(0) for j in jobs])
     rc = L.lib().fv_gemm_bf16_tn_grouped_ld(xs, ys, ps, Kds, Ms, Ns, ldx, ldy, sps, L.i32(k), L.stream_of(jobs[0][0]))
     L.check(rc, "gemm_bf16_tn_grouped")
-    for (x, y, out, sp), part in zip(jobs, parts):
+    todo = [(part, sp, out) for (x, y, out, sp), part in zip(jobs, parts)]
+    if not reduce:
+        return todo
+    for part, sp, out in todo:
         reduce_partials(part, sp, out=out, accumulate=True)
+    return []

@@ -116,6 +116,9 @@ class _GroupedWgrad:
     split-K factor (less fp32 partial traffic) is affordable."""
     enabled = False
     jobs = []
+    # chunk > 0: a group is launched as soon as it holds that many problems (on the weight-gradient stream when there is
+    # one) instead of after the last block.  Measured slower at FastVim-T (flat.py), so off.
+    chunk = 0
 
     @classmethod
     def add(cls, g2, a2, out):
@@ -126,22 +129,40 @@ class _GroupedWgrad:
             # earlier one is issued first -- same-destination sums stay ordered, i.e. deterministic
             cls.flush()
         cls.jobs.append((g2, a2, out, grouped_splits(g2.shape[0])))
+        if cls.chunk and len(cls.jobs) >= cls.chunk:
+            cls.flush()
+
+    sums = []            # (partials, splits, out) of groups launched on the weight-gradient stream, not yet summed
 
     @classmethod
     def flush(cls):
         if cls.jobs:
             from .gemm import gemm_tn_grouped
             jobs, cls.jobs = cls.jobs, []
-            gemm_tn_grouped(jobs)
+            if _SideStream.enabled:
+                # only the GEMM goes to the second stream; its partials are summed after the join (reduce())
+                cls.sums += _SideStream.run(lambda: gemm_tn_grouped(jobs, reduce=False), jobs)
+            else:
+                gemm_tn_grouped(jobs)
+
+    @classmethod
+    def reduce(cls):
+        """After ``_SideStream.join()``: queue the fixed-order sums of the groups that ran on the second stream."""
+        sums, cls.sums = cls.sums, []
+        for part, sp, out in sums:
+            M.reduce_partials(part, sp, out=out, accumulate=True)
 
 
 def group_wgrads(on):
-    _GroupedWgrad.flush()
+    flush_wgrads()
     _GroupedWgrad.enabled = bool(on)
 
 
 def flush_wgrads():
+    """Launch the queued weight-gradient group, wait for the weight-gradient stream, queue the partial sums."""
     _GroupedWgrad.flush()
+    _SideStream.join()
+    _GroupedWgrad.reduce()
 
 
 def linear_wgrad(g2, a2, W=None, splits=None):

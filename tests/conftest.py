@@ -43,5 +43,6 @@ def _reset_flat_training_switches():
         mo._Deferred.enabled = False
     if mf is not None:
         mf._GroupedWgrad.jobs = []
+        mf._GroupedWgrad.sums = []
         mf._GroupedWgrad.enabled = False
         mf._SideStream.enabled = False
