@@ -242,7 +242,8 @@ struct KsFrags {
 // 64x64 wave tile reads 8 KiB of fragments for 16 MFMAs -- at the full MFMA rate that is exactly the 128 B/clk the
 // LDS delivers -- while a 128x64 wave tile reads 12 KiB for 32.
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4, bool XREMAP = true, bool NORM_EPI = false>
-__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id, int split, const NormEpi* ne = nullptr) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id, int split, const NormEpi* ne = nullptr,
+                                               int dbg = 0) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN, WNC = 16 * NB, WMR = 16 * MB;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -331,11 +332,19 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
       const int cur = t & 1;
+#ifdef FASTVIM_TUNING_HOOKS      // phase probe: dbg 1 = no multiply, 2 = no loads, 3 = loads of one K tile only (cache-resident)
+      if (t + 1 < nt && dbg != 2) {
+        ga.issue(sA(cur ^ 1), kbeg + (dbg == 3 ? 0 : (t + 1) * BK), tid);
+        gb.issue(sB(cur ^ 1), kbeg + (dbg == 3 ? 0 : (t + 1) * BK), tid);
+      }
+      if (dbg != 1) compute(cur);
+#else
       if (t + 1 < nt) {
         ga.issue(sA(cur ^ 1), kbeg + (t + 1) * BK, tid);
         gb.issue(sB(cur ^ 1), kbeg + (t + 1) * BK, tid);
       }
       compute(cur);
+#endif
       __syncthreads();
     }
   } else {
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_grouped_kernel(Grou
   // order (neighbours share an XCD and its L2, and start together) instead of every eighth workgroup -- with the
   // round-robin order the 12 tiles of an in_proj slice sat on 8 XCDs and each fetched its operands over the fabric
   int g = blockIdx.x;
-  if (xcd_order) {
+  if (xcd_order & 255) {
     const int n = gridDim.x, q8 = n / 8, r8 = n % 8, xcd = g % 8, k = g / 8;
     g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
   }
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_grouped_kernel(Grou
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int split = local / tiles;
-  gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB, false>(p, local - split * tiles, split);
+  gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB, false>(p, local - split * tiles, split, nullptr, xcd_order >> 8);
 }
 
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
@@ -933,8 +942,8 @@ extern "C" int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* r
 }
 
 // Grouped weight gradients: problem i is x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32,
-// both operands K-slow (rows = tokens), split-K over whole 64-deep tiles, 128x128 tiles, register staging -- exactly
-// the form fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1) launches one at a time.
+// both operands K-slow (rows = tokens), split-K over whole 64-deep tiles -- the arithmetic and fixed split order of
+// fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1), which launches them one at a time.
 extern "C" int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
                                        const int* M, const int* N, const int* splits, int count, fv_stream_t stream) {
   return fv_gemm_bf16_tn_grouped_ld(x, y, parts, Kd, M, N, nullptr, nullptr, splits, count, stream);
@@ -949,7 +958,6 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
   for (int base = 0; base < count; base += per_launch) {
     GroupedParams G{};
     const int n = count - base < per_launch ? count - base : per_launch;
-    int blocks = 0;
     for (int i = 0; i < n; ++i) {
       const int q = base + i;
       FV_CHECK(x[q] && y[q] && parts[q] && Kd[q] > 0 && M[q] > 0 && N[q] > 0 && splits[q] >= 1,
@@ -965,47 +973,60 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
       p.c_split_stride = (long)M[q] * N[q];
       FV_CHECK(fv_cdiv(Kd[q], p.k_per_split) == splits[q],
                "gemm_bf16_tn_grouped: problem %d: K=%d cannot be cut into %d slices of whole 64-deep tiles", q, Kd[q], splits[q]);
-      blocks += fv_cdiv(M[q], 128) * fv_cdiv(N[q], 128) * splits[q];
-      G.blk_end[i] = blocks;
     }
     G.count = n;
-    static const int tile = fv_tune("FASTVIM_WGRAD_GROUP_TILE", 0);   // tuning hook
-    static const int xcd_order = fv_tune("FASTVIM_WGRAD_GROUP_XCD", 1);   // tuning hook
-#ifdef FASTVIM_TUNING_HOOKS
-    if (tile == 7) {          // 8 waves, 256x192 tiles (every N = 192 problem reads its wide operand once)
-      int b2 = 0;
-      for (int i = 0; i < n; ++i) {
-        b2 += fv_cdiv(G.p[i].M, 256) * fv_cdiv(G.p[i].N, 192) * fv_cdiv(G.p[i].K, G.p[i].k_per_split);
-        G.blk_end[i] = b2;
-      }
+    static const int xcd_order = fv_tune("FASTVIM_WGRAD_GROUP_XCD", 1) | (fv_tune("FASTVIM_GEMM_DBG", 0) << 8);   // tuning hooks
+    // LDS-DMA staging needs whole 64-deep K tiles in every slice and whole 16-byte column groups
+    static const bool ks_glds = (fv_tune("FASTVIM_WGRAD_GLDS", 1) != 0);   // tuning hook
+    bool dma = ks_glds;
+    for (int i = 0; i < n; ++i) {
+      const GemmParams& q = G.p[i];
+      dma = dma && q.K % BK == 0 && q.k_per_split % BK == 0 && ((q.M + 7) & ~7) <= q.lda && ((q.N + 7) & ~7) <= q.ldb &&
+            q.M >= 8 && q.N >= 8;
+    }
+    // Tile shape of the launch: the one that pads the problems least -- 128 x 192 for outputs 192 wide (in_proj at
+    // FastVim-T: 768 x 192), 192 x 128 for outputs 192 high (out_proj: 192 x 384), 128 x 128 otherwise and on ties.  A
+    // 128 x 128 tiling computes a quarter more than the output there and re-reads the operands from L2 2.8x / 2.3x;
+    // the launch is bound by L2 -> LDS traffic (phase probe: loads alone 194 us, multiply alone 133 us of 211).  The
+    // caller groups problems of one shape class per call (gemm.py).
+    static const int tile_env = fv_tune("FASTVIM_WGRAD_GROUP_TILE", 0);   // tuning hook: 1 = 128 x 128 always
+    long area[3] = {0, 0, 0};
+    const int bm[3] = {128, 128, 192}, bn[3] = {128, 192, 128};
+    for (int i = 0; i < n; ++i)
+      for (int c = 0; c < 3; ++c)
+        area[c] += (long)fv_cdiv(G.p[i].M, bm[c]) * bm[c] * fv_cdiv(G.p[i].N, bn[c]) * bn[c] * fv_cdiv(G.p[i].K, G.p[i].k_per_split);
+    int cls = 0;
+    if (dma && tile_env != 1) {
+      if (area[1] < area[cls]) cls = 1;
+      if (area[2] < area[cls]) cls = 2;
+    }
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+      blocks += fv_cdiv(G.p[i].M, bm[cls]) * fv_cdiv(G.p[i].N, bn[cls]) * fv_cdiv(G.p[i].K, G.p[i].k_per_split);
+      G.blk_end[i] = blocks;
+    }
+    const size_t smem = (size_t)2 * (bm[cls] + bn[cls]) * BK * 2;
+    // (256 x 192 tiles on 8 waves for the first class, half the L2 traffic again: 310 vs 316 us in the step -- not taken)
+    if (cls == 1) {
       static bool attr = false;
       if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 4, 2, true, 6, 4>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * BK * 2);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 6, 4>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = true;
       }
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 4, 2, true, 6, 4>), dim3(b2), dim3(512),
-                         (size_t)2 * (256 + 192) * BK * 2, st, G, xcd_order);
-    } else
-#endif
-    {
-      (void)tile;
-      // LDS-DMA staging needs whole 64-deep K tiles in every slice and whole 16-byte column groups
-      static const bool ks_glds = (fv_tune("FASTVIM_WGRAD_GLDS", 1) != 0);   // tuning hook
-      bool dma = ks_glds;
-      for (int i = 0; i < n; ++i) {
-        const GemmParams& q = G.p[i];
-        dma = dma && q.K % BK == 0 && q.k_per_split % BK == 0 && ((q.M + 7) & ~7) <= q.lda && ((q.N + 7) & ~7) <= q.ldb &&
-              q.M >= 8 && q.N >= 8;
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 6, 4>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
+    } else if (cls == 2) {
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 6>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
       }
-      // (a deeper LDS ring -- 3 or 4 K tiles in flight, 4 or 8 waves -- changes nothing: with every operand byte coming
-      //  from HBM the launch runs at 3.1 TB/s, and a plain read-only stream of the same size gets 3.7 on this GPU)
-      if (dma)
-        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 4>), dim3(blocks), dim3(256),
-                           (size_t)2 * (128 + 128) * BK * 2, st, G, xcd_order);
-      else
-        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256),
-                           (size_t)2 * (128 + 128) * BK * 2, st, G, xcd_order);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 6>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
+    } else if (dma) {
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 4>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
+    } else {
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
     }
     FV_LAUNCH_CHECK();
   }

@@ -94,6 +94,46 @@ def gemm_tn_grouped(jobs, reduce=True):
     on a second stream must be joined before anything reads the partials)."""
     if not jobs:
         return []
+    # one launch = one tile shape (the C side takes the shape that pads the launch's problems least: 128 x 192 for
+    # outputs 192 wide, 192 x 128 for outputs 192 high, else 128 x 128): problems are grouped by the shape that suits
+    # them, and a problem that does not care (x_proj: 44 x 384) joins the largest group it ties with
+    classes = {}
+    for j in jobs:
+        classes.setdefault(_tile_class(j[0].shape[1], j[1].shape[1]), []).append(j)
+    if len(classes) > 1:
+        todo = []
+        loose = classes.pop(0, [])
+        for j in loose:
+            M, N = j[0].shape[1], j[1].shape[1]
+            ties = [c for c in classes if _padded(M, N, c) == _padded(M, N, 0)]
+            if ties:
+                classes[max(ties, key=lambda c: len(classes[c]))].append(j)
+            else:
+                classes.setdefault(0, []).append(j)
+        for c in sorted(classes):
+            todo += _gemm_tn_grouped_one(classes[c], reduce)
+        return todo
+    return _gemm_tn_grouped_one(jobs, reduce)
+
+
+_TILES = ((128, 128), (128, 192), (192, 128))
+
+
+def _padded(M, N, c):
+    bm, bn = _TILES[c]
+    return -(-M // bm) * bm * -(-N // bn) * bn
+
+
+def _tile_class(M, N):
+    """Index into _TILES of the tile shape that pads an (M, N) output least; ties go to 128 x 128."""
+    best = 0
+    for c in (1, 2):
+        if _padded(M, N, c) < _padded(M, N, best):
+            best = c
+    return best
+
+
+def _gemm_tn_grouped_one(jobs, reduce):
     k = len(jobs)
     parts = []
     for x, y, out, sp in jobs:
