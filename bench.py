@@ -180,32 +180,35 @@ def kernel_table(B, rows, cols, d, depth, dtype):
             "gemm_out_proj_dgrad": (lambda: gemm_nn(do2, W_out), Mt, d_in, d, 0),
             "gemm_in_proj_dgrad": (lambda: gemm_nn(xz2, W_in), Mt, d, 2 * d_in, 0),
         }
-        # weight gradients run as grouped launches of 16 problems at the end of backward: one
-        # launch of 8 in_proj + 8 out_proj problems is timed here (reductions of the fp32 partials included).  As in the
-        # step, every problem has its OWN operands (8 blocks' activations and gradients, 0.6 GB at FastVim-T): re-using
-        # one set eight times would keep it in the 256 MB Infinity Cache and time a different kernel
+        # weight gradients run as grouped launches at the end of backward: the in_proj / out_proj
+        # problems of ALL blocks are timed here exactly as the step issues them (gemm_tn_grouped: one tile-shape class
+        # per launch, <= 40 problems each; reductions of the fp32 partials included).  Every problem has its OWN
+        # operands -- the blocks' activations and gradients, 1.9 GB at FastVim-T -- when they fit 6 GiB: re-using one set
+        # would keep it in the 256 MB Infinity Cache and time a different kernel
         from fastvim_amd.gemm import gemm_tn_grouped, grouped_splits
         from fastvim_amd.mixer_ops import flush_reductions
         sp = grouped_splits(Mt)
-        nset = 8 if Mt * (3 * d_in + 2 * d) * 2 * 8 <= (4 << 30) else 1
+        per_block = Mt * (3 * d_in + 2 * d) * 2
+        nset = depth if per_block * depth <= (6 << 30) else 1
         sets = [(xz2, h2, do2, g2)] + [(rn(Mt, 2 * d_in), rn(Mt, d), rn(Mt, d), rn(Mt, d_in)) for _ in range(nset - 1)]
-        gis = [torch.zeros(2 * d_in * d, device=dev) for _ in range(8)]
-        gos = [torch.zeros(d * d_in, device=dev) for _ in range(8)]
+        gis = [torch.zeros(2 * d_in * d, device=dev) for _ in range(depth)]
+        gos = [torch.zeros(d * d_in, device=dev) for _ in range(depth)]
         group = []
-        for i in range(8):
+        for i in range(depth):
             a, b_, c_, e_ = sets[i % nset]
             group += [(a, b_, gis[i], sp), (c_, e_, gos[i], sp)]
 
         def wgrad_group():
             gemm_tn_grouped(group)
             flush_reductions()
-        t = time_kernel(wgrad_group)
-        fl = 8 * 2.0 * Mt * (2 * d_in * d + d * d_in)
-        nbytes = 8 * (2 * Mt * (2 * d_in + d + d + d_in) + 4 * (2 * sp + 1) * (2 * d_in * d + d * d_in))
-        out["gemm_wgrad_grouped_x16"] = {
+        t = time_kernel(wgrad_group, iters=5)
+        fl = depth * 2.0 * Mt * (2 * d_in * d + d * d_in)
+        nbytes = depth * (2 * Mt * (2 * d_in + d + d + d_in) + 4 * (2 * sp + 1) * (2 * d_in * d + d * d_in))
+        out["gemm_wgrad_grouped"] = {
             "us": round(t * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3), "GBps": round(nbytes / t / 1e9, 1),
             "TFLOPs": round(fl / t / 1e12, 1), "mfma_frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-            "launches_per_step": depth / 8.0, "us_per_step": round(t * 1e6 * depth / 8.0, 1), "split_k": sp}
+            "launches_per_step": 1, "us_per_step": round(t * 1e6, 1), "split_k": sp, "problems": 2 * depth,
+            "own_operands_per_problem": nset == depth}
         for name, (fn, m_, n_, k_, splits) in gemms.items():
             t = time_kernel(fn)
             nbytes = 2 * (m_ * k_ + n_ * k_) + (2 * m_ * n_ if not splits else 4 * m_ * n_ * (2 * splits + 1))
@@ -560,7 +563,7 @@ def main():
             out["kernels"] = kt
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_v2_pmc_traffic.json")))["kernels"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_v4_pmc_traffic.json")))["kernels"]
                 if (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16") and dom in pm:
                     traffic = pm[dom]["traffic_bytes"]
             except (OSError, KeyError, ValueError):

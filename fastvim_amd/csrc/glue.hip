@@ -68,17 +68,29 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(const TI* __restrict_
 }
 
 // ---- token mean pool: out[b][d] = (1/L) sum_l x[b][l][d] ------------------------------------------------------------
-// One workgroup per (batch element, 4*64-channel slab): lane = 4 channels, the 4 waves split the tokens, fixed-order
-// sum through LDS.
+// One 16-wave workgroup per (batch element, 4*64-channel slab): lane = 4 channels, the waves split the tokens (four
+// loads in flight each -- with 4 waves and one load in flight the 196-token sum was 49 dependent round trips, 15 us),
+// fixed-order sum through LDS.
+constexpr int MP_WAVES = 16;
 template <typename T>
-__global__ __launch_bounds__(256) void mean_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int L, int D, float inv) {
-  __shared__ float s_acc[4][256];
+__global__ __launch_bounds__(64 * MP_WAVES) void mean_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int L, int D, float inv) {
+  __shared__ float s_acc[MP_WAVES][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int d = (blockIdx.x * 64 + lane) * 4, b = blockIdx.y;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
   if (d < D) {
     const T* xp = x + (size_t)b * L * D + d;
-    for (int l = wv; l < L; l += 4) {
+    int l = wv;
+    for (; l + 3 * MP_WAVES < L; l += 4 * MP_WAVES) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Vec4<T>::ld(xp + (size_t)(l + u * MP_WAVES) * D, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += v[u][k];
+    }
+    for (; l < L; l += MP_WAVES) {
       float v[4];
       Vec4<T>::ld(xp + (size_t)l * D, v);
 #pragma unroll
@@ -91,8 +103,12 @@ __global__ __launch_bounds__(256) void mean_pool_fwd_kernel(const T* __restrict_
   if (wv == 0 && d < D) {
     float r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      r[k] = ((s_acc[0][lane * 4 + k] + s_acc[1][lane * 4 + k]) + (s_acc[2][lane * 4 + k] + s_acc[3][lane * 4 + k])) * inv;
+    for (int k = 0; k < 4; ++k) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < MP_WAVES; ++w) t += s_acc[w][lane * 4 + k];
+      r[k] = t * inv;
+    }
     Vec4<T>::st(out + (size_t)b * D + d, r);
   }
 }
@@ -181,7 +197,7 @@ extern "C" int fv_mean_pool_fwd(const void* x, void* out, int batch, int tokens,
   FV_CHECK(x && out, "mean_pool_fwd: null pointer");
   FV_CHECK(dt_ok(dtype), "mean_pool_fwd: dtype must be fp32 or bf16");
   FV_CHECK(batch > 0 && tokens > 0 && dim > 0 && dim % 4 == 0 && batch <= 65535, "mean_pool_fwd: bad shape (%d, %d, %d)", batch, tokens, dim);
-  const dim3 grid(fv_cdiv(dim, 256), batch), block(256);
+  const dim3 grid(fv_cdiv(dim, 256), batch), block(64 * MP_WAVES);
   hipStream_t st = (hipStream_t)stream;
   const float inv = 1.f / (float)tokens;
   if (dtype == FV_F32) hipLaunchKernelGGL(mean_pool_fwd_kernel<float>, grid, block, 0, st, (const float*)x, (float*)out, tokens, dim, inv);
