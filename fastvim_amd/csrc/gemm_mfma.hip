@@ -57,6 +57,10 @@ struct NormEpi {
   float* rstd;             // (M)
   int rows_per_scale;
   float eps;
+  // backward form (fv_gemm_bf16_dgrad_addnorm_bwd): the GEMM output is d y of the norm; `residual` is the saved
+  // normalisation input r, `rstd` is read, `y` receives d x (bf16, x row_scale) and `res_out` d residual_in
+  const float* dres_out;   // (M, N) fp32 gradient of the residual stream arriving from above, nullable
+  float* pw;               // (workgroups, N) per-workgroup partial sums of d norm weight
 };
 
 // KS tiles: rows (k) are EXT*2 bytes = a multiple of the 256-byte bank row, and a transposing read
@@ -241,7 +245,7 @@ struct KsFrags {
 // MB = 8 (128-row wave tiles, 256-row block tiles) is for the compute-bound FastVim-S/B widths: a k-step of a
 // 64x64 wave tile reads 8 KiB of fragments for 16 MFMAs -- at the full MFMA rate that is exactly the 128 B/clk the
 // LDS delivers -- while a 128x64 wave tile reads 12 KiB for 32.
-template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4, bool XREMAP = true, bool NORM_EPI = false>
+template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4, bool XREMAP = true, int NORM_EPI = 0>
 __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id, int split, const NormEpi* ne = nullptr,
                                                int dbg = 0) {
   constexpr int NT = 64 * WM * WN;
@@ -272,9 +276,24 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
 #pragma unroll
     for (int b = 0; b < MB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // add + norm epilogue: the residual rows this lane will add are requested now and arrive under the K loop
-  constexpr int NE_IT = NORM_EPI ? BM / 4 / 8 : 1;
+  constexpr bool NE_PRE = NORM_EPI != 0 && BM <= 64;     // taller tiles: no registers left, the epilogue loads its rows itself
+  constexpr int NE_IT = NE_PRE ? BM / 4 / 8 : 1;
   float4 ne_r[NE_IT][2][3];
-  if constexpr (NORM_EPI) {
+  float4 ne_g[NORM_EPI == 2 ? NE_IT : 1][2][3];      // backward: the residual-stream gradient rows as well
+  if constexpr (NORM_EPI == 2 && NE_PRE) {
+    const int lr = lane % 16, gr = lane / 16;
+#pragma unroll
+    for (int it = 0; it < NE_IT; ++it)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row = m0 + wv * (BM / 4) + it * 8 + u * 4 + gr, rowc = row < p.M ? row : p.M - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          ne_g[it][u][k] = ne->dres_out ? *reinterpret_cast<const float4*>(ne->dres_out + (size_t)rowc * BN + (k * 16 + lr) * 4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
+  if constexpr (NE_PRE) {
     const int lr = lane % 16, gr = lane / 16;
 #pragma unroll
     for (int it = 0; it < NE_IT; ++it)
@@ -383,7 +402,113 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
       }
     }
   }
-  if constexpr (NORM_EPI) {
+  if constexpr (NORM_EPI == 2) {
+    // ---- RMSNorm + residual-add ADJOINT of the tile's rows (what fv_add_norm_bwd does with this GEMM's bf16 output as
+    //      its d y; lane mapping and operation order of add_norm_bwd3_kernel<16>)
+    static_assert(BN == 192 && WM * WN == 4 && BM % 32 == 0, "whole 192-wide rows, four waves");
+    constexpr int RSB = BN * 2 + 16, LPR = 16, RPW = 4, RU = 2, RW = BM / 4;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        const f32x4 v = acc[a][b];
+        uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<uint2*>(smem + (wm * WMR + b * 16 + (lane & 15)) * RSB + (wn * WNC + a * 16 + (lane >> 4) * 4) * 2) = pk;
+      }
+    __syncthreads();
+    const int lr = lane % LPR, gr = lane / LPR;
+    const float inv_n = 1.f / (float)BN;
+    float w[3][4], aw[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 t = *reinterpret_cast<const float4*>(ne->w + (k * LPR + lr) * 4);
+      w[k][0] = t.x; w[k][1] = t.y; w[k][2] = t.z; w[k][3] = t.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) aw[k][e] = 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < RW / (RPW * RU); ++it) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int rl = wv * RW + it * (RPW * RU) + u * RPW + gr;
+        const int row = m0 + rl;
+        const bool live = row < p.M;
+        const int rowc = live ? row : p.M - 1;
+        const size_t base = (size_t)rowc * BN;
+        const float rstd = ne->rstd[rowc];
+        const float sc = ne->row_scale ? ne->row_scale[rowc / ne->rows_per_scale] : 1.f;
+        const float lv = live ? 1.f : 0.f;
+        float xh[3][4], dxh[3][4];
+        float c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int c = (k * LPR + lr) * 4;
+          const uint2 xb = *reinterpret_cast<const uint2*>(smem + rl * RSB + c * 2);
+          const float dyv[4] = {__uint_as_float(xb.x << 16), __uint_as_float(xb.x & 0xffff0000u),
+                                __uint_as_float(xb.y << 16), __uint_as_float(xb.y & 0xffff0000u)};
+          float4 rr4;
+          if constexpr (NE_PRE) rr4 = ne_r[it][u][k];
+          else rr4 = *reinterpret_cast<const float4*>(ne->residual + base + c);
+          const float rr[4] = {rr4.x, rr4.y, rr4.z, rr4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dyl = dyv[e] * lv;
+            xh[k][e] = (rr[e] - 0.f) * rstd;
+            dxh[k][e] = dyl * w[k][e];
+            aw[k][e] = fmaf(dyl, xh[k][e], aw[k][e]);
+            c2 = fmaf(dxh[k][e], xh[k][e], c2);
+          }
+        }
+#define FV_DPP_ADD(ctrl) c2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c2), ctrl, 0xf, 0xf, true))
+        FV_DPP_ADD(0xB1);
+        FV_DPP_ADD(0x4E);
+        FV_DPP_ADD(0x141);
+        FV_DPP_ADD(0x140);
+#undef FV_DPP_ADD
+        c2 = c2 * inv_n;
+        const float c1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int c = (k * LPR + lr) * 4;
+          float4 g4;
+          if constexpr (NE_PRE) g4 = ne_g[it][u][k];
+          else g4 = ne->dres_out ? *reinterpret_cast<const float4*>(ne->dres_out + base + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+          float dr[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dr[e] = rstd * (dxh[k][e] - c1 - xh[k][e] * c2) + gg[e];
+          if (live) {
+            *reinterpret_cast<float4*>(ne->res_out + base + c) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+            if (ne->row_scale)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dr[e] *= sc;
+            uint2 pk = {pack_bf16x2(dr[0], dr[1]), pack_bf16x2(dr[2], dr[3])};
+            *reinterpret_cast<uint2*>(ne->y + base + c) = pk;
+          }
+        }
+      }
+    }
+    // d norm weight: the 4 row groups of a wave (permlane swaps), then the 4 waves through LDS, fixed order
+    __syncthreads();
+    float* s_acc = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = aw[k][e];
+        auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);
+        auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+        if (gr == 0) s_acc[wv * BN + (k * LPR + lr) * 4 + e] = v;
+      }
+    __syncthreads();
+    float* dst = ne->pw + (size_t)block_id * BN;
+    for (int c = tid; c < BN; c += NT) dst[c] = (s_acc[c] + s_acc[BN + c]) + (s_acc[2 * BN + c] + s_acc[3 * BN + c]);
+    return;
+  }
+  if constexpr (NORM_EPI == 1) {
     // ---- residual add + RMSNorm of the tile's rows (what fv_add_norm_fwd does to the bf16 GEMM output, same lane
     //      mapping and operation order as add_norm_fwd3_kernel<16>): the product is rounded to bf16 into an LDS tile,
     //      then a wave step takes 4 rows x 16 lanes x (3 x 4) channels.
@@ -421,7 +546,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
           const uint2 xb = *reinterpret_cast<const uint2*>(smem + rl * RSB + c * 2);
           v[u][k][0] = __uint_as_float(xb.x << 16); v[u][k][1] = __uint_as_float(xb.x & 0xffff0000u);
           v[u][k][2] = __uint_as_float(xb.y << 16); v[u][k][3] = __uint_as_float(xb.y & 0xffff0000u);
-          const float4 t = ne_r[it][u][k];
+          float4 t;
+          if constexpr (NE_PRE) t = ne_r[it][u][k];
+          else t = *reinterpret_cast<const float4*>(ne->residual + (size_t)rowc * BN + c);
           r[u][k][0] = t.x; r[u][k][1] = t.y; r[u][k][2] = t.z; r[u][k][3] = t.w;
         }
       }
@@ -542,7 +669,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmParams p
 
 template <int BMROWS>
 __global__ __launch_bounds__(256, 2) void gemm_addnorm_kernel(GemmParams p, NormEpi ne) {
-  gemm_bf16_body<KC, KC, 2, 2, true, 6, BMROWS / 32, true, true>(p, blockIdx.x, 0, &ne);
+  gemm_bf16_body<KC, KC, 2, 2, true, 6, BMROWS / 32, true, 1>(p, blockIdx.x, 0, &ne);
+}
+
+template <int BMROWS>
+__global__ __launch_bounds__(256, 2) void gemm_dgrad_addnorm_bwd_kernel(GemmParams p, NormEpi ne) {
+  gemm_bf16_body<KC, KS, 2, 2, true, 6, BMROWS / 32, true, 2>(p, blockIdx.x, 0, &ne);
 }
 
 // Several independent problems in ONE launch (the weight gradients of a whole backward pass, queued until its end):
@@ -918,7 +1050,8 @@ extern "C" int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* r
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = y; p.bias = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = N; p.c_fp32 = 0;
   p.k_per_split = K;
-  NormEpi ne{residual, norm_weight, row_scale, residual_out, (bf16_t*)y, rstd, rows_per_scale > 0 ? rows_per_scale : 1, eps};
+  NormEpi ne{residual, norm_weight, row_scale, residual_out, (bf16_t*)y, rstd, rows_per_scale > 0 ? rows_per_scale : 1, eps,
+             nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto bm) {
     constexpr int BMR = decltype(bm)::value;
@@ -937,6 +1070,41 @@ extern "C" int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* r
   else
 #endif
   go(std::integral_constant<int, 64>{});
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+extern "C" int fv_gemm_bf16_dgrad_addnorm_blocks(int M) { return fv_cdiv(M, 64); }
+
+extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd(const void* A, const void* W, const float* dresidual_out, const float* r,
+                                              const float* rstd, const float* norm_weight, const float* row_scale,
+                                              int rows_per_scale, void* dx, float* dresidual_in, float* partial_dw, int M,
+                                              int N, int K, long lda, long ldw, fv_stream_t stream) {
+  FV_CHECK(A && W && r && rstd && norm_weight && dx && dresidual_in && partial_dw, "gemm_bf16_dgrad_addnorm_bwd: null pointer");
+  FV_CHECK(M > 0 && K > 0, "gemm_bf16_dgrad_addnorm_bwd: empty problem");
+  if (N != 192 || K % BK != 0) return FV_ERR_UNSUPPORTED;
+  FV_CHECK(lda % 8 == 0 && ldw % 8 == 0 && ldw >= N && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
+               ((uintptr_t)r & 15) == 0 && ((uintptr_t)dresidual_in & 15) == 0 && ((uintptr_t)dx & 7) == 0 &&
+               (!dresidual_out || ((uintptr_t)dresidual_out & 15) == 0),
+           "gemm_bf16_dgrad_addnorm_bwd: operands must be 16-byte aligned with row strides multiples of 8");
+  FV_CHECK(!row_scale || rows_per_scale > 0, "gemm_bf16_dgrad_addnorm_bwd: rows_per_scale must be positive");
+  GemmParams p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = dx; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = N; p.c_fp32 = 0;
+  p.k_per_split = K;
+  NormEpi ne{r, norm_weight, row_scale, dresidual_in, (bf16_t*)dx, const_cast<float*>(rstd),
+             rows_per_scale > 0 ? rows_per_scale : 1, 0.f, dresidual_out, partial_dw};
+  auto go = [&](auto bm) {
+    constexpr int BMR = decltype(bm)::value;
+    const size_t smem = (size_t)2 * (BMR + 192) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_dgrad_addnorm_bwd_kernel<BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_dgrad_addnorm_bwd_kernel<BMR>), dim3(fv_cdiv(M, BMR)), dim3(256), smem, (hipStream_t)stream, p, ne);
+  };
+  go(std::integral_constant<int, 64>{});      // (128-row tiles, no room to prefetch the rows: 46.9 vs 31.0 us)
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

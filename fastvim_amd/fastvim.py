@@ -21,8 +21,8 @@ from torch import Tensor
 
 from .layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
 from . import glue_ops as G
-from .mamba_simple_faster import (LinearFn, Mamba, OutProjAddNormFn, _compute_dtype, _direct_grad, _shadow, linear_wgrad,
-                                  out_proj_add_norm_ok)
+from .mamba_simple_faster import (ChainedBlockFn, LinearFn, Mamba, OutProjAddNormFn, _compute_dtype, _direct_grad, _shadow,
+                                  linear_wgrad, out_proj_add_norm_ok)
 from .mixer_ops import reduce_partials
 
 
@@ -420,9 +420,10 @@ class VisionMamba(nn.Module):
             DropPath.predraw([l.drop_path for l in self.layers] + [self.drop_path], x.shape[0], x.device)
         return x, (H, W)
 
-    def _chainable(self, hidden_states, lo, hi, inference_params, out_indices):
-        """Blocks lo .. hi-1 can run with every interior ``out_proj`` fused into the next block's add + RMSNorm."""
-        if inference_params is not None or out_indices is not None or hi - lo < 2 or not hidden_states.is_cuda:
+    def _chainable(self, hidden_states, lo, hi, inference_params, out_indices, carried=False):
+        """Blocks lo .. hi-1 can run with every interior ``out_proj`` fused into the next block's add + RMSNorm
+        (``carried``: the run is part of a longer chain -- ``_run_layers_open`` -- and may be a single block)."""
+        if inference_params is not None or out_indices is not None or hi - lo < (1 if carried else 2) or not hidden_states.is_cuda:
             return False
         if _compute_dtype(hidden_states) != torch.bfloat16 or self.embed_dim != 192:
             return False
@@ -430,33 +431,57 @@ class VisionMamba(nn.Module):
             mx = blk.mixer
             if (type(blk) is not Block or type(mx) is not Mamba or not blk.fused_add_norm or not blk.residual_in_fp32
                     or not isinstance(blk.norm, RMSNorm) or blk.norm.bias is not None or mx.init_layer_scale is not None
-                    or mx.out_proj.bias is not None or mx.out_proj.weight.shape[1] % 64):
+                    or mx.out_proj.bias is not None or mx.out_proj.weight.shape[1] % 64 or mx.d_conv != 4 or mx.d_state != 16):
                 return False
         return True
 
-    def _run_layers_chained(self, hidden_states, residual, lo, hi):
+    def _run_layers_chained(self, hidden_states, residual, lo, hi, pend=None, close=True):
         """Same values as the plain loop: block i's mixer stops at its gated activations, and ``out_proj`` runs inside the
-        GEMM that also does block i+1's DropPath scale + residual add + RMSNorm (``OutProjAddNormFn``); the range is
-        closed by a plain ``out_proj``."""
-        cdt = _compute_dtype(hidden_states)
-        pend = None                               # (gated activations, out_proj weight) of the previous block
+        GEMM that also does block i+1's DropPath scale + residual add + RMSNorm; from the second block on a block is one
+        autograd node (``ChainedBlockFn``), whose backward also fuses the in_proj data gradient into the norm's adjoint.
+        The range is closed by a plain ``out_proj``.  Parameter gradients equal the plain loop's bit for bit, except the
+        norm weights', whose row sums are grouped differently (fixed order, ~1e-7 relative)."""
+        cdt = _compute_dtype(hidden_states if pend is None else pend[0])
+        # pend: (gated activations, out_proj weight) of the previous block -- None at the start of a chain, or carried in
+        # from the previous run of blocks (``_run_layers_open``: the segmented training step cuts there)
         for layer_idx in range(lo, hi):
             blk = self.layers[layer_idx]
             scale = None
             if residual is not None and isinstance(blk.drop_path, DropPath):
                 scale = blk.drop_path.row_scale(hidden_states if pend is None else pend[0])
+            rot = blk.rotate_every_block is True and blk.layer_idx % 2 != 0
             if pend is not None and out_proj_add_norm_ok(pend[0], pend[1], residual, blk.norm.weight, cdt):
-                hidden_states, residual = OutProjAddNormFn.apply(pend[0], pend[1], residual, blk.norm.weight,
-                                                                 float(blk.norm.eps), scale, cdt)
+                # previous out_proj + this block's add + norm + mixer as ONE autograd node: its backward can hand the
+                # in_proj data gradient straight to the norm's adjoint
+                g, residual = ChainedBlockFn.apply(pend[0], pend[1], residual, blk.norm.weight, float(blk.norm.eps), scale,
+                                                   *blk.mixer.mixer_fn_args(cdt, rot, defer_out_proj=True))
+                pend = (g, blk.mixer.out_proj.weight)
+                continue
             else:
                 if pend is not None:
                     hidden_states = LinearFn.apply(pend[0], pend[1], cdt)
                 hidden_states, residual = layer_norm_fn(
                     hidden_states, blk.norm.weight, blk.norm.bias, residual=residual, eps=blk.norm.eps, prenorm=True,
                     residual_in_fp32=blk.residual_in_fp32, is_rms_norm=True, row_scale=scale, out_dtype=cdt)
-            rot = blk.rotate_every_block is True and blk.layer_idx % 2 != 0
             pend = (blk.mixer(hidden_states, transposed_grid=rot, defer_out_proj=True), blk.mixer.out_proj.weight)
+        if not close:
+            return None, residual, pend
         return LinearFn.apply(pend[0], pend[1], cdt), residual
+
+    def _run_layers_open(self, hidden_states, residual, lo, hi, pend=None):
+        """``_run_layers`` that may leave the run's last ``out_proj`` to whoever continues: returns (hidden_states,
+        residual, pend) with exactly one of hidden_states / pend set; pass ``pend`` back in for the next run and finish
+        with ``_close_run``.  A run cut this way computes exactly what the uncut chain computes."""
+        probe = hidden_states if pend is None else pend[0]
+        if self._chainable(probe, lo, hi, None, None, carried=True):       # an open run may be a single block
+            return self._run_layers_chained(hidden_states, residual, lo, hi, pend=pend, close=False)
+        if pend is not None:
+            hidden_states = self._close_run(pend)
+        hidden_states, residual = self._run_layers(hidden_states, residual, lo, hi)
+        return hidden_states, residual, None
+
+    def _close_run(self, pend):
+        return LinearFn.apply(pend[0], pend[1], _compute_dtype(pend[0]))
 
     def _run_layers(self, hidden_states, residual, lo, hi, inference_params=None, out_indices=None, outs=None):
         if self._chainable(hidden_states, lo, hi, inference_params, out_indices):

@@ -237,21 +237,7 @@ class OutProjAddNormFn(torch.autograd.Function):
         d = W_out.shape[0]
         Mrows = B * Ltok
         with torch.autocast("cuda", enabled=False):
-            g2 = g.view(Mrows, d_in)
-            res2 = residual.reshape(Mrows, d).contiguous()
-            w32 = norm_w.float().contiguous()
-            y = torch.empty(Mrows, d, device=g.device, dtype=cdt)
-            res_out = torch.empty(Mrows, d, device=g.device, dtype=torch.float32)
-            rstd = torch.empty(Mrows, device=g.device, dtype=torch.float32)
-            rows_per_scale = 1
-            if row_scale is not None:
-                row_scale = row_scale.float().contiguous()
-                rows_per_scale = Mrows // row_scale.numel()
-            rc = L.lib().fv_gemm_bf16_addnorm(
-                L.ptr(g2), L.ptr(_shadow(W_out, cdt)), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
-                L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
-                ctypes.c_long(d_in), ctypes.c_float(eps), L.stream_of(g2))
-            L.check(rc, "gemm_bf16_addnorm")
+            y, res_out, rstd, w32, row_scale, rows_per_scale = _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt)
         ctx.save_for_backward(g, W_out, res_out, w32, rstd, row_scale)
         ctx.rows_per_scale = rows_per_scale
         ctx.cdt = cdt
@@ -290,6 +276,107 @@ class OutProjAddNormFn(torch.autograd.Function):
             dg = linear_dgrad(dx, _shadow(W_out, cdt)).view(B, Ltok, d_in)
             dW_out = _SideStream.run(lambda: linear_wgrad(dx, g2, W_out), dx, g)
         return dg, dW_out, dres_in.view(B, Ltok, d), dw, None, None, None
+
+
+class _Ctx:
+    """Stand-in for an autograd context when one Function runs another's forward / backward as plain code."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt):
+    B, Ltok, d_in = g.shape
+    d = W_out.shape[0]
+    Mrows = B * Ltok
+    g2 = g.view(Mrows, d_in)
+    res2 = residual.reshape(Mrows, d).contiguous()
+    w32 = norm_w.float().contiguous()
+    y = torch.empty(Mrows, d, device=g.device, dtype=cdt)
+    res_out = torch.empty(Mrows, d, device=g.device, dtype=torch.float32)
+    rstd = torch.empty(Mrows, device=g.device, dtype=torch.float32)
+    rows_per_scale = 1
+    if row_scale is not None:
+        row_scale = row_scale.float().contiguous()
+        rows_per_scale = Mrows // row_scale.numel()
+    rc = L.lib().fv_gemm_bf16_addnorm(
+        L.ptr(g2), L.ptr(_shadow(W_out, cdt)), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
+        L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
+        ctypes.c_long(d_in), ctypes.c_float(eps), L.stream_of(g2))
+    L.check(rc, "gemm_bf16_addnorm")
+    return y, res_out, rstd, w32, row_scale, rows_per_scale
+
+
+class ChainedBlockFn(torch.autograd.Function):
+    """One block of a chained run (``VisionMamba._run_layers_chained``), d_model = 192: the previous mixer's ``out_proj``
+    + this block's DropPath scale / residual add / RMSNorm (``fv_gemm_bf16_addnorm``), then this block's mixer up to its
+    gated activations.  Inputs: the previous block's gated activations and ``out_proj`` weight, the residual stream, the
+    norm weight, then ``FastVimMixerFn``'s arguments after ``hidden`` (with ``W_out`` / ``b_out`` None).  Returns
+    (gated activations, residual_out).  Backward runs the mixer's adjoint, with the in_proj data gradient produced
+    INSIDE the norm's adjoint (``fv_gemm_bf16_dgrad_addnorm_bwd``: it is needed by nothing else), then the previous
+    ``out_proj``'s two gradients -- the values of ``OutProjAddNormFn`` + ``FastVimMixerFn`` back to back; only the norm
+    weight's gradient is summed in a different (fixed) order."""
+
+    @staticmethod
+    def forward(ctx, g_prev, W_out_prev, residual, norm_w, eps, row_scale, *mixer_args):
+        L.require_gpu(g_prev, W_out_prev, residual, norm_w)
+        B, Ltok, _ = g_prev.shape
+        d = W_out_prev.shape[0]
+        cdt = mixer_args[26]            # FastVimMixerFn.forward(ctx, hidden, <26 arguments>, cdt, fv, tpp, valid)
+        with torch.autocast("cuda", enabled=False):
+            y, res_out, rstd, w32, rs, rps = _out_proj_add_norm_fwd(g_prev, W_out_prev, residual, norm_w, eps, row_scale, cdt)
+        fctx = _Ctx()
+        g = FastVimMixerFn.forward(fctx, y.view(B, Ltok, d), *mixer_args)
+        mixer_saved = fctx.__dict__.pop("saved_tensors")
+        ctx.save_for_backward(g_prev, W_out_prev, res_out, w32, rstd, rs, *mixer_saved)
+        ctx.mixer_attrs = fctx.__dict__
+        ctx.rows_per_scale = rps
+        ctx.cdt = cdt
+        ctx.shape = (B, Ltok, d)
+        ctx.w_param = norm_w
+        ctx.W_in = mixer_args[0]
+        ctx.n_mixer_args = len(mixer_args)
+        return g, res_out.view(B, Ltok, d)
+
+    @staticmethod
+    def backward(ctx, dg, dres_out):
+        g_prev, W_out_prev, r, w32, rstd, row_scale = ctx.saved_tensors[:6]
+        B, Ltok, d = ctx.shape
+        Mrows, cdt, dev = B * Ltok, ctx.cdt, r.device
+        fctx = _Ctx()
+        fctx.__dict__.update(ctx.mixer_attrs)
+        fctx.saved_tensors = ctx.saved_tensors[6:]
+        out = {}
+
+        def fused_in_dgrad(dxz2):
+            lib = L.lib()
+            nb = lib.fv_gemm_bf16_dgrad_addnorm_blocks(L.i32(Mrows))
+            dx = torch.empty(Mrows, d, device=dev, dtype=cdt)
+            dres_in = torch.empty(Mrows, d, device=dev, dtype=torch.float32)
+            pw = torch.empty(nb, d, device=dev, dtype=torch.float32)
+            gg = dres_out.reshape(Mrows, d).contiguous() if dres_out is not None else None
+            rc = lib.fv_gemm_bf16_dgrad_addnorm_bwd(
+                L.ptr(dxz2), L.ptr(_shadow(ctx.W_in, cdt)), L.ptr(gg), L.ptr(r), L.ptr(rstd), L.ptr(w32), L.ptr(row_scale),
+                L.i32(ctx.rows_per_scale), L.ptr(dx), L.ptr(dres_in), L.ptr(pw), L.i32(Mrows), L.i32(d),
+                L.i32(dxz2.shape[1]), ctypes.c_long(dxz2.stride(0)), ctypes.c_long(d), L.stream_of(dxz2))
+            L.check(rc, "gemm_bf16_dgrad_addnorm_bwd")
+            out.update(dx=dx, dres_in=dres_in, pw=pw, nb=nb)
+
+        fctx.fused_in_dgrad = fused_in_dgrad
+        grads = FastVimMixerFn.backward(fctx, dg)
+        with torch.autocast("cuda", enabled=False):
+            gd = _direct_grad(ctx.w_param)
+            if gd is not None:
+                M.reduce_partials(out["pw"], out["nb"], out=gd.view(-1), accumulate=True)
+                dw = None
+            else:
+                dw = M.reduce_partials(out["pw"], out["nb"]).to(ctx.w_param.dtype)
+            dx = out["dx"]
+            d_in = g_prev.shape[2]
+            g2 = g_prev.view(Mrows, d_in)
+            dg_prev = linear_dgrad(dx, _shadow(W_out_prev, cdt)).view(B, Ltok, d_in)
+            dW_out = _SideStream.run(lambda: linear_wgrad(dx, g2, W_out_prev), dx, g_prev)
+        return (dg_prev, dW_out, out["dres_in"].view(B, Ltok, d), dw, None, None) + tuple(grads[1:1 + ctx.n_mixer_args])
 
 
 def out_proj_add_norm_ok(g, W_out, residual, norm_w, cdt):
@@ -419,7 +506,12 @@ class FastVimMixerFn(torch.autograd.Function):
                                  pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None,
                                  tpp=tpp, amax=amax)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
-            dhidden = linear_dgrad(dxz2, _shadow(W_in, cdt)).view(B, Ltok, d).to(ctx.in_dtype)
+            fused_dgrad = getattr(ctx, "fused_in_dgrad", None)
+            if fused_dgrad is not None:
+                fused_dgrad(dxz2)          # ChainedBlockFn: the data gradient goes straight into the norm's adjoint
+                dhidden = None
+            else:
+                dhidden = linear_dgrad(dxz2, _shadow(W_in, cdt)).view(B, Ltok, d).to(ctx.in_dtype)
             dW_in = _SideStream.run(lambda: linear_wgrad(dxz2, h_c.view(B * Ltok, d), W_in), dxz2, h_c)
             db_in = dxz2.float().sum(0) if ctx.has_bias[0] else None
         has_ln = ln_w is not None
@@ -520,6 +612,20 @@ class Mamba(nn.Module):
         self.D_b._no_weight_decay = True
         self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
         self.pre_x_shape = (-1, self.d_inner, self.num_of_rows, self.num_of_col)
+
+    def mixer_fn_args(self, cdt, transposed_grid=False, defer_out_proj=False):
+        """``FastVimMixerFn``'s arguments after ``hidden`` for this module."""
+        ln_w = self.layernorm.weight if self.use_norm_after_ssm else None
+        ln_b = self.layernorm.bias if self.use_norm_after_ssm else None
+        ln_eps = self.layernorm.eps if self.use_norm_after_ssm else 0.0
+        return (self.in_proj.weight, self.in_proj.bias,
+                self.conv1d.weight, self.conv1d.bias, self.conv1d_b.weight, self.conv1d_b.bias,
+                self.x_proj.weight, self.x_proj_b.weight,
+                self.dt_proj.weight, self.dt_proj.bias, self.dt_proj_b.weight, self.dt_proj_b.bias,
+                self.A_log, self.A_b_log, self.D, self.D_b, ln_w, ln_b,
+                None if defer_out_proj else self.out_proj.weight, None if defer_out_proj else self.out_proj.bias,
+                self.num_of_rows, self.num_of_col, bool(transposed_grid), self.collapse_method == "max",
+                float(self.scaling_factor), float(ln_eps), cdt, self.__dict__.get("_fv"))
 
     def forward(self, hidden_states, inference_params=None, transposed_grid=False, defer_out_proj=False):
         """hidden_states: (B, L, D) -> (B, L, D).  ``defer_out_proj``: return the gated activations (B, L, d_inner)

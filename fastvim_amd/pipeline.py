@@ -46,17 +46,27 @@ class SegmentedTrainStep:
         cuts = []              # per run in FORWARD order: (inputs (leaves) or None, outputs)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype != torch.float32):
             h, _ = m._embed(self.x)
-            res = None
+            res, pend = None, None
             fwd_runs = self.runs[::-1]
+            open_runs = hasattr(m, "_run_layers_open")
             for i, (lo, hi) in enumerate(fwd_runs):
                 if i > 0:          # cut: this run's inputs are leaves that alias the previous run's outputs
-                    h = h.detach().requires_grad_()
                     res = res.detach().requires_grad_()
-                    ins = (h, res)
+                    if pend is not None:      # the chain of fused blocks continues across the cut (fastvim._run_layers_open):
+                        pend = (pend[0].detach().requires_grad_(), pend[1])      # its hand-over is the gated activations
+                        ins = (pend[0], res)
+                    else:
+                        h = h.detach().requires_grad_()
+                        ins = (h, res)
                 else:
                     ins = None
-                h, res = m._run_layers(h, res, lo, hi)
-                cuts.append([ins, (h, res)])
+                if open_runs:
+                    h, res, pend = m._run_layers_open(h, res, lo, hi, pend=pend)
+                else:
+                    h, res = m._run_layers(h, res, lo, hi)
+                cuts.append([ins, (h if pend is None else pend[0], res)])
+            if pend is not None:
+                h = m._close_run(pend)
             logits = m._head(m._final(h, res))
         loss = self.loss_fn(logits, self.target)
         cuts[-1][1] = (loss,)

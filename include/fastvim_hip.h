@@ -278,6 +278,18 @@ int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* residual, co
                          const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd, int M,
                          int N, int K, long lda, long ldw, float eps, fv_stream_t stream);
 
+/* in_proj data gradient fused with the SAME block's RMSNorm + residual-add adjoint (mamba_simple_faster.py:189-193
+ * backward followed by ops/triton/layernorm.py:210-304): d y = bf16_round(A W) (A (M, K) bf16 = d xz, W (K, N) bf16 =
+ * in_proj.weight as stored); then exactly fv_add_norm_bwd(is_rms_norm) on it: d residual_in = rstd (d y w - xhat mean(d y
+ * w xhat)) + d residual_out (fp32), d x = d residual_in * row_scale (bf16), partial_dw (fv_gemm_bf16_dgrad_addnorm_blocks(M),
+ * N): per-workgroup sums of d y * xhat (reduce with fv_reduce_partials).  The data gradient itself never reaches HBM.
+ * N == 192, K % 64 == 0; FV_ERR_UNSUPPORTED otherwise. */
+int fv_gemm_bf16_dgrad_addnorm_blocks(int M);
+int fv_gemm_bf16_dgrad_addnorm_bwd(const void* A, const void* W, const float* dresidual_out, const float* r,
+                                   const float* rstd, const float* norm_weight, const float* row_scale,
+                                   int rows_per_scale, void* dx, float* dresidual_in, float* partial_dw, int M, int N,
+                                   int K, long lda, long ldw, fv_stream_t stream);
+
 /* Several weight gradients in one launch (queued until the end of the backward pass): problem i is
  * x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32 partials (sum with fv_reduce_partials);
  * the same arithmetic, tiling and fixed split order as fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1). */

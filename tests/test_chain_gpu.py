@@ -67,4 +67,10 @@ def test_chained_backbone_equals_block_by_block(drop_path):
     assert torch.equal(res[0][0], res[1][0])
     assert res[0][1].keys() == res[1][1].keys()
     for n in res[0][1]:
-        assert torch.equal(res[0][1][n], res[1][1][n]), n
+        a, b = res[0][1][n], res[1][1][n]
+        if n.endswith(".norm.weight"):
+            # the chained backward sums d y * xhat over the rows per 64-row GEMM tile, the stand-alone kernel per
+            # persistent wave: same addends, different (fixed) grouping
+            assert torch.allclose(a, b, rtol=2e-5, atol=1e-6 * b.abs().max().item()), n
+        else:
+            assert torch.equal(a, b), n
