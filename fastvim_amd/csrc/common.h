@@ -66,8 +66,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float v) {
   bf16_t h = __float2bfloat16(v);
   return *reinterpret_cast<uint16_t*>(&h);
 }
+// two floats -> one dword of bf16 (lo in the low half): ONE v_cvt_pk_bf16_f32 (the scalar form above, twice, plus the
+// merge is three instructions)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  typedef float fv_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 fv_bf16x2 __attribute__((ext_vector_type(2)));
+  const fv_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fv_bf16x2));
 }
 
 // ---------------------------------------------------------------- math

@@ -198,13 +198,13 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
 #pragma unroll
         for (int k = 0; k < CW; ++k) a_wf[k] = fma2(nf, x[k0 + k], a_wf[k]);
         a_bf += nf;
-        a_Df = fma2(dov[k3] * 0.5f, pf * sgf, a_Df);
+        a_Df = fma2(dov[k3], pf * sgf, a_Df);            // x 0.5 once, at the flush (exact)
       }
       if (n >= 0) {
 #pragma unroll
         for (int k = 0; k < CW; ++k) a_wb[k] = fma2(nb, x[k3 - k], a_wb[k]);
         a_bb += nb;
-        a_Db = fma2(dov[k0] * 0.5f, pb * sgb, a_Db);
+        a_Db = fma2(dov[k0], pb * sgb, a_Db);
         // dx[n] = sum_k wf[k] dpre_f[n+3-k] + wb[k] dpre_b[n-3+k]
         f2 dx = splat(0.f);
 #pragma unroll
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
     cf_dn = pooled(nxt, 2, false);
     cur = nxt;
   }
-  flush_partials(p, smem, c0, c_lo, nch * 128, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
+  flush_partials(p, smem, c0, c_lo, nch * 128, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df * 0.5f, a_Db * 0.5f);
 }
 
 // Long rows, walked cell by cell like conv_pool_fwd_chan_kernel: CHAN = channel-wise tokenization (tokens_per_patch ==
@@ -364,13 +364,13 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
 #pragma unroll
               for (int k = 0; k < CW; ++k) a_wf[k] = fma2(nf, X[c + k], a_wf[k]);
               a_bf += nf;
-              a_Df = fma2(DO[c + 3] * 0.5f, pf * sgf, a_Df);
+              a_Df = fma2(DO[c + 3], pf * sgf, a_Df);
             }
             if (c >= 3 || !first) {   // position n belongs to this row
 #pragma unroll
               for (int k = 0; k < CW; ++k) a_wb[k] = fma2(nb, X[c + 3 - k], a_wb[k]);
               a_bb += nb;
-              a_Db = fma2(DO[c] * 0.5f, pb * sgb, a_Db);
+              a_Db = fma2(DO[c], pb * sgb, a_Db);
               // dx[n] = sum_k wf[k] dpre_f[n+3-k] + wb[k] dpre_b[n-3+k]
               f2 dx = splat(0.f);
 #pragma unroll
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
       }
     }
   }
-  flush_partials(p, smem, c0, c_lo, nch * 128, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df, a_Db);
+  flush_partials(p, smem, c0, c_lo, nch * 128, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df * 0.5f, a_Db * 0.5f);
 }
 
 template <typename T, int TPP, bool CHAN>

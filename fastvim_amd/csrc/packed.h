@@ -9,9 +9,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 splat(float a) { f2 o; o.x = a; o.y = a; return o; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 sigmoid2(f2 a) {
+  const f2 t = a * splat(-FV_LOG2E);          // one v_pk_mul_f32 instead of two v_mul_f32
   f2 e;
-  e.x = __builtin_amdgcn_exp2f(a.x * -FV_LOG2E);
-  e.y = __builtin_amdgcn_exp2f(a.y * -FV_LOG2E);
+  e.x = __builtin_amdgcn_exp2f(t.x);
+  e.y = __builtin_amdgcn_exp2f(t.y);
   f2 d = e + 1.f, o;
   o.x = __builtin_amdgcn_rcpf(d.x);
   o.y = __builtin_amdgcn_rcpf(d.y);
