@@ -10,6 +10,7 @@ import sys
 KEYS = (("conv_pool_fwd", "conv_pool_fwd"), ("scan_fwd", "scan_cl_fwd"), ("combine_fwd", "combine_fwd"),
         ("combine_bwd", "combine_bwd"), ("scan_bwd", "scan_cl_bwd"), ("conv_pool_bwd", "conv_pool_bwd"),
         ("xproj_bwd", "xproj_bwd"), ("add_norm_fwd", "add_norm_fwd"), ("add_norm_bwd", "add_norm_bwd"),
+        ("gemm_out_proj_addnorm_fwd", "gemm_addnorm_kernel"), ("gemm_in_proj_dgrad_addnorm_bwd", "gemm_dgrad_addnorm_bwd_kernel"),
         ("gemm", "gemm_bf16_kernel"))
 
 

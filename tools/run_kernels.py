@@ -44,4 +44,19 @@ for _ in range(n):
     gemm_nn(do2, W_out); gemm_nn(xz2, W_in)
     gemm_tn(xz2, h2, splits=28); gemm_tn(do2, g2, splits=28)
     M.xproj_bwd(dxd, xc, rn(R_ + 2 * N, d_in, dt=torch.float32), rn(R_ + 2 * N, d_in, dt=torch.float32), dxc)
+    # the two fused projection kernels of a chained block (out_proj + add + RMSNorm; in_proj data gradient + norm adjoint)
+    import ctypes
+    from fastvim_amd import _lib as L_
+    lib = L_.lib()
+    resid, rstd_ = torch.randn(Mtok, d, device=dev, generator=g), torch.rand(Mtok, device=dev, generator=g) + 0.5
+    nw_, sc_ = torch.ones(d, device=dev), torch.ones(B, device=dev)
+    y_, ro_, rs_ = torch.empty(Mtok, d, device=dev, dtype=dtype), torch.empty(Mtok, d, device=dev), torch.empty(Mtok, device=dev)
+    gg_ = torch.randn(Mtok, d, device=dev, generator=g)
+    pw_ = torch.empty(lib.fv_gemm_bf16_dgrad_addnorm_blocks(L_.i32(Mtok)), d, device=dev)
+    L_.check(lib.fv_gemm_bf16_addnorm(L_.ptr(g2), L_.ptr(W_out), L_.ptr(resid), L_.ptr(nw_), L_.ptr(sc_), L_.i32(L), L_.ptr(y_),
+                                      L_.ptr(ro_), L_.ptr(rs_), L_.i32(Mtok), L_.i32(d), L_.i32(d_in), ctypes.c_long(d_in),
+                                      ctypes.c_long(d_in), ctypes.c_float(1e-5), L_.stream_of(g2)), "addnorm")
+    L_.check(lib.fv_gemm_bf16_dgrad_addnorm_bwd(L_.ptr(xz2), L_.ptr(W_in), L_.ptr(gg_), L_.ptr(resid), L_.ptr(rstd_), L_.ptr(nw_),
+                                                L_.ptr(sc_), L_.i32(L), L_.ptr(y_), L_.ptr(ro_), L_.ptr(pw_), L_.i32(Mtok), L_.i32(d),
+                                                L_.i32(2 * d_in), ctypes.c_long(2 * d_in), ctypes.c_long(d), L_.stream_of(xz2)), "dgrad_addnorm_bwd")
 torch.cuda.synchronize()
