@@ -130,6 +130,17 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
   };
   auto row_of = [&](int it) { return (it * gridDim.x + blockIdx.x) * RG + rg; };
   RowSrc cur = locate(row_of(0));
+  // The per-channel parameters are requested FIRST and the first row right behind them, with no wait in between: loads
+  // return in order, so the arithmetic of step -3 starts when the parameters and the first four tokens are there and
+  // the rest of the row streams in under it.  (Requested last, their wait was a wait for the whole row -- and every wave
+  // of the grid asks for its first row at the same moment: 35 MB, 7 us in which nothing was computed.)
+  // (an absent bias / D is read from the taps and multiplied by zero: no branch around the load, no wait inside it)
+  f2 wf[CW], wb[CW];
+  load_taps2(p.wf, c0, wf);
+  load_taps2(p.wb, c0, wb);
+  const f2 bf_raw = load_f2(p.bf ? p.bf : p.wf, c0), bb_raw = load_f2(p.bb ? p.bb : p.wf, c0);
+  const f2 Df_raw = load_f2(p.Df ? p.Df : p.wf, c0), Db_raw = load_f2(p.Db ? p.Db : p.wf, c0);
+  __builtin_amdgcn_sched_barrier(0);
   // Pooled gradients: the forward conv needs rows i (positions of this row) and i+1 (the three halo positions
   // behind it), the backward conv rows i-1 and i.  All are loaded unscaled, one row ahead, in the order of their
   // first use -- here exactly as in the loop, so that the waits the compiler places at the top of the loop body (one
@@ -142,15 +153,9 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
   for (int k = 0; k < NT + 6; ++k) fetch(cur, k);
   __builtin_amdgcn_sched_barrier(0);
   f2 cf_dn = pooled(cur, 2, false);
-  // the per-channel parameters go out behind the first row: one exposed round trip at the start of a wave, not two
-  // (an absent bias / D is read from the taps and multiplied by zero: no branch around the load, no wait inside it)
-  f2 wf[CW], wb[CW], bf, bb, Dfh, Dbh;
-  load_taps2(p.wf, c0, wf);
-  load_taps2(p.wb, c0, wb);
-  bf = load_f2(p.bf ? p.bf : p.wf, c0) * (p.bf ? 1.f : 0.f);
-  bb = load_f2(p.bb ? p.bb : p.wf, c0) * (p.bb ? 1.f : 0.f);
-  Dfh = load_f2(p.Df ? p.Df : p.wf, c0) * (p.Df ? 0.5f : 0.f);
-  Dbh = load_f2(p.Db ? p.Db : p.wf, c0) * (p.Db ? 0.5f : 0.f);
+  __builtin_amdgcn_sched_barrier(0);
+  const f2 bf = bf_raw * (p.bf ? 1.f : 0.f), bb = bb_raw * (p.bb ? 1.f : 0.f);
+  const f2 Dfh = Df_raw * (p.Df ? 0.5f : 0.f), Dbh = Db_raw * (p.Db ? 0.5f : 0.f);
   for (int it = 0; it < nit; ++it) {
     if (row_of(it) >= nrows) break;          // uniform per wave; no block-level sync inside
     const RowSrc nxt = locate(row_of(it + 1));
