@@ -61,6 +61,12 @@ struct NormEpi {
   // normalisation input r, `rstd` is read, `y` receives d x (bf16, x row_scale) and `res_out` d residual_in
   const float* dres_out;   // (M, N) fp32 gradient of the residual stream arriving from above, nullable
   float* pw;               // (workgroups, N) per-workgroup partial sums of d norm weight
+  // second GEMM phase of the backward form, nullable: C2 (M, N2) bf16 = d x (the tile just produced, still in LDS) @ W2
+  // (N, N2) as stored -- the previous block's out_proj data gradient
+  const bf16_t* W2;
+  bf16_t* C2;
+  long ldw2;
+  int N2;
 };
 
 // KS tiles: rows (k) are EXT*2 bytes = a multiple of the 256-byte bank row, and a transposing read
@@ -239,6 +245,76 @@ struct KsFrags {
     return __builtin_bit_cast(bf16x8, t);
   }
 };
+
+// Second GEMM phase of a fused kernel: C2 (BMT rows of this workgroup, N2 columns) = T @ W2, T = the workgroup's BMT x 192
+// bf16 tile in LDS (rows RSB bytes apart), W2 (192, N2) row-major (K-slow), four waves as 2 x 2 of (BMT / 2) x 64, 128
+// columns of C2 at a time, the W2 panel staged by LDS-DMA through two 16 KiB buffers.
+template <int BMT, int RSB>
+__device__ __forceinline__ void tile_times_w2(const char* tile, char* ldsB, char* slabs, const bf16_t* W2, long ldw2, int N2,
+                                              bf16_t* C2, int m0, int M, int tid) {
+  constexpr int MB2 = BMT / 32, NB2 = 4, K2 = 192, STG = 128 * BK * 2;
+  const int lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  KsFrags<128, NB2> kb;
+  kb.init(ldsB, wn * NB2, lane);
+  constexpr int RS = 64 * 2 + 16, CH = 64 / 8;            // epilogue slab: 32 rows x 64 columns per wave
+  char* my = slabs + wv * (32 * RS);
+  for (int n0 = 0; n0 < N2; n0 += 128) {
+    GldsPlan<KS, 128, 256> gb;
+    gb.init(W2, ldw2, n0, N2, tid);
+    f32x4 acc[NB2][MB2];
+#pragma unroll
+    for (int a = 0; a < NB2; ++a)
+#pragma unroll
+      for (int b = 0; b < MB2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gb.issue(ldsB, 0, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < K2 / BK; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < K2 / BK) gb.issue(ldsB + (cur ^ 1) * STG, (kt + 1) * BK, tid);
+      kb.read(cur * STG);
+      kb.wait();
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 fa[MB2];
+#pragma unroll
+        for (int b = 0; b < MB2; ++b)
+          fa[b] = *reinterpret_cast<const bf16x8*>(tile + (wm * (BMT / 2) + b * 16 + (lane & 15)) * RSB +
+                                                   (kt * BK + ks * 32 + (lane >> 4) * 8) * 2);
+#pragma unroll
+        for (int a = 0; a < NB2; ++a)
+#pragma unroll
+          for (int b = 0; b < MB2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb.get(ks, a), fa[b], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    // bf16 through the wave's slab: 16-byte stores, whole 128-byte row segments
+#pragma unroll
+    for (int h = 0; h < (MB2 + 1) / 2; ++h) {
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int b = 2 * h + bb;
+        if (b < MB2) {
+#pragma unroll
+          for (int a = 0; a < NB2; ++a) {
+            const f32x4 v = acc[a][b];
+            uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<uint2*>(my + (bb * 16 + (lane & 15)) * RS + (a * 16 + (lane >> 4) * 4) * 2) = pk;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      constexpr int ROWS = MB2 >= 2 ? 32 : 16;
+#pragma unroll
+      for (int i = 0; i < ROWS * CH / 64; ++i) {
+        const int idx = i * 64 + lane, r = idx / CH, ch = idx - r * CH;
+        const int m = m0 + wm * (BMT / 2) + h * 32 + r, n = n0 + wn * 64 + ch * 8;
+        if (m < M && n < N2) *reinterpret_cast<u32x4*>(C2 + (long)m * N2 + n) = *reinterpret_cast<const u32x4*>(my + r * RS + ch * 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
 
 // WM x WN waves, each 16*MB rows x 16*NB columns: tile BM = 16*MB*WM rows (m), BN = 16*NB*WN cols (n).
 // NB = 6 gives 128x192 tiles: an N = 192 output is one tile wide, so the A panel is read once instead of 3 times.
@@ -485,13 +561,16 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
               for (int e = 0; e < 4; ++e) dr[e] *= sc;
             uint2 pk = {pack_bf16x2(dr[0], dr[1]), pack_bf16x2(dr[2], dr[3])};
             *reinterpret_cast<uint2*>(ne->y + base + c) = pk;
+            *reinterpret_cast<uint2*>(smem + rl * RSB + c * 2) = pk;      // d x stays in the tile for the second phase
+          } else {
+            *reinterpret_cast<uint2*>(smem + rl * RSB + c * 2) = make_uint2(0u, 0u);
           }
         }
       }
     }
     // d norm weight: the 4 row groups of a wave (permlane swaps), then the 4 waves through LDS, fixed order
     __syncthreads();
-    float* s_acc = reinterpret_cast<float*>(smem);
+    float* s_acc = reinterpret_cast<float*>(smem + BM * RSB);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -506,6 +585,12 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     __syncthreads();
     float* dst = ne->pw + (size_t)block_id * BN;
     for (int c = tid; c < BN; c += NT) dst[c] = (s_acc[c] + s_acc[BN + c]) + (s_acc[2 * BN + c] + s_acc[3 * BN + c]);
+    if (ne->W2) {
+      // ---- second phase: the previous block's out_proj data gradient d g = d x @ W_out from the tile in LDS
+      __syncthreads();
+      constexpr int O_B = (BM * RSB + 255) / 256 * 256, O_S = O_B + 2 * 128 * BK * 2;
+      tile_times_w2<BM, RSB>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, p.M, tid);
+    }
     return;
   }
   if constexpr (NORM_EPI == 1) {
@@ -1051,7 +1136,7 @@ extern "C" int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* r
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = N; p.c_fp32 = 0;
   p.k_per_split = K;
   NormEpi ne{residual, norm_weight, row_scale, residual_out, (bf16_t*)y, rstd, rows_per_scale > 0 ? rows_per_scale : 1, eps,
-             nullptr, nullptr};
+             nullptr, nullptr, nullptr, nullptr, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto bm) {
     constexpr int BMR = decltype(bm)::value;
@@ -1080,6 +1165,15 @@ extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd(const void* A, const void* W, cons
                                               const float* rstd, const float* norm_weight, const float* row_scale,
                                               int rows_per_scale, void* dx, float* dresidual_in, float* partial_dw, int M,
                                               int N, int K, long lda, long ldw, fv_stream_t stream) {
+  return fv_gemm_bf16_dgrad_addnorm_bwd2(A, W, dresidual_out, r, rstd, norm_weight, row_scale, rows_per_scale, dx, dresidual_in,
+                                         partial_dw, M, N, K, lda, ldw, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, const float* dresidual_out, const float* r,
+                                               const float* rstd, const float* norm_weight, const float* row_scale,
+                                               int rows_per_scale, void* dx, float* dresidual_in, float* partial_dw, int M,
+                                               int N, int K, long lda, long ldw, const void* W2, void* C2, int N2, long ldw2,
+                                               fv_stream_t stream) {
   FV_CHECK(A && W && r && rstd && norm_weight && dx && dresidual_in && partial_dw, "gemm_bf16_dgrad_addnorm_bwd: null pointer");
   FV_CHECK(M > 0 && K > 0, "gemm_bf16_dgrad_addnorm_bwd: empty problem");
   if (N != 192 || K % BK != 0) return FV_ERR_UNSUPPORTED;
@@ -1092,11 +1186,19 @@ extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd(const void* A, const void* W, cons
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = dx; p.bias = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = N; p.c_fp32 = 0;
   p.k_per_split = K;
+  if (W2) {
+    FV_CHECK(C2 && N2 > 0 && N2 % 128 == 0 && ldw2 >= N2 && ldw2 % 8 == 0 && ((uintptr_t)W2 & 15) == 0 && ((uintptr_t)C2 & 15) == 0,
+             "gemm_bf16_dgrad_addnorm_bwd2: the second weight must be (N, N2) with N2 a multiple of 128, 16-byte aligned");
+  }
   NormEpi ne{r, norm_weight, row_scale, dresidual_in, (bf16_t*)dx, const_cast<float*>(rstd),
-             rows_per_scale > 0 ? rows_per_scale : 1, 0.f, dresidual_out, partial_dw};
+             rows_per_scale > 0 ? rows_per_scale : 1, 0.f, dresidual_out, partial_dw,
+             (const bf16_t*)W2, (bf16_t*)C2, ldw2, N2};
   auto go = [&](auto bm) {
     constexpr int BMR = decltype(bm)::value;
-    const size_t smem = (size_t)2 * (BMR + 192) * BK * 2;
+    // main loop: two (BMR + 192) x 64 stages; second phase: the d x tile, two 128 x 64 stages, four epilogue slabs
+    constexpr size_t s1 = (size_t)2 * (BMR + 192) * BK * 2;
+    constexpr size_t s2 = ((size_t)BMR * 400 + 255) / 256 * 256 + 2 * 128 * BK * 2 + 4 * 32 * 144;
+    const size_t smem = s1 > s2 ? s1 : s2;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)gemm_dgrad_addnorm_bwd_kernel<BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

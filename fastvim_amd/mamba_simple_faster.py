@@ -313,8 +313,9 @@ class ChainedBlockFn(torch.autograd.Function):
     gated activations.  Inputs: the previous block's gated activations and ``out_proj`` weight, the residual stream, the
     norm weight, then ``FastVimMixerFn``'s arguments after ``hidden`` (with ``W_out`` / ``b_out`` None).  Returns
     (gated activations, residual_out).  Backward runs the mixer's adjoint, with the in_proj data gradient produced
-    INSIDE the norm's adjoint (``fv_gemm_bf16_dgrad_addnorm_bwd``: it is needed by nothing else), then the previous
-    ``out_proj``'s two gradients -- the values of ``OutProjAddNormFn`` + ``FastVimMixerFn`` back to back; only the norm
+    INSIDE the norm's adjoint (``fv_gemm_bf16_dgrad_addnorm_bwd2``: it is needed by nothing else) and the previous
+    ``out_proj``'s data gradient as a second GEMM phase of the same launch (from the d x tile still in LDS), then that
+    ``out_proj``'s weight gradient -- the values of ``OutProjAddNormFn`` + ``FastVimMixerFn`` back to back; only the norm
     weight's gradient is summed in a different (fixed) order."""
 
     @staticmethod
@@ -355,12 +356,17 @@ class ChainedBlockFn(torch.autograd.Function):
             dres_in = torch.empty(Mrows, d, device=dev, dtype=torch.float32)
             pw = torch.empty(nb, d, device=dev, dtype=torch.float32)
             gg = dres_out.reshape(Mrows, d).contiguous() if dres_out is not None else None
-            rc = lib.fv_gemm_bf16_dgrad_addnorm_bwd(
+            # second phase of the same launch: the previous block's out_proj data gradient, from the d x tile in LDS
+            d_prev = g_prev.shape[2]
+            W2 = _shadow(W_out_prev, cdt) if d_prev % 128 == 0 else None
+            dg_prev = torch.empty(Mrows, d_prev, device=dev, dtype=cdt) if W2 is not None else None
+            rc = lib.fv_gemm_bf16_dgrad_addnorm_bwd2(
                 L.ptr(dxz2), L.ptr(_shadow(ctx.W_in, cdt)), L.ptr(gg), L.ptr(r), L.ptr(rstd), L.ptr(w32), L.ptr(row_scale),
                 L.i32(ctx.rows_per_scale), L.ptr(dx), L.ptr(dres_in), L.ptr(pw), L.i32(Mrows), L.i32(d),
-                L.i32(dxz2.shape[1]), ctypes.c_long(dxz2.stride(0)), ctypes.c_long(d), L.stream_of(dxz2))
+                L.i32(dxz2.shape[1]), ctypes.c_long(dxz2.stride(0)), ctypes.c_long(d), L.ptr(W2), L.ptr(dg_prev),
+                L.i32(d_prev if W2 is not None else 0), ctypes.c_long(d_prev), L.stream_of(dxz2))
             L.check(rc, "gemm_bf16_dgrad_addnorm_bwd")
-            out.update(dx=dx, dres_in=dres_in, pw=pw, nb=nb)
+            out.update(dx=dx, dres_in=dres_in, pw=pw, nb=nb, dg_prev=dg_prev)
 
         fctx.fused_in_dgrad = fused_in_dgrad
         grads = FastVimMixerFn.backward(fctx, dg)
@@ -374,7 +380,8 @@ class ChainedBlockFn(torch.autograd.Function):
             dx = out["dx"]
             d_in = g_prev.shape[2]
             g2 = g_prev.view(Mrows, d_in)
-            dg_prev = linear_dgrad(dx, _shadow(W_out_prev, cdt)).view(B, Ltok, d_in)
+            dg_prev = out["dg_prev"] if out["dg_prev"] is not None else linear_dgrad(dx, _shadow(W_out_prev, cdt))
+            dg_prev = dg_prev.view(B, Ltok, d_in)
             dW_out = _SideStream.run(lambda: linear_wgrad(dx, g2, W_out_prev), dx, g_prev)
         return (dg_prev, dW_out, out["dres_in"].view(B, Ltok, d), dw, None, None) + tuple(grads[1:1 + ctx.n_mixer_args])
 

@@ -290,6 +290,15 @@ int fv_gemm_bf16_dgrad_addnorm_bwd(const void* A, const void* W, const float* dr
                                    int rows_per_scale, void* dx, float* dresidual_in, float* partial_dw, int M, int N,
                                    int K, long lda, long ldw, fv_stream_t stream);
 
+/* The same with a second GEMM phase: C2 (M, N2) bf16 = d x @ W2, W2 (N, N2) bf16 row-major -- the PREVIOUS block's out_proj
+ * data gradient (d g = d x @ out_proj.weight), computed from the d x tile while it is still in LDS; bit-identical to
+ * fv_gemm_bf16(b_k_slow = 1) on d x.  W2 null: no second phase.  N2 % 128 == 0. */
+int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, const float* dresidual_out, const float* r,
+                                    const float* rstd, const float* norm_weight, const float* row_scale,
+                                    int rows_per_scale, void* dx, float* dresidual_in, float* partial_dw, int M, int N,
+                                    int K, long lda, long ldw, const void* W2, void* C2, int N2, long ldw2,
+                                    fv_stream_t stream);
+
 /* Several weight gradients in one launch (queued until the end of the backward pass): problem i is
  * x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32 partials (sum with fv_reduce_partials);
  * the same arithmetic, tiling and fixed split order as fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1). */
