@@ -249,17 +249,19 @@ struct KsFrags {
 // Second GEMM phase of a fused kernel: C2 (BMT rows of this workgroup, N2 columns) = T @ W2, T = the workgroup's BMT x 192
 // bf16 tile in LDS (rows RSB bytes apart), W2 (192, N2) row-major (K-slow), four waves as 2 x 2 of (BMT / 2) x 64, 128
 // columns of C2 at a time, the W2 panel staged by LDS-DMA through two 16 KiB buffers.
-template <int BMT, int RSB>
+// WMODE = KS: W2 (192, N2) row-major (a weight as stored, used as a data gradient); WMODE = KC: W2 (N2, 192) row-major
+// (a weight as stored, used forward: C2 = T @ W2^T).
+template <int BMT, int RSB, int WMODE>
 __device__ __forceinline__ void tile_times_w2(const char* tile, char* ldsB, char* slabs, const bf16_t* W2, long ldw2, int N2,
                                               bf16_t* C2, int m0, int M, int tid) {
   constexpr int MB2 = BMT / 32, NB2 = 4, K2 = 192, STG = 128 * BK * 2;
   const int lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-  KsFrags<128, NB2> kb;
-  kb.init(ldsB, wn * NB2, lane);
+  KsFrags<128, WMODE == KS ? NB2 : 1> kb;
+  if constexpr (WMODE == KS) kb.init(ldsB, wn * NB2, lane);
   constexpr int RS = 64 * 2 + 16, CH = 64 / 8;            // epilogue slab: 32 rows x 64 columns per wave
   char* my = slabs + wv * (32 * RS);
   for (int n0 = 0; n0 < N2; n0 += 128) {
-    GldsPlan<KS, 128, 256> gb;
+    GldsPlan<WMODE, 128, 256> gb;
     gb.init(W2, ldw2, n0, N2, tid);
     f32x4 acc[NB2][MB2];
 #pragma unroll
@@ -272,19 +274,26 @@ __device__ __forceinline__ void tile_times_w2(const char* tile, char* ldsB, char
     for (int kt = 0; kt < K2 / BK; ++kt) {
       const int cur = kt & 1;
       if (kt + 1 < K2 / BK) gb.issue(ldsB + (cur ^ 1) * STG, (kt + 1) * BK, tid);
-      kb.read(cur * STG);
-      kb.wait();
+      if constexpr (WMODE == KS) {
+        kb.read(cur * STG);
+        kb.wait();
+      }
 #pragma unroll
       for (int ks = 0; ks < BK / 32; ++ks) {
-        bf16x8 fa[MB2];
+        bf16x8 fa[MB2], fb[NB2];
 #pragma unroll
         for (int b = 0; b < MB2; ++b)
           fa[b] = *reinterpret_cast<const bf16x8*>(tile + (wm * (BMT / 2) + b * 16 + (lane & 15)) * RSB +
                                                    (kt * BK + ks * 32 + (lane >> 4) * 8) * 2);
 #pragma unroll
+        for (int a = 0; a < NB2; ++a) {
+          if constexpr (WMODE == KS) fb[a] = kb.get(ks, a);
+          else fb[a] = frag<KC, 128>(ldsB + cur * STG, wn * NB2 + a, ks, lane);
+        }
+#pragma unroll
         for (int a = 0; a < NB2; ++a)
 #pragma unroll
-          for (int b = 0; b < MB2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb.get(ks, a), fa[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < MB2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[a], fa[b], acc[a][b], 0, 0, 0);
       }
       __syncthreads();
     }
@@ -589,7 +598,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
       // ---- second phase: the previous block's out_proj data gradient d g = d x @ W_out from the tile in LDS
       __syncthreads();
       constexpr int O_B = (BM * RSB + 255) / 256 * 256, O_S = O_B + 2 * 128 * BK * 2;
-      tile_times_w2<BM, RSB>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, p.M, tid);
+      tile_times_w2<BM, RSB, KS>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, p.M, tid);
     }
     return;
   }
@@ -674,12 +683,19 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
             asm volatile("" : "+v"(t));
             o[e] = t * w[k][e];
           }
-          if (live) {
-            uint2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-            *reinterpret_cast<uint2*>(ne->y + base + c) = pk;
-          }
+          uint2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+          if (live) *reinterpret_cast<uint2*>(ne->y + base + c) = pk;
+          else pk = make_uint2(0u, 0u);
+          // the normalised row replaces the product in the tile (same lane, same bytes) for the second phase
+          *reinterpret_cast<uint2*>(smem + (wv * RW + it * (RPW * RU) + u * RPW + gr) * RSB + c * 2) = pk;
         }
       }
+    }
+    if (ne->W2) {
+      // ---- second phase: this block's in_proj, xz = y @ W_in^T, from the normalised tile in LDS
+      __syncthreads();
+      constexpr int O_B = (BM * RSB + 255) / 256 * 256, O_S = O_B + 2 * 128 * BK * 2;
+      tile_times_w2<BM, RSB, KC>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, p.M, tid);
     }
     return;
   }
@@ -1124,6 +1140,14 @@ static int gemm_entry(const void* A, const void* B, void* C, const float* bias, 
 extern "C" int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* residual, const float* norm_weight,
                                     const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd,
                                     int M, int N, int K, long lda, long ldw, float eps, fv_stream_t stream) {
+  return fv_gemm_bf16_addnorm2(A, W, residual, norm_weight, row_scale, rows_per_scale, y, residual_out, rstd, M, N, K, lda, ldw, eps,
+                               nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* residual, const float* norm_weight,
+                                     const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd,
+                                     int M, int N, int K, long lda, long ldw, float eps, const void* W2, void* C2, int N2,
+                                     long ldw2, fv_stream_t stream) {
   FV_CHECK(A && W && residual && norm_weight && y && residual_out && rstd, "gemm_bf16_addnorm: null pointer");
   FV_CHECK(M > 0 && K > 0, "gemm_bf16_addnorm: empty problem");
   if (N != 192 || K % BK != 0) return FV_ERR_UNSUPPORTED;      // whole 192-wide rows per workgroup, LDS-DMA staging
@@ -1135,12 +1159,19 @@ extern "C" int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* r
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)W; p.C = y; p.bias = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = N; p.c_fp32 = 0;
   p.k_per_split = K;
+  if (W2) {
+    FV_CHECK(C2 && N2 > 0 && N2 % 128 == 0 && ldw2 >= N && ldw2 % 8 == 0 && ((uintptr_t)W2 & 15) == 0 && ((uintptr_t)C2 & 15) == 0,
+             "gemm_bf16_addnorm2: the second weight must be (N2, N) with N2 a multiple of 128, 16-byte aligned");
+  }
   NormEpi ne{residual, norm_weight, row_scale, residual_out, (bf16_t*)y, rstd, rows_per_scale > 0 ? rows_per_scale : 1, eps,
-             nullptr, nullptr, nullptr, nullptr, 0, 0};
+             nullptr, nullptr, (const bf16_t*)W2, (bf16_t*)C2, ldw2, N2};
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto bm) {
     constexpr int BMR = decltype(bm)::value;
-    const size_t smem = (size_t)2 * (BMR + 192) * BK * 2;
+    // main loop: two (BMR + 192) x 64 stages; second phase: the normalised tile, two 128 x 64 stages, four epilogue slabs
+    constexpr size_t s1 = (size_t)2 * (BMR + 192) * BK * 2;
+    constexpr size_t s2 = ((size_t)BMR * 400 + 255) / 256 * 256 + 2 * 128 * BK * 2 + 4 * 32 * 144;
+    const size_t smem = s1 > s2 ? s1 : s2;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)gemm_addnorm_kernel<BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -285,7 +285,8 @@ class _Ctx:
         self.saved_tensors = tensors
 
 
-def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt):
+def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in=None):
+    """``W_in`` (2 d_inner, d): also run this block's in_proj as a second phase of the launch; returns xz last."""
     B, Ltok, d_in = g.shape
     d = W_out.shape[0]
     Mrows = B * Ltok
@@ -299,11 +300,22 @@ def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt):
     if row_scale is not None:
         row_scale = row_scale.float().contiguous()
         rows_per_scale = Mrows // row_scale.numel()
-    rc = L.lib().fv_gemm_bf16_addnorm(
-        L.ptr(g2), L.ptr(_shadow(W_out, cdt)), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
+    xz = None
+    if W_in is not None and W_in.shape[0] % 128 == 0:
+        xz = torch.empty(Mrows, W_in.shape[0], device=g.device, dtype=cdt)
+    # (the compute-dtype weights are held in locals across the launch: without a flat training state ``_shadow`` returns a
+    #  fresh cast, and a temporary inside the argument list is freed -- and its memory handed to the next cast -- before
+    #  the kernel is even enqueued)
+    W_out_c = _shadow(W_out, cdt)
+    W_in_c = _shadow(W_in, cdt) if xz is not None else None
+    rc = L.lib().fv_gemm_bf16_addnorm2(
+        L.ptr(g2), L.ptr(W_out_c), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
         L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
-        ctypes.c_long(d_in), ctypes.c_float(eps), L.stream_of(g2))
+        ctypes.c_long(d_in), ctypes.c_float(eps), L.ptr(W_in_c), L.ptr(xz),
+        L.i32(W_in.shape[0] if xz is not None else 0), ctypes.c_long(d), L.stream_of(g2))
     L.check(rc, "gemm_bf16_addnorm")
+    if W_in is not None:
+        return y, res_out, rstd, w32, row_scale, rows_per_scale, xz
     return y, res_out, rstd, w32, row_scale, rows_per_scale
 
 
@@ -318,17 +330,30 @@ class ChainedBlockFn(torch.autograd.Function):
     ``out_proj``'s weight gradient -- the values of ``OutProjAddNormFn`` + ``FastVimMixerFn`` back to back; only the norm
     weight's gradient is summed in a different (fixed) order."""
 
+    # this block's in_proj as a second GEMM phase of the forward launch (fv_gemm_bf16_addnorm2): bit-identical and 4 us
+    # faster stand-alone (32.3 vs 36.3 us), but 0.07 ms SLOWER per FastVim-T step (5.94 vs 5.87 ms, same box): the
+    # 38 MB of xz stores at the end of a 392-workgroup launch cost more than the launch they save.  Off.
+    in_proj_in_launch = False
+
     @staticmethod
     def forward(ctx, g_prev, W_out_prev, residual, norm_w, eps, row_scale, *mixer_args):
         L.require_gpu(g_prev, W_out_prev, residual, norm_w)
         B, Ltok, _ = g_prev.shape
         d = W_out_prev.shape[0]
         cdt = mixer_args[26]            # FastVimMixerFn.forward(ctx, hidden, <26 arguments>, cdt, fv, tpp, valid)
+        W_in, b_in = mixer_args[0], mixer_args[1]
         with torch.autocast("cuda", enabled=False):
-            y, res_out, rstd, w32, rs, rps = _out_proj_add_norm_fwd(g_prev, W_out_prev, residual, norm_w, eps, row_scale, cdt)
+            if ChainedBlockFn.in_proj_in_launch and b_in is None:
+                y, res_out, rstd, w32, rs, rps, xz = _out_proj_add_norm_fwd(g_prev, W_out_prev, residual, norm_w, eps,
+                                                                          row_scale, cdt, W_in=W_in)
+            else:
+                y, res_out, rstd, w32, rs, rps = _out_proj_add_norm_fwd(g_prev, W_out_prev, residual, norm_w, eps, row_scale, cdt)
+                xz = None
         fctx = _Ctx()
+        fctx.precomputed_xz = xz
         g = FastVimMixerFn.forward(fctx, y.view(B, Ltok, d), *mixer_args)
         mixer_saved = fctx.__dict__.pop("saved_tensors")
+        fctx.__dict__.pop("precomputed_xz", None)
         ctx.save_for_backward(g_prev, W_out_prev, res_out, w32, rstd, rs, *mixer_saved)
         ctx.mixer_attrs = fctx.__dict__
         ctx.rows_per_scale = rps
@@ -359,9 +384,10 @@ class ChainedBlockFn(torch.autograd.Function):
             # second phase of the same launch: the previous block's out_proj data gradient, from the d x tile in LDS
             d_prev = g_prev.shape[2]
             W2 = _shadow(W_out_prev, cdt) if d_prev % 128 == 0 else None
+            W_in_c = _shadow(ctx.W_in, cdt)                  # (held across the launch, see _out_proj_add_norm_fwd)
             dg_prev = torch.empty(Mrows, d_prev, device=dev, dtype=cdt) if W2 is not None else None
             rc = lib.fv_gemm_bf16_dgrad_addnorm_bwd2(
-                L.ptr(dxz2), L.ptr(_shadow(ctx.W_in, cdt)), L.ptr(gg), L.ptr(r), L.ptr(rstd), L.ptr(w32), L.ptr(row_scale),
+                L.ptr(dxz2), L.ptr(W_in_c), L.ptr(gg), L.ptr(r), L.ptr(rstd), L.ptr(w32), L.ptr(row_scale),
                 L.i32(ctx.rows_per_scale), L.ptr(dx), L.ptr(dres_in), L.ptr(pw), L.i32(Mrows), L.i32(d),
                 L.i32(dxz2.shape[1]), ctypes.c_long(dxz2.stride(0)), ctypes.c_long(d), L.ptr(W2), L.ptr(dg_prev),
                 L.i32(d_prev if W2 is not None else 0), ctypes.c_long(d_prev), L.stream_of(dxz2))
@@ -420,7 +446,10 @@ class FastVimMixerFn(torch.autograd.Function):
             h_c = hidden.to(cdt).contiguous()
             W_in_c = _shadow(W_in, cdt)
             W_out_c = _shadow(W_out, cdt) if W_out is not None else None
-            xz = linear_fwd(h_c.view(B * Ltok, d), W_in_c, b_in).view(B, Ltok, 2 * d_in)  # (B, L, 2 d_in)
+            xz = getattr(ctx, "precomputed_xz", None)          # ChainedBlockFn: in_proj ran inside the previous launch
+            if xz is None:
+                xz = linear_fwd(h_c.view(B * Ltok, d), W_in_c, b_in)
+            xz = xz.view(B, Ltok, 2 * d_in)                                                # (B, L, 2 d_in)
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             amax = None
             if pool_max:

@@ -299,6 +299,14 @@ int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, const float* d
                                     int K, long lda, long ldw, const void* W2, void* C2, int N2, long ldw2,
                                     fv_stream_t stream);
 
+/* fv_gemm_bf16_addnorm with a second GEMM phase: C2 (M, N2) bf16 = y @ W2^T, W2 (N2, N) bf16 row-major -- the block's
+ * in_proj (mamba_simple_faster.py:189-193) computed from the normalised tile while it is still in LDS; bit-identical to
+ * fv_gemm_bf16 on y.  W2 null: no second phase.  N2 % 128 == 0. */
+int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* residual, const float* norm_weight,
+                          const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd, int M,
+                          int N, int K, long lda, long ldw, float eps, const void* W2, void* C2, int N2, long ldw2,
+                          fv_stream_t stream);
+
 /* Several weight gradients in one launch (queued until the end of the backward pass): problem i is
  * x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32 partials (sum with fv_reduce_partials);
  * the same arithmetic, tiling and fixed split order as fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1). */

@@ -74,3 +74,39 @@ def test_chained_backbone_equals_block_by_block(drop_path):
             assert torch.allclose(a, b, rtol=2e-5, atol=1e-6 * b.abs().max().item()), n
         else:
             assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("M", [25088, 784, 100])
+def test_second_gemm_phases_bitwise(M):
+    """fv_gemm_bf16_addnorm2 / fv_gemm_bf16_dgrad_addnorm_bwd2: the GEMM run from the tile still in LDS equals the
+    stand-alone GEMM on the tensor the first phase wrote."""
+    import ctypes
+    from fastvim_amd import _lib as L
+    from fastvim_amd.gemm import gemm_nn, gemm_nt
+    d, d_in = 192, 384
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    rn = lambda *s: torch.randn(*s, device=_dev(), generator=gen)
+    lib = L.lib()
+    W_out, W_in = (rn(d, d_in) * d_in ** -0.5).bfloat16(), (rn(2 * d_in, d) * d ** -0.5).bfloat16()
+    nw = 1 + 0.1 * rn(d)
+    # forward: out_proj + add + RMSNorm, then in_proj from the normalised tile
+    g, res = rn(M, d_in).bfloat16(), rn(M, d)
+    y, ro, rs = torch.empty(M, d, device=_dev(), dtype=torch.bfloat16), torch.empty(M, d, device=_dev()), torch.empty(M, device=_dev())
+    xz = torch.empty(M, 2 * d_in, device=_dev(), dtype=torch.bfloat16)
+    rc = lib.fv_gemm_bf16_addnorm2(L.ptr(g), L.ptr(W_out), L.ptr(res), L.ptr(nw), L.ptr(None), L.i32(1), L.ptr(y), L.ptr(ro), L.ptr(rs),
+                                   L.i32(M), L.i32(d), L.i32(d_in), ctypes.c_long(d_in), ctypes.c_long(d_in), ctypes.c_float(1e-5),
+                                   L.ptr(W_in), L.ptr(xz), L.i32(2 * d_in), ctypes.c_long(d), L.stream_of(g))
+    L.check(rc, "addnorm2")
+    assert torch.equal(xz, gemm_nt(y, W_in))
+    # backward: in_proj data gradient + norm adjoint, then the out_proj data gradient from the d x tile
+    dxz, gg, r = rn(M, 2 * d_in).bfloat16(), rn(M, d), rn(M, d)
+    rstd = torch.rand(M, device=_dev(), generator=gen) + 0.5
+    dx, dri = torch.empty(M, d, device=_dev(), dtype=torch.bfloat16), torch.empty(M, d, device=_dev())
+    pw = torch.empty(lib.fv_gemm_bf16_dgrad_addnorm_blocks(L.i32(M)), d, device=_dev())
+    dg = torch.empty(M, d_in, device=_dev(), dtype=torch.bfloat16)
+    Wt = W_in.contiguous()
+    rc = lib.fv_gemm_bf16_dgrad_addnorm_bwd2(L.ptr(dxz), L.ptr(Wt), L.ptr(gg), L.ptr(r), L.ptr(rstd), L.ptr(nw), L.ptr(None), L.i32(1),
+                                             L.ptr(dx), L.ptr(dri), L.ptr(pw), L.i32(M), L.i32(d), L.i32(2 * d_in), ctypes.c_long(2 * d_in),
+                                             ctypes.c_long(d), L.ptr(W_out), L.ptr(dg), L.i32(d_in), ctypes.c_long(d_in), L.stream_of(dxz))
+    L.check(rc, "dgrad_addnorm_bwd2")
+    assert torch.equal(dg, gemm_nn(dx, W_out))
