@@ -211,8 +211,9 @@ def kernel_table(B, rows, cols, d, depth, dtype):
             "own_operands_per_problem": nset == depth}
         if d == 192:
             # inside a run of blocks (fastvim._run_layers_chained) out_proj runs fused with the next block's add + RMSNorm,
-            # and the in_proj data gradient fused with the block's norm adjoint: the rows above for those GEMMs and for
-            # add_rmsnorm_fwd are then launched once per step (first block / closing out_proj), these depth - 1 times
+            # and the in_proj data gradient fused with the block's norm adjoint and the previous block's out_proj data
+            # gradient: the rows for those GEMMs and for add_rmsnorm_fwd are then launched once per step (first block /
+            # closing out_proj), these depth - 1 times
             import ctypes
             from fastvim_amd import _lib as L_
             lib = L_.lib()
@@ -228,14 +229,18 @@ def kernel_table(B, rows, cols, d, depth, dtype):
                                                   L_.ptr(y_), L_.ptr(ro_), L_.ptr(rs_), L_.i32(Mt), L_.i32(d), L_.i32(d_in),
                                                   ctypes.c_long(d_in), ctypes.c_long(d_in), ctypes.c_float(1e-5), L_.stream_of(g2)), "addnorm")
 
-            def fused_bwd():
-                L_.check(lib.fv_gemm_bf16_dgrad_addnorm_bwd(L_.ptr(xz2), L_.ptr(W_in_t), L_.ptr(gg_), L_.ptr(resid), L_.ptr(rstd_),
-                                                            L_.ptr(nw_), L_.ptr(sc_), L_.i32(L), L_.ptr(y_), L_.ptr(ro_), L_.ptr(pw_),
-                                                            L_.i32(Mt), L_.i32(d), L_.i32(2 * d_in), ctypes.c_long(2 * d_in),
-                                                            ctypes.c_long(d), L_.stream_of(xz2)), "dgrad_addnorm_bwd")
+            dg_ = torch.empty(Mt, d_in, device=dev, dtype=dtype)
+
+            def fused_bwd():        # with its second phase: the previous block's out_proj data gradient from the d x tile
+                L_.check(lib.fv_gemm_bf16_dgrad_addnorm_bwd2(L_.ptr(xz2), L_.ptr(W_in_t), L_.ptr(gg_), L_.ptr(resid), L_.ptr(rstd_),
+                                                             L_.ptr(nw_), L_.ptr(sc_), L_.i32(L), L_.ptr(y_), L_.ptr(ro_), L_.ptr(pw_),
+                                                             L_.i32(Mt), L_.i32(d), L_.i32(2 * d_in), ctypes.c_long(2 * d_in),
+                                                             ctypes.c_long(d), L_.ptr(W_out), L_.ptr(dg_), L_.i32(d_in),
+                                                             ctypes.c_long(d_in), L_.stream_of(xz2)), "dgrad_addnorm_bwd")
             for name, fn, nbytes, fl in (
                     ("gemm_out_proj_addnorm_fwd", fused_fwd, Mt * (d_in * e + d * (4 + 4 + e) + 4), 2.0 * Mt * d * d_in),
-                    ("gemm_in_proj_dgrad_addnorm_bwd", fused_bwd, Mt * (2 * d_in * e + d * (4 + 4 + 4 + e) + 4), 2.0 * Mt * d * 2 * d_in)):
+                    ("gemm_in_proj_dgrad_addnorm_bwd", fused_bwd, Mt * (2 * d_in * e + d * (4 + 4 + 4 + e) + 4 + d_in * e),
+                     2.0 * Mt * d * 3 * d_in)):
                 t = time_kernel(fn)
                 out[name] = {"us": round(t * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3), "GBps": round(nbytes / t / 1e9, 1),
                              "TFLOPs": round(fl / t / 1e12, 1), "mfma_frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -251,7 +256,7 @@ def kernel_table(B, rows, cols, d, depth, dtype):
                          "mfma_frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                          "launches_per_step": depth, "us_per_step": round(t * 1e6 * depth, 1)}
         if d == 192:
-            for k_ in ("gemm_out_proj_fwd", "gemm_in_proj_dgrad"):
+            for k_ in ("gemm_out_proj_fwd", "gemm_in_proj_dgrad", "gemm_out_proj_dgrad"):
                 out[k_]["launches_per_step"], out[k_]["us_per_step"] = 1, out[k_]["us"]
     return out
 
@@ -599,7 +604,7 @@ def main():
             out["kernels"] = kt
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_v5_pmc_traffic.json")))["kernels"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_v6_pmc_traffic.json")))["kernels"]
                 if (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16") and dom in pm:
                     traffic = pm[dom]["traffic_bytes"]
             except (OSError, KeyError, ValueError):

@@ -56,7 +56,9 @@ for _ in range(n):
     L_.check(lib.fv_gemm_bf16_addnorm(L_.ptr(g2), L_.ptr(W_out), L_.ptr(resid), L_.ptr(nw_), L_.ptr(sc_), L_.i32(L), L_.ptr(y_),
                                       L_.ptr(ro_), L_.ptr(rs_), L_.i32(Mtok), L_.i32(d), L_.i32(d_in), ctypes.c_long(d_in),
                                       ctypes.c_long(d_in), ctypes.c_float(1e-5), L_.stream_of(g2)), "addnorm")
-    L_.check(lib.fv_gemm_bf16_dgrad_addnorm_bwd(L_.ptr(xz2), L_.ptr(W_in), L_.ptr(gg_), L_.ptr(resid), L_.ptr(rstd_), L_.ptr(nw_),
-                                                L_.ptr(sc_), L_.i32(L), L_.ptr(y_), L_.ptr(ro_), L_.ptr(pw_), L_.i32(Mtok), L_.i32(d),
-                                                L_.i32(2 * d_in), ctypes.c_long(2 * d_in), ctypes.c_long(d), L_.stream_of(xz2)), "dgrad_addnorm_bwd")
+    dg_ = torch.empty(Mtok, d_in, device=dev, dtype=dtype)
+    L_.check(lib.fv_gemm_bf16_dgrad_addnorm_bwd2(L_.ptr(xz2), L_.ptr(W_in), L_.ptr(gg_), L_.ptr(resid), L_.ptr(rstd_), L_.ptr(nw_),
+                                                 L_.ptr(sc_), L_.i32(L), L_.ptr(y_), L_.ptr(ro_), L_.ptr(pw_), L_.i32(Mtok), L_.i32(d),
+                                                 L_.i32(2 * d_in), ctypes.c_long(2 * d_in), ctypes.c_long(d), L_.ptr(W_out), L_.ptr(dg_),
+                                                 L_.i32(d_in), ctypes.c_long(d_in), L_.stream_of(xz2)), "dgrad_addnorm_bwd")
 torch.cuda.synchronize()
