@@ -95,8 +95,9 @@ def gemm_tn_grouped(jobs, reduce=True):
     if not jobs:
         return []
     # one launch = one tile shape (the C side takes the shape that pads the launch's problems least: 128 x 192 for
-    # outputs 192 wide, 192 x 128 for outputs 192 high, else 128 x 128): problems are grouped by the shape that suits
-    # them, and a problem that does not care (x_proj: 44 x 384) joins the largest group it ties with
+    # outputs 192 wide, 192 x 128 for outputs 192 high, 256 x 256 when every output is a large multiple of it, else
+    # 128 x 128): problems are grouped by the shape that suits them, and a problem that does not care (x_proj: 44 x 384)
+    # joins the largest 128-row group it ties with
     classes = {}
     for j in jobs:
         classes.setdefault(_tile_class(j[0].shape[1], j[1].shape[1]), []).append(j)
@@ -105,7 +106,7 @@ def gemm_tn_grouped(jobs, reduce=True):
         loose = classes.pop(0, [])
         for j in loose:
             M, N = j[0].shape[1], j[1].shape[1]
-            ties = [c for c in classes if _padded(M, N, c) == _padded(M, N, 0)]
+            ties = [c for c in classes if c != 3 and _padded(M, N, c) == _padded(M, N, 0)]
             if ties:
                 classes[max(ties, key=lambda c: len(classes[c]))].append(j)
             else:
@@ -116,7 +117,7 @@ def gemm_tn_grouped(jobs, reduce=True):
     return _gemm_tn_grouped_one(jobs, reduce)
 
 
-_TILES = ((128, 128), (128, 192), (192, 128))
+_TILES = ((128, 128), (128, 192), (192, 128), (256, 256))
 
 
 def _padded(M, N, c):
@@ -126,6 +127,8 @@ def _padded(M, N, c):
 
 def _tile_class(M, N):
     """Index into _TILES of the tile shape that pads an (M, N) output least; ties go to 128 x 128."""
+    if M % 256 == 0 and N % 256 == 0 and M * N >= 512 * 512:
+        return 3          # large outputs (FastVim-B: 3072 x 768, 768 x 1536): 256 x 256 tiles on 8 waves halve the L2 traffic
     best = 0
     for c in (1, 2):
         if _padded(M, N, c) < _padded(M, N, best):
