@@ -114,3 +114,32 @@ def test_grouped_weight_gradients_match_single_launches():
         got = out.view(ref.shape)
         assert (got.double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
         assert torch.equal(got, single)
+
+
+def test_grouped_weight_gradients_tile_classes():
+    """One grouped call mixing every tile-shape class (gemm.py groups them; the C side picks 128x192 / 192x128 /
+    256x256 / 128x128 per launch) and padded x_proj-like operands: every problem against fp64 and, bit for bit, against
+    the single-launch split-K GEMM (same K order whatever the tile)."""
+    from fastvim_amd.gemm import _tile_class, gemm_tn, gemm_tn_grouped
+    from fastvim_amd.mixer_ops import flush_reductions
+    torch.manual_seed(1)
+    shapes = [(1792, 768, 192, 7), (1792, 192, 384, 7), (1792, 3072, 768, 4), (1792, 768, 1536, 4), (896, 44, 384, 7),
+              (896, 80, 1536, 7), (640, 128, 128, 5)]
+    assert sorted({_tile_class(M_, N_) for _, M_, N_, _ in shapes}) == [0, 1, 2, 3]
+    jobs, refs, singles = [], [], []
+    for Kd, M_, N_, sp in shapes * 2:
+        Mp = (M_ + 7) // 8 * 8
+        xb = torch.randn(Kd, Mp, device="cuda").bfloat16()
+        xb[:, M_:] = 0
+        x = xb[:, :M_]                                   # a column slice of a padded buffer when M_ % 8 != 0
+        y = torch.randn(Kd, N_, device="cuda").bfloat16()
+        out = torch.zeros(M_ * N_, device="cuda")
+        jobs.append((x, y, out, sp))
+        refs.append(x.double().t() @ y.double())
+        singles.append(gemm_tn(xb, y, splits=sp)[:M_] if Mp != M_ else gemm_tn(x, y, splits=sp))
+    gemm_tn_grouped(jobs)
+    flush_reductions()
+    for (x, y, out, sp), ref, single in zip(jobs, refs, singles):
+        got = out.view(ref.shape)
+        assert (got.double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+        assert torch.equal(got, single)
