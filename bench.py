@@ -187,7 +187,8 @@ def kernel_table(B, rows, cols, d, depth, dtype):
         # would keep it in the 256 MB Infinity Cache and time a different kernel
         from fastvim_amd.gemm import gemm_tn_grouped, grouped_splits
         from fastvim_amd.mixer_ops import flush_reductions
-        sp = grouped_splits(Mt)
+        sp_i, sp_o = grouped_splits(Mt, M=2 * d_in, N=d), grouped_splits(Mt, M=d, N=d_in)
+        sp = sp_i
         per_block = Mt * (3 * d_in + 2 * d) * 2
         nset = depth if per_block * depth <= (6 << 30) else 1
         sets = [(xz2, h2, do2, g2)] + [(rn(Mt, 2 * d_in), rn(Mt, d), rn(Mt, d), rn(Mt, d_in)) for _ in range(nset - 1)]
@@ -196,14 +197,14 @@ def kernel_table(B, rows, cols, d, depth, dtype):
         group = []
         for i in range(depth):
             a, b_, c_, e_ = sets[i % nset]
-            group += [(a, b_, gis[i], sp), (c_, e_, gos[i], sp)]
+            group += [(a, b_, gis[i], sp_i), (c_, e_, gos[i], sp_o)]
 
         def wgrad_group():
             gemm_tn_grouped(group)
             flush_reductions()
         t = time_kernel(wgrad_group, iters=5)
         fl = depth * 2.0 * Mt * (2 * d_in * d + d * d_in)
-        nbytes = depth * (2 * Mt * (2 * d_in + d + d + d_in) + 4 * (2 * sp + 1) * (2 * d_in * d + d * d_in))
+        nbytes = depth * (2 * Mt * (2 * d_in + d + d + d_in) + 4 * ((2 * sp_i + 1) * 2 * d_in * d + (2 * sp_o + 1) * d * d_in))
         out["gemm_wgrad_grouped"] = {
             "us": round(t * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3), "GBps": round(nbytes / t / 1e9, 1),
             "TFLOPs": round(fl / t / 1e12, 1), "mfma_frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -71,12 +71,18 @@ def gemm_tn(x, y, splits=1, out=None, accumulate=False, defer=True):
     return part[0] if splits == 1 else reduce_partials(part, splits)
 
 
-def grouped_splits(Kd, target=None):
-    """Split-K factor inside a grouped launch: the queue of workgroups is long whatever the factor, so it only trades
-    the length of one workgroup's K loop against the fp32 partial traffic -- the largest divisor of the K tiles not
-    above ``target`` (default 7)."""
+def grouped_splits(Kd, target=None, M=None, N=None):
+    """Split-K factor inside a grouped launch: the queue of workgroups is long whatever the factor, so it trades the
+    length of one workgroup's K loop and the rounds of workgroups the launch needs against the fp32 partial traffic
+    (every slice writes and re-reads an (M, N) partial: at 7 slices 171 MB per FastVim-T step, 2.4 GB per FastVim-B
+    step).  The largest divisor of the K tiles not above ``target``: 4 for outputs below 512 x 512 (FastVim-T: 5.90 ->
+    5.87 ms per step against 7; 2 and 14 are slower, and so is a per-problem factor that evens out the workgroup
+    counts), 2 below 1024 x 1024, 1 above (FastVim-B: 32.5 -> 32.1 ms)."""
     if target is None:
-        target = 7
+        if M is None or N is None or M * N < 512 * 512:
+            target = 4
+        else:
+            target = 2 if M * N < 1024 * 1024 else 1
     if Kd % 64:
         return 1
     kt = Kd // 64

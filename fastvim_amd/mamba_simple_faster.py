@@ -128,7 +128,7 @@ class _GroupedWgrad:
             # finish_backward): problems of one grouped launch are summed into ``out`` concurrently, so the
             # earlier one is issued first -- same-destination sums stay ordered, i.e. deterministic
             cls.flush()
-        cls.jobs.append((g2, a2, out, grouped_splits(g2.shape[0])))
+        cls.jobs.append((g2, a2, out, grouped_splits(g2.shape[0], M=g2.shape[1], N=a2.shape[1])))
         if cls.chunk and len(cls.jobs) >= cls.chunk:
             cls.flush()
 

@@ -8,7 +8,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 Mt, d, d_in, dev = 128 * 196, 192, 384, "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g).bfloat16()
-sp = grouped_splits(Mt)
+sp = grouped_splits(Mt, M=192, N=384)
 group = []
 for i in range(8):
     group += [(rn(Mt, 2 * d_in), rn(Mt, d), torch.zeros(2 * d_in * d, device=dev), sp),
