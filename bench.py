@@ -202,7 +202,13 @@ def kernel_table(B, rows, cols, d, depth, dtype):
         def wgrad_group():
             gemm_tn_grouped(group)
             flush_reductions()
-        t = time_kernel(wgrad_group, iters=5)
+        from fastvim_amd.mixer_ops import _Deferred, defer_reductions
+        was = _Deferred.enabled
+        defer_reductions(True)          # as in the step: the partial sums of a group go out as ONE multi-reduction launch
+        try:
+            t = time_kernel(wgrad_group, iters=5)
+        finally:
+            defer_reductions(was)
         fl = depth * 2.0 * Mt * (2 * d_in * d + d * d_in)
         nbytes = depth * (2 * Mt * (2 * d_in + d + d + d_in) + 4 * ((2 * sp_i + 1) * 2 * d_in * d + (2 * sp_o + 1) * d * d_in))
         out["gemm_wgrad_grouped"] = {
