@@ -369,7 +369,7 @@ def scan_op_table(cpu=True):
 
 
 def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, rank, world, dev, use_graph=True,
-                       trace=False, buckets=4, comm_dtype=None, force_segmented=False):
+                       trace=False, buckets=3, comm_dtype=None, force_segmented=False):
     """Build the model + flat training state + fused optimizer, capture the whole step (fwd + loss + bwd + AdamW + EMA;
     the gradient exchange sits between graph replay and optimizer when world > 1) and time exactly ``steps`` steps
     after ``warmup`` untimed ones, bracketed by barrier + synchronize.  Returns (seconds, final loss, extras)."""
@@ -537,7 +537,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
-    ap.add_argument("--buckets", type=int, default=4,
+    ap.add_argument("--buckets", type=int, default=3,
                     help="N > 1: gradient buckets = backward graph segments the all-reduce overlaps with (0: one all-reduce after backward)")
     ap.add_argument("--segmented", action="store_true",
                     help="use the segmented (N > 1) step also on one GPU: measures what the chain of graphs costs by itself")

@@ -13,8 +13,9 @@ contiguous BUCKETS of that buffer across ranks with RCCL (``torch.distributed`` 
   (torch DDP's mean semantics) -- the optimizer goes after it.
 
 xGMI is point-to-point (7 links per GPU), so ring collectives are per-link bound: a few LARGE buckets (default:
-4 per step, 7 MB each at FastVim-T, 98 MB at FastVim-B) instead of torch DDP's 25 MB default, and an optional
-bf16 wire format (``comm_dtype``) that halves the bytes per link.  No BatchNorm exists in FastVim, so nothing
+3 per step, tapered 10 : 8 : 6 blocks -- 12 / 9 / 7 MB at FastVim-T, 160 / 130 / 100 MB at FastVim-B -- so that the
+one nothing overlaps is the smallest; fastvim_amd/flat.py ``buckets``) instead of torch DDP's 25 MB default, and an
+optional bf16 wire format (``comm_dtype``) that halves the bytes per link.  No BatchNorm exists in FastVim, so nothing
 else is exchanged.  The same class is the whole-buffer exchange (one bucket) used by
 ``FlatTrainingState.allreduce_mean_`` and by the CPU (gloo) tests.
 """

@@ -208,11 +208,14 @@ class FlatTrainingState:
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def buckets(self, n_buckets):
-        """Cut the block stack into ``n_buckets`` runs of whole blocks of about equal gradient size.  Returns them in
-        the order BACKWARD completes them (last blocks first): a list of dicts with ``bounds`` (element range of the
-        flat gradient: the run's blocks plus, for the first / last run, the parameters after / before the stack) and
-        ``layers`` ((lo, hi) block indices of the run, in forward order)."""
+    def buckets(self, n_buckets, taper=True):
+        """Cut the block stack into ``n_buckets`` runs of whole blocks.  Returns them in the order BACKWARD completes
+        them (last blocks first): a list of dicts with ``bounds`` (element range of the flat gradient: the run's blocks
+        plus, for the first / last run, the parameters after / before the stack) and ``layers`` ((lo, hi) block indices of
+        the run, in forward order).  ``taper``: the runs shrink towards the front of the stack (gradient sizes in the
+        ratio n+1 : n : ... : 2 in backward order; 24 blocks in 3 buckets: 10, 8, 6) -- the exchange of the run backward
+        reaches last is the one nothing overlaps, so it is the smallest, and the runs exchanged under the rest of
+        backward are the large ones (whose weight-gradient groups also fill the chip better).  False: equal sizes."""
         blocks = [(i, u) for i, u in enumerate(self.unit_ranges) if u[0] is not None]
         if not blocks:
             return [{"bounds": (0, self.grad_flat.numel()), "layers": (0, 0)}]
@@ -220,11 +223,13 @@ class FlatTrainingState:
         nb = len(blocks)
         n_buckets = max(1, min(n_buckets, nb))
         sizes = [u[2] - u[1] for _, u in blocks]
-        target, runs, acc, lo = sum(sizes) / n_buckets, [], 0, 0
+        w = [i + 2 if taper else 1 for i in range(n_buckets)]              # forward order: the first run is the smallest
+        cum = [sum(sizes) * sum(w[:i + 1]) / sum(w) for i in range(n_buckets)]
+        runs, acc, lo = [], 0, 0
         for j, sz in enumerate(sizes):
             acc += sz
             left = nb - 1 - j
-            if (acc >= target * (len(runs) + 1) - 1e-9 and len(runs) < n_buckets - 1 and left >= n_buckets - 1 - len(runs)) \
+            if (len(runs) < n_buckets - 1 and acc >= cum[len(runs)] - 1e-9 and left >= n_buckets - 1 - len(runs)) \
                     or j == nb - 1:
                 runs.append((lo, j + 1))
                 lo = j + 1

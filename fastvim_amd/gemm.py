@@ -118,9 +118,9 @@ def gemm_tn_grouped(jobs, reduce=True):
             else:
                 classes.setdefault(0, []).append(j)
         for c in sorted(classes):
-            todo += _gemm_tn_grouped_one(classes[c], reduce)
+            todo += _gemm_tn_grouped_one(classes[c], reduce, c)
         return todo
-    return _gemm_tn_grouped_one(jobs, reduce)
+    return _gemm_tn_grouped_one(jobs, reduce, next(iter(classes)))
 
 
 _TILES = ((128, 128), (128, 192), (192, 128), (256, 256))
@@ -142,8 +142,43 @@ def _tile_class(M, N):
     return best
 
 
-def _gemm_tn_grouped_one(jobs, reduce):
+_SLOTS = (512, 512, 512, 256)     # workgroups of the grouped kernel the chip holds at once, per tile class (two per CU;
+                                  # one of the 8-wave 256 x 256 tiles)
+FILL = True      # False: the factors of grouped_splits whatever the group (a segmented step then sums every weight
+                 # gradient in the order of the single-graph step: tests/test_pipeline_gpu.py)
+
+
+def fill_splits(jobs, c):
+    """Split-K factors of one launch, raised where the launch would leave the chip part empty.  A group of all the
+    blocks (the single-graph step) is 576-768 workgroups at the factors of ``grouped_splits`` and is left alone; a group
+    of one backward segment of the data-parallel step (6 blocks: 144-192 workgroups, each walking a quarter of K) runs
+    at half the rate per problem.  The work of the launch, in K tiles over all output tiles, spread over the 512 slots
+    gives the K tiles one workgroup should walk; a problem is cut into the largest whole number of slices that does
+    not go below that (and not below 14 tiles).  Measured, 6 blocks at FastVim-T: in_proj problems 156 -> 97 us,
+    out_proj + x_proj 152 -> 102 us (tools/probe/wgrad_fill.py)."""
+    bm, bn = _TILES[c]
+    work = 0
+    for x, y, out, sp in jobs:
+        if x.shape[0] % 64 or not FILL:
+            return [j[3] for j in jobs]
+        work += -(-x.shape[1] // bm) * -(-y.shape[1] // bn) * (x.shape[0] // 64)
+    per_slot = max(work / _SLOTS[c], 14.0)
+    out_sp = []
+    for x, y, out, sp in jobs:
+        kt = x.shape[0] // 64
+        best = sp
+        for s_ in range(sp + 1, int(kt / per_slot) + 1):
+            if kt % s_ == 0:
+                best = s_
+        out_sp.append(best)
+    return out_sp
+
+
+def _gemm_tn_grouped_one(jobs, reduce, c=None):
     k = len(jobs)
+    if c is None:
+        c = _tile_class(jobs[0][0].shape[1], jobs[0][1].shape[1]) if k == 1 else 0
+    jobs = [(x, y, out, s_) for (x, y, out, _), s_ in zip(jobs, fill_splits(jobs, c))]
     parts = []
     for x, y, out, sp in jobs:
         Kd, M = x.shape

@@ -24,7 +24,7 @@ class SegmentedTrainStep:
     ``loss_fn(logits, target) -> scalar``.  ``x`` / ``target`` are the static input buffers the graphs read; copy
     new batches into them between steps."""
 
-    def __init__(self, model, flat, opt, loss_fn, x, target, n_segments=4, amp_dtype=torch.bfloat16, use_graph=True,
+    def __init__(self, model, flat, opt, loss_fn, x, target, n_segments=3, amp_dtype=torch.bfloat16, use_graph=True,
                  warmup=2):
         self.model, self.flat, self.opt, self.loss_fn = model, flat, opt, loss_fn
         self.x, self.target, self.amp_dtype = x, target, amp_dtype

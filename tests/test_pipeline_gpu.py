@@ -14,8 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("n_seg,graph", [(3, True), (6, True), (2, False)])
-def test_segmented_step_equals_single_step(n_seg, graph):
+@pytest.mark.parametrize("n_seg,graph,batch,fill", [(3, True, 16, True), (6, True, 16, True), (2, False, 16, True),
+                                                    (3, True, 128, False), (3, True, 128, True)])
+def test_segmented_step_equals_single_step(n_seg, graph, batch, fill, monkeypatch):
+    """Bit for bit when every weight gradient is cut into the same K slices in both steps: batch 16 (49 K tiles: one
+    slice whatever the group) and batch 128 with ``gemm.FILL`` off.  With it on, the small groups of a segment are cut
+    finer (fastvim_amd.gemm.fill_splits) -- same sums in another order: losses and weights agree to rounding."""
+    import fastvim_amd.gemm as gemm_mod
+    monkeypatch.setattr(gemm_mod, "FILL", fill)
+    exact = batch == 16 or not fill
     from fastvim_amd.fastvim import VisionMamba
     from fastvim_amd.flat import FlatAdamW, FlatTrainingState
     from fastvim_amd.losses import SoftTargetCrossEntropy
@@ -30,8 +37,8 @@ def test_segmented_step_equals_single_step(n_seg, graph):
               or getattr(p, "_no_weight_decay", False)}
         return m, flat, FlatAdamW(flat, m, lr=1e-3, weight_decay=0.05, no_decay=nd, ema_decay=0.999)
 
-    x = torch.randn(16, 3, 224, 224, device="cuda")
-    tgt = torch.softmax(torch.randn(16, 100, device="cuda"), -1)
+    x = torch.randn(batch, 3, 224, 224, device="cuda")
+    tgt = torch.softmax(torch.randn(batch, 100, device="cuda"), -1)
     crit = SoftTargetCrossEntropy()
     m1, f1, o1 = make()
     torch.manual_seed(7)
@@ -51,9 +58,16 @@ def test_segmented_step_equals_single_step(n_seg, graph):
     got = []
     for _ in range(5 - (2 if graph else 0)):
         got.append(seg.step().item())
-    assert got == ref[2 if graph else 0:], (got, ref)
     torch.cuda.synchronize()
-    assert torch.equal(f1.param_flat, f2.param_flat)
+    if exact:
+        assert got == ref[2 if graph else 0:], (got, ref)
+        assert torch.equal(f1.param_flat, f2.param_flat)
+    else:
+        assert got != ref[2:] or not torch.equal(f1.param_flat, f2.param_flat)    # the finer cut was taken
+        torch.testing.assert_close(torch.tensor(got), torch.tensor(ref[2:]), rtol=0, atol=2e-3)
+        # AdamW turns a rounding-level difference of a near-zero gradient into a step of up to lr: 5 steps of 1e-3
+        assert (f1.param_flat - f2.param_flat).abs().max().item() <= 5.5e-3
+        assert (f1.param_flat - f2.param_flat).abs().mean().item() <= 2e-5
     f1.close(); f2.close()
 
 
