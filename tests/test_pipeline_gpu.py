@@ -84,3 +84,62 @@ def test_two_rank_segmented_bench_line():
     assert out["n_gpus"] == 2 and out["ddp"]["overlapped"] and out["ddp"]["buckets"] == 3 and out["ddp"]["ranks"] == 2
     assert abs(sum(out["ddp"]["bucket_MB"]) - 28.7) < 0.5            # FastVim-T: 7.17 M fp32 gradients
     assert out["ddp"]["allreduce_exposed_ms"] is not None and out["config"]["final_loss"] == out["config"]["final_loss"]
+
+
+_RCCL_SCRIPT = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+import torch, torch.distributed as dist
+from fastvim_amd.fastvim import VisionMamba
+from fastvim_amd.flat import FlatAdamW, FlatTrainingState
+from fastvim_amd.losses import SoftTargetCrossEntropy
+from fastvim_amd.pipeline import SegmentedTrainStep
+from fastvim_amd import ddp
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1)
+# one rank: make the exchange believe there are two, so every bucket really goes through RCCL (a one-rank all-reduce is
+# the identity) and the mean halves the gradient
+ddp.GradExchange.world_size = property(lambda self: 2)
+def run(pretend):
+    torch.manual_seed(0)
+    m = VisionMamba(img_size=224, depth=6, embed_dim=192, num_classes=100, rms_norm=True, residual_in_fp32=True,
+                    fused_add_norm=True, final_pool_type="mean", if_abs_pos_embed=True).cuda().train()
+    flat = FlatTrainingState(m)
+    opt = FlatAdamW(flat, m, lr=1e-3, weight_decay=0.0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(16, 3, 224, 224, device="cuda", generator=g)
+    tgt = torch.softmax(torch.randn(16, 100, device="cuda", generator=g), -1)
+    seg = SegmentedTrainStep(m, flat, opt, SoftTargetCrossEntropy(), x, tgt, n_segments=3, use_graph=True, warmup=1)
+    if not pretend:
+        seg.exchange.launch = lambda k: None
+        seg.exchange.finish = lambda: flat.grad_flat.div_(2)
+    losses = [seg.step(time_exposed=pretend).item() for _ in range(4)]
+    torch.cuda.synchronize()
+    gsum = flat.grad_flat.double().abs().sum().item()
+    exp = seg.exposed_ms() if pretend else None
+    pend = len(seg.exchange._pending)
+    flat.close()
+    return losses, gsum, exp, pend
+a = run(True)
+b = run(False)
+dist.destroy_process_group()
+print(json.dumps({"rccl": a, "plain": b}))
+'''
+
+
+def test_rccl_buckets_between_backward_graphs(tmp_path):
+    """The exchange of the segmented step over the real RCCL backend (one rank; the exchange is told there are two so
+    that every bucket is launched): asynchronous all-reduces on the process group's stream between the replays of the
+    backward graphs, joined before the optimizer graph.  A one-rank all-reduce is the identity, so losses and gradients
+    must equal, bit for bit, those of the same step with the exchange replaced by the bare division."""
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT, "29547"], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    (la, ga, exp, pend), (lb, gb, _, _) = out["rccl"], out["plain"]
+    assert la == lb and ga == gb and all(v == v for v in la), out
+    assert pend == 0 and exp is not None and exp >= 0.0
