@@ -131,6 +131,13 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_kernel(ScanClParams p) {
         if (ln.act && ln.q == 0) y[(size_t)lk[k] * p.d_in] = acc;
       }
     }
+    // training: the state entering every 16-step chunk but the first is left behind for the chunked backward kernel
+    // (scan_cl_bwd_chunked_kernel, which then skips its own forward sweep)
+    if (p.ckpt && ((s0 + 4) & 15) == 0 && s0 + 4 < p.Lc && ln.act) {
+      const int nchunk = (p.Lc + 15) >> 4;
+      float* ck = p.ckpt + ((((size_t)ln.dir * p.B + ln.b) * nchunk + ((s0 + 4) >> 4)) * p.d_in + ln.d) * N + ln.q * 4;
+      *reinterpret_cast<float4*>(ck) = make_float4(st[0], st[1], st[2], st[3]);
+    }
   }
 }
 
@@ -651,6 +658,347 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Backward for LONG pooled lengths (Lc > 16: the 2048 px grid, the channel model, unpooled Vim) with the short kernel's
+// treatment.  Time is cut into chunks of 16 steps; a 6-wave workgroup (96 channels of one direction, two workgroups
+// per CU) walks a batch element's chunks twice:
+//   * forward over chunks 0 .. n-2: stage the chunk's x_dbl rows, delta on the fp32 matrix cores, softplus once per
+//     (step, channel), the recurrence in registers; the state leaving a chunk is its successor's checkpoint (one
+//     16-byte store per lane and chunk to the scratch buffer; the generic kernel writes one per 4 steps: 352 MB
+//     written and re-read per launch at FastChannelVim-S, 88 MB here).  Skipped when the forward launch of the
+//     training step has left the checkpoints behind (CK_GIVEN);
+//   * backward over chunks n-1 .. 0: the short kernel's body on the chunk -- states of the 16 steps recomputed from the
+//     checkpoint into registers, adjoint sweep, dt_proj adjoint on the matrix cores, dB / dC reduce-scatter -- with
+//     the adjoint state, dA, d dt_bias and the d Wdt accumulator tile carried across chunks in registers.
+// What goes compared with the generic kernel: delta per quad lane (dt_rank / 4 FMAs + softplus, three times per step),
+// the LDS butterfly of the channel sums, a workgroup barrier per 4 steps.
+template <int RQ, int NWV>
+struct ChunkLds {
+  static constexpr int LCT = 16, CH = 16 * NWV, DRS = CH + 2;
+  static constexpr int RQP = (RQ + 3) / 4 * 4, RT = RQP / 4, WP = 4 * RQP + 2 * N;
+  static constexpr int o_dbl = 0;                                  // 16 * WP
+  static constexpr int o_ch = o_dbl + LCT * WP;                    // 16 * CH * 4   {delta, u, dy, sigmoid}
+  static constexpr int o_dr = o_ch + LCT * CH * 4;                 // 16 * DRS      d delta_raw
+  static constexpr int o_du = o_dr + 16 * DRS;                     // 16 * CH       d u
+  static constexpr int o_part = o_du + LCT * CH;                   // 16 * NWV * 4 * 8   dB / dC wave partials
+  static constexpr int o_pd = o_part + LCT * NWV * 4 * 8;          // NWV * 16 * 16 * RT  d dt_low wave partials
+  static constexpr int floats = o_pd + NWV * 16 * 16 * RT;
+};
+constexpr int CK_NWV = 4, CK_CH = 16 * CK_NWV;
+
+template <typename T, int RQ, int NWV, bool CK_GIVEN>
+__global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanClParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef ChunkLds<RQ, NWV> LD;
+  constexpr int RQP = LD::RQP, RT = LD::RT, WP = LD::WP, LCT = 16, CH = LD::CH, DRS = LD::DRS, NTH = 64 * NWV;
+  float* s_dbl = smem + LD::o_dbl;
+  float* s_ch = smem + LD::o_ch;
+  float* s_dr = smem + LD::o_dr;
+  float* s_du = smem + LD::o_du;
+  float* s_part = smem + LD::o_part;
+  float* s_pd = smem + LD::o_pd;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dir = blockIdx.z, ch0 = blockIdx.x * CH;
+  const int W = p.R + 2 * N;
+  const int Lc = p.Lc, nchunk = (Lc + LCT - 1) / LCT;
+  // ---- scan role: lane = (channel c of the wave, state quad q)
+  const int q = lane & 3, ch = wv * 16 + (lane >> 2);
+  const int d = ch0 + ch;
+  const bool act = d < p.d_in;
+  const int dd = act ? d : 0;
+  sf2 A2[2], Araw[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    Araw[h].x = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h]);
+    Araw[h].y = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h + 1]);
+    A2[h] = Araw[h] * FV_LOG2E;
+  }
+  sf2 dA[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float dbias = 0.f;
+  f32x4_t accW[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // stage the x_dbl rows of chunk c of (dir, b) in scan order: fp32, dt_low regrouped by quad lane, rows past Lc zero
+  auto stage = [&](size_t bd, int c) {
+    const T* dbl = (const T*)p.xdbl + bd * W;
+    for (int e = opaque_tid(); e < LCT * WP; e += NTH) {
+      const int srow = e / WP, col = e - srow * WP;
+      const int sg = c * LCT + srow;
+      const int l = dir ? Lc - 1 - sg : sg;
+      float v = 0.f;
+      if (sg < Lc) {
+        if (col < 4 * RQP) {
+          const int qq = col / RQP, i = col - qq * RQP, r = qq + 4 * i;
+          if (i < RQ && r < p.R) v = io<T>::ld(dbl + (size_t)l * W + r);
+        } else {
+          v = io<T>::ld(dbl + (size_t)l * W + p.R + (col - 4 * RQP));
+        }
+      }
+      s_dbl[e] = v;
+    }
+  };
+  // delta_raw of the staged chunk on the matrix cores, softplus (and sigmoid) once per (step, channel), the table row
+  // {delta, u, dy, sigmoid} of this wave's 16 channels to LDS
+  auto table = [&](const float (&um)[4], const float (&gm)[4], float bias_m, int valid) {
+    const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv2 = t2 >> 6, dm = ch0 + wv2 * 16 + cm;
+    const bool actm = dm < p.d_in;
+    const int ddm = actm ? dm : 0;
+    f32x4_t D = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kg = 0; kg < RQP; ++kg) {           // r = 4 kg + (lane >> 4): stored at [q = r & 3][i = r >> 2]
+      const float a = s_dbl[cm * WP + tg * RQP + kg];
+      const int r = 4 * kg + tg;
+      const float w = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
+      D = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, D, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = 4 * tg + r;
+      const bool on = actm && s < valid;
+      const float dt = on ? fv_softplus(D[r] + bias_m) : 0.f;     // delta = 0: identity step (a = 1, b = 0)
+      const float sg = 1.f - __expf(-dt);                         // sigmoid(raw) = 1 - exp(-softplus(raw))
+      *reinterpret_cast<float4*>(s_ch + ((size_t)s * CH + wv2 * 16 + cm) * 4) = make_float4(dt, um[r], gm[r], sg);
+    }
+  };
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  for (int bi = 0; bi < p.NBB; ++bi) {
+    const int b = blockIdx.y * p.NBB + bi;
+    const size_t bd = ((size_t)dir * p.B + b) * Lc;
+    float* ck = p.ckpt + (((size_t)dir * p.B + b) * nchunk * p.d_in + dd) * N + q * 4;      // + c * d_in * N
+    const size_t ck_c = (size_t)p.d_in * N;
+    const float* my_bc = s_dbl + 4 * RQP + q * 4;                   // this quad lane's B states of row 0 (C: + N)
+    const float* my_ch = s_ch + (size_t)ch * 4;
+
+    if constexpr (!CK_GIVEN) {
+      // ---- forward over the full chunks 0 .. nchunk - 2: checkpoint the state entering every later chunk
+      sf2 st[2] = {{0.f, 0.f}, {0.f, 0.f}};
+      for (int c = 0; c + 1 < nchunk; ++c) {
+        float um[4], gm[4] = {0.f, 0.f, 0.f, 0.f};
+        float bias_m;
+        {
+          const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + cm;
+          const int ddm = dm < p.d_in ? dm : 0;
+          bias_m = p.dtb[dir][ddm];
+          const T* u = (const T*)p.xc + bd * p.d_in + ddm;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int sg = c * LCT + 4 * tg + r, l = dir ? Lc - 1 - sg : sg;
+            um[r] = io<T>::ld(u + (size_t)l * p.d_in);
+          }
+        }
+        stage(bd, c);
+        __syncthreads();
+        table(um, gm, bias_m, LCT);
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < LCT; ++s) {
+          asm volatile("" ::: "memory");
+          const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+          const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (CH * 4));
+          const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
+          const float dt = cv.x, dtu = cv.x * cv.y;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+        }
+        if (act) *reinterpret_cast<float4*>(ck + (size_t)(c + 1) * ck_c) = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
+        __syncthreads();        // every wave is done with the staged rows
+      }
+    }
+
+    // ---- backward over the chunks, last first
+    sf2 dxa[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int c = nchunk - 1; c >= 0; --c) {
+      const int valid = min(LCT, Lc - c * LCT);
+      // the state entering the chunk (requested first: it is needed after the staging barrier)
+      float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c > 0 && act) e4 = *reinterpret_cast<const float4*>(ck + (size_t)c * ck_c);
+      float um[4], gm[4];
+      float bias_m;
+      {
+        const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + cm;
+        const bool actm = dm < p.d_in;
+        const int ddm = actm ? dm : 0;
+        bias_m = p.dtb[dir][ddm];
+        const T* u = (const T*)p.xc + bd * p.d_in + ddm;
+        const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + ddm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int s = 4 * tg + r, sg = min(c * LCT + s, Lc - 1), l = dir ? Lc - 1 - sg : sg;
+          um[r] = io<T>::ld(u + (size_t)l * p.d_in);
+          const float gv = gy[(size_t)l * p.d_in];
+          gm[r] = (actm && s < valid) ? gv : 0.f;
+        }
+      }
+      stage(bd, c);
+      __syncthreads();      // rows staged; the previous chunk's readers of s_part / s_pd are done as well
+      table(um, gm, bias_m, valid);
+      wave_sync();
+
+      // ---- recompute the chunk's states from its checkpoint
+      const sf2 entry[2] = {{e4.x, e4.y}, {e4.z, e4.w}};
+      sf2 xs[LCT][2];
+      {
+        sf2 st[2] = {entry[0], entry[1]};
+#pragma unroll
+        for (int s = 0; s < LCT; ++s) {
+          asm volatile("" ::: "memory");
+          if (s < valid) {          // uniform
+            const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+            const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (CH * 4));
+            const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
+            const float dt = cv.x, dtu = cv.x * cv.y;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) xs[s][h] = st[h];
+        }
+      }
+
+      // ---- adjoint sweep over the chunk, high to low
+      float* my_part = s_part + (wv * 4 + q) * 8 + (lane >> 3);
+      float* my_dr = s_dr + ch;
+      float* my_du = s_du + ch;
+#pragma unroll
+      for (int s = LCT - 1; s >= 0; --s) {
+        asm volatile("" ::: "memory");
+        if (s < valid) {         // uniform
+          const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+          const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
+          const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (CH * 4));
+          const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
+          const float dt = cv.x, uu = cv.y, g = cv.z, sg = cv.w;
+          const float dtu = dt * uu;
+          float vals[8];
+          sf2 du2 = {0.f, 0.f}, dd2 = {0.f, 0.f};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const sf2 a = sexp2_2(A2[h] * dt);
+            const sf2 dx = sfma2(Cn[h], ssplat(g), dxa[h]);
+            const sf2 pj = dx * (a * (s > 0 ? xs[s > 0 ? s - 1 : 0][h] : entry[h]));   // dx * a_t * x_{t-1}
+            du2 = sfma2(dx, Bn[h], du2);
+            dd2 = sfma2(Araw[h], pj, dd2);
+            dA[h] = sfma2(pj, ssplat(dt), dA[h]);
+            const sf2 vb = dx * dtu, vc = xs[s][h] * g;
+            vals[2 * h] = vb.x; vals[2 * h + 1] = vb.y;            // dB[4q + 2h ..]
+            vals[4 + 2 * h] = vc.x; vals[5 + 2 * h] = vc.y;        // dC[4q + 2h ..]
+            dxa[h] = a * dx;
+          }
+          const float du_acc = quad_sum(du2.x + du2.y);
+          const float dd_acc = quad_sum(dd2.x + dd2.y);
+          const float ddraw = fmaf(uu, du_acc, dd_acc) * sg;
+          dbias += ddraw;
+          if (q == 0) {
+            my_dr[s * DRS] = ddraw;
+            my_du[s * CH] = dt * du_acc;
+          }
+          rs_swap32<4, 8>(vals);
+          rs_swap16<2, 8>(vals);
+          rs_row8<1, 8>(vals, lane);
+          const float tot = add_dpp<0x12C>(vals[0]);             // + lane i + 4 (the channel with bit 0 set)
+          if ((lane & 4) == 0) my_part[s * (NWV * 4 * 8)] = tot;
+        } else if (q == 0) {
+          my_dr[s * DRS] = 0.f;        // rows past the sequence feed the K / M padding of the MFMAs below
+        }
+      }
+      wave_sync();
+
+      // ---- dt_proj adjoint on the matrix cores, from this wave's 16 columns of the d delta_raw table
+      {
+        const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv2 = t2 >> 6, dm = ch0 + wv2 * 16 + cm;
+        const bool actm = dm < p.d_in;
+        f32x4_t Dl[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) Dl[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          const int chk = wv2 * 16 + 4 * kg + tg;                 // channel of this lane's k
+          const float a = s_dr[cm * DRS + chk];                   // step cm
+          const int dk = ch0 + chk;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int r = 16 * rt + cm;
+            const float w = (dk < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dk * p.R + r] : 0.f;
+            Dl[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, Dl[rt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_pd[((size_t)wv2 * 16 + 4 * tg + r) * (16 * RT) + 16 * rt + cm] = Dl[rt][r];
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          const int t = 4 * kg + tg;
+          const float a = s_dr[t * DRS + wv2 * 16 + cm];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int r = 16 * rt + cm;                           // stored at [q = r & 3][i = r >> 2]; r < 4 RQP always
+            const float bq = s_dbl[t * WP + (r & 3) * RQP + (r >> 2)];
+            accW[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, accW[rt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int s = 4 * tg + r, sg = c * LCT + s;
+          const int l = dir ? Lc - 1 - sg : sg;
+          if (actm && s < valid) p.dxc[(bd + l) * p.d_in + dm] = s_du[s * CH + wv2 * 16 + cm];
+        }
+      }
+      __syncthreads();
+      // ---- sum the waves in fixed order and scatter to the x_dbl column layout [dt_low | B | C]
+      {
+        const int t4 = opaque_tid();
+        float* out = p.dxdbl + (((size_t)blockIdx.x * 2 + dir) * p.B + b) * Lc * W;
+        for (int e = t4; e < valid * 32; e += NTH) {
+          const int s = e >> 5, rem = e & 31, qq = rem >> 3, v = rem & 7;
+          const int col = v < 4 ? p.R + qq * 4 + v : p.R + N + qq * 4 + (v - 4);
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < NWV; ++w) t += s_part[((s * NWV + w) * 4 + qq) * 8 + v];
+          const int sg = c * LCT + s, l = dir ? Lc - 1 - sg : sg;
+          out[(size_t)l * W + col] = t;
+        }
+        for (int e = t4; e < valid * (16 * RT); e += NTH) {
+          const int s = e / (16 * RT), r = e - s * (16 * RT);
+          if (r < p.R) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) t += s_pd[(w * 16 + s) * (16 * RT) + r];
+            const int sg = c * LCT + s, l = dir ? Lc - 1 - sg : sg;
+            out[(size_t)l * W + r] = t;
+          }
+        }
+      }
+    }   // chunks
+    if (bi + 1 < p.NBB) __syncthreads();      // the next element's forward sweep restages the rows
+  }   // batch elements of this block
+  const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
+  float* base = p.pP + ((size_t)blockIdx.y * 2 + dir) * per_dir;
+  const int t3 = opaque_tid(), cm = t3 & 15, tg = (t3 >> 4) & 3;
+  if (act) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                                             // dA_log = dA * A
+      const sf2 v = dA[h] * Araw[h];
+      base[(size_t)d * N + q * 4 + 2 * h] = v.x;
+      base[(size_t)d * N + q * 4 + 2 * h + 1] = v.y;
+    }
+    if (q == 0) base[(size_t)p.d_in * (N + p.R) + d] = dbias;           // identical in the four lanes of a channel
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dw = ch0 + wv * 16 + 4 * tg + r, rr = 16 * rt + cm;
+      if (dw < p.d_in && rr < p.R) base[(size_t)p.d_in * N + (size_t)dw * p.R + rr] = accW[rt][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Forward for SHORT pooled lengths with x_proj fused in (bf16): one 768-thread workgroup per (direction, batch
 // element) -- 256 workgroups at bs 128, one round.
 //   1. x_dbl[t][:] = xc[t][:] . Wx^T on the bf16 matrix cores: the 14 pooled rows go to LDS once (they are also the
@@ -840,6 +1188,14 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
                                  const float* A_log, const float* dt_w_b, const float* dt_bias_b,
                                  const float* A_log_b, float* yc, int batch, int Lc, int d_inner, int dt_rank,
                                  int d_state, int dtype, fv_stream_t stream) {
+  return fv_mixer_scan_fwd_ckpt(xc, x_dbl, dt_w, dt_bias, A_log, dt_w_b, dt_bias_b, A_log_b, yc, nullptr, batch, Lc, d_inner,
+                                dt_rank, d_state, dtype, stream);
+}
+
+extern "C" int fv_mixer_scan_fwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                      const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                      const float* A_log_b, float* yc, float* ckpt, int batch, int Lc, int d_inner,
+                                      int dt_rank, int d_state, int dtype, fv_stream_t stream) {
   FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_fwd: empty dimension");
   FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_fwd: dtype must be fp32 or bf16");
   FV_CHECK(d_state == N, "mixer_scan_fwd: only d_state == 16 is built (got %d)", d_state);
@@ -847,7 +1203,7 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
   FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && yc,
            "mixer_scan_fwd: null pointer");
   ScanClParams p{};
-  p.xc = xc; p.xdbl = x_dbl; p.yc = yc;
+  p.xc = xc; p.xdbl = x_dbl; p.yc = yc; p.ckpt = ckpt;
   p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
   p.Alog[0] = A_log; p.Alog[1] = A_log_b;
   p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
@@ -933,8 +1289,17 @@ static bool bwd_short(int Lc, int dt_rank) {
   static const int off = (fv_tune("FASTVIM_SCAN_SHORT", 1) == 0);   // A/B hook
   return Lc <= 16 && dt_rank <= 48 && !off;
 }
+// longer ones the chunked form of it (96-channel workgroups); dt_rank above 48 (d_model > 768) the generic kernel
+static bool bwd_chunked(int Lc, int dt_rank) {
+  static const int off = (fv_tune("FASTVIM_SCAN_CHUNKED", 1) == 0);   // A/B hook
+  return Lc > 16 && dt_rank <= 48 && !off;
+}
+extern "C" size_t fv_mixer_scan_ckpt_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank) {
+  return bwd_chunked(Lc, dt_rank) ? (size_t)2 * batch * ((Lc + 15) / 16) * d_inner * d_state : 0;
+}
+
 extern "C" int fv_mixer_scan_bwd_chunks(int d_inner, int Lc, int dt_rank) {
-  return fv_cdiv(d_inner, bwd_short(Lc, dt_rank) ? SH_CH : CPB);
+  return fv_cdiv(d_inner, bwd_short(Lc, dt_rank) ? SH_CH : bwd_chunked(Lc, dt_rank) ? CK_CH : CPB);
 }
 
 // A block can walk several batch elements (fewer, longer blocks; parameter-gradient partials shrink by the same
@@ -949,7 +1314,9 @@ extern "C" int fv_mixer_scan_bwd_partials(int batch, int Lc, int dt_rank) { retu
 static bool ck_in_lds(int Lc) { return ((Lc + 3) / 4) * 4096 + Lc * CPB * 4 <= 32 * 1024; }
 
 extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank) {
-  if (bwd_short(Lc, dt_rank) || ck_in_lds(Lc)) return 0;
+  if (bwd_short(Lc, dt_rank)) return 0;
+  if (bwd_chunked(Lc, dt_rank)) return (size_t)2 * batch * ((Lc + 15) / 16) * d_inner * d_state;   // one state per 16 steps
+  if (ck_in_lds(Lc)) return 0;
   return (size_t)2 * batch * ((Lc + 3) / 4) * d_inner * d_state;
 }
 
@@ -967,12 +1334,24 @@ extern "C" int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const fl
                                      const float* A_log_b, const float* dyc, int dyc_per_direction, float* dxc,
                                      float* dx_dbl, float* ckpt, float* partials, int batch, int Lc, int d_inner,
                                      int dt_rank, int d_state, int dtype, fv_stream_t stream) {
+  return fv_mixer_scan_bwd_ckpt(xc, x_dbl, dt_w, dt_bias, A_log, dt_w_b, dt_bias_b, A_log_b, dyc, dyc_per_direction, dxc, dx_dbl,
+                                ckpt, 0, partials, batch, Lc, d_inner, dt_rank, d_state, dtype, stream);
+}
+
+extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                      const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                      const float* A_log_b, const float* dyc, int dyc_per_direction, float* dxc,
+                                      float* dx_dbl, float* ckpt, int ckpt_given, float* partials, int batch, int Lc,
+                                      int d_inner, int dt_rank, int d_state, int dtype, fv_stream_t stream) {
+  FV_CHECK(!ckpt_given || (ckpt && bwd_chunked(Lc, dt_rank)),
+           "mixer_scan_bwd: checkpoints of the forward launch are only taken by the chunked kernel (fv_mixer_scan_ckpt_floats > 0)");
   FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_bwd: empty dimension");
   FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_bwd: dtype must be fp32 or bf16");
   FV_CHECK(d_state == N, "mixer_scan_bwd: only d_state == 16 is built (got %d)", d_state);
   FV_CHECK(dt_rank <= 96, "mixer_scan_bwd: dt_rank %d > 96", dt_rank);
   FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && dyc && dxc && dx_dbl &&
-               partials && (ckpt || ck_in_lds(Lc) || bwd_short(Lc, dt_rank)), "mixer_scan_bwd: null pointer");
+               partials && (ckpt || (ck_in_lds(Lc) && !bwd_chunked(Lc, dt_rank)) || bwd_short(Lc, dt_rank)),
+           "mixer_scan_bwd: null pointer");
   ScanClParams p{};
   p.xc = xc; p.xdbl = x_dbl; p.dyc = dyc; p.dxc = dxc; p.dxdbl = dx_dbl; p.ckpt = ckpt; p.pP = partials;
   p.dyc_dir = dyc_per_direction ? (size_t)batch * Lc * d_inner : 0;
@@ -1009,6 +1388,25 @@ extern "C" int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const fl
 #undef FV_SD
 #undef FV_SL
 #undef FV_S
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
+  if (bwd_chunked(Lc, dt_rank)) {
+    dim3 cgrid(fv_cdiv(d_inner, CK_CH), batch / p.NBB, 2), cblock(64 * CK_NWV);
+#define FV_C(TT, RQQ)                                                                        \
+  do {                                                                                       \
+    size_t smem = (size_t)ChunkLds<RQQ, CK_NWV>::floats * 4;                                 \
+    static_assert(ChunkLds<RQQ, CK_NWV>::floats * 4 <= 64 * 1024, "dynamic LDS above 64 KiB needs the attribute"); \
+    if (ckpt_given) hipLaunchKernelGGL((scan_cl_bwd_chunked_kernel<TT, RQQ, CK_NWV, true>), cgrid, cblock, smem, st, p); \
+    else hipLaunchKernelGGL((scan_cl_bwd_chunked_kernel<TT, RQQ, CK_NWV, false>), cgrid, cblock, smem, st, p); \
+  } while (0)
+#define FV_CD(TT)                                                                            \
+  do {                                                                                       \
+    if (RQ <= 3) FV_C(TT, 3); else if (RQ <= 6) FV_C(TT, 6); else FV_C(TT, 12);              \
+  } while (0)
+    if (dtype == FV_F32) FV_CD(float); else FV_CD(bf16_t);
+#undef FV_CD
+#undef FV_C
     FV_LAUNCH_CHECK();
     return FV_OK;
   }

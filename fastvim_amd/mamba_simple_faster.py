@@ -475,7 +475,11 @@ class FastVimMixerFn(torch.autograd.Function):
                 x_dbl, yc = fused
             else:
                 x_dbl = M.xproj_fwd(xc, Wx2_c)                                           # (2, B*Lc, R+2N)
-                yc = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)
+                # long pooled lengths: when a backward pass will follow, the scan leaves the state entering every
+                # 16-step chunk behind and the backward kernel does not sweep forward again
+                nig = getattr(ctx, "needs_input_grad", None)
+                yc, ctx.scan_ckpt = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log,
+                                               want_ckpt=nig is None or any(nig))
             g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
             # W_out None: out_proj is the caller's (fused with the next block's add + norm, OutProjAddNormFn); the
             # gated activations g (B, L, d_in) are returned and their gradient comes back as ``dout``
@@ -514,7 +518,8 @@ class FastVimMixerFn(torch.autograd.Function):
             W_ = x_dbl.shape[-1]
             fused_xproj = W_ in M.XPROJ_WIDTHS
             dxc, dx_dbl, ps = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
-                                         grad_out=fv.get("scan_grad"), keep_chunks=fused_xproj)
+                                         grad_out=fv.get("scan_grad"), keep_chunks=fused_xproj,
+                                         ckpt=getattr(ctx, "scan_ckpt", None))
             # x_proj adjoint (selective_scan_interface.py:726-734), both directions
             Mrows = B * rows * tpp
             if (fused_xproj and _GroupedWgrad.enabled and "Wx2_grad" in fv and xc.dtype == torch.bfloat16

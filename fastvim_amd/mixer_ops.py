@@ -34,17 +34,25 @@ def conv_pool_fwd(xz, conv_w, conv_b, conv_w_b, conv_b_b, rows, cols, transposed
     return xc if D is None else (xc, skip)
 
 
-def scan_fwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
+def scan_fwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, want_ckpt=False):
+    """yc (2, B, Lc, d_in) fp32.  ``want_ckpt`` (training): returns (yc, ckpt) -- ckpt the state entering every 16-step
+    chunk, which ``scan_bwd(..., ckpt=ckpt)`` takes instead of sweeping forward itself; None where the chunked backward
+    kernel does not apply (short pooled lengths, dt_rank > 48)."""
     _, B, Lc, d_in = xc.shape
     R = dt_w.shape[1]
     N = A_log.shape[1]
+    lib = L.lib()
     yc = torch.empty(2, B, Lc, d_in, device=xc.device, dtype=torch.float32)
-    rc = L.lib().fv_mixer_scan_fwd(
+    ckpt = None
+    if want_ckpt:
+        nck = lib.fv_mixer_scan_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R))
+        ckpt = torch.empty(nck, device=xc.device, dtype=torch.float32) if nck else None
+    rc = lib.fv_mixer_scan_fwd_ckpt(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
-        L.ptr(A_log_b), L.ptr(yc), L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N),
+        L.ptr(A_log_b), L.ptr(yc), L.ptr(ckpt), L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N),
         L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
     L.check(rc, "mixer_scan_fwd")
-    return yc
+    return (yc, ckpt) if want_ckpt else yc
 
 
 def xproj_scan_fwd(xc, Wx2_c, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
@@ -205,7 +213,7 @@ def combine_bwd(dg, xz, skip, yc, ln_w, ln_b, mean, rstd, dxz, rows, cols, trans
 
 
 def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_out=None, keep_chunks=False,
-             dyc_per_direction=False):
+             dyc_per_direction=False, ckpt=None):
     """Returns (dxc, dx_dbl, pr) with pr (2, d_in*(N+R+1)) = per direction [dA_log | d dt_w | d dt_bias];
     when ``grad_out`` (flat fp32 view of exactly that layout) is given, the sums are accumulated into
     it instead and pr is None.  ``dyc_per_direction``: dyc is (2, B, Lc, d_in) instead of one (B, Lc, d_in)
@@ -220,14 +228,16 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     f32o = dict(device=dev, dtype=torch.float32)
     dxc = torch.empty(2, B, Lc, d_in, **f32o)
     dx_dbl = torch.empty(nchunks, 2, B * Lc, W, **f32o)
-    nck = lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R))
-    ckpt = torch.empty(nck, **f32o) if nck else None
+    given = ckpt is not None          # checkpoints of the forward launch (scan_fwd(want_ckpt=True))
+    if not given:
+        nck = lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R))
+        ckpt = torch.empty(nck, **f32o) if nck else None
     nprt = lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc), L.i32(R))
     part = torch.empty(nprt, 2 * d_in * (N + R + 1), **f32o)
-    rc = lib.fv_mixer_scan_bwd_dir(
+    rc = lib.fv_mixer_scan_bwd_ckpt(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
-        L.ptr(A_log_b), L.ptr(dyc), L.i32(int(dyc_per_direction)), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.ptr(part),
-        L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
+        L.ptr(A_log_b), L.ptr(dyc), L.i32(int(dyc_per_direction)), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.i32(int(given)),
+        L.ptr(part), L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
     L.check(rc, "mixer_scan_bwd")
     if not keep_chunks:       # keep_chunks: the x_proj adjoint kernel sums the chunk partials itself
         dx_dbl = dx_dbl[0] if nchunks == 1 else reduce_partials(dx_dbl, nchunks)

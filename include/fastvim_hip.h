@@ -134,6 +134,16 @@ int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float* dt_w, cons
                       const float* A_log, const float* dt_w_b, const float* dt_bias_b,
                       const float* A_log_b, float* yc, int batch, int Lc, int d_inner, int dt_rank,
                       int d_state, int dtype, fv_stream_t stream);
+/* Training form for long pooled lengths (Lc > 16, dt_rank <= 48): the forward launch also leaves the state entering
+ * every 16-step chunk in `ckpt` (fv_mixer_scan_ckpt_floats() fp32; 0 = shape not covered, pass NULL), laid out
+ * (2, batch, ceil(Lc/16), d_inner, d_state); fv_mixer_scan_bwd_ckpt(ckpt_given = 1) then skips its own forward sweep --
+ * the states of the reference's forward kernel that its backward kernel re-derives (selective_scan_bwd_kernel.cuh:75-528
+ * recomputes them chunk by chunk from `x`, the per-chunk running state saved by selective_scan_fwd_kernel.cuh:67-345). */
+size_t fv_mixer_scan_ckpt_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank);
+int fv_mixer_scan_fwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                           const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                           const float* A_log_b, float* yc, float* ckpt, int batch, int Lc, int d_inner, int dt_rank,
+                           int d_state, int dtype, fv_stream_t stream);
 
 /* x_proj + dt_proj + softplus + selective scan in ONE launch for short pooled lengths (Lc <= 16, bf16, dt_rank <= 48:
  * the 224 / 256 px grids): x_dbl (2, batch*Lc, dt_rank + 2*d_state) = xc @ x_proj_w2[dir]^T is computed on the matrix
@@ -195,6 +205,14 @@ int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const float* dt_w, 
                           const float* dyc, int dyc_per_direction, float* dxc, float* dx_dbl, float* ckpt,
                           float* partials, int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
                           fv_stream_t stream);
+/* Same; ckpt_given != 0: `ckpt` holds the checkpoints written by fv_mixer_scan_fwd_ckpt for the same inputs (read, not
+ * scratch).  Pooled lengths above 16 take the chunked kernel (16-step chunks, states of a chunk recomputed into
+ * registers from its checkpoint); without given checkpoints it derives them with a forward sweep of its own. */
+int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                           const float* A_log, const float* dt_w_b, const float* dt_bias_b, const float* A_log_b,
+                           const float* dyc, int dyc_per_direction, float* dxc, float* dx_dbl, float* ckpt,
+                           int ckpt_given, float* partials, int batch, int Lc, int d_inner, int dt_rank, int d_state,
+                           int dtype, fv_stream_t stream);
 
 /* ---- MAE masked mixer: kept tokens <-> pooling rows --------------------------
  * Replaces compute_row_means_constantdivide (index_add_ over the kept tokens, divide by cols;

@@ -202,18 +202,24 @@ def _scan_cl_case(Bsz, Lc, d_in, R, dtype, seed):
     return xc, x_dbl, Wdt, bdt, A_log, dyc
 
 
-@pytest.mark.parametrize("Bsz,Lc,d_in,R", [(2, 128, 1536, 48),      # config 4: global-checkpoint branch, 24 channel chunks
+@pytest.mark.parametrize("Bsz,Lc,d_in,R", [(2, 128, 1536, 48),      # config 4: 8 chunks of 16 steps, 24 channel chunks
                                            (3, 128, 384, 12),       # long scan at the FastVim-T width
                                            (4, 14, 1536, 48),       # config 3
                                            (5, 14, 384, 12),        # config 2
                                            (2, 112, 768, 24),       # config 5 (pooled length rows * channels)
-                                           (2, 37, 192, 6)])        # ragged: Lc not a multiple of the 4-step segment
+                                           (2, 37, 192, 6),         # ragged: last chunk 5 steps
+                                           (2, 17, 384, 12),        # a second chunk of one step
+                                           (1, 197, 384, 12),       # unpooled Vim-T: 12 chunks + 5 steps
+                                           (2, 40, 1024, 64)])      # dt_rank > 48: the generic kernel (4-step segments)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_scan_cl_kernels_vs_selective_scan_oracle(Bsz, Lc, d_in, R, dtype):
+@pytest.mark.parametrize("given", [False, True])
+def test_scan_cl_kernels_vs_selective_scan_oracle(Bsz, Lc, d_in, R, dtype, given):
     """fv_mixer_scan_fwd / fv_mixer_scan_bwd (dt_proj + softplus + scan over the pooled rows, channel-last, both
     directions in one launch) == selective_scan_ref semantics: delta = softplus(dt_low @ Wdt^T + bias), forward
     direction in ascending and backward direction in descending row order; all gradients (u, x_dbl = [dt_low|B|C],
-    A_log, dt_proj weight and bias) against fp64 autograd of the oracle."""
+    A_log, dt_proj weight and bias) against fp64 autograd of the oracle.  ``given``: the training form -- the forward
+    launch leaves the state entering every 16-step chunk behind and the backward kernel takes it instead of sweeping
+    forward itself (long pooled lengths only; elsewhere the forward launch returns no checkpoints)."""
     from fastvim_amd import mixer_ops as M
     from oracle import selective_scan_oracle
     N = 16
@@ -221,10 +227,19 @@ def test_scan_cl_kernels_vs_selective_scan_oracle(Bsz, Lc, d_in, R, dtype):
     dev = "cuda"
     yc = M.scan_fwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
                     Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev))
+    ck = None
+    if given:
+        yc_t, ck = M.scan_fwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
+                              Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev), want_ckpt=True)
+        assert torch.equal(yc_t, yc)
+        assert (ck is not None) == (Lc > 16 and R <= 48)
+        if ck is None:
+            pytest.skip("no checkpoints for this shape: same launch as given=False")
+        assert ck.numel() == 2 * Bsz * ((Lc + 15) // 16) * d_in * N
     dxc, dx_dbl, pr = M.scan_bwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
-                                 Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev), dyc.to(dev))
+                                 Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev), dyc.to(dev), ckpt=ck)
     dxc2, dx_dbl2, pr2 = M.scan_bwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
-                                    Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev), dyc.to(dev))
+                                    Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev), dyc.to(dev), ckpt=ck)
     assert torch.equal(dxc, dxc2) and torch.equal(dx_dbl, dx_dbl2) and torch.equal(pr, pr2)     # no atomics: bitwise
     for k in range(2):
         u = xc[k].double().requires_grad_()                                      # (B, Lc, d_in)
