@@ -999,6 +999,134 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Forward for LONG pooled lengths, same chunking: a 4-wave workgroup owns 64 channels of one (direction, batch element)
+// and walks the 16-step chunks.  Per chunk: the x_dbl rows are staged (the next chunk's rows and inputs are requested
+// before this chunk's arithmetic and land in the other LDS buffer after it: one workgroup barrier per chunk), delta_raw
+// on the fp32 matrix cores and softplus once per (step, channel) -- the generic kernel does dt_rank / 4 FMAs and a
+// softplus per state-quad lane and step -- then the recurrence in registers.  The state leaving a chunk goes to `ckpt`
+// when the backward pass will want it.
+template <typename T, int RQ>
+__global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p) {
+  constexpr int NWV = 4, CH = 64, LCT = 16, NTH = 256;
+  constexpr int RQP = (RQ + 3) / 4 * 4, WP = 4 * RQP + 2 * N;
+  constexpr int NST = (LCT * WP + NTH - 1) / NTH;           // staged values per thread and chunk
+  __shared__ __attribute__((aligned(16))) float s_dbl[2][LCT * WP];
+  __shared__ __attribute__((aligned(16))) float s_ch[LCT * CH * 2];       // {delta, delta * u}
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dir = blockIdx.z, b = blockIdx.y, ch0 = blockIdx.x * CH;
+  const int W = p.R + 2 * N, Lc = p.Lc, nchunk = (Lc + LCT - 1) / LCT;
+  const size_t bd = ((size_t)dir * p.B + b) * Lc;
+  // scan role
+  const int q = lane & 3, ch = wv * 16 + (lane >> 2), d = ch0 + ch;
+  const bool act = d < p.d_in;
+  const int dd = act ? d : 0;
+  sf2 A2[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    A2[h].x = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h]) * FV_LOG2E;
+    A2[h].y = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h + 1]) * FV_LOG2E;
+  }
+  // matrix role: lane = (channel cm of the wave, step group tg)
+  const int cm = lane & 15, tg = lane >> 4, dm = ch0 + wv * 16 + cm;
+  const bool actm = dm < p.d_in;
+  const int ddm = actm ? dm : 0;
+  const float bias_m = p.dtb[dir][ddm];
+  float wdt[RQP];                              // this lane's B operands of the dt_proj MFMAs: r = 4 kg + tg
+#pragma unroll
+  for (int kg = 0; kg < RQP; ++kg) {
+    const int r = 4 * kg + tg;
+    wdt[kg] = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
+  }
+  const T* dbl = (const T*)p.xdbl + bd * W;
+  const T* u = (const T*)p.xc + bd * p.d_in + ddm;
+  float* y = p.yc + bd * p.d_in + dd;
+  float* ck = p.ckpt ? p.ckpt + (((size_t)dir * p.B + b) * nchunk * p.d_in + dd) * N + q * 4 : nullptr;
+
+  float pre[NST], um[4];
+  auto fetch = [&](int c) {            // chunk c's rows (this thread's share) and inputs into registers
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = tid + i * NTH;
+      const int srow = e / WP, col = e - srow * WP;
+      const int sg = c * LCT + srow;
+      const int l = dir ? Lc - 1 - sg : sg;
+      float v = 0.f;
+      if (e < LCT * WP && sg < Lc) {
+        if (col < 4 * RQP) {
+          const int qq = col / RQP, k = col - qq * RQP, r = qq + 4 * k;
+          if (k < RQ && r < p.R) v = io<T>::ld(dbl + (size_t)l * W + r);
+        } else {
+          v = io<T>::ld(dbl + (size_t)l * W + p.R + (col - 4 * RQP));
+        }
+      }
+      pre[i] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int sg = min(c * LCT + 4 * tg + r, Lc - 1), l = dir ? Lc - 1 - sg : sg;
+      um[r] = io<T>::ld(u + (size_t)l * p.d_in);
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int e = tid + i * NTH;
+      if (e < LCT * WP) s_dbl[buf][e] = pre[i];
+    }
+  };
+  fetch(0);
+  put(0);
+  __syncthreads();
+  sf2 st[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    const int valid = min(LCT, Lc - c * LCT);
+    // delta of this chunk: its inputs are in registers / LDS
+    {
+      f32x4_t D = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kg = 0; kg < RQP; ++kg)
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(s_dbl[buf][cm * WP + tg * RQP + kg], wdt[kg], D, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s = 4 * tg + r;
+        const float dt = (actm && s < valid) ? fv_softplus(D[r] + bias_m) : 0.f;
+        *reinterpret_cast<float2*>(s_ch + ((size_t)s * CH + wv * 16 + cm) * 2) = make_float2(dt, dt * um[r]);
+      }
+    }
+    if (c + 1 < nchunk) fetch(c + 1);          // in flight under the recurrence
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();           // the table columns of this wave's 16 channels are read by this wave only
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float* my_bc = s_dbl[buf] + 4 * RQP + q * 4;
+    const float* my_ch = s_ch + (size_t)ch * 2;
+#pragma unroll
+    for (int s = 0; s < LCT; ++s) {
+      if (s < valid) {          // uniform
+        const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+        const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
+        const float2 cv = *reinterpret_cast<const float2*>(my_ch + s * (CH * 2));
+        const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
+        sf2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
+          acc = sfma2(Cn[h], st[h], acc);
+        }
+        const float yv = quad_sum(acc.x + acc.y);
+        const int sg = c * LCT + s, l = dir ? Lc - 1 - sg : sg;
+        if (act && q == 0) y[(size_t)l * p.d_in] = yv;
+      }
+    }
+    if (ck && c + 1 < nchunk && act)
+      *reinterpret_cast<float4*>(ck + (size_t)(c + 1) * p.d_in * N) = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
+    if (c + 1 < nchunk) put(buf ^ 1);          // the other buffer's readers passed the barrier of the previous chunk
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Forward for SHORT pooled lengths with x_proj fused in (bf16): one 768-thread workgroup per (direction, batch
 // element) -- 256 workgroups at bs 128, one round.
 //   1. x_dbl[t][:] = xc[t][:] . Wx^T on the bf16 matrix cores: the 14 pooled rows go to LDS once (they are also the
@@ -1210,6 +1338,19 @@ extern "C" int fv_mixer_scan_fwd_ckpt(const void* xc, const void* x_dbl, const f
   const int RQ = rq_of(dt_rank);
   dim3 grid(fv_cdiv(d_inner, CPB), batch, 2), block(256);
   hipStream_t st = (hipStream_t)stream;
+  static const int fwd_chunked = fv_tune("FASTVIM_SCAN_FWD_CHUNKED", 1);   // A/B hook
+  if (fwd_chunked && Lc > 16 && dt_rank <= 48) {
+#define FV_FC(TT)                                                                            \
+  do {                                                                                       \
+    if (RQ <= 3) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 3>), grid, block, 0, st, p);        \
+    else if (RQ <= 6) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 6>), grid, block, 0, st, p);   \
+    else hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 12>), grid, block, 0, st, p);               \
+  } while (0)
+    if (dtype == FV_F32) FV_FC(float); else FV_FC(bf16_t);
+#undef FV_FC
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
 #define FV_F(TT, RQQ)                                                                        \
   do {                                                                                       \
     size_t smem = (size_t)Lc * (4 * RQQ + 2 * N) * 4;                                        \
