@@ -659,8 +659,9 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
 
 // ------------------------------------------------------------------------------------------------------------
 // Backward for LONG pooled lengths (Lc > 16: the 2048 px grid, the channel model, unpooled Vim) with the short kernel's
-// treatment.  Time is cut into chunks of 16 steps; a 6-wave workgroup (96 channels of one direction, two workgroups
-// per CU) walks a batch element's chunks twice:
+// treatment.  Time is cut into chunks of 16 steps; a workgroup -- 12 waves and 192 channels of one direction, one per CU,
+// when that fills the chip (ck_waves below), else 4 waves and 64 channels, three per CU; 6 waves do not pack: two such
+// workgroups want 4 + 4 + 2 + 2 waves on the four SIMDs of a CU where 3 each fit -- walks a batch element's chunks twice:
 //   * forward over chunks 0 .. n-2: stage the chunk's x_dbl rows, delta on the fp32 matrix cores, softplus once per
 //     (step, channel), the recurrence in registers; the state leaving a chunk is its successor's checkpoint (one
 //     16-byte store per lane and chunk to the scratch buffer; the generic kernel writes one per 4 steps: 352 MB
@@ -683,7 +684,6 @@ struct ChunkLds {
   static constexpr int o_pd = o_part + LCT * NWV * 4 * 8;          // NWV * 16 * 16 * RT  d dt_low wave partials
   static constexpr int floats = o_pd + NWV * 16 * 16 * RT;
 };
-constexpr int CK_NWV = 4, CK_CH = 16 * CK_NWV;
 
 template <typename T, int RQ, int NWV, bool CK_GIVEN>
 __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanClParams p) {
@@ -1439,8 +1439,19 @@ extern "C" size_t fv_mixer_scan_ckpt_floats(int batch, int Lc, int d_inner, int 
   return bwd_chunked(Lc, dt_rank) ? (size_t)2 * batch * ((Lc + 15) / 16) * d_inner * d_state : 0;
 }
 
+// waves of a chunked-kernel workgroup: 12 (192 channels, one workgroup per CU) when those workgroups fill the chip's 256
+// CUs, else 4 (64 channels, three per CU).  Measured with 12 against 4: Vim-T bs 128 22.28 -> 21.83 ms per step,
+// FastChannelVim-S bs 64 47.4 -> 47.0; FastVim-B 2048 px bs 8 (128 workgroups of 12 waves) 123.0 -> 123.4
+static int ck_waves(int batch, int d_inner) {
+  static const int force = fv_tune("FASTVIM_SCAN_CK_WAVES", 0);   // tuning hook
+  if (force == 4 || force == 12) return force;
+  return (long)fv_cdiv(d_inner, 192) * batch * 2 >= 256 ? 12 : 4;
+}
+extern "C" int fv_mixer_scan_bwd_chunks_b(int batch, int d_inner, int Lc, int dt_rank) {
+  return fv_cdiv(d_inner, bwd_short(Lc, dt_rank) ? SH_CH : bwd_chunked(Lc, dt_rank) ? 16 * ck_waves(batch, d_inner) : CPB);
+}
 extern "C" int fv_mixer_scan_bwd_chunks(int d_inner, int Lc, int dt_rank) {
-  return fv_cdiv(d_inner, bwd_short(Lc, dt_rank) ? SH_CH : bwd_chunked(Lc, dt_rank) ? CK_CH : CPB);
+  return fv_mixer_scan_bwd_chunks_b(1 << 20, d_inner, Lc, dt_rank);      // large batch
 }
 
 // A block can walk several batch elements (fewer, longer blocks; parameter-gradient partials shrink by the same
@@ -1533,13 +1544,25 @@ extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const f
     return FV_OK;
   }
   if (bwd_chunked(Lc, dt_rank)) {
-    dim3 cgrid(fv_cdiv(d_inner, CK_CH), batch / p.NBB, 2), cblock(64 * CK_NWV);
+    const int nwv = ck_waves(batch, d_inner);
+    dim3 cgrid(fv_cdiv(d_inner, 16 * nwv), batch / p.NBB, 2), cblock(64 * nwv);
+#define FV_CW(TT, RQQ, NWW)                                                                  \
+  do {                                                                                       \
+    size_t smem = (size_t)ChunkLds<RQQ, NWW>::floats * 4;                                    \
+    static bool done = false;                                                                \
+    if (!done && smem > 64 * 1024) {                                                         \
+      (void)hipFuncSetAttribute((const void*)scan_cl_bwd_chunked_kernel<TT, RQQ, NWW, true>, \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      (void)hipFuncSetAttribute((const void*)scan_cl_bwd_chunked_kernel<TT, RQQ, NWW, false>, \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      done = true;                                                                           \
+    }                                                                                        \
+    if (ckpt_given) hipLaunchKernelGGL((scan_cl_bwd_chunked_kernel<TT, RQQ, NWW, true>), cgrid, cblock, smem, st, p); \
+    else hipLaunchKernelGGL((scan_cl_bwd_chunked_kernel<TT, RQQ, NWW, false>), cgrid, cblock, smem, st, p); \
+  } while (0)
 #define FV_C(TT, RQQ)                                                                        \
   do {                                                                                       \
-    size_t smem = (size_t)ChunkLds<RQQ, CK_NWV>::floats * 4;                                 \
-    static_assert(ChunkLds<RQQ, CK_NWV>::floats * 4 <= 64 * 1024, "dynamic LDS above 64 KiB needs the attribute"); \
-    if (ckpt_given) hipLaunchKernelGGL((scan_cl_bwd_chunked_kernel<TT, RQQ, CK_NWV, true>), cgrid, cblock, smem, st, p); \
-    else hipLaunchKernelGGL((scan_cl_bwd_chunked_kernel<TT, RQQ, CK_NWV, false>), cgrid, cblock, smem, st, p); \
+    if (nwv == 12) FV_CW(TT, RQQ, 12); else FV_CW(TT, RQQ, 4);                               \
   } while (0)
 #define FV_CD(TT)                                                                            \
   do {                                                                                       \
@@ -1548,6 +1571,7 @@ extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const f
     if (dtype == FV_F32) FV_CD(float); else FV_CD(bf16_t);
 #undef FV_CD
 #undef FV_C
+#undef FV_CW
     FV_LAUNCH_CHECK();
     return FV_OK;
   }

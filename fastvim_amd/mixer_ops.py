@@ -224,7 +224,7 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     W = R + 2 * N
     dev = xc.device
     lib = L.lib()
-    nchunks = lib.fv_mixer_scan_bwd_chunks(L.i32(d_in), L.i32(Lc), L.i32(R))
+    nchunks = lib.fv_mixer_scan_bwd_chunks_b(L.i32(B), L.i32(d_in), L.i32(Lc), L.i32(R))
     f32o = dict(device=dev, dtype=torch.float32)
     dxc = torch.empty(2, B, Lc, d_in, **f32o)
     dx_dbl = torch.empty(nchunks, 2, B * Lc, W, **f32o)

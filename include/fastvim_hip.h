@@ -190,6 +190,9 @@ int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* skip, const
  *          segments [dA_log (d_inner*d_state) | d dt_proj.weight (d_inner*dt_rank) | d dt_proj.bias (d_inner)]
  *          (sum over batch with fv_reduce_partials). */
 int fv_mixer_scan_bwd_chunks(int d_inner, int Lc, int dt_rank);
+/* the same for a given batch: long pooled lengths pick the channel-chunk width by how many workgroups the launch has
+ * (fv_mixer_scan_bwd_chunks answers for a large batch); size dx_dbl with this one */
+int fv_mixer_scan_bwd_chunks_b(int batch, int d_inner, int Lc, int dt_rank);
 /* rows of the `partials` buffer of fv_mixer_scan_bwd: (rows, 2, d_inner*(d_state + dt_rank + 1)) fp32 */
 int fv_mixer_scan_bwd_partials(int batch, int Lc, int dt_rank);
 size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank);
