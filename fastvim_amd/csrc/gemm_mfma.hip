@@ -778,6 +778,210 @@ __global__ __launch_bounds__(256, 2) void gemm_dgrad_addnorm_bwd_kernel(GemmPara
   gemm_bf16_body<KC, KS, 2, 2, true, 6, BMROWS / 32, true, 2>(p, blockIdx.x, 0, &ne);
 }
 
+// ---- phased 256 x 256 form of the forward GEMM (K-contiguous A and B, bf16 out) -----------------------------------
+// The kernels above stage a K tile per __syncthreads() -- a vmcnt(0) with the next tile's LDS-DMA in flight -- and stop
+// near 900 TFLOP/s at the FastVim-B widths whatever the tile shape.  Here the prefetch stays in
+// flight across barriers: 8 waves as 2 (128-row halves) x 4 (64-column quarters), 128 KiB of LDS = 2 K tiles x {A lo, A hi,
+// B lo, B hi} half tiles of 128 x 64, counted s_waitcnt vmcnt, raw s_barrier, LDS reads as inline asm (no memory operand:
+// the compiler would order them behind every outstanding LDS-DMA load).  A K tile is four phases of 16 MFMAs per wave
+// (one 64 x 32 quadrant of its 128 x 64 output over the tile's two 32-deep steps):
+//     phase      reads (ds_read_b128)                 multiplies       LDS-DMA issued
+//     P1(t)      A rows 0-63 [8], B cols 0-31 [4]     (m0, n0)         A lo, A hi of tile t+1
+//     P2(t)      B cols 32-63 [4]                     (m0, n1)         --
+//     P3(t)      A rows 64-127 [8]                    (m1, n1)         --
+//     P4(t)      --   (B cols 0-31 kept)              (m1, n0)         B lo, B hi of tile t+2; then vmcnt: tile t+1 landed
+// Each phase is  [reads, DMA issue, wait] s_barrier [lgkmcnt(0), MFMAs] s_barrier.  The row-half groups run one barrier
+// apart (the second group takes one barrier up front, the first one at the end), so one group's MFMAs run under the
+// other's reads.  What orders LDS-DMA against reads (MI355X guide, "pipelining across barriers"):
+//   * a half tile is read no earlier than the phase AFTER the one whose wait retired it (both groups have then passed a
+//     barrier behind every wave's wait);
+//   * a half tile is refilled no earlier than TWO phases after its last read (the reader's lgkmcnt(0) sits behind the
+//     barrier that ends its read section; the next barrier is behind that wait for both groups).
+// B halves of tile t are last read in P2(t) and refilled in P4(t) (tile t+2, same parity); A halves are last read in P3(t)
+// and refilled in P1(t+1).  Accumulation order per output element is the K order, as in the kernels above: bitwise the
+// same C.
+template <int NV_>
+__device__ __forceinline__ void wait_vmc() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV_) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ u32x4 ds_read_b128_imm(uint32_t a) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HALF = 128 * BK * 2;            // bytes of a 128 x 64 half tile
+  constexpr int PAR = 4 * HALF;                 // one K tile: A lo | A hi | B lo | B hi
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wv >> 2, wc = wv & 3;
+  const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256, nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q8 = nblk / 8, r8 = nblk % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+  }
+  const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;
+  const int nt = p.K / BK;
+  // LDS-DMA sources: thread -> physical 16-byte slot e = tid + 512 i of a half tile (rows 8 slots wide, chunk ^= row & 7)
+  const int sr = tid >> 3, sc = (tid & 7) ^ (sr & 7);
+  const bf16_t* srcA[4];
+  const bf16_t* srcB[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {                 // row groups of 64: g = 2 half + i
+    srcA[g] = p.A + (long)min(m0 + g * 64 + sr, p.M - 1) * p.lda + sc * 8;
+    srcB[g] = p.B + (long)min(n0 + g * 64 + sr, p.N - 1) * p.ldb + sc * 8;
+  }
+  typedef __attribute__((address_space(1))) const void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  auto issueA = [&](int t) {
+    char* base = smem + (t & 1) * PAR;
+#ifdef FASTVIM_TUNING_HOOKS
+    if (p.rb_period & 16) return;
+#endif
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      __builtin_amdgcn_global_load_lds((gptr)(srcA[g] + (long)t * BK), (lptr)(base + (g >> 1) * HALF + ((g & 1) * 512 + wv * 64) * 16), 16, 0, 0);
+  };
+  auto issueB = [&](int t) {
+    char* base = smem + (t & 1) * PAR + 2 * HALF;
+#ifdef FASTVIM_TUNING_HOOKS
+    if (p.rb_period & 16) return;
+#endif
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      __builtin_amdgcn_global_load_lds((gptr)(srcB[g] + (long)t * BK), (lptr)(base + (g >> 1) * HALF + ((g & 1) * 512 + wv * 64) * 16), 16, 0, 0);
+  };
+  // fragment addresses: row (lane & 15) of a 16-row block, 16-byte chunk ks * 4 + (lane >> 4), swizzled by row & 7
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+  const uint32_t off0 = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);     // ks = 0; ks = 1: ^ 64
+  const uint32_t aA = lds0 + wr * HALF + off0;                                         // + parity * PAR + blk * 2048
+  const uint32_t aB = lds0 + 2 * HALF + (wc >> 1) * HALF + (wc & 1) * (64 * 128) + off0;
+
+  f32x4 acc[4][8];       // [n tile][m tile]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 fA[2][4], fB0[2][2], fB1[2][2];          // [ks][block]
+#ifdef FASTVIM_TUNING_HOOKS
+  const int dbgf = p.rb_period;                  // phase probe: 1 no stores, 2 no vmcnt waits, 4 no MFMAs, 8 no LDS reads
+  if (dbgf & 8) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fA[ks][i] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fB0[ks][i] = fB1[ks][i] = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+#else
+  constexpr int dbgf = 0;
+#endif
+
+  // prologue: tiles 0 and 1 in flight, tile 0 landed
+  issueA(0); issueB(0);
+  if (nt > 1) { issueA(1); wait_vmc<4>(); } else wait_vmc<0>();
+  __builtin_amdgcn_s_barrier();
+  if (nt > 1) issueB(1);
+  if (wr == 1) __builtin_amdgcn_s_barrier();      // the second row-half group runs one barrier behind
+
+#define FV_RD_A(PARITY, MH)                                                                                  \
+  if (!(dbgf & 8)) static_for<4>([&](auto mt) {                                                                               \
+    fA[0][mt] = ds_read_b128_imm<(MH * 4 + mt) * 2048>(aA + (PARITY) * PAR);                                 \
+    fA[1][mt] = ds_read_b128_imm<(MH * 4 + mt) * 2048>((aA + (PARITY) * PAR) ^ 64u);                         \
+  })
+#define FV_RD_B(DST, PARITY, NH)                                                                             \
+  if (!(dbgf & 8)) static_for<2>([&](auto nn) {                                                                               \
+    DST[0][nn] = ds_read_b128_imm<(NH * 2 + nn) * 2048>(aB + (PARITY) * PAR);                                \
+    DST[1][nn] = ds_read_b128_imm<(NH * 2 + nn) * 2048>((aB + (PARITY) * PAR) ^ 64u);                        \
+  })
+#define FV_MM(BF, MH, NH)                                                                                    \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(fA[ks][mt])); }              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int nn = 0; nn < 2; ++nn) { asm volatile("" : "+v"(BF[ks][nn])); }              \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    if (!(dbgf & 4))                                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int nn = 0; nn < 2; ++nn)                                                       \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                     \
+          acc[NH * 2 + nn][MH * 4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
+              __builtin_bit_cast(bf16x8, BF[ks][nn]), __builtin_bit_cast(bf16x8, fA[ks][mt]),                \
+              acc[NH * 2 + nn][MH * 4 + mt], 0, 0, 0);                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+
+  for (int t = 0; t < nt; ++t) {
+    const uint32_t par = t & 1;
+    // P1
+    FV_RD_A(par, 0);
+    FV_RD_B(fB0, par, 0);
+    if (t >= 1 && t + 1 < nt) issueA(t + 1);       // (tile 1's A went out in the prologue)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    FV_MM(fB0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+    // P2
+    FV_RD_B(fB1, par, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    FV_MM(fB1, 0, 1);
+    __builtin_amdgcn_s_barrier();
+    // P3
+    FV_RD_A(par, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    FV_MM(fB1, 1, 1);
+    __builtin_amdgcn_s_barrier();
+    // P4: B of tile t + 2 into this tile's B halves (last read in P2); everything older -- tile t + 1 -- has landed
+#ifdef FASTVIM_TUNING_HOOKS
+    if (p.rb_period & 2) { if (t + 2 < nt) issueB(t + 2); } else
+#endif
+    if (t + 2 < nt) { issueB(t + 2); wait_vmc<4>(); } else wait_vmc<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    FV_MM(fB0, 1, 0);
+    __builtin_amdgcn_s_barrier();
+  }
+#undef FV_MM
+#undef FV_RD_B
+#undef FV_RD_A
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  // epilogue: bf16 through a wave-private LDS slab (64 rows x 64 columns at a time), 16-byte stores of whole 128-byte
+  // row segments.  Every wave is past its last LDS read and every LDS-DMA load has landed (vmcnt(0) in the last P4).
+  __syncthreads();
+  constexpr int RS = 64 * 2 + 16;
+  char* my = smem + wv * (64 * RS);
+  bf16_t* C = (bf16_t*)p.C;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const f32x4 v = acc[a][h * 4 + b];
+        uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<uint2*>(my + (b * 16 + (lane & 15)) * RS + (a * 16 + (lane >> 4) * 4) * 2) = pk;
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = i * 64 + lane, r = idx >> 3, ch = idx & 7;
+      const int m = m0 + wr * 128 + h * 64 + r, n = n0 + wc * 64 + ch * 8;
+#ifdef FASTVIM_TUNING_HOOKS
+      if (p.rb_period & 1) continue;
+#endif
+      if (m < p.M) *reinterpret_cast<u32x4*>(C + (long)m * p.ldc + n) = *reinterpret_cast<const u32x4*>(my + r * RS + ch * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Several independent problems in ONE launch (the weight gradients of a whole backward pass, queued until its end):
 // a single weight-gradient GEMM at FastVim-T is 168-336 workgroups -- a third to two thirds of what the chip holds at
 // once -- and every launch pays that tail; the grouped launch is one long queue of workgroups.
@@ -1069,6 +1273,24 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
     if (tall == 7 && p.N % 192 == 0) return launch_k<AMODE, BMODE, 4, 2, G, 6, 4>(p, splits, st);   // 8 waves of 64x96: 256x192
   }
 #endif
+  // phased 256 x 256 kernel (gemm_nt256p_kernel): one workgroup per CU, so it wants whole rounds of 256 tiles -- from
+  // four rounds on.  Measured against the kernels below (same C, bit for bit): M = 131072 (2048 px, bs 8) N = 3072
+  // K = 768 684 -> 608 us, N = 768 K = 1536 360 -> 331; M = 100352 (channel model) N = 1536 K = 384 188 -> 158;
+  // M = 25088 N = 3072 132 -> 120-128 (4.6 rounds); M = 25088 N = 768 (1.15 rounds) 70.9 -> 72.9: stays below
+  static const int phased = fv_tune("FASTVIM_GEMM_P256", 1);   // tuning hook: 0 off
+  if (phased && AMODE == KC && BMODE == KC && p.N % 256 == 0 && p.K % BK == 0 && p.K >= 2 * BK && splits == 1 &&
+      !p.c_fp32 && !p.bias && p.ldc % 8 == 0 && (long)fv_cdiv(p.M, 256) * (p.N / 256) >= 4 * 256) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr = true;
+    }
+    GemmParams q = p;
+    q.rb_period = fv_tune("FASTVIM_GEMM_P256_DBG", 0);      // phase probe (tuning builds)
+    hipLaunchKernelGGL(gemm_nt256p_kernel, dim3(fv_cdiv(p.M, 256) * (p.N / 256)), dim3(512), 128 * 1024, st, q);
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
   // FastVim-B in_proj forward (N = 3072, K = 768): eight waves of 128x64 on a 256x256 tile, -10 % (161 -> 144 us);
   // measured slower at every FastVim-T/S shape and for the data-gradient forms, which keep the 4-wave tiles
   static const bool big = (fv_tune("FASTVIM_GEMM_BIG", 1) != 0);   // tuning hook
