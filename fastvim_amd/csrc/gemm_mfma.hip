@@ -809,6 +809,7 @@ __device__ __forceinline__ u32x4 ds_read_b128_imm(uint32_t a) {
   return v;
 }
 
+template <int BMODE>       // KC: B (N, K) K-contiguous (forward);  KS: B (K, N) row-major as stored (data gradient)
 __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HALF = 128 * BK * 2;            // bytes of a 128 x 64 half tile
@@ -826,11 +827,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
   // LDS-DMA sources: thread -> physical 16-byte slot e = tid + 512 i of a half tile (rows 8 slots wide, chunk ^= row & 7)
   const int sr = tid >> 3, sc = (tid & 7) ^ (sr & 7);
   const bf16_t* srcA[4];
-  const bf16_t* srcB[4];
+  const bf16_t* srcB[4];        // KC: as A;  KS: [half][piece] sources of the K-slow image ([k][128 cols], chunk-swizzled)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {                 // row groups of 64: g = 2 half + i
     srcA[g] = p.A + (long)min(m0 + g * 64 + sr, p.M - 1) * p.lda + sc * 8;
-    srcB[g] = p.B + (long)min(n0 + g * 64 + sr, p.N - 1) * p.ldb + sc * 8;
+    if constexpr (BMODE == KC) srcB[g] = p.B + (long)min(n0 + g * 64 + sr, p.N - 1) * p.ldb + sc * 8;
+  }
+  if constexpr (BMODE == KS) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      GldsPlan<KS, 128, 512> gb;
+      gb.init(p.B, p.ldb, n0 + h * 128, p.N, tid);
+      srcB[2 * h] = gb.src[0];
+      srcB[2 * h + 1] = gb.src[1];
+    }
   }
   typedef __attribute__((address_space(1))) const void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
@@ -850,13 +860,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
 #endif
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      __builtin_amdgcn_global_load_lds((gptr)(srcB[g] + (long)t * BK), (lptr)(base + (g >> 1) * HALF + ((g & 1) * 512 + wv * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(srcB[g] + (long)t * BK * (BMODE == KC ? 1 : p.ldb)),
+                                       (lptr)(base + (g >> 1) * HALF + ((g & 1) * 512 + wv * 64) * 16), 16, 0, 0);
   };
   // fragment addresses: row (lane & 15) of a 16-row block, 16-byte chunk ks * 4 + (lane >> 4), swizzled by row & 7
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
   const uint32_t off0 = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);     // ks = 0; ks = 1: ^ 64
   const uint32_t aA = lds0 + wr * HALF + off0;                                         // + parity * PAR + blk * 2048
   const uint32_t aB = lds0 + 2 * HALF + (wc >> 1) * HALF + (wc & 1) * (64 * 128) + off0;
+  // K-slow B: one address per 16-column block of the wave's 64 columns (transposing reads, see KsFrags)
+  uint32_t aBk[4];
+  if constexpr (BMODE == KS) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, kl = g * 8 + q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      aBk[j] = lds0 + 2 * HALF + (wc >> 1) * HALF + kl * 256 + ((((wc & 1) * 4 + j) ^ ks_swz<128>(kl)) << 5) + pp * 8;
+  }
 
   f32x4 acc[4][8];       // [n tile][m tile]
 #pragma unroll
@@ -864,6 +883,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   u32x4 fA[2][4], fB0[2][2], fB1[2][2];          // [ks][block]
+  unsigned long long kB0[2][2][2], kB1[2][2][2];  // K-slow B: [ks][block][lo | hi], joined behind the wait
 #ifdef FASTVIM_TUNING_HOOKS
   const int dbgf = p.rb_period;                  // phase probe: 1 no stores, 2 no vmcnt waits, 4 no MFMAs, 8 no LDS reads
   if (dbgf & 8) {
@@ -891,19 +911,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
     fA[0][mt] = ds_read_b128_imm<(MH * 4 + mt) * 2048>(aA + (PARITY) * PAR);                                 \
     fA[1][mt] = ds_read_b128_imm<(MH * 4 + mt) * 2048>((aA + (PARITY) * PAR) ^ 64u);                         \
   })
-#define FV_RD_B(DST, PARITY, NH)                                                                             \
-  if (!(dbgf & 8)) static_for<2>([&](auto nn) {                                                                               \
-    DST[0][nn] = ds_read_b128_imm<(NH * 2 + nn) * 2048>(aB + (PARITY) * PAR);                                \
-    DST[1][nn] = ds_read_b128_imm<(NH * 2 + nn) * 2048>((aB + (PARITY) * PAR) ^ 64u);                        \
+#define FV_RD_B(DST, KDST, PARITY, NH)                                                                       \
+  if (!(dbgf & 8)) static_for<2>([&](auto nn) {                                                              \
+    if constexpr (BMODE == KC) {                                                                             \
+      DST[0][nn] = ds_read_b128_imm<(NH * 2 + nn) * 2048>(aB + (PARITY) * PAR);                              \
+      DST[1][nn] = ds_read_b128_imm<(NH * 2 + nn) * 2048>((aB + (PARITY) * PAR) ^ 64u);                      \
+    } else {                                                                                                 \
+      const uint32_t a_ = aBk[NH * 2 + nn] + (PARITY) * PAR;                                                 \
+      KDST[0][nn][0] = ds_read_tr16_b64<0>(a_);                                                              \
+      KDST[0][nn][1] = ds_read_tr16_b64<4 * 256>(a_);                                                        \
+      KDST[1][nn][0] = ds_read_tr16_b64<32 * 256>(a_);                                                       \
+      KDST[1][nn][1] = ds_read_tr16_b64<32 * 256 + 4 * 256>(a_);                                             \
+    }                                                                                                        \
   })
-#define FV_MM(BF, MH, NH)                                                                                    \
+#define FV_MM(BF, KBF, MH, NH)                                                                               \
   do {                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(fA[ks][mt])); }              \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
-      _Pragma("unroll") for (int nn = 0; nn < 2; ++nn) { asm volatile("" : "+v"(BF[ks][nn])); }              \
+      _Pragma("unroll") for (int nn = 0; nn < 2; ++nn) {                                                     \
+        if constexpr (BMODE == KC) { asm volatile("" : "+v"(BF[ks][nn])); }                                  \
+        else {                                                                                               \
+          asm volatile("" : "+v"(KBF[ks][nn][0]));                                                           \
+          asm volatile("" : "+v"(KBF[ks][nn][1]));                                                           \
+          typedef unsigned long long u64x2_ __attribute__((ext_vector_type(2)));                             \
+          const u64x2_ j_ = {KBF[ks][nn][0], KBF[ks][nn][1]};                                                \
+          BF[ks][nn] = __builtin_bit_cast(u32x4, j_);                                                        \
+        }                                                                                                    \
+      }                                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                           \
     if (!(dbgf & 4))                                                                                         \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
@@ -920,23 +957,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
     const uint32_t par = t & 1;
     // P1
     FV_RD_A(par, 0);
-    FV_RD_B(fB0, par, 0);
+    FV_RD_B(fB0, kB0, par, 0);
     if (t >= 1 && t + 1 < nt) issueA(t + 1);       // (tile 1's A went out in the prologue)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    FV_MM(fB0, 0, 0);
+    FV_MM(fB0, kB0, 0, 0);
     __builtin_amdgcn_s_barrier();
     // P2
-    FV_RD_B(fB1, par, 1);
+    FV_RD_B(fB1, kB1, par, 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    FV_MM(fB1, 0, 1);
+    FV_MM(fB1, kB1, 0, 1);
     __builtin_amdgcn_s_barrier();
     // P3
     FV_RD_A(par, 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    FV_MM(fB1, 1, 1);
+    FV_MM(fB1, kB1, 1, 1);
     __builtin_amdgcn_s_barrier();
     // P4: B of tile t + 2 into this tile's B halves (last read in P2); everything older -- tile t + 1 -- has landed
 #ifdef FASTVIM_TUNING_HOOKS
@@ -945,7 +982,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
     if (t + 2 < nt) { issueB(t + 2); wait_vmc<4>(); } else wait_vmc<0>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    FV_MM(fB0, 1, 0);
+    FV_MM(fB0, kB0, 1, 0);
     __builtin_amdgcn_s_barrier();
   }
 #undef FV_MM
@@ -1276,18 +1313,20 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   // phased 256 x 256 kernel (gemm_nt256p_kernel): one workgroup per CU, so it wants whole rounds of 256 tiles -- from
   // four rounds on.  Measured against the kernels below (same C, bit for bit): M = 131072 (2048 px, bs 8) N = 3072
   // K = 768 684 -> 608 us, N = 768 K = 1536 360 -> 331; M = 100352 (channel model) N = 1536 K = 384 188 -> 158;
-  // M = 25088 N = 3072 132 -> 120-128 (4.6 rounds); M = 25088 N = 768 (1.15 rounds) 70.9 -> 72.9: stays below
-  static const int phased = fv_tune("FASTVIM_GEMM_P256", 1);   // tuning hook: 0 off
-  if (phased && AMODE == KC && BMODE == KC && p.N % 256 == 0 && p.K % BK == 0 && p.K >= 2 * BK && splits == 1 &&
+  // M = 25088 N = 3072 132 -> 120-128 (4.6 rounds); M = 25088 N = 768 (1.15 rounds) 70.9 -> 72.9: stays below.
+  // Data gradients (B as stored, transposing reads): M = 131072 N = 768 K = 3072 613 -> 547, N = 1536 K = 768 397 -> 341
+  static const int phased = fv_tune("FASTVIM_GEMM_P256", 3);   // tuning hook: bit 0 forward (<KC, KC>), bit 1 data gradient (<KC, KS>)
+  // (short K loops lose: K = 128 / 192 forward +2-8 %, K = 384 data gradient even, K = 192 data gradient +8 %)
+  if ((phased & (BMODE == KC ? 1 : 2)) && AMODE == KC && p.N % 256 == 0 && p.K % BK == 0 && p.K >= (BMODE == KC ? 384 : 512) && splits == 1 &&
       !p.c_fp32 && !p.bias && p.ldc % 8 == 0 && (long)fv_cdiv(p.M, 256) * (p.N / 256) >= 4 * 256) {
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<BMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       attr = true;
     }
     GemmParams q = p;
     q.rb_period = fv_tune("FASTVIM_GEMM_P256_DBG", 0);      // phase probe (tuning builds)
-    hipLaunchKernelGGL(gemm_nt256p_kernel, dim3(fv_cdiv(p.M, 256) * (p.N / 256)), dim3(512), 128 * 1024, st, q);
+    hipLaunchKernelGGL(gemm_nt256p_kernel<BMODE>, dim3(fv_cdiv(p.M, 256) * (p.N / 256)), dim3(512), 128 * 1024, st, q);
     FV_LAUNCH_CHECK();
     return FV_OK;
   }

@@ -29,27 +29,33 @@ def test_gemm_nt_nn(M, N, K):
     assert (c2.double().cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(100352, 1536, 384),     # FastChannelVim-S in_proj forward: 2352 tiles of 256 x 256
-                                   (25088, 3072, 768),      # FastVim-B in_proj forward
-                                   (65500, 1024, 128),      # ragged last row tile, two K tiles (prologue == whole loop)
-                                   (40000, 2048, 192)])     # odd number of K tiles
-def test_gemm_phased_256_form(M, N, K):
-    """The phased 256 x 256 forward kernel (gemm_nt256p_kernel: LDS-DMA in flight across barriers, counted waits) takes
-    K-contiguous bf16 GEMMs of four rounds of tiles and more.  Against fp64 on the same inputs, against the fp32-output
-    call of the same product (which runs the per-tile kernel; both accumulate in K order: the bf16 roundings must be
-    equal), and bit-stable over repeated launches (a staging race shows as a tile that differs between launches)."""
-    from fastvim_amd.gemm import gemm_nt
+@pytest.mark.parametrize("kind,M,N,K", [("nt", 100352, 1536, 384),    # FastChannelVim-S in_proj forward: 2352 tiles of 256 x 256
+                                        ("nt", 25088, 3072, 768),     # FastVim-B in_proj forward
+                                        ("nt", 65500, 1024, 384),     # ragged last row tile
+                                        ("nt", 40000, 2048, 448),     # odd number of K tiles
+                                        ("nn", 131072, 768, 3072),    # FastVim-B 2048 px in_proj data gradient (B as stored)
+                                        ("nn", 70000, 1024, 512),     # ragged rows
+                                        ("nn", 40000, 2048, 576)])    # odd number of K tiles
+def test_gemm_phased_256_form(kind, M, N, K):
+    """The phased 256 x 256 kernel (gemm_nt256p_kernel: LDS-DMA in flight across barriers, counted waits) takes forward
+    (K-contiguous weight) and data-gradient (weight as stored, transposing LDS reads) bf16 GEMMs of four rounds of tiles
+    and more.  Against fp64 on the same inputs, against the fp32-output call of the same product (which runs the per-tile
+    kernel; both accumulate in K order: the bf16 roundings must be equal), and bit-stable over repeated launches (a
+    staging race shows as a tile that differs between launches)."""
+    from fastvim_amd.gemm import gemm_nn, gemm_nt
     torch.manual_seed(M + N + K)
     a = torch.randn(M, K, device="cuda").bfloat16()
-    w = torch.randn(N, K, device="cuda").bfloat16()
-    c = gemm_nt(a, w)
-    c32 = gemm_nt(a, w, out_dtype=torch.float32)
+    w = (torch.randn(N, K, device="cuda") if kind == "nt" else torch.randn(K, N, device="cuda")).bfloat16()
+    fn = gemm_nt if kind == "nt" else gemm_nn
+    c = fn(a, w)
+    c32 = fn(a, w, out_dtype=torch.float32)
     assert torch.equal(c, c32.bfloat16())
     for _ in range(10):
-        assert torch.equal(gemm_nt(a, w), c)
+        assert torch.equal(fn(a, w), c)
     rows = torch.randint(0, M, (512,), device="cuda")
     rows[:4] = torch.tensor([0, 255, M - 1, M - 2], device="cuda")
-    ref = a[rows].double().cpu() @ w.double().cpu().t()
+    wt = w.double().cpu().t() if kind == "nt" else w.double().cpu()
+    ref = a[rows].double().cpu() @ wt
     assert (c[rows].double().cpu() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
 
 
