@@ -1311,14 +1311,16 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   }
 #endif
   // phased 256 x 256 kernel (gemm_nt256p_kernel): one workgroup per CU, so it wants whole rounds of 256 tiles -- from
-  // four rounds on.  Measured against the kernels below (same C, bit for bit): M = 131072 (2048 px, bs 8) N = 3072
+  // two rounds on.  Measured against the kernels below (same C, bit for bit): M = 131072 (2048 px, bs 8) N = 3072
   // K = 768 684 -> 608 us, N = 768 K = 1536 360 -> 331; M = 100352 (channel model) N = 1536 K = 384 188 -> 158;
   // M = 25088 N = 3072 132 -> 120-128 (4.6 rounds); M = 25088 N = 768 (1.15 rounds) 70.9 -> 72.9: stays below.
   // Data gradients (B as stored, transposing reads): M = 131072 N = 768 K = 3072 613 -> 547, N = 1536 K = 768 397 -> 341
+  // fewest tiles it takes: two rounds (FastVim-B 224 px out_proj data gradient, 588 tiles: step 30.53 -> 30.36 ms)
+  static const int p256_min = fv_tune("FASTVIM_GEMM_P256_MIN", 2 * 256);   // tuning hook
   static const int phased = fv_tune("FASTVIM_GEMM_P256", 3);   // tuning hook: bit 0 forward (<KC, KC>), bit 1 data gradient (<KC, KS>)
   // (short K loops lose: K = 128 / 192 forward +2-8 %, K = 384 data gradient even, K = 192 data gradient +8 %)
   if ((phased & (BMODE == KC ? 1 : 2)) && AMODE == KC && p.N % 256 == 0 && p.K % BK == 0 && p.K >= (BMODE == KC ? 384 : 512) && splits == 1 &&
-      !p.c_fp32 && !p.bias && p.ldc % 8 == 0 && (long)fv_cdiv(p.M, 256) * (p.N / 256) >= 4 * 256) {
+      !p.c_fp32 && !p.bias && p.ldc % 8 == 0 && (long)fv_cdiv(p.M, 256) * (p.N / 256) >= p256_min) {
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<BMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
