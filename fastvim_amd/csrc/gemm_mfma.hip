@@ -809,37 +809,40 @@ __device__ __forceinline__ u32x4 ds_read_b128_imm(uint32_t a) {
   return v;
 }
 
-template <int BMODE>       // KC: B (N, K) K-contiguous (forward);  KS: B (K, N) row-major as stored (data gradient)
-__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// AMODE / BMODE: KC = operand K-contiguous, KS = K-slow (row-major as stored, transposing LDS reads).  <KC, KC> forward,
+// <KC, KS> data gradient, <KS, KS> weight gradient (CF32: fp32 partial of K slice `split`).  bid = tile of the problem.
+template <int AMODE, int BMODE, bool CF32>
+__device__ __forceinline__ void p256_body(const GemmParams& p, int bid, int split, char* smem) {
   constexpr int HALF = 128 * BK * 2;            // bytes of a 128 x 64 half tile
   constexpr int PAR = 4 * HALF;                 // one K tile: A lo | A hi | B lo | B hi
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wv >> 2, wc = wv & 3;
-  const int tiles_n = p.N / 256, tiles_m = (p.M + 255) / 256, nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q8 = nblk / 8, r8 = nblk % 8, xcd = bid % 8, j = bid / 8;
-    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
-  }
+  const int tiles_n = p.N / 256;
   const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;
-  const int nt = p.K / BK;
+  const int kbeg = split * p.k_per_split;
+  const int nt = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;
   // LDS-DMA sources: thread -> physical 16-byte slot e = tid + 512 i of a half tile (rows 8 slots wide, chunk ^= row & 7)
   const int sr = tid >> 3, sc = (tid & 7) ^ (sr & 7);
   const bf16_t* srcA[4];
   const bf16_t* srcB[4];        // KC: as A;  KS: [half][piece] sources of the K-slow image ([k][128 cols], chunk-swizzled)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {                 // row groups of 64: g = 2 half + i
-    srcA[g] = p.A + (long)min(m0 + g * 64 + sr, p.M - 1) * p.lda + sc * 8;
-    if constexpr (BMODE == KC) srcB[g] = p.B + (long)min(n0 + g * 64 + sr, p.N - 1) * p.ldb + sc * 8;
+    if constexpr (AMODE == KC) srcA[g] = p.A + (long)min(m0 + g * 64 + sr, p.M - 1) * p.lda + sc * 8 + kbeg;
+    if constexpr (BMODE == KC) srcB[g] = p.B + (long)min(n0 + g * 64 + sr, p.N - 1) * p.ldb + sc * 8 + kbeg;
   }
-  if constexpr (BMODE == KS) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < 2; ++h) {
+    if constexpr (AMODE == KS) {
+      GldsPlan<KS, 128, 512> ga;
+      ga.init(p.A, p.lda, m0 + h * 128, p.M, tid);
+      srcA[2 * h] = ga.src[0] + (long)kbeg * p.lda;
+      srcA[2 * h + 1] = ga.src[1] + (long)kbeg * p.lda;
+    }
+    if constexpr (BMODE == KS) {
       GldsPlan<KS, 128, 512> gb;
       gb.init(p.B, p.ldb, n0 + h * 128, p.N, tid);
-      srcB[2 * h] = gb.src[0];
-      srcB[2 * h + 1] = gb.src[1];
+      srcB[2 * h] = gb.src[0] + (long)kbeg * p.ldb;
+      srcB[2 * h + 1] = gb.src[1] + (long)kbeg * p.ldb;
     }
   }
   typedef __attribute__((address_space(1))) const void* gptr;
@@ -851,7 +854,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
 #endif
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      __builtin_amdgcn_global_load_lds((gptr)(srcA[g] + (long)t * BK), (lptr)(base + (g >> 1) * HALF + ((g & 1) * 512 + wv * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(srcA[g] + (long)t * BK * (AMODE == KC ? 1 : p.lda)),
+                                       (lptr)(base + (g >> 1) * HALF + ((g & 1) * 512 + wv * 64) * 16), 16, 0, 0);
   };
   auto issueB = [&](int t) {
     char* base = smem + (t & 1) * PAR + 2 * HALF;
@@ -868,7 +872,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
   const uint32_t off0 = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);     // ks = 0; ks = 1: ^ 64
   const uint32_t aA = lds0 + wr * HALF + off0;                                         // + parity * PAR + blk * 2048
   const uint32_t aB = lds0 + 2 * HALF + (wc >> 1) * HALF + (wc & 1) * (64 * 128) + off0;
-  // K-slow B: one address per 16-column block of the wave's 64 columns (transposing reads, see KsFrags)
+  // K-slow operands: one address per 16-wide block (transposing reads, see KsFrags): the 8 row blocks of the wave's A half,
+  // the 4 column blocks of its 64 columns
+  uint32_t aAk[8];
+  if constexpr (AMODE == KS) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, kl = g * 8 + q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aAk[j] = lds0 + wr * HALF + kl * 256 + ((j ^ ks_swz<128>(kl)) << 5) + pp * 8;
+  }
   uint32_t aBk[4];
   if constexpr (BMODE == KS) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, kl = g * 8 + q;
@@ -884,6 +895,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
     for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   u32x4 fA[2][4], fB0[2][2], fB1[2][2];          // [ks][block]
   unsigned long long kB0[2][2][2], kB1[2][2][2];  // K-slow B: [ks][block][lo | hi], joined behind the wait
+  unsigned long long kA[2][4][2];                 // K-slow A likewise
 #ifdef FASTVIM_TUNING_HOOKS
   const int dbgf = p.rb_period;                  // phase probe: 1 no stores, 2 no vmcnt waits, 4 no MFMAs, 8 no LDS reads
   if (dbgf & 8) {
@@ -907,9 +919,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();      // the second row-half group runs one barrier behind
 
 #define FV_RD_A(PARITY, MH)                                                                                  \
-  if (!(dbgf & 8)) static_for<4>([&](auto mt) {                                                                               \
-    fA[0][mt] = ds_read_b128_imm<(MH * 4 + mt) * 2048>(aA + (PARITY) * PAR);                                 \
-    fA[1][mt] = ds_read_b128_imm<(MH * 4 + mt) * 2048>((aA + (PARITY) * PAR) ^ 64u);                         \
+  if (!(dbgf & 8)) static_for<4>([&](auto mt) {                                                              \
+    if constexpr (AMODE == KC) {                                                                             \
+      fA[0][mt] = ds_read_b128_imm<(MH * 4 + mt) * 2048>(aA + (PARITY) * PAR);                               \
+      fA[1][mt] = ds_read_b128_imm<(MH * 4 + mt) * 2048>((aA + (PARITY) * PAR) ^ 64u);                       \
+    } else {                                                                                                 \
+      const uint32_t a_ = aAk[MH * 4 + mt] + (PARITY) * PAR;                                                 \
+      kA[0][mt][0] = ds_read_tr16_b64<0>(a_);                                                                \
+      kA[0][mt][1] = ds_read_tr16_b64<4 * 256>(a_);                                                          \
+      kA[1][mt][0] = ds_read_tr16_b64<32 * 256>(a_);                                                         \
+      kA[1][mt][1] = ds_read_tr16_b64<32 * 256 + 4 * 256>(a_);                                               \
+    }                                                                                                        \
   })
 #define FV_RD_B(DST, KDST, PARITY, NH)                                                                       \
   if (!(dbgf & 8)) static_for<2>([&](auto nn) {                                                              \
@@ -929,7 +949,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
-      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(fA[ks][mt])); }              \
+      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                     \
+        if constexpr (AMODE == KC) { asm volatile("" : "+v"(fA[ks][mt])); }                                  \
+        else {                                                                                               \
+          asm volatile("" : "+v"(kA[ks][mt][0]));                                                            \
+          asm volatile("" : "+v"(kA[ks][mt][1]));                                                            \
+          typedef unsigned long long u64x2a_ __attribute__((ext_vector_type(2)));                            \
+          const u64x2a_ j_ = {kA[ks][mt][0], kA[ks][mt][1]};                                                 \
+          fA[ks][mt] = __builtin_bit_cast(u32x4, j_);                                                        \
+        }                                                                                                    \
+      }                                                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int nn = 0; nn < 2; ++nn) {                                                     \
         if constexpr (BMODE == KC) { asm volatile("" : "+v"(BF[ks][nn])); }                                  \
@@ -991,6 +1020,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();
   // epilogue: bf16 through a wave-private LDS slab (64 rows x 64 columns at a time), 16-byte stores of whole 128-byte
   // row segments.  Every wave is past its last LDS read and every LDS-DMA load has landed (vmcnt(0) in the last P4).
+  if constexpr (CF32) {
+    // fp32 partial of this K slice: 16 bytes per lane (64-byte row segments); with thousands of K tiles per output tile
+    // the epilogue does not matter
+    float* Cf = (float*)p.C + (long)split * p.c_split_stride;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int m = m0 + wr * 128 + b * 16 + (lane & 15), n = n0 + wc * 64 + a * 16 + (lane >> 4) * 4;
+        if (m < p.M) *reinterpret_cast<f32x4*>(Cf + (long)m * p.ldc + n) = acc[a][b];
+      }
+    return;
+  }
   __syncthreads();
   constexpr int RS = 64 * 2 + 16;
   char* my = smem + wv * (64 * RS);
@@ -1017,6 +1059,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <int BMODE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nblk = ((p.M + 255) / 256) * (p.N / 256);
+  int bid = blockIdx.x;
+  {      // XCD-aware order: the tiles of one A row panel are consecutive on one XCD
+    const int q8 = nblk / 8, r8 = nblk % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+  }
+  p256_body<KC, BMODE, false>(p, bid, 0, smem);
 }
 
 // Several independent problems in ONE launch (the weight gradients of a whole backward pass, queued until its end):
@@ -1048,6 +1102,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_grouped_kernel(Grou
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int split = local / tiles;
   gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB, false>(p, local - split * tiles, split, nullptr, xcd_order >> 8);
+}
+
+// the phased 256 x 256 form for the weight gradients of the large outputs (M and N multiples of 256: FastVim-B)
+__global__ __launch_bounds__(512, 2) void gemm_p256_grouped_kernel(GroupedParams G, int xcd_order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int g = blockIdx.x;
+  if (xcd_order & 255) {
+    const int n = gridDim.x, q8 = n / 8, r8 = n % 8, xcd = g % 8, k = g / 8;
+    g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  }
+  int j = 0;
+  while (j + 1 < G.count && g >= G.blk_end[j]) ++j;
+  const GemmParams& p = G.p[j];
+  const int local = g - (j ? G.blk_end[j - 1] : 0);
+  const int tiles = (p.M / 256) * (p.N / 256);
+  const int split = local / tiles;
+  p256_body<KS, KS, true>(p, local - split * tiles, split, smem);
 }
 
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
@@ -1581,8 +1652,16 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
         if (!attr) {
           (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 2, 4, true, 4, 8>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * BK * 2);
+          (void)hipFuncSetAttribute((const void*)gemm_p256_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * (256 + 256) * BK * 2);
           attr = true;
         }
+        static const int wg_phased = fv_tune("FASTVIM_WGRAD_P256", 1);   // tuning hook
+        bool two_tiles = true;             // the phased loop wants at least two K tiles per slice
+        for (int i = 0; i < n; ++i) two_tiles = two_tiles && G.p[i].k_per_split >= 2 * BK && G.p[i].K % G.p[i].k_per_split == 0;
+        if (wg_phased && two_tiles)
+          hipLaunchKernelGGL(gemm_p256_grouped_kernel, dim3(b2), dim3(512), (size_t)2 * (256 + 256) * BK * 2, st, G, xcd_order);
+        else
         hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 4, true, 4, 8>), dim3(b2), dim3(512),
                            (size_t)2 * (256 + 256) * BK * 2, st, G, xcd_order);
         FV_LAUNCH_CHECK();
