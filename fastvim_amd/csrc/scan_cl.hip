@@ -417,6 +417,28 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // the d delta_raw table's rows past Lc feed the K / M padding of the MFMAs: zero once
   for (int e = tid; e < 16 * SH_DRS; e += SH_THREADS) s_dr[e] = 0.f;
+  // dt_rank <= 12: this lane's dt_proj weights of both MFMA roles are loaded once per workgroup instead of once per batch
+  // element behind the staging barrier (an L2 round trip on every wave's critical path, twice per element); wider ranks
+  // have no registers left for them
+  constexpr bool HOIST = RQ <= 3;
+  float wt_h[HOIST ? RQP : 1], wa_h[HOIST ? 4 * RT : 1];
+  if constexpr (HOIST) {
+    const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv2 = t2 >> 6, dm = ch0 + wv2 * 16 + cm;
+#pragma unroll
+    for (int kg = 0; kg < RQP; ++kg) {
+      const int r = 4 * kg + tg;
+      wt_h[kg] = (dm < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dm * p.R + r] : 0.f;
+    }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const int dk = ch0 + wv2 * 16 + 4 * kg + tg;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int r = 16 * rt + cm;
+        wa_h[kg * RT + rt] = (dk < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dk * p.R + r] : 0.f;
+      }
+    }
+  }
 
   for (int bi = 0; bi < p.NBB; ++bi) {
     const int b = blockIdx.y * p.NBB + bi;
@@ -471,7 +493,9 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
       for (int kg = 0; kg < RQP; ++kg) {           // r = 4 kg + (lane >> 4): stored at [q = r & 3][i = r >> 2]
         const float a = s_dbl[ta * WP + tg * RQP + kg];
         const int r = 4 * kg + tg;
-        const float w = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
+        float w;
+        if constexpr (HOIST) w = wt_h[kg];
+        else w = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
         D = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, D, 0, 0, 0);
       }
 #pragma unroll
@@ -581,7 +605,9 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int r = 16 * rt + cm;
-          const float w = (dk < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dk * p.R + r] : 0.f;
+          float w;
+          if constexpr (HOIST) w = wa_h[kg * RT + rt];
+          else w = (dk < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dk * p.R + r] : 0.f;
           Dl[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, Dl[rt], 0, 0, 0);
         }
       }
