@@ -711,6 +711,7 @@ struct ChunkLds {
   static constexpr int floats = o_pd + NWV * 16 * 16 * RT;
 };
 
+constexpr int CK_HOIST_MAX_RQ = 12;
 template <typename T, int RQ, int NWV, bool CK_GIVEN>
 __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -743,6 +744,27 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
   f32x4_t accW[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // this lane's dt_proj weights of both MFMA roles, loaded once per workgroup: per chunk they would be an L2 round trip on
+  // every wave's critical path, twice per chunk
+  constexpr bool HOIST = CK_HOIST_MAX_RQ >= RQ;
+  float wt_h[HOIST ? RQP : 1], wa_h[HOIST ? 4 * RT : 1];
+  if constexpr (HOIST) {
+    const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv2 = t2 >> 6, dm = ch0 + wv2 * 16 + cm;
+#pragma unroll
+    for (int kg = 0; kg < RQP; ++kg) {
+      const int r = 4 * kg + tg;
+      wt_h[kg] = (dm < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dm * p.R + r] : 0.f;
+    }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const int dk = ch0 + wv2 * 16 + 4 * kg + tg;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int r = 16 * rt + cm;
+        wa_h[kg * RT + rt] = (dk < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dk * p.R + r] : 0.f;
+      }
+    }
+  }
 
   // stage the x_dbl rows of chunk c of (dir, b) in scan order: fp32, dt_low regrouped by quad lane, rows past Lc zero
   auto stage = [&](size_t bd, int c) {
@@ -774,7 +796,9 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
     for (int kg = 0; kg < RQP; ++kg) {           // r = 4 kg + (lane >> 4): stored at [q = r & 3][i = r >> 2]
       const float a = s_dbl[cm * WP + tg * RQP + kg];
       const int r = 4 * kg + tg;
-      const float w = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
+      float w;
+      if constexpr (HOIST) w = wt_h[kg];
+      else w = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
       D = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, D, 0, 0, 0);
     }
 #pragma unroll
@@ -949,7 +973,9 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
             const int r = 16 * rt + cm;
-            const float w = (dk < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dk * p.R + r] : 0.f;
+            float w;
+            if constexpr (HOIST) w = wa_h[kg * RT + rt];
+            else w = (dk < p.d_in && r < p.R) ? p.Wdt[dir][(size_t)dk * p.R + r] : 0.f;
             Dl[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, Dl[rt], 0, 0, 0);
           }
         }
