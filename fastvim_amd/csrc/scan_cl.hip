@@ -1508,10 +1508,17 @@ extern "C" int fv_mixer_scan_bwd_chunks(int d_inner, int Lc, int dt_rank) {
 
 // A block can walk several batch elements (fewer, longer blocks; parameter-gradient partials shrink by the same
 // factor).  Measured on FastVim-T: 2 per block 49.0 us vs 47-48 us, 4 per block 65 us -- so one, unless forced.
+// The short kernel walks 2 (its dt_proj weights, parameter partials and prologue are per workgroup), and 4 where the
+// launch keeps two rounds of workgroups: the reference models have d_inner = 32 dt_rank, so FastVim-B (dt_rank 48: 8
+// channel chunks) at batch 128 is 512 workgroups of 4 elements (step 30.72 -> 30.57 ms), FastVim-T (2 chunks) stays at 2.
+// The choice depends on (batch, Lc, dt_rank) only: fv_mixer_scan_bwd_partials must give the launch's row count.
 static int scan_bwd_nbb(int batch, int Lc, int dt_rank) {
   static const int force = fv_tune("FASTVIM_SCAN_NBB", 0);   // tuning hook
   if (force > 0 && batch % force == 0) return force;
-  return (bwd_short(Lc, dt_rank) && batch % 2 == 0) ? 2 : 1;
+  if (!bwd_short(Lc, dt_rank)) return 1;
+  const long chunks = fv_cdiv(32 * dt_rank, SH_CH);
+  if (batch % 4 == 0 && chunks * (batch / 4) * 2 >= 512) return 4;
+  return batch % 2 == 0 ? 2 : 1;
 }
 extern "C" int fv_mixer_scan_bwd_partials(int batch, int Lc, int dt_rank) { return batch / scan_bwd_nbb(batch, Lc, dt_rank); }
 

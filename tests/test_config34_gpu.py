@@ -211,6 +211,7 @@ def _scan_cl_case(Bsz, Lc, d_in, R, dtype, seed):
                                            (2, 17, 384, 12),        # a second chunk of one step
                                            (1, 197, 384, 12),       # unpooled Vim-T: 12 chunks + 5 steps
                                            (64, 37, 384, 12),       # enough workgroups for the 12-wave form (192 channels)
+                                           (64, 14, 1536, 48),      # short kernel walking 4 batch elements per workgroup
                                            (2, 40, 1024, 64)])      # dt_rank > 48: the generic kernel (4-step segments)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("given", [False, True])
