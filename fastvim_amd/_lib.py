@@ -4,6 +4,7 @@ The product path fails loudly when the library is absent -- there is no fallback
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -29,14 +30,16 @@ C_ABI_SYMBOLS = (
 )
 
 
-_launch_dev = None      # device index of the tensor the last ``stream_of`` was asked about
+_tls = threading.local()      # .dev: device index of the tensor this THREAD's last ``stream_of`` was asked about
 
 
 class _DeviceGuarded:
     """The CDLL with every entry point wrapped in a device guard: a kernel is launched with the device of the
     tensor whose stream it was given (``stream_of``) current, like the reference's ops do with
     ``at::cuda::CUDAGuard`` (selective_scan.cpp:326-327) -- costs one ``current_device()`` query per launch, and a
-    ``torch.cuda.device`` switch only when the tensors live on another GPU than the current one."""
+    ``torch.cuda.device`` switch only when the tensors live on another GPU than the current one.  The launch device is
+    per host thread (two threads driving two GPUs do not see each other's), and a call that no ``stream_of`` preceded
+    in its thread runs on the current device."""
 
     def __init__(self, cdll):
         self._cdll = cdll
@@ -48,7 +51,7 @@ class _DeviceGuarded:
             fn = getattr(self._cdll, name)
 
             def call(*args, _fn=fn):
-                dev = _launch_dev
+                dev = getattr(_tls, "dev", None)
                 if dev is None or dev == torch.cuda.current_device():
                     return _fn(*args)
                 with torch.cuda.device(dev):
@@ -87,8 +90,7 @@ def ptr(t):
 
 
 def stream_of(t):
-    global _launch_dev
-    _launch_dev = t.device.index
+    _tls.dev = t.device.index
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

@@ -33,6 +33,21 @@ void fv_set_error(const char* fmt, ...);
 
 static inline int fv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: a launcher's "already done" flag is kept per
+// device (one bit each), so a process that drives several GPUs sets it on every one of them.  A race between two host
+// threads only repeats an idempotent call.
+struct FvOncePerDevice {
+  unsigned long long seen = 0;
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (seen & bit) return false;
+    seen |= bit;
+    return true;
+  }
+};
+
 // A/B hooks of the kernel dispatchers.  The shipped library takes the measured default of every choice and reads NO
 // environment variable; a build with -DFASTVIM_TUNING_HOOKS (python -m fastvim_amd.build --tuning) reads FASTVIM_<NAME>
 // once per process so that an experiment can be repeated on one box in one call (tools/README.md lists them).

@@ -423,10 +423,10 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
 template <typename T, int TPP, bool CHAN>
 int launch_chan(const BwdParams& p, int nch, int rgr, int grid, int groups, size_t smem, hipStream_t st) {
   if (smem > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
+    static FvOncePerDevice done;   
+    if (done.first()) {
       (void)hipFuncSetAttribute((const void*)conv_pool_bwd_chan_kernel<T, TPP, CHAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
+      (void)0;     
     }
   }
   hipLaunchKernelGGL((conv_pool_bwd_chan_kernel<T, TPP, CHAN>), dim3(grid, groups), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
@@ -437,10 +437,10 @@ int launch_chan(const BwdParams& p, int nch, int rgr, int grid, int groups, size
 template <typename T, int NT>
 int launch_row(const BwdParams& p, int nch, int rgr, int grid, int groups, size_t smem, hipStream_t st) {
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
-    static bool done = false;
-    if (!done) {
+    static FvOncePerDevice done;   
+    if (done.first()) {
       (void)hipFuncSetAttribute((const void*)conv_pool_bwd_row_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
+      (void)0;     
     }
   }
   hipLaunchKernelGGL((conv_pool_bwd_row_kernel<T, NT>), dim3(grid, groups), dim3(64 * nch * rgr), smem, st, p, nch, rgr);

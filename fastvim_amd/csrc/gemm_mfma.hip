@@ -1126,11 +1126,11 @@ int launch_k(const GemmParams& p, int splits, hipStream_t st) {
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
   const int tiles = fv_cdiv(p.M, BM) * fv_cdiv(p.N, BN);
   const size_t smem = (size_t)2 * (BM + BN) * BK * 2;
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
+  static FvOncePerDevice attr_set;   
+  if (smem > 64 * 1024 && attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS, NB, MB>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+    (void)0;         
   }
   hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, BMODE, WM, WN, GLDS, NB, MB>), dim3(tiles, 1, splits), dim3(64 * WM * WN), smem, st, p);
   FV_LAUNCH_CHECK();
@@ -1322,7 +1322,8 @@ int launch_stream(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
   constexpr size_t smem = (size_t)S * (BM + BN) * BK * 2 + (size_t)WM * WN * 16 * (16 * NB * 2 + 16);
   static int cus = 0;
-  if (!cus) {
+  static FvOncePerDevice attr_set;
+  if (attr_set.first()) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -1392,10 +1393,10 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   // (short K loops lose: K = 128 / 192 forward +2-8 %, K = 384 data gradient even, K = 192 data gradient +8 %)
   if ((phased & (BMODE == KC ? 1 : 2)) && AMODE == KC && p.N % 256 == 0 && p.K % BK == 0 && p.K >= (BMODE == KC ? 384 : 512) && splits == 1 &&
       !p.c_fp32 && !p.bias && p.ldc % 8 == 0 && (long)fv_cdiv(p.M, 256) * (p.N / 256) >= p256_min) {
-    static bool attr = false;
-    if (!attr) {
+    static FvOncePerDevice attr;   
+    if (attr.first()) {
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<BMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      attr = true;
+      (void)0;     
     }
     GemmParams q = p;
     q.rb_period = fv_tune("FASTVIM_GEMM_P256_DBG", 0);      // phase probe (tuning builds)
@@ -1506,10 +1507,10 @@ extern "C" int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* 
     constexpr size_t s1 = (size_t)2 * (BMR + 192) * BK * 2;
     constexpr size_t s2 = ((size_t)BMR * 400 + 255) / 256 * 256 + 2 * 128 * BK * 2 + 4 * 32 * 144;
     const size_t smem = s1 > s2 ? s1 : s2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static FvOncePerDevice attr_set;   
+    if (attr_set.first()) {
       (void)hipFuncSetAttribute((const void*)gemm_addnorm_kernel<BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_set = true;
+      (void)0;         
     }
     hipLaunchKernelGGL((gemm_addnorm_kernel<BMR>), dim3(fv_cdiv(M, BMR)), dim3(256), smem, st, p, ne);
   };
@@ -1564,10 +1565,10 @@ extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, con
     constexpr size_t s1 = (size_t)2 * (BMR + 192) * BK * 2;
     constexpr size_t s2 = ((size_t)BMR * 400 + 255) / 256 * 256 + 2 * 128 * BK * 2 + 4 * 32 * 144;
     const size_t smem = s1 > s2 ? s1 : s2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static FvOncePerDevice attr_set;   
+    if (attr_set.first()) {
       (void)hipFuncSetAttribute((const void*)gemm_dgrad_addnorm_bwd_kernel<BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_set = true;
+      (void)0;         
     }
     hipLaunchKernelGGL((gemm_dgrad_addnorm_bwd_kernel<BMR>), dim3(fv_cdiv(M, BMR)), dim3(256), smem, (hipStream_t)stream, p, ne);
   };
@@ -1648,13 +1649,13 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
           b2 += (G.p[i].M / 256) * (G.p[i].N / 256) * fv_cdiv(G.p[i].K, G.p[i].k_per_split);
           G.blk_end[i] = b2;
         }
-        static bool attr = false;
-        if (!attr) {
+        static FvOncePerDevice attr;   
+        if (attr.first()) {
           (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 2, 4, true, 4, 8>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * BK * 2);
           (void)hipFuncSetAttribute((const void*)gemm_p256_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * (256 + 256) * BK * 2);
-          attr = true;
+          (void)0;     
         }
         static const int wg_phased = fv_tune("FASTVIM_WGRAD_P256", 1);   // tuning hook
         bool two_tiles = true;             // the phased loop wants at least two K tiles per slice
@@ -1676,19 +1677,19 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
     const size_t smem = (size_t)2 * (bm[cls] + bn[cls]) * BK * 2;
     // (256 x 192 tiles on 8 waves for the first class, half the L2 traffic again: 310 vs 316 us in the step -- not taken)
     if (cls == 1) {
-      static bool attr = false;
-      if (!attr) {
+      static FvOncePerDevice attr;   
+      if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 6, 4>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = true;
+        (void)0;     
       }
       hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 6, 4>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
     } else if (cls == 2) {
-      static bool attr = false;
-      if (!attr) {
+      static FvOncePerDevice attr;   
+      if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 6>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = true;
+        (void)0;     
       }
       hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 6>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
     } else if (dma) {

@@ -553,12 +553,12 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
   size_t smem = (size_t)12 * p.d_in * 4;
   FV_CHECK(smem <= 160 * 1024, "mixer_conv_pool_bwd: d_inner %d too large", p.d_in);
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
-    static bool done = false;
-    if (!done) {
+    static FvOncePerDevice done;   
+    if (done.first()) {
       (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 17, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
+      (void)0;     
     }
   }
   // short rows: the whole-row kernel (convpool_bwd_row.hip) over the same persistent grid / partial layout
@@ -569,11 +569,11 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
   }
   if (p.amax) {      // max pooling: generic kernels only
     if (smem > 64 * 1024) {
-      static bool done_pm = false;
-      if (!done_pm) {
+      static FvOncePerDevice done_pm;   
+      if (done_pm.first()) {
         (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_pool_bwd_kernel<T, VEC, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        done_pm = true;
+        (void)0;        
       }
     }
     if (p.geo.tpp > 1) hipLaunchKernelGGL((conv_pool_bwd_kernel<T, VEC, 8, true, true>), grid, block, smem, st, p, nch, rg);

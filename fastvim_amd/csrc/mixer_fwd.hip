@@ -339,11 +339,11 @@ int launch_conv_pool(const FwdParams& p, int pool_max, hipStream_t st) {
   const size_t smem = (tp && p.geo.pcols > 1) ? (size_t)(pool_max ? 4 : 2) * p.geo.tpp * 64 * nch * VEC * 4 : 0;
   FV_CHECK(smem <= 160 * 1024, "mixer_conv_pool_fwd: tokens_per_patch %d too large", p.geo.tpp);
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
-    static bool done = false;
-    if (!done) {
+    static FvOncePerDevice done;   
+    if (done.first()) {
       (void)hipFuncSetAttribute((const void*)conv_pool_fwd_kernel<T, VEC, 8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_pool_fwd_kernel<T, VEC, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
+      (void)0;     
     }
   }
 #define FV_CP(K, ...)                                                                        \

@@ -822,10 +822,10 @@ int launch_short(const ScanParams& p, int bwd, hipStream_t st) {
     hipLaunchKernelGGL((scan_short_fwd_kernel<T>), grid, block, (size_t)p.L * 2 * SN * 4, st, p);
   } else {
     const size_t smem = ((size_t)p.L * 2 * SN + SKS * 4 * 4 * 16 + 7 * SCPB * SWLP) * 4;
-    static bool done = false;
-    if (!done && smem > 64 * 1024) {
+    static FvOncePerDevice done;   
+    if (smem > 64 * 1024 && done.first()) {
       (void)hipFuncSetAttribute((const void*)scan_short_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
+      (void)0;     
     }
     hipLaunchKernelGGL((scan_short_bwd_kernel<T>), grid, block, smem, st, p);
   }

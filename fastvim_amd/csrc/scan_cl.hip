@@ -1456,11 +1456,11 @@ extern "C" int fv_mixer_xproj_scan_fwd(const void* xc, const void* x_proj_w2, co
 #define FV_XS(RQQ, LCC, EXX)                                                                 \
   do {                                                                                       \
     const size_t smem = (size_t)ShortFwdLds<RQQ, LCC>::bytes(d_inner, NT);                   \
-    static bool done = false;                                                                \
-    if (!done) {                                                                             \
+    static FvOncePerDevice done;                                                                   \
+    if (done.first()) {                                                                             \
       (void)hipFuncSetAttribute((const void*)xproj_scan_fwd_short_kernel<RQQ, LCC, EXX>,     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      done = true;                                                                           \
+      (void)0;                                                                                \
     }                                                                                        \
     hipLaunchKernelGGL((xproj_scan_fwd_short_kernel<RQQ, LCC, EXX>), grid, block, smem, st, p, \
                        (const bf16_t*)x_proj_w2, (bf16_t*)x_dbl, NT);                        \
@@ -1578,11 +1578,11 @@ extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const f
 #define FV_S(TT, RQQ, LCC, EXX)                                                              \
   do {                                                                                       \
     size_t smem = (size_t)ShortLds<RQQ, LCC>::floats * 4;                                    \
-    static bool done = false;                                                                \
-    if (!done && smem > 64 * 1024) {                                                         \
+    static FvOncePerDevice done;                                                                   \
+    if (smem > 64 * 1024 && done.first()) {                                                         \
       (void)hipFuncSetAttribute((const void*)scan_cl_bwd_short_kernel<TT, RQQ, LCC, EXX>,    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      done = true;                                                                           \
+      (void)0;                                                                                \
     }                                                                                        \
     hipLaunchKernelGGL((scan_cl_bwd_short_kernel<TT, RQQ, LCC, EXX>), sgrid, sblock, smem, st, p); \
   } while (0)
@@ -1608,13 +1608,13 @@ extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const f
 #define FV_CW(TT, RQQ, NWW)                                                                  \
   do {                                                                                       \
     size_t smem = (size_t)ChunkLds<RQQ, NWW>::floats * 4;                                    \
-    static bool done = false;                                                                \
-    if (!done && smem > 64 * 1024) {                                                         \
+    static FvOncePerDevice done;                                                                   \
+    if (smem > 64 * 1024 && done.first()) {                                                         \
       (void)hipFuncSetAttribute((const void*)scan_cl_bwd_chunked_kernel<TT, RQQ, NWW, true>, \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       (void)hipFuncSetAttribute((const void*)scan_cl_bwd_chunked_kernel<TT, RQQ, NWW, false>, \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      done = true;                                                                           \
+      (void)0;                                                                                \
     }                                                                                        \
     if (ckpt_given) hipLaunchKernelGGL((scan_cl_bwd_chunked_kernel<TT, RQQ, NWW, true>), cgrid, cblock, smem, st, p); \
     else hipLaunchKernelGGL((scan_cl_bwd_chunked_kernel<TT, RQQ, NWW, false>), cgrid, cblock, smem, st, p); \
@@ -1641,11 +1641,11 @@ extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const f
                    (CKK ? (size_t)((Lc + 3) / 4) * 1024 : 0)) * 4;                           \
     FV_CHECK(smem <= 160 * 1024, "mixer_scan_bwd: pooled length %d too long for the LDS stage", Lc); \
     if (smem > 64 * 1024) {                                                                  \
-      static bool done = false;                                                              \
-      if (!done) {                                                                           \
+      static FvOncePerDevice done;                                                                 \
+      if (done.first()) {                                                                           \
         (void)hipFuncSetAttribute((const void*)scan_cl_bwd_kernel<TT, RQQ, PVV, CKK, DTT>,   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-        done = true;                                                                         \
+        (void)0;                                                                              \
       }                                                                                      \
     }                                                                                        \
     hipLaunchKernelGGL((scan_cl_bwd_kernel<TT, RQQ, PVV, CKK, DTT>), grid, block, smem, st, p); \

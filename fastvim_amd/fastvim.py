@@ -22,7 +22,7 @@ from torch import Tensor
 from .layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
 from . import glue_ops as G
 from .mamba_simple_faster import (ChainedBlockFn, LinearFn, Mamba, OutProjAddNormFn, _compute_dtype, _direct_grad, _shadow,
-                                  linear_wgrad, out_proj_add_norm_ok)
+                                  linear_dgrad, linear_wgrad, out_proj_add_norm_ok)
 from .mixer_ops import reduce_partials
 
 
@@ -100,10 +100,14 @@ class _PatchProjFn(torch.autograd.Function):
                     reduce_partials(per_tok.view(Ltok, D), Ltok, out=gd.view(-1), accumulate=True)
                 else:
                     dbias = reduce_partials(per_tok.view(Ltok, D), Ltok)                    # then over tokens
-            dW = linear_wgrad(g.view(B * Ltok, D).to(ctx.cdt), patches.view(B * Ltok, K), W)
+            g_c = g.view(B * Ltok, D).to(ctx.cdt)
+            dpatches = None
+            if ctx.needs_input_grad[0]:      # the image asks for its gradient (saliency maps, adversarial inputs)
+                dpatches = linear_dgrad(g_c, _shadow(W, ctx.cdt).reshape(D, K)).view(B, Ltok, K)
+            dW = linear_wgrad(g_c, patches.view(B * Ltok, K), W)
             if dW is not None:
                 dW = dW.view(W.shape)
-        return None, dW, dbias, dpos, None
+        return dpatches, dW, dbias, dpos, None
 
 
 def to_2tuple(v):
@@ -224,7 +228,10 @@ class PatchEmbed(nn.Module):
         cdt = _compute_dtype(x)
         # unfold and cast in ONE strided copy (fp32 image read once, compute-dtype patches written once); the GEMM then
         # needs no second pass over the patches
-        if G.patch_unfold_ok(x, ph, pw) and cdt in (torch.float32, torch.bfloat16):
+        # (the kernel has no autograd node: an image that requires grad takes the strided copy below, whose adjoint --
+        # the fold -- autograd knows)
+        want_dx = x.requires_grad and torch.is_grad_enabled()
+        if G.patch_unfold_ok(x, ph, pw) and cdt in (torch.float32, torch.bfloat16) and not want_dx:
             patches = G.patch_unfold(x, ph, pw, cdt)                # one HIP launch through LDS: 16-byte accesses both ways
         else:
             patches = torch.empty(B, gh * gw, C * ph * pw, device=x.device, dtype=cdt)

@@ -323,9 +323,10 @@ class FlatAdamW:
         self.betas, self.eps, self.weight_decay = tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
 
     def ema_state_dict(self, prefix=""):
-        """The EMA weights under the model's own ``state_dict`` key names (``prefix`` + name): the
-        ``state_dict_ema`` entry of the reference's Lightning checkpoints (supervised_imagenet.py:107-110) with
-        ``prefix="backbone."`` -- what ``MM_FastVim.load_pretrained`` prefers when present."""
+        """The EMA weights under the model's own ``state_dict`` key names (``prefix`` + name).  The reference's
+        Lightning checkpoints store them UNPREFIXED as ``state_dict_ema`` -- ``get_state_dict(self.ema, unwrap_model)``
+        is ``ModelEmaV2.module.state_dict()``, reloaded by ``self.ema.module.load_state_dict``
+        (supervised_imagenet.py:107-114) -- and ``MM_FastVim.load_pretrained`` prefers that entry when present."""
         if self.ema is None:
             raise RuntimeError("FlatAdamW was built without ema_decay")
         return {prefix + n: v.detach().clone() for n, v in self._named_slices(self.ema).items()}
@@ -344,12 +345,13 @@ class FlatAdamW:
 
 def save_checkpoint(path, model, opt, prefix="backbone.", **extra):
     """Write a checkpoint in the layout of the reference's Lightning checkpoints: ``state_dict`` (model keys behind
-    ``prefix``), ``state_dict_ema`` (when the optimizer tracks an EMA) and the optimizer state -- loadable by
-    ``MM_FastVim.load_pretrained`` / ``load_checkpoint``."""
+    ``prefix``: the LightningModule holds the model as ``self.backbone``), ``state_dict_ema`` (when the optimizer tracks an
+    EMA; UNPREFIXED model keys, as ``on_save_checkpoint`` writes it, supervised_imagenet.py:107-110) and the optimizer
+    state -- loadable by the reference's ``on_load_checkpoint``, ``MM_FastVim.load_pretrained`` and ``load_checkpoint``."""
     ck = {"state_dict": {prefix + k: v.detach().clone() for k, v in model.state_dict().items()},
           "optimizer_states": [opt.state_dict()], **extra}
     if opt.ema is not None:
-        ck["state_dict_ema"] = opt.ema_state_dict(prefix)
+        ck["state_dict_ema"] = opt.ema_state_dict("")
     torch.save(ck, path)
     return ck
 
@@ -359,7 +361,9 @@ def load_checkpoint(path_or_dict, model, opt=None, prefix="backbone.", use_ema=F
     state's bf16 shadow follows through the load_state_dict hook."""
     ck = torch.load(path_or_dict, map_location="cpu", weights_only=False) if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
     sd = ck["state_dict_ema"] if (use_ema and "state_dict_ema" in ck) else ck["state_dict"]
-    model.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, strict=True)
+    # the prefix is stripped where it is present (``key.replace("backbone.", "")``, models/fastvim.py:617): ``state_dict``
+    # carries it, the reference's ``state_dict_ema`` does not
+    model.load_state_dict({(k[len(prefix):] if prefix and k.startswith(prefix) else k): v for k, v in sd.items()}, strict=True)
     if opt is not None:
         opt.load_state_dict(ck["optimizer_states"][0])
     return ck

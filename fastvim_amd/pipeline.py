@@ -13,16 +13,24 @@ behind graph k by an event) and runs under backward graphs k+1 .. K-1:
 Only the last bucket (the first blocks + patch embedding) is exposed.  Cutting backward needs the activations at the
 cuts to be graph leaves: each run's input (hidden, residual) is a detached view of the previous run's output, and
 backward of run k is ``torch.autograd.backward(outputs_k, grads of run k+1's inputs)``.  With one rank nothing is
-exchanged and the chain computes, bit for bit, what the single-graph step computes
-(tests/test_pipeline_gpu.py).
+exchanged and the chain computes what the single-graph step computes: bit for bit with ``gemm.FILL = False``; with
+the shipped default (``gemm.fill_splits`` re-cuts a segment's smaller weight-gradient groups into more K slices) the
+same sums are taken in another order and the two agree to rounding (tests/test_pipeline_gpu.py asserts both).
 """
+import warnings
+
 import torch
 
 
 class SegmentedTrainStep:
     """``model`` must expose ``_embed / _run_layers / _final / _head`` (fastvim_amd.fastvim.VisionMamba).
     ``loss_fn(logits, target) -> scalar``.  ``x`` / ``target`` are the static input buffers the graphs read; copy
-    new batches into them between steps."""
+    new batches into them between steps.
+
+    Capture needs ``warmup`` eager steps first (allocator, lazily built buffers, RCCL communicators).  They are real
+    steps on whatever ``x`` / ``target`` hold, so the training state they touch -- parameters, bf16 shadow, Adam moments,
+    EMA, step count, the CPU and GPU RNG streams -- is snapshotted before and put back after them: constructing the
+    step object leaves the model, the optimizer and the DropPath stream exactly as it found them."""
 
     def __init__(self, model, flat, opt, loss_fn, x, target, n_segments=3, amp_dtype=torch.bfloat16, use_graph=True,
                  warmup=2):
@@ -95,13 +103,39 @@ class SegmentedTrainStep:
         self.opt.step()
         return loss
 
+    def _snapshot(self):
+        f, o = self.flat, self.opt
+        bufs = [f.param_flat, f.shadow_flat] + [b for b in (getattr(o, "exp_avg", None), getattr(o, "exp_avg_sq", None),
+                                                            getattr(o, "ema", None), getattr(o, "step_t", None))
+                                                 if b is not None]
+        dev = f.param_flat.device
+        return ([(b, b.clone()) for b in bufs], torch.get_rng_state(), torch.cuda.get_rng_state(dev), dev)
+
+    @staticmethod
+    def _restore(snap):
+        bufs, cpu_rng, gpu_rng, dev = snap
+        with torch.no_grad():
+            for b, saved in bufs:
+                b.copy_(saved)
+        torch.set_rng_state(cpu_rng)
+        torch.cuda.set_rng_state(gpu_rng, dev)
+
     def _capture(self, warmup):
+        from . import graph_capture_safe
+        if not graph_capture_safe():
+            warnings.warn("SegmentedTrainStep: HIP was initialised before `import fastvim_amd` could switch graph packet "
+                          "capture off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): on ROCm 7.2 some captured training steps replay "
+                          "wrongly (DESIGN.md section 5).  Import fastvim_amd first, or export the variable.",
+                          RuntimeWarning, stacklevel=3)
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._restore(snap)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         g_fwd = torch.cuda.CUDAGraph()

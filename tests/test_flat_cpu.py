@@ -53,10 +53,22 @@ def test_optimizer_state_dict_round_trip_and_ema_keys(tmp_path):
                 assert torch.equal(a[o:o + k], b[f2.offsets[n]:f2.offsets[n] + k])
         assert o2.step_t.item() == 17.0 and abs(o2.lr.item() - 3e-4) < 1e-10 and o2.betas == (0.9, 0.95)
         assert torch.equal(f2.shadow_flat.float(), f2.param_flat.bfloat16().float())
-        assert set(ck["state_dict_ema"]) == {"backbone." + k for k in m1.state_dict()}
+        # reference layout (supervised_imagenet.py:107-114): `state_dict` behind "backbone.", `state_dict_ema` =
+        # ModelEmaV2.module.state_dict(), i.e. UNPREFIXED -- its on_load_checkpoint feeds it to load_state_dict as is
+        assert set(ck["state_dict"]) == {"backbone." + k for k in m1.state_dict()}
+        assert set(ck["state_dict_ema"]) == set(m1.state_dict())
+        _tiny().load_state_dict(ck["state_dict_ema"], strict=True)
         # the EMA weights load into a model (what MM_FastVim.load_pretrained prefers)
         load_checkpoint(ck, m2, use_ema=True)
         assert torch.equal(named2["head.weight"], o1.ema_state_dict()["head.weight"])
+        # a dict shaped like the reference's own checkpoint, and one whose EMA entry carries the prefix as well
+        ref_like = {"state_dict": {"backbone." + k: v.clone() for k, v in m1.state_dict().items()},
+                    "state_dict_ema": {k: v.clone() + 1.0 for k, v in m1.state_dict().items()}}
+        load_checkpoint(ref_like, m2, use_ema=True)
+        assert torch.equal(named2["head.weight"], named1["head.weight"] + 1.0)
+        both = dict(ref_like, state_dict_ema={"backbone." + k: v + 1.0 for k, v in ref_like["state_dict_ema"].items()})
+        load_checkpoint(both, m2, use_ema=True)
+        assert torch.equal(named2["head.weight"], both["state_dict_ema"]["backbone.head.weight"])
 
 
 def test_zero_grad_warns_about_unfinished_backward_and_close_restores_switches():

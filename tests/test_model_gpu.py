@@ -89,6 +89,32 @@ def test_fastvim_t_bf16_autocast_close_to_fp32_reference():
     assert rel <= 3e-2, rel   # 24 blocks of bf16 activations; fp32 residual stream keeps it ~1e-2
 
 
+def test_image_gradient_flows_through_patch_embed():
+    """An input image that requires grad gets its gradient through the fused patch projection (bf16 autocast: the
+    projection + bias + position table GEMM; fp32: LinearFn): both must agree with each other to bf16 accuracy and the
+    fp32 one with a finite-difference probe along a random direction."""
+    torch.manual_seed(0)
+    m = _tiny(64).cuda().eval()
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    grads = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        xi = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=dt, enabled=dt != torch.float32):
+            out = m(xi)
+        out.float().square().sum().backward()
+        assert xi.grad is not None and torch.isfinite(xi.grad).all() and xi.grad.abs().max() > 0
+        grads[name] = xi.grad.clone()
+    rel = (grads["bf16"] - grads["fp32"]).norm() / grads["fp32"].norm()
+    assert rel <= 5e-2, rel
+    d = torch.randn_like(x)
+    d /= d.norm()
+    f = lambda t: m(t).double().square().sum().item()
+    with torch.no_grad():
+        fd = (f(x + 1e-2 * d) - f(x - 1e-2 * d)) / 2e-2
+    an = (grads["fp32"].double() * d.double()).sum().item()
+    assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (fd, an)
+
+
 def test_training_mode_droppath_vs_oracle():
     """train() with stochastic depth: same per-sample scales fed to the model and the oracle."""
     from fastvim_amd import fastvim as fv
