@@ -437,14 +437,14 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
         def step():
             graph.replay()
             if world > 1:
-                flat.allreduce_mean_()
-                opt.step()
+                flat.allreduce_sum_()
+                opt.step(grad_scale=1.0 / world)
             return loss_buf
     else:
         def step():
             l = fwd_bwd()
-            flat.allreduce_mean_()
-            opt.step()
+            flat.allreduce_sum_()
+            opt.step(grad_scale=1.0 / world)
             return l
 
     for i in range(warmup):
@@ -478,7 +478,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
             "backend": dist.get_backend(), "ranks": dist.get_world_size(), "overlapped": seg is not None,
             "buckets": len(ex.bounds) if ex is not None else 1,
             "bucket_MB": [round((b - a) * 4 / 1e6, 2) for a, b in ex.bounds] if ex is not None else None,
-            "wire_dtype": str(comm_dtype or torch.float32).replace("torch.", ""),
+            "wire_dtype": ex.wire_names() if ex is not None else None,
             "allreduce_exposed_ms": None if seg is None else round(seg.exposed_ms(), 3)}
     flat.close()
     return elapsed, loss_val, extras
@@ -541,7 +541,8 @@ def main():
                     help="N > 1: gradient buckets = backward graph segments the all-reduce overlaps with (0: one all-reduce after backward)")
     ap.add_argument("--segmented", action="store_true",
                     help="use the segmented (N > 1) step also on one GPU: measures what the chain of graphs costs by itself")
-    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce")
+    ap.add_argument("--comm-dtype", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="wire format of the gradient all-reduce (auto: bf16 for buckets of >= 100 MB of fp32 gradient, else fp32)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
     ap.add_argument("--no-scan-op", action="store_true",
@@ -572,7 +573,7 @@ def main():
     use_graph = not args.no_graph
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)
-    comm_dtype = {"fp32": None, "bf16": torch.bfloat16}[args.comm_dtype]
+    comm_dtype = {"auto": "auto", "fp32": None, "bf16": torch.bfloat16}[args.comm_dtype]
     elapsed, loss_val, extras = run_training_steps(args.model, args.img, args.batch, args.channels, args.dtype, args.steps,
                                                    args.warmup, rank, world, dev, use_graph=use_graph, trace=trace,
                                                    buckets=args.buckets, comm_dtype=comm_dtype,

@@ -16,6 +16,7 @@ struct AdamParams {
   const float* lr;             // device scalar
   float* step;                 // device scalar (float), incremented by this launch
   float beta1, beta2, eps, weight_decay, ema_decay;
+  float grad_scale;            // every gradient element is multiplied by this as it is read (1 / world size after a sum all-reduce)
   size_t n;
 };
 
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(AdamParams a) {
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < a.n; i += stride) {
     float4 p = *reinterpret_cast<const float4*>(a.p + i);
-    const float4 g = *reinterpret_cast<const float4*>(a.g + i);
+    float4 g = *reinterpret_cast<const float4*>(a.g + i);
+    g.x *= a.grad_scale; g.y *= a.grad_scale; g.z *= a.grad_scale; g.w *= a.grad_scale;
     float4 m = *reinterpret_cast<const float4*>(a.m + i);
     float4 v = *reinterpret_cast<const float4*>(a.v + i);
     const uint32_t mask = *reinterpret_cast<const uint32_t*>(a.decay_mask + i);
@@ -63,14 +65,14 @@ __global__ void bump_step_kernel(float* step) { step[0] += 1.f; }
 
 extern "C" int fv_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema,
                              void* shadow_bf16, const uint8_t* decay_mask, const float* lr, float* step,
-                             float beta1, float beta2, float eps, float weight_decay, float ema_decay, size_t n,
-                             fv_stream_t stream) {
+                             float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
+                             size_t n, fv_stream_t stream) {
   FV_CHECK(params && grads && exp_avg && exp_avg_sq && decay_mask && lr && step, "adamw_flat: null pointer");
   FV_CHECK(n % 4 == 0, "adamw_flat: element count must be a multiple of 4 (pad the flat buffer)");
   AdamParams a{};
   a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.ema = ema; a.shadow = (bf16_t*)shadow_bf16;
   a.decay_mask = decay_mask; a.lr = lr; a.step = step;
-  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.ema_decay = ema_decay; a.n = n;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.ema_decay = ema_decay; a.grad_scale = grad_scale; a.n = n;
   if (n == 0) return FV_OK;
   long blocks = fv_cdiv((long)(n / 4), 256);
   if (blocks > 2048) blocks = 2048;

@@ -10,13 +10,19 @@ contiguous BUCKETS of that buffer across ranks with RCCL (``torch.distributed`` 
   work already queued on the current stream -- the backward segment that produced the bucket -- and runs on the
   process group's own stream, so the next backward segment overlaps it;
 * ``finish()`` makes the current stream wait for every outstanding bucket and divides by the world size
-  (torch DDP's mean semantics) -- the optimizer goes after it.
+  (torch DDP's mean semantics) -- the optimizer goes after it.  ``finish(mean=False)`` leaves the SUMS: the fused
+  optimizer kernel takes ``1 / world`` as its gradient scale (``FlatAdamW.step(grad_scale=...)``), which saves a full
+  read-modify-write pass over the gradient per step (391 MB at FastVim-B).
 
 xGMI is point-to-point (7 links per GPU), so ring collectives are per-link bound: a few LARGE buckets (default:
 3 per step, tapered 10 : 8 : 6 blocks -- 12 / 9 / 7 MB at FastVim-T, 160 / 130 / 100 MB at FastVim-B -- so that the
-one nothing overlaps is the smallest; fastvim_amd/flat.py ``buckets``) instead of torch DDP's 25 MB default, and an
-optional bf16 wire format (``comm_dtype``) that halves the bytes per link.  No BatchNorm exists in FastVim, so nothing
-else is exchanged.  The same class is the whole-buffer exchange (one bucket) used by
+one nothing overlaps is the smallest; fastvim_amd/flat.py ``buckets``) instead of torch DDP's 25 MB default, and a
+bf16 wire format that halves the bytes per link: ``comm_dtype="auto"`` (the default of ``FlatTrainingState``) sends a
+bucket as bf16 when its fp32 size is at least ``bf16_min_bytes`` (100 MB: the FastVim-B buckets, where the exchange is
+bandwidth-bound) and as fp32 below (FastVim-T / -S, where it is latency-bound and the bytes do not matter).  The gradient
+itself stays fp32 on both sides of the wire: a bucket is rounded once to bf16, summed by RCCL, and written back into the
+fp32 buffer (relative error <= 2^-8 per addend, tests/test_ddp_cpu.py).  No BatchNorm exists in FastVim, so nothing else is
+exchanged.  The same class is the whole-buffer exchange (one bucket) used by
 ``FlatTrainingState.allreduce_mean_`` and by the CPU (gloo) tests.
 """
 import torch
@@ -28,15 +34,22 @@ class GradExchange:
 
     ``bounds``: list of (lo, hi) element ranges, in the order the backward pass completes them; default one bucket
     covering the buffer.  ``chunk_bytes`` caps the size of a single collective call (very large buckets are sent
-    as several calls).  ``comm_dtype``: wire dtype (e.g. torch.bfloat16); None = fp32."""
+    as several calls).  ``comm_dtype``: wire dtype -- None / torch.float32, torch.bfloat16, or "auto" (bf16 for buckets of
+    at least ``bf16_min_bytes`` of fp32 gradient, fp32 below)."""
 
-    def __init__(self, flat_grad, bounds=None, process_group=None, comm_dtype=None, chunk_bytes=256 << 20):
+    def __init__(self, flat_grad, bounds=None, process_group=None, comm_dtype=None, chunk_bytes=256 << 20,
+                 bf16_min_bytes=100 << 20):
         assert flat_grad.dtype == torch.float32 and flat_grad.is_contiguous() and flat_grad.dim() == 1
         self.flat = flat_grad
         self.group = process_group
-        self.comm_dtype = None if comm_dtype in (None, torch.float32) else comm_dtype
         self.chunk = max(1, chunk_bytes // 4)
         self.bounds = [(0, flat_grad.numel())] if bounds is None else [(int(a), int(b)) for a, b in bounds]
+        if isinstance(comm_dtype, str):
+            assert comm_dtype == "auto", comm_dtype
+            self.wire_dtypes = [torch.bfloat16 if (b - a) * 4 >= bf16_min_bytes else None for a, b in self.bounds]
+        else:
+            self.wire_dtypes = [None if comm_dtype in (None, torch.float32) else comm_dtype] * len(self.bounds)
+        self.comm_dtype = comm_dtype
         covered = sorted(self.bounds)
         assert covered[0][0] == 0 and covered[-1][1] == flat_grad.numel() and \
             all(a[1] == b[0] for a, b in zip(covered[:-1], covered[1:])), "buckets must tile the gradient buffer"
@@ -55,10 +68,11 @@ class GradExchange:
         for s in range(lo, hi, self.chunk):
             e = min(hi, s + self.chunk)
             view = self.flat[s:e]
-            if self.comm_dtype is not None:
+            wire = self.wire_dtypes[k]
+            if wire is not None:
                 buf = self._wire.get((s, e))
                 if buf is None:
-                    buf = self._wire[(s, e)] = torch.empty(e - s, device=view.device, dtype=self.comm_dtype)
+                    buf = self._wire[(s, e)] = torch.empty(e - s, device=view.device, dtype=wire)
                 buf.copy_(view)
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._pending.append((work, view, buf))
@@ -66,8 +80,9 @@ class GradExchange:
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._pending.append((work, view, None))
 
-    def finish(self):
-        """Wait (stream-wise on GPUs) for every launched bucket and turn the sums into means."""
+    def finish(self, mean=True):
+        """Wait (stream-wise on GPUs) for every launched bucket; ``mean``: turn the sums into means (one more pass over
+        the buffer -- pass False when the optimizer applies ``1 / world_size`` itself)."""
         ws = self.world_size
         if ws == 1:
             return
@@ -76,13 +91,20 @@ class GradExchange:
             work.wait()
             if buf is not None:
                 view.copy_(buf)
-        self.flat.div_(ws)
+        if mean:
+            self.flat.div_(ws)
 
-    def allreduce_mean_(self):
+    def wire_names(self):
+        return [str(d or torch.float32).replace("torch.", "") for d in self.wire_dtypes]
+
+    def allreduce_(self, mean=True):
         """Whole buffer in one go: every bucket launched, then finished."""
         for k in range(len(self.bounds)):
             self.launch(k)
-        self.finish()
+        self.finish(mean=mean)
+
+    def allreduce_mean_(self):
+        self.allreduce_(mean=True)
 
 
 class FlatGradAllReduce:

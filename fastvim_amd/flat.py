@@ -37,7 +37,7 @@ _MIXER_GROUPS = (
 
 
 class FlatTrainingState:
-    def __init__(self, model, shadow_dtype=torch.bfloat16, process_group=None, comm_dtype=None,
+    def __init__(self, model, shadow_dtype=torch.bfloat16, process_group=None, comm_dtype="auto",
                  chunk_bytes=256 << 20):
         self.group = process_group
         self.comm_dtype = comm_dtype
@@ -252,12 +252,20 @@ class FlatTrainingState:
         """Sum the flat gradient across ranks (RCCL) and divide by the world size (torch DDP semantics).  Finishes
         the backward pass first (queued weight-gradient GEMMs and partial sums), so ``backward -> allreduce_mean_ ->
         step`` is a complete sequence."""
+        self._allreduce(True)
+
+    def allreduce_sum_(self):
+        """The same without the division: follow it with ``FlatAdamW.step(grad_scale=1 / world_size)`` -- the optimizer
+        kernel scales the gradient as it reads it, which saves the full pass over the buffer that the mean costs."""
+        self._allreduce(False)
+
+    def _allreduce(self, mean):
         self.finish_backward()
         if self.world_size == 1:
             return
         if getattr(self, "exchange", None) is None:
             self.make_exchange(1)
-        self.exchange.allreduce_mean_()
+        self.exchange.allreduce_(mean=mean)
 
 
 class FlatAdamW:
@@ -331,15 +339,17 @@ class FlatAdamW:
             raise RuntimeError("FlatAdamW was built without ema_decay")
         return {prefix + n: v.detach().clone() for n, v in self._named_slices(self.ema).items()}
 
-    def step(self):
+    def step(self, grad_scale=1.0):
+        """``grad_scale``: factor applied to every gradient element as it is read (``1 / world_size`` after an
+        ``allreduce_sum_`` / ``GradExchange.finish(mean=False)``: the data-parallel mean without its own pass)."""
         f = self.flat
         f.finish_backward()         # idempotent: nothing queued in the steady state of a captured step
         rc = L.lib().fv_adamw_flat(
             L.ptr(f.param_flat), L.ptr(f.grad_flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(self.ema),
             L.ptr(f.shadow_flat), L.ptr(self.decay_mask), L.ptr(self.lr), L.ptr(self.step_t),
             ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
-            ctypes.c_float(self.weight_decay), ctypes.c_float(self.ema_decay), ctypes.c_size_t(f.param_flat.numel()),
-            L.stream_of(f.param_flat))
+            ctypes.c_float(self.weight_decay), ctypes.c_float(self.ema_decay), ctypes.c_float(grad_scale),
+            ctypes.c_size_t(f.param_flat.numel()), L.stream_of(f.param_flat))
         L.check(rc, "adamw_flat")
 
 

@@ -39,6 +39,7 @@ class SegmentedTrainStep:
         self.exchange = flat.make_exchange(n_segments)
         self.runs = self.exchange.layers                 # (lo, hi) block ranges in BACKWARD order
         self.K = len(self.runs)
+        self._gscale = 1.0 / self.exchange.world_size
         self.use_graph = use_graph
         self.loss = None
         self._cuts = None
@@ -99,8 +100,8 @@ class SegmentedTrainStep:
         for k in range(self.K):
             self._backward(k)
             self.exchange.launch(k)
-        self.exchange.finish()
-        self.opt.step()
+        self.exchange.finish(mean=False)         # sums: the optimizer kernel applies 1 / world as it reads the gradient
+        self.opt.step(grad_scale=self._gscale)
         return loss
 
     def _snapshot(self):
@@ -149,7 +150,7 @@ class SegmentedTrainStep:
             g_bwd.append(g)
         g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_opt, pool=pool):
-            self.opt.step()
+            self.opt.step(grad_scale=self._gscale)
         self.graphs = (g_fwd, g_bwd, g_opt)
 
     def step(self, time_exposed=False):
@@ -166,7 +167,7 @@ class SegmentedTrainStep:
         if time_exposed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.exchange.finish()
+        self.exchange.finish(mean=False)
         if time_exposed:
             e1.record()
             self._exposed.append((e0, e1))

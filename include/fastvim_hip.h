@@ -403,11 +403,14 @@ int fv_column_sum(const void* x, int dtype, float* out, int rows, int cols, int 
  * bf16 shadow weights in the same pass.  Replaces the optimizer + EMA + autocast casts of the
  * reference step (imagenet_classification/supervised_imagenet.py:134-147, 270-276).
  * decay_mask: one byte per element (1 = weight decay applies).  lr, step: device scalars (fp32);
- * step is incremented by the call.  n % 4 == 0.
+ * step is incremented by the call.  grad_scale multiplies every gradient element as it is read: 1, or
+ * 1 / world_size when `grads` holds the SUM over data-parallel ranks (the mean torch DDP produces,
+ * imagenet_classification/train.py:34-43, without a pass of its own).  n % 4 == 0.
  * ---------------------------------------------------------------------- */
 int fv_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema,
                   void* shadow_bf16, const uint8_t* decay_mask, const float* lr, float* step, float beta1,
-                  float beta2, float eps, float weight_decay, float ema_decay, size_t n, fv_stream_t stream);
+                  float beta2, float eps, float weight_decay, float ema_decay, float grad_scale, size_t n,
+                  fv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,55 @@ def test_bucketed_exchange_bitwise_equals_single_allreduce(tmp_path):
     assert torch.equal(res["four"], res["one"]) and torch.equal(res["chunked"], res["one"])
 
 
+def _auto_wire_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastvim_amd.ddp import GradExchange
+    g = torch.Generator().manual_seed(20 + rank)
+    base = torch.randn(4096, generator=g) * torch.logspace(-6, 2, 4096)      # eight decades of gradient magnitude
+    bounds = [(1024, 4096), (0, 1024)]
+    res = {}
+    # "auto" with the threshold between the two bucket sizes: the 12 KiB bucket goes over the wire as bf16, the 4 KiB one as fp32
+    ex = GradExchange(base.clone(), bounds, comm_dtype="auto", bf16_min_bytes=8 << 10)
+    res["wire"] = ex.wire_names()
+    ex.allreduce_(mean=False)
+    res["auto_sum"] = ex.flat
+    ex32 = GradExchange(base.clone(), bounds, comm_dtype=None)
+    ex32.allreduce_(mean=False)
+    res["fp32_sum"] = ex32.flat
+    exm = GradExchange(base.clone(), bounds, comm_dtype=None)
+    exm.allreduce_mean_()
+    res["fp32_mean"] = exm.flat
+    res["default_T"] = GradExchange(torch.zeros(7_200_000), None, comm_dtype="auto").wire_names()       # 28.8 MB: fp32
+    res["default_B"] = GradExchange(torch.zeros(40_000_000), None, comm_dtype="auto").wire_names()      # 160 MB: bf16
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_auto_wire_format_keeps_fp32_accumulation_error_bound(tmp_path):
+    """``comm_dtype="auto"``: buckets of >= bf16_min_bytes travel as bf16, smaller ones as fp32.  The gradient stays fp32
+    on both sides of the wire, so the error of a bf16 bucket is the rounding of each addend and of the wire sum: at most
+    2^-8 of (|a| + |b|) + 2^-8 of |a + b| per element -- checked elementwise over eight decades of magnitude; the fp32
+    bucket is exact.  Sums followed by the optimizer's ``grad_scale = 1 / world`` equal the mean for a power-of-two world."""
+    out = str(tmp_path / "w.pt")
+    mp.spawn(_auto_wire_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["wire"] == ["bfloat16", "float32"] and r["default_T"] == ["float32"] and r["default_B"] == ["bfloat16"]
+    sc = torch.logspace(-6, 2, 4096)
+    a = torch.randn(4096, generator=torch.Generator().manual_seed(20)) * sc
+    b = torch.randn(4096, generator=torch.Generator().manual_seed(21)) * sc
+    assert torch.equal(r["fp32_sum"], a + b)
+    assert torch.equal(r["auto_sum"][:1024], (a + b)[:1024])                        # the small bucket went as fp32
+    err = (r["auto_sum"][1024:] - (a + b)[1024:]).abs()
+    bound = 2.0 ** -8 * (a.abs() + b.abs() + (a + b).abs())[1024:]
+    assert (err <= bound).all() and err.max() > 0                                   # bf16 on the wire, within its bound
+    assert r["auto_sum"].dtype == torch.float32
+    assert torch.equal(r["fp32_sum"] * 0.5, r["fp32_mean"])                         # grad_scale = 1 / 2 == the mean
+
+
 def test_layer_major_buckets_tile_the_flat_gradient():
     """FlatTrainingState lays the gradient out block by block; buckets() cuts it into runs of whole blocks, last
     blocks first, that tile the buffer (CPU: no kernels involved)."""

@@ -75,18 +75,25 @@ def test_segmented_step_equals_single_step(n_seg, graph, batch, fill, monkeypatc
     f1.close(); f2.close()
 
 
-def test_two_rank_segmented_bench_line():
+@pytest.mark.parametrize("model,batch,total_mb,wire", [
+    ("T", 16, 28.7, ["float32"] * 3),                                # FastVim-T: 7.17 M fp32 gradients, 12 / 9 / 7 MB buckets
+    ("B", 8, 390.7, ["bfloat16", "bfloat16", "float32"]),            # FastVim-B: 97.7 M, 163 / 131 / 98 MB: bf16 from 100 MB on
+])
+def test_two_rank_segmented_bench_line(model, batch, total_mb, wire):
     """Two ranks on GPU 0 over gloo (FASTVIM_BENCH_ONE_GPU=1): the N > 1 bench path = segmented step with bucketed,
-    asynchronously launched all-reduces; the line reports the exchange."""
+    asynchronously launched all-reduces, sums scaled by 1 / world inside the optimizer kernel; the line reports the
+    exchange (bucket sizes, wire format per bucket, exposed time).  FastVim-T and FastVim-B widths."""
     env = dict(os.environ, FASTVIM_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--batch", "16", "--buckets", "3", "--no-cpu-baseline", "--no-kernels", "--no-scan-op"]
+           "127.0.0.1", "--master-port", "29541" if model == "T" else "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--model", model, "--steps", "3", "--warmup", "1", "--batch", str(batch), "--buckets", "3", "--no-cpu-baseline",
+           "--no-kernels", "--no-scan-op"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["ddp"]["overlapped"] and out["ddp"]["buckets"] == 3 and out["ddp"]["ranks"] == 2
-    assert abs(sum(out["ddp"]["bucket_MB"]) - 28.7) < 0.5            # FastVim-T: 7.17 M fp32 gradients
+    assert abs(sum(out["ddp"]["bucket_MB"]) - total_mb) < 0.5
+    assert out["ddp"]["wire_dtype"] == wire
     assert out["ddp"]["allreduce_exposed_ms"] is not None and out["config"]["final_loss"] == out["config"]["final_loss"]
 
 
@@ -117,7 +124,7 @@ def run(pretend):
     seg = SegmentedTrainStep(m, flat, opt, SoftTargetCrossEntropy(), x, tgt, n_segments=3, use_graph=True, warmup=1)
     if not pretend:
         seg.exchange.launch = lambda k: None
-        seg.exchange.finish = lambda: flat.grad_flat.div_(2)
+        seg.exchange.finish = lambda mean=True: None      # (the 1 / 2 is the optimizer kernel's gradient scale either way)
     losses = [seg.step(time_exposed=pretend).item() for _ in range(4)]
     torch.cuda.synchronize()
     gsum = flat.grad_flat.double().abs().sum().item()
