@@ -564,6 +564,67 @@ def other_configs_block(dtype, rank, dev, steps=5, warmup=2):
     return out
 
 
+def inference_throughput(model_name, img, batch, dev, steps=5, warmup=2):
+    """Forward-only images/s (eval mode, no_grad, bf16 autocast, HIP-graph replay): the quantity the reference's headline
+    claim is about (README.md:15: FastVim vs Vim inference speed at 2048 x 2048)."""
+    import gc
+    torch.manual_seed(1234)
+    model = build_model(model_name, img, 0.0).to(dev).eval()
+    x = torch.randn(batch, 3, img, img, generator=torch.Generator().manual_seed(7)).to(dev)
+
+    def fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(x)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            out = fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fwd()
+    for _ in range(warmup):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = bool(torch.isfinite(out.float()).all())
+    del g, model, x, out
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"ms_per_batch": round(el / steps * 1e3, 3), "images_per_sec": round(batch * steps / el, 2), "finite": ok}
+
+
+def vim_vs_fastvim_block(dev, img=2048, batch=8):
+    """the un-pooled Vim baseline against FastVim at the resolution of the paper's headline claim ("up to
+    72.5 % speedup in inference speed ... on high resolution (2048x2048) images", /root/reference README.md:15).  Same
+    kernels, same widths; Vim scans all L + 1 = 16 385 tokens per direction, FastVim the 128 pooled rows."""
+    out = {"img": img, "batch": batch, "reference_claim": "up to 72.5 % speedup in inference speed at 2048 x 2048 (README.md:15)"}
+    for size, fv_name, vim_name in (("T", "T", "V"),):
+        try:
+            a = inference_throughput(fv_name, img, batch, dev)
+            b = inference_throughput(vim_name, img, batch, dev)
+            out[f"FastVim-{size}"], out[f"Vim-{size}"] = a, b
+            out[f"speedup_{size}_pct"] = round((a["images_per_sec"] / b["images_per_sec"] - 1.0) * 100.0, 1)
+        except Exception as e:
+            out[f"error_{size}"] = f"{type(e).__name__}: {e}"[:300]
+    try:      # and the training step of the baseline at that resolution (fwd + bwd + AdamW + EMA)
+        el, lv, ex = run_training_steps("V", img, batch, 3, "bf16", 3, 1, 0, 1, dev)
+        out["Vim-T_train_ms_per_step"] = round(el / 3 * 1e3, 2)
+        el, lv2, ex = run_training_steps("T", img, batch, 3, "bf16", 3, 1, 0, 1, dev)
+        out["FastVim-T_train_ms_per_step"] = round(el / 3 * 1e3, 2)
+        out["train_finite"] = lv == lv and lv2 == lv2
+    except Exception as e:
+        out["error_train"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -587,6 +648,7 @@ def main():
                     help="wire format of the gradient all-reduce (auto: bf16 for buckets of >= 100 MB of fp32 gradient, else fp32)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
+    ap.add_argument("--vim-2048", action="store_true", help="only the Vim-vs-FastVim block at 2048 px (SURVEY row f2), as JSON")
     ap.add_argument("--no-scan-op", action="store_true",
                     help="skip timing the reference-layout op selective_scan_fn at every config's (B, d_in, Lc, N)")
     args = ap.parse_args()
@@ -612,6 +674,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
+    if args.vim_2048:
+        print(json.dumps(vim_vs_fastvim_block(dev, args.img if args.img != 224 else 2048, args.batch if args.batch != 128 else 8)), flush=True)
+        return
     use_graph = not args.no_graph
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)
@@ -692,6 +757,7 @@ def main():
         if (not args.no_other_configs and world == 1 and use_graph
                 and (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16")):
             out["other_configs"] = other_configs_block(args.dtype, rank, dev)
+            out["other_configs"]["f2_vim_vs_fastvim_2048px"] = vim_vs_fastvim_block(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

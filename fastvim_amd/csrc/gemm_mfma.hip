@@ -67,6 +67,9 @@ struct NormEpi {
   bf16_t* C2;
   long ldw2;
   int N2;
+  // rows of the output a workgroup owns (<= the tile height BM; 0 = BM): trimmed so that every resident workgroup gets the
+  // same share of the rows -- M = 25 088 over 512 slots is 49 rows each instead of 392 tiles of 64 (1.53 per slot)
+  int rpt;
 };
 
 // KS tiles: rows (k) are EXT*2 bytes = a multiple of the 256-byte bank row, and a transposing read
@@ -343,14 +346,16 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
   const int wm = wv / WN, wn = wv % WN;
   // XCD-aware tile order: the N tiles that share an A row panel are consecutive on one XCD
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int nblk = tiles_m * tiles_n;
+  const int nblk = NORM_EPI != 0 ? (int)gridDim.x : tiles_m * tiles_n;      // (trimmed row tiles: the launch knows how many)
   int bid = block_id;
   if constexpr (XREMAP) {      // block_id is the hardware block index (XCD = block_id % 8); the grouped kernel remaps itself
     const int q8 = nblk / 8, r8 = nblk % 8, xcd = bid % 8, j = bid / 8;
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;   // bijective remap
   }
   const int tm = bid / tiles_n, tn = bid % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int rpt = (NORM_EPI != 0 && ne->rpt > 0) ? ne->rpt : BM;
+  const int m0 = tm * rpt, n0 = tn * BN;
+  const int mlim = NORM_EPI != 0 ? min(p.M, m0 + rpt) : p.M;      // rows [m0, mlim) are this workgroup's
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
@@ -518,7 +523,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
       for (int u = 0; u < RU; ++u) {
         const int rl = wv * RW + it * (RPW * RU) + u * RPW + gr;
         const int row = m0 + rl;
-        const bool live = row < p.M;
+        const bool live = row < mlim;
         const int rowc = live ? row : p.M - 1;
         const size_t base = (size_t)rowc * BN;
         const float rstd = ne->rstd[rowc];
@@ -598,7 +603,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
       // ---- second phase: the previous block's out_proj data gradient d g = d x @ W_out from the tile in LDS
       __syncthreads();
       constexpr int O_B = (BM * RSB + 255) / 256 * 256, O_S = O_B + 2 * 128 * BK * 2;
-      tile_times_w2<BM, RSB, KS>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, p.M, tid);
+      tile_times_w2<BM, RSB, KS>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, mlim, tid);
     }
     return;
   }
@@ -649,7 +654,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
         const int row = m0 + wv * RW + it * (RPW * RU) + u * RPW + gr;
-        const bool live = row < p.M;
+        const bool live = row < mlim;
         const size_t base = (size_t)(live ? row : p.M - 1) * BN;
         const float sc = sc_u[u];
 #pragma unroll
@@ -695,7 +700,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
       // ---- second phase: this block's in_proj, xz = y @ W_in^T, from the normalised tile in LDS
       __syncthreads();
       constexpr int O_B = (BM * RSB + 255) / 256 * 256, O_S = O_B + 2 * 128 * BK * 2;
-      tile_times_w2<BM, RSB, KC>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, p.M, tid);
+      tile_times_w2<BM, RSB, KC>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, mlim, tid);
     }
     return;
   }
@@ -1472,6 +1477,27 @@ static int gemm_entry(const void* A, const void* B, void* C, const float* bias, 
   return FV_ERR_UNSUPPORTED;
 }
 
+// Rows per workgroup of the fused projection + norm kernels (64-row MFMA tiles, two workgroups resident per CU).  Dealing
+// the rows out evenly over whole rounds of the 2 x CUs slots -- M = 25 088 (FastVim-T, batch 128) as 512 x 49 instead of
+// 392 x 64, where 136 CUs carry two tiles and 120 carry one -- was measured and LOST: every workgroup streams the whole
+// weight panel (442 KB for the backward kernel) from L2 whatever its height, so more, shorter workgroups cost more than
+// the imbalance (same box, FastVim-T step: 64 rows 5.822 ms, 56 rows 5.805-5.816, 49 rows 5.844-5.865, 33 rows 6.41).
+// The full 64 rows stay; FASTVIM_FUSED_RPT = n (tuning build) sets another height, 0 the even deal.
+static int fused_rpt(int M) {
+  static const int force = fv_tune("FASTVIM_FUSED_RPT", 64);      // tuning hook
+  if (force > 0) return force < 64 ? force : 64;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const long slots = 2L * cus, rounds = (M + 64 * slots - 1) / (64 * slots);
+  long rpt = (M + slots * rounds - 1) / (slots * rounds);
+  if (rpt < 16) rpt = 16;
+  return (int)(rpt > 64 ? 64 : rpt);
+}
+
 extern "C" int fv_gemm_bf16_addnorm(const void* A, const void* W, const float* residual, const float* norm_weight,
                                     const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd,
                                     int M, int N, int K, long lda, long ldw, float eps, fv_stream_t stream) {
@@ -1499,7 +1525,7 @@ extern "C" int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* 
              "gemm_bf16_addnorm2: the second weight must be (N2, N) with N2 a multiple of 128, 16-byte aligned");
   }
   NormEpi ne{residual, norm_weight, row_scale, residual_out, (bf16_t*)y, rstd, rows_per_scale > 0 ? rows_per_scale : 1, eps,
-             nullptr, nullptr, (const bf16_t*)W2, (bf16_t*)C2, ldw2, N2};
+             nullptr, nullptr, (const bf16_t*)W2, (bf16_t*)C2, ldw2, N2, fused_rpt(M)};
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto bm) {
     constexpr int BMR = decltype(bm)::value;
@@ -1512,7 +1538,8 @@ extern "C" int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* 
       (void)hipFuncSetAttribute((const void*)gemm_addnorm_kernel<BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)0;         
     }
-    hipLaunchKernelGGL((gemm_addnorm_kernel<BMR>), dim3(fv_cdiv(M, BMR)), dim3(256), smem, st, p, ne);
+    if (ne.rpt > BMR) ne.rpt = BMR;
+    hipLaunchKernelGGL((gemm_addnorm_kernel<BMR>), dim3(fv_cdiv(M, ne.rpt)), dim3(256), smem, st, p, ne);
   };
 #ifdef FASTVIM_TUNING_HOOKS
   static const int bm = fv_tune("FASTVIM_ADDNORM_BM", 64);
@@ -1525,7 +1552,7 @@ extern "C" int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* 
   return FV_OK;
 }
 
-extern "C" int fv_gemm_bf16_dgrad_addnorm_blocks(int M) { return fv_cdiv(M, 64); }
+extern "C" int fv_gemm_bf16_dgrad_addnorm_blocks(int M) { return fv_cdiv(M, fused_rpt(M)); }
 
 extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd(const void* A, const void* W, const float* dresidual_out, const float* r,
                                               const float* rstd, const float* norm_weight, const float* row_scale,
@@ -1558,7 +1585,7 @@ extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, con
   }
   NormEpi ne{r, norm_weight, row_scale, dresidual_in, (bf16_t*)dx, const_cast<float*>(rstd),
              rows_per_scale > 0 ? rows_per_scale : 1, 0.f, dresidual_out, partial_dw,
-             (const bf16_t*)W2, (bf16_t*)C2, ldw2, N2};
+             (const bf16_t*)W2, (bf16_t*)C2, ldw2, N2, fused_rpt(M)};
   auto go = [&](auto bm) {
     constexpr int BMR = decltype(bm)::value;
     // main loop: two (BMR + 192) x 64 stages; second phase: the d x tile, two 128 x 64 stages, four epilogue slabs
@@ -1570,7 +1597,7 @@ extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, con
       (void)hipFuncSetAttribute((const void*)gemm_dgrad_addnorm_bwd_kernel<BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)0;         
     }
-    hipLaunchKernelGGL((gemm_dgrad_addnorm_bwd_kernel<BMR>), dim3(fv_cdiv(M, BMR)), dim3(256), smem, (hipStream_t)stream, p, ne);
+    hipLaunchKernelGGL((gemm_dgrad_addnorm_bwd_kernel<BMR>), dim3(fv_cdiv(M, ne.rpt)), dim3(256), smem, (hipStream_t)stream, p, ne);
   };
   go(std::integral_constant<int, 64>{});      // (128-row tiles, no room to prefetch the rows: 46.9 vs 31.0 us)
   FV_LAUNCH_CHECK();

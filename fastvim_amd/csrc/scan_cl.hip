@@ -1391,7 +1391,11 @@ extern "C" int fv_mixer_scan_fwd_ckpt(const void* xc, const void* x_dbl, const f
   dim3 grid(fv_cdiv(d_inner, CPB), batch, 2), block(256);
   hipStream_t st = (hipStream_t)stream;
   static const int fwd_chunked = fv_tune("FASTVIM_SCAN_FWD_CHUNKED", 1);   // A/B hook
-  if (fwd_chunked && Lc > 16 && dt_rank <= 48) {
+  // short pooled lengths reach this entry only when the fused x_proj + scan launch does not take them (d_inner > 768,
+  // fp32): one chunk of the chunked kernel (delta on the fp32 matrix cores, softplus once per (step, channel)) against the
+  // round-1 kernel (delta per state-quad lane)
+  static const int fwd_short_ck = fv_tune("FASTVIM_SCAN_FWD_SHORT_CK", 0);   // A/B hook
+  if (fwd_chunked && (Lc > 16 || fwd_short_ck) && dt_rank <= 48) {
 #define FV_FC(TT)                                                                            \
   do {                                                                                       \
     if (RQ <= 3) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 3>), grid, block, 0, st, p);        \

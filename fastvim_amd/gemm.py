@@ -14,6 +14,87 @@ def _call(A, B, C, bias, M, N, K, lda, ldb, ldc, a_ks, b_ks, splits):
     L.check(rc, "gemm_bf16")
 
 
+def gemm_f32(A, B, C, bias, M, N, K, lda, ldb, ldc, a_ks, b_ks, batch=1, sA=0, sB=0, sC=0):
+    """The fp32-MFMA GEMM (csrc/gemm_f32.hip, C ABI fv_gemm_f32): fp32 or bf16 operands of any shape / alignment."""
+    L.require_gpu(A, B, C)
+    rc = L.lib().fv_gemm_f32(L.ptr(A), L.i32(L.dtype_code(A.dtype)), L.ptr(B), L.i32(L.dtype_code(B.dtype)), L.ptr(C),
+                             L.i32(L.dtype_code(C.dtype)), L.ptr(bias), L.i32(M), L.i32(N), L.i32(K), ctypes.c_long(lda),
+                             ctypes.c_long(ldb), ctypes.c_long(ldc), L.i32(a_ks), L.i32(b_ks), L.i32(batch),
+                             ctypes.c_long(sA), ctypes.c_long(sB), ctypes.c_long(sC), L.stream_of(A))
+    L.check(rc, "gemm_f32")
+
+
+def _rows(t):
+    """(tensor with unit inner stride, row stride): what the generic kernel needs of a 2-D operand."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+def gemm_any_nt(a, w, bias=None, out_dtype=None):
+    """a (M, K) @ w (N, K)^T (+ bias) through the fp32-MFMA kernel: fp32 operands, or bf16 ones the tuned kernels do not take."""
+    (a, lda), (w, ldw) = _rows(a), _rows(w)
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
+    gemm_f32(a, w, c, None if bias is None else bias.float().contiguous(), M, N, K, lda, ldw, N, 0, 0)
+    return c
+
+
+def gemm_any_nn(a, b, out_dtype=None):
+    """a (M, K) @ b (K, N), b row-major as stored."""
+    (a, lda), (b, ldb) = _rows(a), _rows(b)
+    M, K = a.shape
+    N = b.shape[1]
+    c = torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
+    gemm_f32(a, b, c, None, M, N, K, lda, ldb, N, 0, 1)
+    return c
+
+
+def gemm_any_tn(x, y, splits=1):
+    """x (Kd, M)^T @ y (Kd, N) -> (splits, M, N) fp32 partials over `splits` equal slices of Kd (the last one takes the
+    remainder rows when Kd does not divide: then ``splits`` is cut to 1)."""
+    (x, ldx), (y, ldy) = _rows(x), _rows(y)
+    Kd, M = x.shape
+    N = y.shape[1]
+    if splits < 1 or Kd % splits:
+        splits = 1
+    ks = Kd // splits
+    part = torch.empty(splits, M, N, device=x.device, dtype=torch.float32)
+    gemm_f32(x, y, part, None, M, N, ks, ldx, ldy, N, 1, 1, batch=splits, sA=ks * ldx, sB=ks * ldy, sC=M * N)
+    return part
+
+
+def gemm_any_bnt(a, w, out_dtype=None):
+    """Batched a (G, M, K) @ w (G, N, K)^T -> (G, M, N) in one launch (x_proj of both scan directions)."""
+    a, w = a.contiguous(), w.contiguous()
+    G, M, K = a.shape
+    N = w.shape[1]
+    c = torch.empty(G, M, N, device=a.device, dtype=out_dtype or a.dtype)
+    gemm_f32(a, w, c, None, M, N, K, K, K, N, 0, 0, batch=G, sA=M * K, sB=N * K, sC=M * N)
+    return c
+
+
+def gemm_any_bnn(a, b, out_dtype=None):
+    """Batched a (G, M, K) @ b (G, K, N) -> (G, M, N), b row-major as stored."""
+    a, b = a.contiguous(), b.contiguous()
+    G, M, K = a.shape
+    N = b.shape[2]
+    c = torch.empty(G, M, N, device=a.device, dtype=out_dtype or a.dtype)
+    gemm_f32(a, b, c, None, M, N, K, K, N, N, 0, 1, batch=G, sA=M * K, sB=K * N, sC=M * N)
+    return c
+
+
+def gemm_any_btn(x, y):
+    """Batched x (G, Kd, M)^T @ y (G, Kd, N) -> (G, M, N) fp32."""
+    x, y = x.contiguous(), y.contiguous()
+    G, Kd, M = x.shape
+    N = y.shape[2]
+    c = torch.empty(G, M, N, device=x.device, dtype=torch.float32)
+    gemm_f32(x, y, c, None, M, N, Kd, M, N, N, 1, 1, batch=G, sA=Kd * M, sB=Kd * N, sC=M * N)
+    return c
+
+
 def gemm_nt(a, w, bias=None, out_dtype=torch.bfloat16):
     """a (M, K) @ w (N, K)^T -> (M, N): F.linear(a, w, bias) with bf16 operands."""
     M, K = a.shape

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import mixer_ops as M
-from .gemm import gemm_nn, gemm_nt, gemm_tn
+from .gemm import gemm_any_bnn, gemm_any_btn, gemm_any_nn, gemm_any_nt, gemm_any_tn, gemm_nn, gemm_nt, gemm_tn
 
 
 def _shadow(w, cdt):
@@ -49,11 +49,11 @@ def _wgrad(X, Y, W=None, splits=16):
     preallocated flat gradient, the sum is accumulated straight into it and None is returned."""
     M_, I = X.shape
     J = Y.shape[1]
-    while splits > 1 and M_ % splits:
+    while splits > 1 and (M_ % splits or M_ // splits < 256):
         splits //= 2
-    part = torch.bmm(X.view(splits, M_ // splits, I).transpose(1, 2), Y.view(splits, M_ // splits, J),
-                     out_dtype=torch.float32) if X.dtype != torch.float32 else \
-        torch.bmm(X.view(splits, M_ // splits, I).transpose(1, 2), Y.view(splits, M_ // splits, J))
+    # fp32 operands, and bf16 ones whose token count is not a multiple of 64 (the head at batch 8): the fp32-MFMA kernel,
+    # the K slices as its batch dimension
+    part = gemm_any_tn(X, Y, splits)
     g = _direct_grad(W) if W is not None else None
     if g is not None:
         M.reduce_partials(part, splits, out=g.view(-1), accumulate=True)
@@ -65,17 +65,26 @@ def _mfma_ok(*ts):
     return all(t.dtype == torch.bfloat16 and t.stride(-1) == 1 and t.data_ptr() % 16 == 0 for t in ts)
 
 
+def _any_ok(*ts):
+    return all(t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 2 for t in ts)
+
+
 def linear_fwd(a2, w_c, bias=None):
-    """a2 (M, K) x w_c (N, K)^T (+ bias) in the compute dtype: hand-written MFMA GEMM for bf16, rocBLAS for fp32."""
+    """a2 (M, K) x w_c (N, K)^T (+ bias) in the compute dtype: the bf16 MFMA GEMM where its alignment rules hold, the
+    fp32-MFMA GEMM otherwise (fp32 -- the reference's default precision -- and odd bf16 shapes): no library GEMM."""
     if _mfma_ok(a2, w_c) and a2.shape[1] % 8 == 0 and w_c.shape[0] % 8 == 0:      # 16-byte rows of A, W and C
         return gemm_nt(a2, w_c, bias=None if bias is None else bias.float())
-    return F.linear(a2, w_c, None if bias is None else bias.to(a2.dtype))
+    if _any_ok(a2, w_c):
+        return gemm_any_nt(a2, w_c, bias)
+    return F.linear(a2, w_c, None if bias is None else bias.to(a2.dtype))      # fp16 / fp64 / CPU callers of the op-level API
 
 
 def linear_dgrad(g2, w_c):
     """g2 (M, N) x w_c (N, K) -> (M, K): data gradient with the weight as stored."""
     if _mfma_ok(g2, w_c) and w_c.shape[1] % 8 == 0 and g2.shape[1] % 8 == 0:
         return gemm_nn(g2, w_c)
+    if _any_ok(g2, w_c):
+        return gemm_any_nn(g2, w_c)
     return g2 @ w_c
 
 
@@ -221,6 +230,15 @@ class LinearFn(torch.autograd.Function):
                 else:
                     db = g2.float().sum(0)
         return da, dW, None, db
+
+
+def linear_module(mod, x):
+    """``mod(x)`` for an ``nn.Linear`` through the build's own GEMMs (``LinearFn``: MFMA kernel + deterministic split-K
+    weight gradient, bias in the epilogue) -- what the classification heads and the MAE decoder's embedding / prediction
+    layers call instead of ``F.linear``; CPU tensors (checkpoint tooling, tests without a GPU) take the module's own path."""
+    if isinstance(mod, nn.Linear) and x.is_cuda:
+        return LinearFn.apply(x, mod.weight, _compute_dtype(x), mod.bias)
+    return mod(x)
 
 
 class OutProjAddNormFn(torch.autograd.Function):
@@ -536,13 +554,13 @@ class FastVimMixerFn(torch.autograd.Function):
                 if dWx2 is None:
                     dWx2 = (None, None)
             else:
+                # widths the x_proj adjoint kernel is not built for: the fp32-MFMA GEMM, both directions as its batch
                 xc2 = xc.view(2, B * rows * tpp, d_in)
+                dWx2 = gemm_any_btn(dx_dbl, xc2)                                          # (2, R+2N, d_in) fp32
                 if "Wx2_grad" in fv:
-                    fv["Wx2_grad"].baddbmm_(dx_dbl.transpose(1, 2), xc2.float())
+                    fv["Wx2_grad"].add_(dWx2)
                     dWx2 = (None, None)
-                else:
-                    dWx2 = torch.bmm(dx_dbl.transpose(1, 2), xc2.float())                # (2, R+2N, d_in)
-                dxc = torch.baddbmm(dxc.view(2, B * rows * tpp, d_in), dx_dbl, Wx2)            # + dx_dbl @ Wx
+                dxc = dxc.view(2, B * rows * tpp, d_in) + gemm_any_bnn(dx_dbl, Wx2.float(), out_dtype=torch.float32)   # + dx_dbl @ Wx
             p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
                                  pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None,
                                  tpp=tpp, amax=amax)

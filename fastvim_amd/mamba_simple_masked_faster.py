@@ -22,6 +22,7 @@ import torch
 from . import _lib as L
 from . import mixer_ops as M
 from .mamba_simple import _split_rows_exact as _split_rows
+from .gemm import gemm_any_bnn, gemm_any_btn
 from .mamba_simple_faster import (Mamba as _FastVimMamba, _compute_dtype, _shadow, linear_dgrad, linear_fwd,
                                   linear_wgrad)
 
@@ -86,8 +87,8 @@ class MaskedFastVimMixerFn(torch.autograd.Function):
                                             dyc_per_direction=True)
             # x_proj adjoint (selective_scan_interface.py:726-734), both directions
             xc2 = xcomp.view(2, B * rows, d_in)
-            dWx2 = torch.bmm(dx_dbl.transpose(1, 2), xc2.float())
-            dxcomp = torch.baddbmm(dxcomp.view(2, B * rows, d_in), dx_dbl, Wx2).view(2, B, rows, d_in)
+            dWx2 = gemm_any_btn(dx_dbl, xc2)                       # (2, W, d_in) fp32 = dx_dbl^T xc, fp32-MFMA GEMM
+            dxcomp = (dxcomp.view(2, B * rows, d_in) + gemm_any_bnn(dx_dbl, Wx2, out_dtype=torch.float32)).view(2, B, rows, d_in)
             dxc_tok = M.rows_gather(dxcomp, idx, 1.0 / cols)                              # (2, B, Lk, d_in) fp32
             p2 = M.conv_pool_bwd(xz, d_o, dxc_tok, cw2, cb, cwb2, cb_b, D, D_b, dxz, srows, 1, False, False, 1.0, tpp=t)
             dxz2 = dxz.view(B * Lk, 2 * d_in)

@@ -275,12 +275,15 @@ def xproj_fwd(xc, Wx2_c):
     """x_dbl (2, M, W) = xc (2, B, Lc, d_in) @ Wx2_c (2, W, d_in)^T, both directions in one launch (bf16 operands,
     fp32 accumulate).  The LDS-free kernel wins where the weight is small (FastVim-T: 4.0 vs 4.9-5.2 us for
     hipBLASLt) and loses for wider models, where every 16-row block re-reads a 100+ KB weight from L2 (FastVim-B:
-    11.4 vs 7.7 us) -- those, fp32 and odd shapes go to torch.bmm."""
+    11.4 vs 7.7 us) -- fp32 and odd shapes go to the fp32-MFMA GEMM, both directions as its batch dimension."""
     d_in = xc.shape[-1]
     Mrows = xc.numel() // (2 * d_in)
     W = Wx2_c.shape[1]
     if (xc.dtype != torch.bfloat16 or Wx2_c.dtype != torch.bfloat16 or d_in % 32 or W > 112
             or not xc.is_contiguous() or not Wx2_c.is_contiguous() or xc.data_ptr() % 16 or Wx2_c.data_ptr() % 16):
+        if xc.is_cuda and xc.dtype in (torch.float32, torch.bfloat16) and Wx2_c.dtype in (torch.float32, torch.bfloat16):
+            from .gemm import gemm_any_bnt
+            return gemm_any_bnt(xc.reshape(2, Mrows, d_in), Wx2_c)
         return torch.bmm(xc.view(2, Mrows, d_in), Wx2_c.transpose(1, 2))
     out = torch.empty(2, Mrows, W, device=xc.device, dtype=xc.dtype)
     rc = L.lib().fv_mixer_xproj_fwd(L.ptr(xc), L.ptr(Wx2_c), L.ptr(out), L.i32(Mrows), L.i32(d_in), L.i32(W), L.stream_of(xc))

@@ -22,7 +22,7 @@ from .fastvim import (DropPath, _compute_dtype, _init_weights, segm_init_weights
                       to_2tuple, trunc_normal_)
 from .layernorm import RMSNorm, layer_norm_fn
 from .mamba_simple_channel_faster import Mamba
-from .mamba_simple_faster import LinearFn
+from .mamba_simple_faster import LinearFn, linear_module
 from .mixer_ops import reduce_partials
 
 
@@ -329,7 +329,7 @@ class VisionMamba(nn.Module):
         x = self.forward_features(x, inference_params)
         if return_features:
             return x
-        x = self.head(x)
+        x = linear_module(self.head, x)
         if self.final_pool_type == "max":
             x = x.max(dim=1)[0]
         return x

@@ -23,6 +23,7 @@ from torch import Tensor
 
 from .fastvim import PatchEmbed, _compute_dtype, _init_weights, trunc_normal_
 from .layernorm import RMSNorm, layer_norm_fn
+from .mamba_simple_faster import linear_module
 from .mamba_simple_masked_faster import Mamba_masked
 from .vim import create_block
 
@@ -253,7 +254,7 @@ class MaskedAutoencoderViM(nn.Module):
         return self._final_norm(self.norm_f, hidden_states, residual), mask, ids_restore
 
     def forward_decoder(self, x, ids_restore, inference_params=None):
-        x = self.decoder_embed(x)
+        x = linear_module(self.decoder_embed, x)
         mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
         x = torch.cat([x, mask_tokens.to(x.dtype)], dim=1)
         x = torch.gather(x, dim=1, index=ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2]))    # unshuffle
@@ -262,7 +263,7 @@ class MaskedAutoencoderViM(nn.Module):
         for layer in self.decoder_blocks:
             x, residual = layer(x, residual, inference_params=inference_params)
         x = self._final_norm(self.decoder_norm, x, residual)
-        return self.decoder_pred(x)
+        return linear_module(self.decoder_pred, x)
 
     def forward_loss(self, imgs, pred, mask):
         """imgs (N, 3, H, W); pred (N, L, p*p*3); mask (N, L), 1 = removed: mean squared error on removed patches."""

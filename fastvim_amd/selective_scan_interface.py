@@ -178,8 +178,12 @@ def FastVim_mamba_inner_fn_no_out_proj_withoutZ(
         if scaling_factor != 1:
             pooled = pooled * scaling_factor
         Bsz, dim, Lc = pooled.shape
-        x_dbl = F.linear(pooled.transpose(1, 2).reshape(Bsz * Lc, dim), x_proj_weight.to(pooled.dtype))
-        delta = (delta_proj_weight.to(pooled.dtype) @ x_dbl[:, :delta_rank].t()).view(dim, Bsz, Lc).transpose(0, 1)
+        # x_proj / dt_proj through the build's own MFMA GEMMs (LinearFn: bf16 kernel where its alignment rules hold, the
+        # fp32-MFMA kernel otherwise) with their deterministic split-K weight gradients -- no library GEMM
+        from .mamba_simple_faster import LinearFn
+        x_dbl = LinearFn.apply(pooled.transpose(1, 2).reshape(Bsz * Lc, dim), x_proj_weight.to(pooled.dtype), pooled.dtype)
+        delta = LinearFn.apply(x_dbl[:, :delta_rank], delta_proj_weight.to(pooled.dtype), pooled.dtype)      # (B Lc, dim)
+        delta = delta.t().reshape(dim, Bsz, Lc).transpose(0, 1)
         if B is None:
             B = x_dbl[:, delta_rank:delta_rank + d_state]
             if B_proj_bias is not None:
@@ -221,8 +225,11 @@ def mamba_inner_fn_no_out_proj_withoutZ(x, conv1d_weight, conv1d_bias, x_proj_we
     with torch.autocast("cuda", enabled=False):
         conv_out = causal_conv1d_fn(x, conv1d_weight.reshape(conv1d_weight.shape[0], -1), conv1d_bias, activation="silu")
         Bsz, dim, L = conv_out.shape
-        x_dbl = F.linear(conv_out.transpose(1, 2).reshape(Bsz * L, dim), x_proj_weight.to(conv_out.dtype))   # (b l) d
-        delta = (delta_proj_weight.to(conv_out.dtype) @ x_dbl[:, :delta_rank].t()).view(dim, Bsz, L).transpose(0, 1)
+        from .mamba_simple_faster import LinearFn
+        x_dbl = LinearFn.apply(conv_out.transpose(1, 2).reshape(Bsz * L, dim), x_proj_weight.to(conv_out.dtype),
+                               conv_out.dtype)                                                                   # (b l) d
+        delta = LinearFn.apply(x_dbl[:, :delta_rank], delta_proj_weight.to(conv_out.dtype), conv_out.dtype)
+        delta = delta.t().reshape(dim, Bsz, L).transpose(0, 1)
         if B is None:                      # variable B (:826-838)
             B = x_dbl[:, delta_rank:delta_rank + d_state]
             if B_proj_bias is not None:

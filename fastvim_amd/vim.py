@@ -17,6 +17,7 @@ from .fastvim import (Block as _FastVimBlock, DropPath, PatchEmbed as _PatchEmbe
                       trunc_normal_)
 from .layernorm import RMSNorm, layer_norm_fn
 from .mamba_simple import Mamba
+from .mamba_simple_faster import linear_module
 
 
 class PatchEmbed(_PatchEmbed):
@@ -164,7 +165,7 @@ class VisionMamba(nn.Module):
         x = self.forward_features(x, inference_params)
         if return_features:
             return x
-        x = self.head(x)
+        x = linear_module(self.head, x)
         if self.final_pool_type == "max":
             x = x.max(dim=1)[0]
         return x

@@ -288,6 +288,18 @@ int fv_add_norm_bwd(const void* dy, int dy_dtype, const void* dresidual_out, int
 int fv_gemm_bf16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                  long ldb, long ldc, int a_k_slow, int b_k_slow, int c_fp32, int splits, fv_stream_t stream);
 
+/* fp32-MFMA GEMM (v_mfma_f32_16x16x4_f32), batched:  C_b[M][N] = sum_k A_b(m,k) B_b(k,n) (+ bias[n]),  b < batch.
+ * The projections in the reference's DEFAULT precision (fp32, imagenet_classification/train.py:17) -- F.linear / matmul /
+ * bmm behind in_proj, x_proj, out_proj, patch embed, head and their adjoints (mamba_simple_faster.py:189-193, 321-327,
+ * 435-444; models/fastvim.py:95, 537) -- and every shape fv_gemm_bf16 does not take (odd extents, unaligned rows).
+ * Operand layouts as fv_gemm_bf16 (a_k_slow / b_k_slow); operands FV_F32 or FV_BF16 (widened exactly), C FV_F32 or
+ * FV_BF16, fp32 accumulate in K order; any M, N, K, leading dimensions and alignment.  Batch b uses A + b*strideA,
+ * B + b*strideB, C + b*strideC (elements): both scan directions of x_proj in one launch, or the K slices of a deterministic
+ * split-K weight gradient (C = fp32 partials for fv_reduce_partials). */
+int fv_gemm_f32(const void* A, int a_dtype, const void* B, int b_dtype, void* C, int c_dtype, const float* bias, int M,
+                int N, int K, long lda, long ldb, long ldc, int a_k_slow, int b_k_slow, int batch, long strideA,
+                long strideB, long strideC, fv_stream_t stream);
+
 /* out_proj fused with the NEXT block's residual add + RMSNorm (mamba_simple_faster.py:435-444 followed by
  * models/fastvim.py:168-190 / layernorm.py:66-121):
  *   h = bf16_round(A W^T);  r = residual + row_scale[row / rows_per_scale] * h;  residual_out = r (fp32);

@@ -15,7 +15,39 @@ from .conv import causal_conv1d_oracle
 from .scan import selective_scan_oracle
 
 
-def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd, rq=None):
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose GRADIENT takes a round trip through ``dt``: marks a tensor whose gradient the HIP path stores in
+    the compute dtype (the output of a bf16 GEMM, a bf16 tensor written by a backward kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+class _XProjStorage(torch.autograd.Function):
+    """x_dbl = pooled @ round(Wx)^T as the HIP path differentiates it under autocast: the data gradient multiplies the
+    fp32 gradient rows by the fp32 MASTER weight (fv_mixer_xproj_bwd2 reads the parameter, not its bf16 shadow), the
+    weight gradient multiplies the bf16-ROUNDED gradient rows by the stored pooled rows (it joins the grouped bf16 GEMM,
+    as the reference's autocast backward does)."""
+
+    @staticmethod
+    def forward(ctx, pooled2, Wx, dt):
+        ctx.save_for_backward(pooled2, Wx)
+        ctx.dt = dt
+        return pooled2 @ Wx.to(dt).to(Wx.dtype).t()
+
+    @staticmethod
+    def backward(ctx, g):
+        pooled2, Wx = ctx.saved_tensors
+        return g @ Wx, g.to(ctx.dt).to(g.dtype).t() @ pooled2, None
+
+
+def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd, rq=None, rgrad=None):
     """One scan direction.  x_bdl: (B, d_in, L) in compute dtype.
     Returns out (B, d_in, L) = expand(scan(pool(conv(x)))) + D * conv(x); with ``rq`` (a storage-rounding function,
     see fastvim_mixer_oracle) the pair (expand(scan(...)), D * conv(x)) with the pooled tensor and x_dbl rounded where
@@ -44,9 +76,12 @@ def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd, r
     Wdt = p[f"dt_proj{sfx}.weight"].to(cd)
     R = Wdt.shape[1]
     N = (Wx.shape[0] - R) // 2
-    if rq is not None:
-        Wx = rq(Wx)                                                      # bf16 shadow weight
-    x_dbl = pooled.permute(0, 2, 1).reshape(Bsz * Lc, d_in) @ Wx.t()    # (B*Lc, R+2N)
+    if rgrad is not None:                                                # storage-rounded forward AND backward
+        x_dbl = _XProjStorage.apply(pooled.permute(0, 2, 1).reshape(Bsz * Lc, d_in), Wx, rgrad)
+    else:
+        if rq is not None:
+            Wx = rq(Wx)                                                  # bf16 shadow weight
+        x_dbl = pooled.permute(0, 2, 1).reshape(Bsz * Lc, d_in) @ Wx.t()    # (B*Lc, R+2N)
     if rq is not None:
         x_dbl = rq(x_dbl)                                                # stored in the compute dtype
     dt = (x_dbl[:, :R] @ Wdt.t()).reshape(Bsz, Lc, d_in).permute(0, 2, 1)
@@ -65,7 +100,7 @@ def _direction(x_bdl, p, sfx, rows, cols, tpp, collapse, scaling, reverse, cd, r
 
 def fastvim_mixer_oracle(p, hidden, token_size, tokens_per_patch=1, collapse_method="mean",
                          scaling_factor=1, use_norm_after_ssm=True, ln_eps=1e-5,
-                         compute_dtype=torch.float64, out_dtype=None, storage_dtype=None):
+                         compute_dtype=torch.float64, out_dtype=None, storage_dtype=None, round_grads=False):
     """p: dict of tensors keyed like the reference mixer's state_dict
     (``in_proj.weight``, ``conv1d.weight`` (d_in,1,W), ``conv1d.bias``, ``x_proj.weight``,
     ``dt_proj.weight``, ``dt_proj.bias``, ``A_log``, ``D``, the same with ``_b``,
@@ -75,7 +110,12 @@ def fastvim_mixer_oracle(p, hidden, token_size, tokens_per_patch=1, collapse_met
     ``compute_dtype``, with a round trip through ``storage_dtype`` at every tensor the HIP path STORES in it: the
     input, the projection weights (bf16 shadows), xz, the pooled conv output xc, x_dbl, the skip term
     D*conv_f + D_b*conv_b (rounded once), the gated output g and the result.  Lets a bf16 parity test use a
-    tolerance of a few bf16 ulps instead of percent-level bounds."""
+    tolerance of a few bf16 ulps instead of percent-level bounds.
+    ``round_grads`` (with ``storage_dtype``): the same for the BACKWARD pass -- autograd through this function then rounds
+    the gradient wherever the HIP backward stores it in the compute dtype: d g (out_proj's data gradient), d xz (both
+    halves, written by combine_bwd / conv_pool_bwd), the gradient of the skip term (d_o; the pooled gradient dyc is
+    accumulated in fp32 BEFORE that rounding, csrc/combine_wave.hip), and x_proj as ``_XProjStorage`` describes.  The
+    caller rounds d hidden (the in_proj data gradient is a bf16 GEMM output)."""
     cd = compute_dtype
     out_dtype = hidden.dtype if out_dtype is None else out_dtype
     rows, cols = token_size
@@ -83,6 +123,8 @@ def fastvim_mixer_oracle(p, hidden, token_size, tokens_per_patch=1, collapse_met
     Bsz, L, d = hidden.shape
     assert L == rows * cols * tpp
     rq = None if storage_dtype is None else (lambda t: t.to(storage_dtype).to(cd))
+    rgrad = storage_dtype if (round_grads and storage_dtype is not None) else None
+    rg = (lambda t: _RoundGrad.apply(t, storage_dtype)) if rgrad is not None else (lambda t: t)
     W_in = p["in_proj.weight"].to(cd)
     W_out = p["out_proj.weight"].to(cd)
     hid = hidden.to(cd)
@@ -93,20 +135,20 @@ def fastvim_mixer_oracle(p, hidden, token_size, tokens_per_patch=1, collapse_met
     if p.get("in_proj.bias") is not None:
         xz = xz + p["in_proj.bias"].to(cd)
     if rq is not None:
-        xz = rq(xz)
+        xz = rg(rq(xz))
     x = xz[..., :d_in].permute(0, 2, 1)                                  # (B, d_in, L)
     z = xz[..., d_in:]                                                   # (B, L, d_in)
-    out_f = _direction(x, p, "", rows, cols, tpp, collapse_method, scaling_factor, False, cd, rq)
-    out_b = _direction(x, p, "_b", rows, cols, tpp, collapse_method, scaling_factor, True, cd, rq)
+    out_f = _direction(x, p, "", rows, cols, tpp, collapse_method, scaling_factor, False, cd, rq, rgrad)
+    out_b = _direction(x, p, "_b", rows, cols, tpp, collapse_method, scaling_factor, True, cd, rq, rgrad)
     if rq is not None:                                                   # (y_f + y_b + round(D conv_f + D_b conv_b)) / 2
-        o = ((out_f[0] + out_b[0] + rq(out_f[1] + out_b[1])) / 2).permute(0, 2, 1)
+        o = ((out_f[0] + out_b[0] + rg(rq(out_f[1] + out_b[1]))) / 2).permute(0, 2, 1)
     else:
         o = ((out_f + out_b) / 2).permute(0, 2, 1)                       # :434-444
     if use_norm_after_ssm:
         o = F.layer_norm(o, (d_in,), p["layernorm.weight"].to(cd), p["layernorm.bias"].to(cd), ln_eps)
     g = o * F.silu(z)
     if rq is not None:
-        g = rq(g)
+        g = rg(rq(g))
     y = g @ W_out.t()
     if p.get("out_proj.bias") is not None:
         y = y + p["out_proj.bias"].to(cd)

@@ -154,6 +154,45 @@ def test_mixer_bf16_forward_within_ulps_of_storage_rounded_oracle(d_model, grid)
     assert _err(y, yr) <= 2 * 2.0 ** -8 * scale + 1e-6, (_err(y, yr), scale)
 
 
+@pytest.mark.parametrize("d_model,grid", [(192, (14, 14)), (768, (14, 14))])
+def test_mixer_bf16_backward_within_ulps_of_storage_rounded_oracle(d_model, grid):
+    """The backward twin of the test above.  The oracle differentiates its storage-rounded forward
+    with the gradient rounded wherever the HIP backward stores it in bf16 (d g, d xz, the skip gradient d_o; x_proj with
+    the fp32 master weight on the data side and bf16 gradient rows on the weight side -- oracle/mixer.py ``round_grads``),
+    so what is left is accumulation order and the occasional one-ulp flip of an intermediate: d hidden must agree with the
+    bf16-rounded oracle gradient to 2 bf16 ulps of its scale and 2e-3 in relative L2, every parameter gradient to 3e-3
+    in relative L2 (sums over 784 tokens of values that each carry a 2^-9 rounding) -- an order of magnitude below the
+    3e-2 of the unrounded comparison above."""
+    from fastvim_amd.mamba_simple_faster import Mamba
+    from oracle import fastvim_mixer_oracle
+    torch.manual_seed(7 * d_model + grid[0])
+    m = Mamba(d_model, token_size=list(grid)).cuda()
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if n in ("D", "D_b", "layernorm.weight") or n.endswith("bias"):
+                p_.add_(0.1 * torch.randn_like(p_))
+    sd = {k: v.detach().cpu().double().requires_grad_() for k, v in m.state_dict().items()}
+    Bsz = 4
+    h = torch.randn(Bsz, grid[0] * grid[1], d_model)
+    g = torch.randn(Bsz, grid[0] * grid[1], d_model).bfloat16()
+    hg = h.cuda().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(hg)
+    y.backward(g.cuda())
+    hr = h.double().requires_grad_()
+    yr = fastvim_mixer_oracle(sd, hr, grid, compute_dtype=F64, out_dtype=F64, storage_dtype=torch.bfloat16, round_grads=True)
+    yr.backward(g.double())
+    dh_ref = hr.grad.bfloat16().double()                      # the in_proj data gradient is a bf16 GEMM output
+    scale = dh_ref.abs().max().item()
+    assert _rel(hg.grad, dh_ref) <= 2e-3, _rel(hg.grad, dh_ref)
+    assert _err(hg.grad, dh_ref) <= 2 * 2.0 ** -8 * scale + 1e-6, (_err(hg.grad, dh_ref), scale)
+    worst = {}
+    for n, q in m.named_parameters():
+        worst[n] = _rel(q.grad, sd[n].grad)
+    bad = {n: r for n, r in worst.items() if r > 3e-3}
+    assert not bad, (bad, worst)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_mixer_b_128x128_vs_oracle(dtype):
     """BASELINE config 4 geometry: d_model 768 on the 128 x 128 token grid (16 384 tokens, pooled scan length 128),
@@ -301,34 +340,41 @@ def test_fused_xproj_scan_fwd_short(Bsz, Lc, d_in, R):
 
 
 # --------------------------------------------------------------------------- full-size configs: properties + graph replay
-_FULL = {        # BASELINE configs -> (factory name, image size, per-GPU batch, drop_path)
-    "cfg2_FastVimT_224_bs128": ("FastVimT", 224, 128, 0.05),
-    "cfg3_FastVimB_224_bs128": ("FastVimB", 224, 128, 0.4),
-    "cfg4_FastVimB_2048_bs8": ("FastVimB", 2048, 8, 0.4),
+_FULL = {        # BASELINE configs -> (module, factory name, image size, per-GPU batch, drop_path, input channels, factory kwargs)
+    "cfg2_FastVimT_224_bs128": ("fastvim", "FastVimT", 224, 128, 0.05, 3, {}),
+    "cfg3_FastVimB_224_bs128": ("fastvim", "FastVimB", 224, 128, 0.4, 3, {}),
+    "cfg4_FastVimB_2048_bs8": ("fastvim", "FastVimB", 2048, 8, 0.4, 3, {}),
+    # config 5: FastChannelVim-S/16 on 8-channel images, hierarchical channel sampling off so that L = 196 * 8 is fixed
+    "cfg5_FastChannelVimS16_8ch_224_bs64": ("models_channel_mamba_faster",
+                                            "channelvim_small_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2",
+                                            224, 64, 0.1, 8, {"channels": 8, "hcs": False}),
+    # the un-pooled Vim-T baseline: 197-step scans on the chunked kernels, forward checkpoints handed over
+    "f2_VimT_224_bs128": ("vim", "vim_tiny_patch16_224_final_pool_mean_abs_pos_embed_with_midclstok_div2", 224, 128, 0.05, 3, {}),
 }
 
 
 @pytest.mark.parametrize("cfg", sorted(_FULL))
 def test_full_size_step_graph_replay_equals_eager(cfg):
-    """The benchmarked training step at the FULL size of BASELINE configs 2, 3 and 4 (bf16 autocast, train mode with
+    """The benchmarked training step at the FULL size of BASELINE configs 2, 3, 4, 5 and of the Vim-T baseline (bf16 autocast, train mode with
     the config's DropPath rate, soft-target cross-entropy, backward, fused AdamW + EMA on the flat training state):
     finite, bitwise reproducible run to run, and 10 HIP-graph replays bitwise equal to 12 eager steps (2 warm-up +
     10) of an identically initialised copy -- under DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, the setting fastvim_amd applies
     on import and bench.py runs with."""
+    import importlib
     import fastvim_amd
-    from fastvim_amd import fastvim as fv
     from fastvim_amd.flat import FlatAdamW, FlatTrainingState
     from fastvim_amd.losses import SoftTargetCrossEntropy
     assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and fastvim_amd.graph_capture_safe()
-    name, img, bs, dpr = _FULL[cfg]
+    modname, name, img, bs, dpr, in_ch, kw = _FULL[cfg]
+    fv = importlib.import_module("fastvim_amd." + modname)
     n_replay = 10
     crit = SoftTargetCrossEntropy()
-    x = torch.randn(bs, 3, img, img, generator=torch.Generator().manual_seed(1)).cuda()
+    x = torch.randn(bs, in_ch, img, img, generator=torch.Generator().manual_seed(1)).cuda()
     tgt = torch.softmax(torch.randn(bs, 1000, generator=torch.Generator().manual_seed(2)), -1).cuda()
 
     def make():
         torch.manual_seed(1234)
-        m = getattr(fv, name)(img_size=img, drop_path_rate=dpr).cuda().train()
+        m = getattr(fv, name)(img_size=img, drop_path_rate=dpr, **kw).cuda().train()
         flat = FlatTrainingState(m)
         nd = {n for n, p in m.named_parameters() if p.ndim <= 1 or n.endswith(".bias") or n in m.no_weight_decay()
               or getattr(p, "_no_weight_decay", False)}

@@ -173,3 +173,62 @@ def test_grouped_weight_gradients_tile_classes():
         got = out.view(ref.shape)
         assert (got.double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
         assert torch.equal(got, single)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 192), (392, 44, 384), (25088, 192, 384), (130, 72, 41),
+                                   (7, 5, 3), (128, 1000, 192), (3584, 80, 1536), (8, 1000, 768)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_f32_mfma_all_layouts(M, N, K, dt):
+    """fv_gemm_f32 (v_mfma_f32_16x16x4_f32; csrc/gemm_f32.hip) against fp64 matmul of the same operands: the three
+    layouts the projections use (x W^T, g W, X^T Y) plus the fourth, fp32 and bf16 operands, bias epilogue, shapes with
+    no alignment at all.  fp32 accumulate in K order: error <= K * 2^-23 of the sum of |products| (checked as 3e-6
+    relative to the result scale -- a library GEMM is no tighter)."""
+    from fastvim_amd.gemm import gemm_any_nn, gemm_any_nt, gemm_any_tn, gemm_f32
+    torch.manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, device="cuda").to(dt)
+    w = torch.randn(N, K, device="cuda").to(dt)
+    bias = torch.randn(N, device="cuda")
+    ref = _ref(a, w.t())
+    scale = max(1.0, ref.abs().max().item())
+    tol = 3e-6 * scale * max(1.0, (K / 64) ** 0.5)
+    c = gemm_any_nt(a, w, out_dtype=torch.float32)
+    assert c.dtype == torch.float32 and (c.double().cpu() - ref).abs().max().item() <= tol
+    cb = gemm_any_nt(a, w, bias=bias, out_dtype=torch.float32)
+    assert (cb.double().cpu() - (ref + bias.double().cpu())).abs().max().item() <= tol
+    c2 = gemm_any_nn(a, w.t().contiguous(), out_dtype=torch.float32)                     # B (K, N) as stored
+    assert (c2.double().cpu() - ref).abs().max().item() <= tol
+    if dt == torch.bfloat16:                                                               # bf16 C: one rounding of the fp32 result
+        c16 = gemm_any_nt(a, w)
+        assert c16.dtype == torch.bfloat16 and torch.equal(c16, c.bfloat16())
+    # X^T Y: x (Kd, M), y (Kd, N)
+    x, y = a.t().contiguous(), w.t().contiguous()
+    for sp in (1, 2):
+        part = gemm_any_tn(x, y, sp)
+        assert (part.sum(0).double().cpu() - ref).abs().max().item() <= tol
+    # the fourth layout (A K-slow, B K-contiguous), and row strides larger than the extents
+    ap = torch.zeros(K, M + 5, device="cuda", dtype=dt)
+    ap[:, :M] = x
+    wp = torch.zeros(N, K + 3, device="cuda", dtype=dt)
+    wp[:, :K] = w
+    c4 = torch.empty(M, N, device="cuda")
+    gemm_f32(ap, wp, c4, None, M, N, K, M + 5, K + 3, N, 1, 0)
+    assert (c4.double().cpu() - ref).abs().max().item() <= tol
+    # deterministic: bitwise the same on a second launch
+    assert torch.equal(gemm_any_nt(a, w, out_dtype=torch.float32), c)
+
+
+def test_gemm_f32_batched_forms():
+    from fastvim_amd.gemm import gemm_any_bnn, gemm_any_bnt, gemm_any_btn
+    torch.manual_seed(3)
+    a = torch.randn(2, 1792, 384, device="cuda")
+    w = torch.randn(2, 44, 384, device="cuda")
+    ref = torch.bmm(a.double().cpu(), w.double().cpu().transpose(1, 2))
+    got = gemm_any_bnt(a, w)
+    assert (got.double().cpu() - ref).abs().max().item() <= 1e-4
+    g = torch.randn(2, 1792, 44, device="cuda")
+    ref2 = torch.bmm(g.double().cpu(), w.double().cpu())
+    assert (gemm_any_bnn(g, w).double().cpu() - ref2).abs().max().item() <= 1e-4
+    ref3 = torch.bmm(g.double().cpu().transpose(1, 2), a.double().cpu())
+    assert (gemm_any_btn(g, a.bfloat16()).double().cpu()
+            - torch.bmm(g.double().cpu().transpose(1, 2), a.bfloat16().double().cpu())).abs().max().item() <= 2e-3
+    assert (gemm_any_btn(g, a).double().cpu() - ref3).abs().max().item() <= 2e-3

@@ -1,0 +1,16 @@
+"""One configuration's step time with Python-side knobs set from the command line (C-side knobs: FASTVIM_* environment
+variables of a tuning build).  usage: python tools/probe/ab_step.py MODEL IMG BATCH STEPS [--presum N]"""
+import json, os, sys
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+import torch
+import bench
+from fastvim_amd import mixer_ops
+a = sys.argv[1:]
+model, img, batch, steps = a[0], int(a[1]), int(a[2]), int(a[3])
+if "--presum" in a:
+    mixer_ops._XPROJ_PRESUM = int(a[a.index("--presum") + 1])
+torch.cuda.set_device(0)
+el, lv, ex = bench.run_training_steps(model, img, batch, 8, "bf16", steps, 3, 0, 1, torch.device("cuda", 0))
+print(json.dumps({"ms_per_step": round(el / steps * 1e3, 3), "loss": round(lv, 4)}))
