@@ -304,6 +304,34 @@ def kernel_table(B, rows, cols, d, depth, dtype):
     return out
 
 
+# kernel-table row -> name prefix of the kernel in a rocprofv3 kernel trace of the graph-replayed step
+TRACE_NAMES = {
+    "conv_pool_fwd": "conv_pool_fwd_row_kernel", "scan_fwd": "xproj_scan_fwd_short_kernel", "combine_fwd": "combine_fwd_wave_kernel",
+    "combine_bwd": "combine_bwd_wave_kernel", "scan_bwd": "scan_cl_bwd_short_kernel", "conv_pool_bwd": "conv_pool_bwd_row_kernel",
+    "add_rmsnorm_fwd": "add_norm_fwd3_kernel", "gemm_out_proj_addnorm_fwd": "gemm_addnorm_kernel",
+    "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 4>",
+}
+PMC_TRAFFIC_JSON = "r03_v2_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
+STEP_TRACE_CSV = "r03_v2_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r03_v2 (profiles/README.md)
+
+
+def in_step_trace_us():
+    """Average duration of each table row's kernel INSIDE the replayed FastVim-T step, from the committed rocprofv3
+    kernel trace (profiles/): what the HBM-cold `us` of the table should agree with.  {} when the file is absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", STEP_TRACE_CSV)
+    if not os.path.exists(path):
+        return {}
+    rows = list(csv.DictReader(open(path)))
+    out = {}
+    for key, prefix in TRACE_NAMES.items():
+        for r in rows:
+            if r["Name"].startswith(prefix):
+                out[key] = round(float(r["AverageNs"]) / 1e3, 2)
+                break
+    return out
+
+
 # --------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(seconds_budget=15.0):
     """The CPU oracle (port of the reference's pure-PyTorch FastVim path incl. selective_scan_ref)
@@ -716,10 +744,14 @@ def main():
         if not args.no_kernels and args.model not in ("C", "V", "M"):
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
             dom = max(kt, key=lambda k: kt[k]["us_per_step"])     # the kernel that costs the most time per step
+            if (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16"):
+                for k_, v_ in in_step_trace_us().items():         # the same kernel inside the step (committed rocprofv3 trace)
+                    if k_ in kt:
+                        kt[k_]["us_in_step_trace"] = v_
             out["kernels"] = kt
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_v6_pmc_traffic.json")))["kernels"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_JSON)))["kernels"]
                 if (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16") and dom in pm:
                     traffic = pm[dom]["traffic_bytes"]
             except (OSError, KeyError, ValueError):
@@ -731,6 +763,7 @@ def main():
                                # avg_us is HBM-cold (operand sets rotated past the 256 MB Infinity Cache, as the step sees
                                # the kernel); the cache-resident repeat of one operand set is kept beside it
                                "timing": "hbm_cold_rotating_operands", "operand_sets": kt[dom].get("operand_sets"),
+                               "avg_us_in_step_trace": kt[dom].get("us_in_step_trace"),
                                "avg_us_warm": kt[dom].get("us_warm"),
                                "frac_warm": (round(kt[dom]["algorithmic_MB"] * 1e6 / (kt[dom]["us_warm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                                              if kt[dom].get("us_warm") else None)}

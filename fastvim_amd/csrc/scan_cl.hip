@@ -42,6 +42,12 @@ struct ScanClParams {
   float* pP;             // (B / NBB, 2, d_in*(N+R+1)) partials, per direction [dA_log | d dt_w | d dt_bias]
   int B, Lc, d_in, R;
   int NBB;               // backward: batch elements one block walks (its parameter-gradient partial covers them all)
+  // segment-parallel forward (long sequences, few batch elements): time is cut into `seg` runs of whole 16-step chunks
+  // that are scanned side by side (grid.y = B * seg)
+  int seg;               // 0 / 1: the whole sequence per workgroup
+  float* hend;           // (2, B, seg, d_in, N)  pass A out: state a segment reaches from a zero start
+  float* sumdt;          // (2, B, seg, d_in)     pass A out: sum of delta over the segment (its decay is exp(A * sum))
+  const float* hin;      // (2, B, seg, d_in, N)  pass C in: state entering the segment
 };
 
 
@@ -1057,7 +1063,15 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
 // on the fp32 matrix cores and softplus once per (step, channel) -- the generic kernel does dt_rank / 4 FMAs and a
 // softplus per state-quad lane and step -- then the recurrence in registers.  The state leaving a chunk goes to `ckpt`
 // when the backward pass will want it.
-template <typename T, int RQ>
+// Few batch elements and a long sequence (un-pooled Vim at 2048 px: L = 16 385, batch 8 -- 96 workgroups walking 1 025
+// chunks each) leave the chip idle; the recurrence h_t = a_t h_{t-1} + b_t is linear in the state, so time is cut into
+// `seg` segments scanned side by side in three launches:
+//   A (STATE_ONLY): every segment from a zero state -> the state it reaches (hend) and sum of delta over it (its total
+//     decay is exp(A * sum delta), one number per channel);
+//   B (scan_seg_combine_kernel): the states entering the segments, serially over the few segments, per (channel, state);
+//   C: every segment again from its true entry state -> y and the per-chunk checkpoints, exactly the serial kernel's.
+// Twice the arithmetic on seg times the workgroups.
+template <typename T, int RQ, bool STATE_ONLY = false>
 __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p) {
   constexpr int NWV = 4, CH = 64, LCT = 16, NTH = 256;
   constexpr int RQP = (RQ + 3) / 4 * 4, WP = 4 * RQP + 2 * N;
@@ -1065,8 +1079,11 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
   __shared__ __attribute__((aligned(16))) float s_dbl[2][LCT * WP];
   __shared__ __attribute__((aligned(16))) float s_ch[LCT * CH * 2];       // {delta, delta * u}
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int dir = blockIdx.z, b = blockIdx.y, ch0 = blockIdx.x * CH;
+  const int nseg = p.seg > 1 ? p.seg : 1;
+  const int dir = blockIdx.z, b = blockIdx.y / nseg, sgi = blockIdx.y - b * nseg, ch0 = blockIdx.x * CH;
   const int W = p.R + 2 * N, Lc = p.Lc, nchunk = (Lc + LCT - 1) / LCT;
+  const int cps = (nchunk + nseg - 1) / nseg, c0 = sgi * cps, c1 = min(nchunk, c0 + cps);      // this workgroup's chunks
+  if (c0 >= c1) return;
   const size_t bd = ((size_t)dir * p.B + b) * Lc;
   // scan role
   const int q = lane & 3, ch = wv * 16 + (lane >> 2), d = ch0 + ch;
@@ -1126,11 +1143,17 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
       if (e < LCT * WP) s_dbl[buf][e] = pre[i];
     }
   };
-  fetch(0);
-  put(0);
+  fetch(c0);
+  put(c0 & 1);
   __syncthreads();
   sf2 st[2] = {{0.f, 0.f}, {0.f, 0.f}};
-  for (int c = 0; c < nchunk; ++c) {
+  const size_t sidx = (((size_t)dir * p.B + b) * nseg + sgi) * p.d_in + dd;      // (dir, b, segment, channel)
+  if (!STATE_ONLY && p.hin && act) {
+    const float4 h0 = *reinterpret_cast<const float4*>(p.hin + sidx * N + q * 4);
+    st[0].x = h0.x; st[0].y = h0.y; st[1].x = h0.z; st[1].y = h0.w;
+  }
+  float sdt = 0.f;
+  for (int c = c0; c < c1; ++c) {
     const int buf = c & 1;
     const int valid = min(LCT, Lc - c * LCT);
     // delta of this chunk: its inputs are in registers / LDS
@@ -1146,7 +1169,7 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
         *reinterpret_cast<float2*>(s_ch + ((size_t)s * CH + wv * 16 + cm) * 2) = make_float2(dt, dt * um[r]);
       }
     }
-    if (c + 1 < nchunk) fetch(c + 1);          // in flight under the recurrence
+    if (c + 1 < c1) fetch(c + 1);          // in flight under the recurrence
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();           // the table columns of this wave's 16 channels are read by this wave only
@@ -1160,21 +1183,52 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
         const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
         const float2 cv = *reinterpret_cast<const float2*>(my_ch + s * (CH * 2));
         const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
-        sf2 acc = {0.f, 0.f};
+        if constexpr (STATE_ONLY) {
+          sdt += cv.x;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
-          acc = sfma2(Cn[h], st[h], acc);
+          for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
+        } else {
+          sf2 acc = {0.f, 0.f};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
+            acc = sfma2(Cn[h], st[h], acc);
+          }
+          const float yv = quad_sum(acc.x + acc.y);
+          const int sg = c * LCT + s, l = dir ? Lc - 1 - sg : sg;
+          if (act && q == 0) y[(size_t)l * p.d_in] = yv;
         }
-        const float yv = quad_sum(acc.x + acc.y);
-        const int sg = c * LCT + s, l = dir ? Lc - 1 - sg : sg;
-        if (act && q == 0) y[(size_t)l * p.d_in] = yv;
       }
     }
-    if (ck && c + 1 < nchunk && act)
+    if (!STATE_ONLY && ck && c + 1 < nchunk && act)
       *reinterpret_cast<float4*>(ck + (size_t)(c + 1) * p.d_in * N) = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
-    if (c + 1 < nchunk) put(buf ^ 1);          // the other buffer's readers passed the barrier of the previous chunk
+    if (c + 1 < c1) put(buf ^ 1);          // the other buffer's readers passed the barrier of the previous chunk
     __syncthreads();
+  }
+  if constexpr (STATE_ONLY) {
+    if (act) {
+      *reinterpret_cast<float4*>(p.hend + sidx * N + q * 4) = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
+      if (q == 0) p.sumdt[sidx] = sdt;
+    }
+  }
+}
+
+// Pass B of the segment-parallel forward: thread = (direction, batch element, channel, state); the state entering segment
+// s + 1 is exp(A * sum delta of s) * (state entering s) + (state s reaches from zero).
+__global__ __launch_bounds__(256) void scan_seg_combine_kernel(ScanClParams p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)p.d_in * N, total = (size_t)2 * p.B * per;
+  if (i >= total) return;
+  const int n = (int)(i % N), d = (int)((i / N) % p.d_in);
+  const size_t db = i / per;                    // dir * B + b
+  const int dir = (int)(db / p.B);
+  const float A = -__expf(p.Alog[dir][(size_t)d * N + n]);
+  float* hin = const_cast<float*>(p.hin);
+  float H = 0.f;
+  for (int s = 0; s < p.seg; ++s) {
+    const size_t sidx = (db * p.seg + s) * p.d_in + d;
+    hin[sidx * N + n] = H;
+    H = fmaf(__expf(A * p.sumdt[sidx]), H, p.hend[sidx * N + n]);
   }
 }
 
@@ -1372,10 +1426,36 @@ extern "C" int fv_mixer_scan_fwd(const void* xc, const void* x_dbl, const float*
                                 dt_rank, d_state, dtype, stream);
 }
 
+// Segments of the segment-parallel forward: enough to put ~1024 workgroups on the chip, at least 8 chunks each; 1 (the
+// serial kernel) when the launch fills the chip anyway or the sequence is short.
+extern "C" int fv_mixer_scan_fwd_segments(int batch, int Lc, int d_inner, int dt_rank) {
+  static const int force = fv_tune("FASTVIM_SCAN_FWD_SEG", 0);   // tuning hook: > 0 fixed segment count (1 = serial)
+  const int nchunk = (Lc + 15) / 16;
+  if (Lc <= 16 || dt_rank > 48) return 1;
+  if (force > 0) return force < nchunk ? force : nchunk;
+  const long wgs = (long)fv_cdiv(d_inner, CPB) * batch * 2;
+  if (wgs >= 512 || nchunk < 16) return 1;
+  long s = (1024 + wgs - 1) / wgs;
+  if (s > nchunk / 8) s = nchunk / 8;
+  return (int)(s < 1 ? 1 : s);
+}
+extern "C" size_t fv_mixer_scan_fwd_seg_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank) {
+  const int S = fv_mixer_scan_fwd_segments(batch, Lc, d_inner, dt_rank);
+  return S > 1 ? (size_t)2 * batch * S * d_inner * (2 * d_state + 1) : 0;
+}
+
 extern "C" int fv_mixer_scan_fwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
                                       const float* A_log, const float* dt_w_b, const float* dt_bias_b,
                                       const float* A_log_b, float* yc, float* ckpt, int batch, int Lc, int d_inner,
                                       int dt_rank, int d_state, int dtype, fv_stream_t stream) {
+  return fv_mixer_scan_fwd_seg(xc, x_dbl, dt_w, dt_bias, A_log, dt_w_b, dt_bias_b, A_log_b, yc, ckpt, nullptr, batch, Lc, d_inner,
+                               dt_rank, d_state, dtype, stream);
+}
+
+extern "C" int fv_mixer_scan_fwd_seg(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                     const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                     const float* A_log_b, float* yc, float* ckpt, float* seg_ws, int batch, int Lc,
+                                     int d_inner, int dt_rank, int d_state, int dtype, fv_stream_t stream) {
   FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_fwd: empty dimension");
   FV_CHECK(dtype == FV_F32 || dtype == FV_BF16, "mixer_scan_fwd: dtype must be fp32 or bf16");
   FV_CHECK(d_state == N, "mixer_scan_fwd: only d_state == 16 is built (got %d)", d_state);
@@ -1396,13 +1476,26 @@ extern "C" int fv_mixer_scan_fwd_ckpt(const void* xc, const void* x_dbl, const f
   // round-1 kernel (delta per state-quad lane)
   static const int fwd_short_ck = fv_tune("FASTVIM_SCAN_FWD_SHORT_CK", 0);   // A/B hook
   if (fwd_chunked && (Lc > 16 || fwd_short_ck) && dt_rank <= 48) {
-#define FV_FC(TT)                                                                            \
+    const int S = seg_ws ? fv_mixer_scan_fwd_segments(batch, Lc, d_inner, dt_rank) : 1;
+#define FV_FC(TT, SO)                                                                        \
   do {                                                                                       \
-    if (RQ <= 3) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 3>), grid, block, 0, st, p);        \
-    else if (RQ <= 6) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 6>), grid, block, 0, st, p);   \
-    else hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 12>), grid, block, 0, st, p);               \
+    if (RQ <= 3) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 3, SO>), grid, block, 0, st, p);        \
+    else if (RQ <= 6) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 6, SO>), grid, block, 0, st, p);   \
+    else hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 12, SO>), grid, block, 0, st, p);               \
   } while (0)
-    if (dtype == FV_F32) FV_FC(float); else FV_FC(bf16_t);
+    if (S > 1) {
+      // segment-parallel: A (states the segments reach from zero) -> B (states entering them) -> C (the scan proper)
+      const size_t nst = (size_t)2 * batch * S * d_inner;
+      p.seg = S;
+      p.hend = seg_ws;
+      p.sumdt = seg_ws + nst * N;
+      float* hin = seg_ws + nst * (N + 1);
+      grid = dim3(fv_cdiv(d_inner, CPB), batch * S, 2);
+      if (dtype == FV_F32) FV_FC(float, true); else FV_FC(bf16_t, true);
+      p.hin = hin;
+      hipLaunchKernelGGL(scan_seg_combine_kernel, dim3(fv_cdiv((long)2 * batch * d_inner * N, 256)), dim3(256), 0, st, p);
+    }
+    if (dtype == FV_F32) FV_FC(float, false); else FV_FC(bf16_t, false);
 #undef FV_FC
     FV_LAUNCH_CHECK();
     return FV_OK;

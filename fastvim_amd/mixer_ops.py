@@ -47,9 +47,12 @@ def scan_fwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, want_ckpt=Fa
     if want_ckpt:
         nck = lib.fv_mixer_scan_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R))
         ckpt = torch.empty(nck, device=xc.device, dtype=torch.float32) if nck else None
-    rc = lib.fv_mixer_scan_fwd_ckpt(
+    # long sequences on few batch elements (un-pooled Vim at high resolution): segments of the sequence side by side
+    nws = lib.fv_mixer_scan_fwd_seg_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R))
+    ws = torch.empty(nws, device=xc.device, dtype=torch.float32) if nws else None
+    rc = lib.fv_mixer_scan_fwd_seg(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
-        L.ptr(A_log_b), L.ptr(yc), L.ptr(ckpt), L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N),
+        L.ptr(A_log_b), L.ptr(yc), L.ptr(ckpt), L.ptr(ws), L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N),
         L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
     L.check(rc, "mixer_scan_fwd")
     return (yc, ckpt) if want_ckpt else yc
@@ -291,7 +294,8 @@ def xproj_fwd(xc, Wx2_c):
     return out
 
 
-_XPROJ_PRESUM = 16      # chunk count from which dx_dbl is summed by the reduction kernel first
+_XPROJ_PRESUM = 8       # chunk count from which dx_dbl is summed by the reduction kernel first (FastVim-B: 8 chunks of 192
+                        # channels; same box 30.85 -> 30.78 ms per step, twice; 16 in round 2)
 
 
 def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True):
@@ -303,7 +307,7 @@ def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True):
     d_in = xc.shape[-1]
     lib = L.lib()
     # every 128-channel block of the adjoint kernel re-sums the chunk partials of its rows: nchunks x d_in / 128 reads
-    # of each row (24 x 12 at FastVim-B, 330 MB).  From 16 chunks up (d_inner >= 1024) they are summed once, by the reduction
+    # of each row (8 x 12 at FastVim-B with the short kernel's 192-channel chunks).  From 8 chunks up they are summed once, by the reduction
     # kernel: FastVim-B 37.2 -> 36.6 ms per step; neutral to slightly worse at 12 chunks (FastVim-S), so not there.
     if nchunks >= _XPROJ_PRESUM:
         dx_dbl_chunks = reduce_partials(dx_dbl_chunks, nchunks, defer=False).view(1, 2, Mrows, W)

@@ -205,7 +205,7 @@ class MaskedAutoencoderViM(nn.Module):
         assert imgs.shape[2] == imgs.shape[3] and imgs.shape[2] % p == 0
         h = w = imgs.shape[2] // p
         x = imgs.reshape(imgs.shape[0], 3, h, p, w, p)
-        x = torch.einsum("nchpwq->nhwpqc", x)
+        x = x.permute(0, 2, 4, 3, 5, 1)                 # "nchpwq->nhwpqc": a pure permutation, no contraction
         return x.reshape(imgs.shape[0], h * w, p ** 2 * 3)
 
     def unpatchify(self, x):
@@ -214,7 +214,7 @@ class MaskedAutoencoderViM(nn.Module):
         h = w = int(x.shape[1] ** 0.5)
         assert h * w == x.shape[1]
         x = x.reshape(x.shape[0], h, w, p, p, 3)
-        x = torch.einsum("nhwpqc->nchpwq", x)
+        x = x.permute(0, 5, 1, 3, 2, 4)                 # "nhwpqc->nchpwq"
         return x.reshape(x.shape[0], 3, h * p, h * p)
 
     def random_masking(self, x, mask_ratio, noise=None):

@@ -144,6 +144,18 @@ int fv_mixer_scan_fwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w,
                            const float* A_log, const float* dt_w_b, const float* dt_bias_b,
                            const float* A_log_b, float* yc, float* ckpt, int batch, int Lc, int d_inner, int dt_rank,
                            int d_state, int dtype, fv_stream_t stream);
+/* Segment-parallel form for long sequences on few batch elements (the un-pooled Vim baseline at 2048 px: 16 385 steps,
+ * batch 8; mamba_simple.py:210-255 -- the reference scans it with a parallel scan over L,
+ * selective_scan_fwd_kernel.cuh:67-345): time is cut into fv_mixer_scan_fwd_segments() runs of whole 16-step chunks that
+ * are scanned side by side -- states reached from zero, a serial combine over the segments, then the scan proper from the
+ * true entry states (the recurrence is linear in the state).  seg_ws: fv_mixer_scan_fwd_seg_floats() fp32 of workspace
+ * (0 = one segment: pass NULL, the call is fv_mixer_scan_fwd_ckpt).  yc / ckpt as there. */
+int fv_mixer_scan_fwd_segments(int batch, int Lc, int d_inner, int dt_rank);
+size_t fv_mixer_scan_fwd_seg_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank);
+int fv_mixer_scan_fwd_seg(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                          const float* A_log, const float* dt_w_b, const float* dt_bias_b, const float* A_log_b,
+                          float* yc, float* ckpt, float* seg_ws, int batch, int Lc, int d_inner, int dt_rank,
+                          int d_state, int dtype, fv_stream_t stream);
 
 /* x_proj + dt_proj + softplus + selective scan in ONE launch for short pooled lengths (Lc <= 16, bf16, dt_rank <= 48:
  * the 224 / 256 px grids): x_dbl (2, batch*Lc, dt_rank + 2*d_state) = xc @ x_proj_w2[dir]^T is computed on the matrix

@@ -249,6 +249,9 @@ def _scan_cl_case(Bsz, Lc, d_in, R, dtype, seed):
                                            (2, 37, 192, 6),         # ragged: last chunk 5 steps
                                            (2, 17, 384, 12),        # a second chunk of one step
                                            (1, 197, 384, 12),       # unpooled Vim-T: 12 chunks + 5 steps
+                                           (1, 4104, 192, 6),       # Lc >= 4096 (un-pooled Vim at 1024 px): 257 chunks; the
+                                                                    # forward launch runs segment-parallel (32 segments)
+                                           (2, 1000, 384, 12),      # 63 chunks in 7 segments of 9, ragged last chunk
                                            (64, 37, 384, 12),       # enough workgroups for the 12-wave form (192 channels)
                                            (64, 14, 1536, 48),      # short kernel walking 4 batch elements per workgroup
                                            (2, 40, 1024, 64)])      # dt_rank > 48: the generic kernel (4-step segments)
@@ -268,6 +271,9 @@ def test_scan_cl_kernels_vs_selective_scan_oracle(Bsz, Lc, d_in, R, dtype, given
     dev = "cuda"
     yc = M.scan_fwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
                     Wdt[1].to(dev), bdt[1].to(dev), A_log[1].to(dev))
+    if Lc >= 1000:      # long sequences on few batch elements take the segment-parallel forward (fv_mixer_scan_fwd_seg)
+        from fastvim_amd import _lib as L_
+        assert L_.lib().fv_mixer_scan_fwd_segments(L_.i32(Bsz), L_.i32(Lc), L_.i32(d_in), L_.i32(R)) > 1
     ck = None
     if given:
         yc_t, ck = M.scan_fwd(xc.to(dev, dtype), x_dbl.to(dev, dtype), Wdt[0].to(dev), bdt[0].to(dev), A_log[0].to(dev),
