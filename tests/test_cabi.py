@@ -42,3 +42,26 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_host_side_launch_planning_functions():
+    """The size / plan queries of the C ABI are plain host code (no HIP call): checked here without a GPU."""
+    import ctypes
+    from fastvim_amd import _lib
+    lib = _lib.lib()
+    i = ctypes.c_int
+    # segment-parallel forward scan: only long sequences on few batch elements are cut, into >= 8-chunk segments
+    seg = lambda b, lc, d, r: lib.fv_mixer_scan_fwd_segments(i(b), i(lc), i(d), i(r))
+    s_vim = seg(8, 16392, 384, 12)                      # un-pooled Vim-T at 2048 px, batch 8: 96 workgroups, 1025 chunks
+    assert 8 <= s_vim <= 1025 // 8 and s_vim * 96 >= 1024
+    assert seg(128, 200, 384, 12) == 1                  # Vim-T 224 px batch 128: 1536 workgroups already
+    assert seg(8, 128, 1536, 48) == 1                   # FastVim-B 2048 px: 8 chunks, nothing to cut
+    assert seg(128, 14, 384, 12) == 1 and seg(1, 4104, 192, 80) == 1      # short; dt_rank > 48 (generic kernel)
+    assert seg(1, 4104, 192, 6) == 32                   # 257 chunks / 8
+    n = lib.fv_mixer_scan_fwd_seg_floats(i(8), i(16392), i(384), i(16), i(12))
+    assert n == 2 * 8 * s_vim * 384 * (2 * 16 + 1)
+    assert lib.fv_mixer_scan_fwd_seg_floats(i(128), i(200), i(384), i(16), i(12)) == 0
+    # checkpoints of the chunked scan: one state per 16-step chunk
+    assert lib.fv_mixer_scan_ckpt_floats(i(8), i(16392), i(384), i(16), i(12)) == 2 * 8 * 1025 * 384 * 16
+    # the fused in_proj-data-gradient kernel: one partial row of the norm weight's gradient per 64-row workgroup
+    assert lib.fv_gemm_bf16_dgrad_addnorm_blocks(i(25088)) == 392 and lib.fv_gemm_bf16_dgrad_addnorm_blocks(i(65)) == 2
