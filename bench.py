@@ -439,7 +439,7 @@ def scan_op_table(cpu=True):
 
 
 def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, rank, world, dev, use_graph=True,
-                       trace=False, buckets=3, comm_dtype=None, force_segmented=False, wgrad_overlap="default"):
+                       trace=False, buckets=3, comm_dtype=None, force_segmented=False):
     """Build the model + flat training state + fused optimizer, capture the whole step (fwd + loss + bwd + AdamW + EMA;
     the gradient exchange sits between graph replay and optimizer when world > 1) and time exactly ``steps`` steps
     after ``warmup`` untimed ones, bracketed by barrier + synchronize.  Returns (seconds, final loss, extras)."""
@@ -453,9 +453,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     in_ch = channels if model_name == "C" else 3
     x = torch.randn(batch, in_ch, img, img, generator=gen).to(dev)
     tgt = soft_targets(batch, 1000, gen, dev)
-    if wgrad_overlap == "default":
-        wgrad_overlap = WGRAD_OVERLAP.get(model_name) if world == 1 and not force_segmented else None
-    flat = FlatTrainingState(model, comm_dtype=comm_dtype, wgrad_overlap=wgrad_overlap)   # flat fp32 params / grads + bf16 shadow weights
+    flat = FlatTrainingState(model, comm_dtype=comm_dtype)      # flat fp32 params / grads + bf16 shadow weights
     no_decay = {n for n, p in model.named_parameters()
                 if p.ndim <= 1 or n.endswith(".bias") or n in model.no_weight_decay() or getattr(p, "_no_weight_decay", False)}
     # one fused kernel: AdamW (the reference recipe's two param groups) + ModelEmaV2 lerp + bf16 shadow refresh
@@ -554,9 +552,6 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
             "allreduce_exposed_ms": None if seg is None else round(seg.exposed_ms(), 3)}
     flat.close()
     return elapsed, loss_val, extras
-
-
-WGRAD_OVERLAP = {}      # model -> (problems per early weight-gradient group, workgroups of its throttled launch); measured below
 
 
 OTHER_CONFIGS = (      # BASELINE configs[2..4] (per-GPU shape) + the paper's comparison point; model, img, batch, channels

@@ -1094,48 +1094,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_grouped_kernel(Grou
   // operands: in the logical order [problem][slice][tile] they are neighbours, so XCD x takes the x-th eighth of that
   // order (neighbours share an XCD and its L2, and start together) instead of every eighth workgroup -- with the
   // round-robin order the 12 tiles of an in_proj slice sat on 8 XCDs and each fetched its operands over the fabric
-  // A launch with fewer workgroups than work items (fv_gemm_bf16_tn_grouped_bg: a throttled background launch that leaves
-  // most of the chip to the kernels it runs beside) walks its items in a grid-stride loop; the grid is then a multiple of
-  // 8, so item w = blockIdx.x + k gridDim.x stays on this workgroup's XCD and the XCD-aware order below still holds.
-  const int total = G.blk_end[G.count - 1];
-  for (int w = blockIdx.x; w < total; w += gridDim.x) {
-    int g = w;
-    if (xcd_order & 255) {
-      const int n = total, q8 = n / 8, r8 = n % 8, xcd = g % 8, k = g / 8;
-      g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-    }
-    int j = 0;
-    while (j + 1 < G.count && g >= G.blk_end[j]) ++j;
-    const GemmParams& p = G.p[j];
-    const int local = g - (j ? G.blk_end[j - 1] : 0);
-    constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    const int split = local / tiles;
-    // (the body's K loop ends with a workgroup barrier and the fp32 epilogue stores from registers: the staging buffers are
-    //  free when the next item's first loads are issued)
-    gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB, false>(p, local - split * tiles, split, nullptr, xcd_order >> 8);
+  int g = blockIdx.x;
+  if (xcd_order & 255) {
+    const int n = gridDim.x, q8 = n / 8, r8 = n % 8, xcd = g % 8, k = g / 8;
+    g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
   }
+  int j = 0;
+  while (j + 1 < G.count && g >= G.blk_end[j]) ++j;
+  const GemmParams& p = G.p[j];
+  const int local = g - (j ? G.blk_end[j - 1] : 0);
+  constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int split = local / tiles;
+  gemm_bf16_body<AMODE, BMODE, WM, WN, GLDS, NB, MB, false>(p, local - split * tiles, split, nullptr, xcd_order >> 8);
 }
 
 // the phased 256 x 256 form for the weight gradients of the large outputs (M and N multiples of 256: FastVim-B)
 __global__ __launch_bounds__(512, 2) void gemm_p256_grouped_kernel(GroupedParams G, int xcd_order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int total = G.blk_end[G.count - 1];
-  for (int w = blockIdx.x; w < total; w += gridDim.x) {      // grid-stride over the work items (see gemm_bf16_grouped_kernel)
-    int g = w;
-    if (xcd_order & 255) {
-      const int n = total, q8 = n / 8, r8 = n % 8, xcd = g % 8, k = g / 8;
-      g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
-    }
-    int j = 0;
-    while (j + 1 < G.count && g >= G.blk_end[j]) ++j;
-    const GemmParams& p = G.p[j];
-    const int local = g - (j ? G.blk_end[j - 1] : 0);
-    const int tiles = (p.M / 256) * (p.N / 256);
-    const int split = local / tiles;
-    p256_body<KS, KS, true>(p, local - split * tiles, split, smem);
-    __builtin_amdgcn_s_barrier();      // both row-half groups are out of the item before its buffers are refilled
+  int g = blockIdx.x;
+  if (xcd_order & 255) {
+    const int n = gridDim.x, q8 = n / 8, r8 = n % 8, xcd = g % 8, k = g / 8;
+    g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
   }
+  int j = 0;
+  while (j + 1 < G.count && g >= G.blk_end[j]) ++j;
+  const GemmParams& p = G.p[j];
+  const int local = g - (j ? G.blk_end[j - 1] : 0);
+  const int tiles = (p.M / 256) * (p.N / 256);
+  const int split = local / tiles;
+  p256_body<KS, KS, true>(p, local - split * tiles, split, smem);
 }
 
 template <int AMODE, int BMODE, int WM, int WN, bool GLDS, int NB = 4, int MB = 4>
@@ -1627,21 +1615,7 @@ extern "C" int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* 
 extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* const* y, float* const* parts,
                                           const int* Kd, const int* M, const int* N, const int* ldx, const int* ldy,
                                           const int* splits, int count, fv_stream_t stream) {
-  return fv_gemm_bf16_tn_grouped_bg(x, y, parts, Kd, M, N, ldx, ldy, splits, count, 0, stream);
-}
-
-// max_workgroups > 0: a THROTTLED launch -- at most that many workgroups (rounded down to a multiple of 8, at least 8)
-// walk the work items in a grid-stride loop.  For weight gradients issued on a second stream while the backward chain is
-// still running: the gradients are only needed before the optimizer step, one workgroup alone streams its slice at the
-// latency-bound rate of a double-buffered loop, and a few dozen of them finish a run of blocks' gradients in the time the
-// chain takes for the next run -- while leaving > 90 % of the CU slots (and of the HBM bandwidth) to the chain.  Same
-// arithmetic, same partials, same fixed order as the unthrottled launch.
-extern "C" int fv_gemm_bf16_tn_grouped_bg(const void* const* x, const void* const* y, float* const* parts,
-                                          const int* Kd, const int* M, const int* N, const int* ldx, const int* ldy,
-                                          const int* splits, int count, int max_workgroups, fv_stream_t stream) {
   FV_CHECK(x && y && parts && Kd && M && N && splits && count > 0, "gemm_bf16_tn_grouped: bad arguments");
-  const int cap = max_workgroups > 0 ? (max_workgroups >= 8 ? max_workgroups / 8 * 8 : 8) : 0;
-  auto grid_of = [cap](int blocks) { return cap > 0 && blocks > cap ? cap : blocks; };
   hipStream_t st = (hipStream_t)stream;
   const int launches = fv_cdiv(count, GROUP_MAX), per_launch = fv_cdiv(count, launches);   // balanced, no one-problem tail launch
   for (int base = 0; base < count; base += per_launch) {
@@ -1714,9 +1688,9 @@ extern "C" int fv_gemm_bf16_tn_grouped_bg(const void* const* x, const void* cons
         bool two_tiles = true;             // the phased loop wants at least two K tiles per slice
         for (int i = 0; i < n; ++i) two_tiles = two_tiles && G.p[i].k_per_split >= 2 * BK && G.p[i].K % G.p[i].k_per_split == 0;
         if (wg_phased && two_tiles)
-          hipLaunchKernelGGL(gemm_p256_grouped_kernel, dim3(grid_of(b2)), dim3(512), (size_t)2 * (256 + 256) * BK * 2, st, G, xcd_order);
+          hipLaunchKernelGGL(gemm_p256_grouped_kernel, dim3(b2), dim3(512), (size_t)2 * (256 + 256) * BK * 2, st, G, xcd_order);
         else
-        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 4, true, 4, 8>), dim3(grid_of(b2)), dim3(512),
+        hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 4, true, 4, 8>), dim3(b2), dim3(512),
                            (size_t)2 * (256 + 256) * BK * 2, st, G, xcd_order);
         FV_LAUNCH_CHECK();
         continue;
@@ -1736,7 +1710,7 @@ extern "C" int fv_gemm_bf16_tn_grouped_bg(const void* const* x, const void* cons
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)0;     
       }
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 6, 4>), dim3(grid_of(blocks)), dim3(256), smem, st, G, xcd_order);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 6, 4>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
     } else if (cls == 2) {
       static FvOncePerDevice attr;   
       if (attr.first()) {
@@ -1744,11 +1718,11 @@ extern "C" int fv_gemm_bf16_tn_grouped_bg(const void* const* x, const void* cons
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)0;     
       }
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 6>), dim3(grid_of(blocks)), dim3(256), smem, st, G, xcd_order);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 6>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
     } else if (dma) {
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 4>), dim3(grid_of(blocks)), dim3(256), smem, st, G, xcd_order);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, true, 4, 4>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
     } else {
-      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(grid_of(blocks)), dim3(256), smem, st, G, xcd_order);
+      hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 2, false, 4, 4>), dim3(blocks), dim3(256), smem, st, G, xcd_order);
     }
     FV_LAUNCH_CHECK();
   }

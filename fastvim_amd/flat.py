@@ -38,10 +38,7 @@ _MIXER_GROUPS = (
 
 class FlatTrainingState:
     def __init__(self, model, shadow_dtype=torch.bfloat16, process_group=None, comm_dtype="auto",
-                 chunk_bytes=256 << 20, wgrad_overlap=None):
-        """``wgrad_overlap`` = (problems per early group, workgroups): weight gradients are launched during backward, every
-        that many problems, as THROTTLED grouped launches on a second lowest-priority stream (fv_gemm_bf16_tn_grouped_bg)
-        instead of all after the last block; None: after the last block."""
+                 chunk_bytes=256 << 20):
         self.group = process_group
         self.comm_dtype = comm_dtype
         self.chunk = max(1, chunk_bytes // 4)
@@ -145,8 +142,7 @@ class FlatTrainingState:
         # queued gradient work (deferred partial sums, grouped weight-gradient GEMMs) is process-wide state of the
         # kernels' wrappers: remember what it was so ``close()`` can put it back
         from .mixer_ops import _Deferred
-        self._saved_switches = (_Deferred.enabled, _GroupedWgrad.enabled, _SideStream.enabled, _GroupedWgrad.chunk,
-                                _GroupedWgrad.bg_wgs)
+        self._saved_switches = (_Deferred.enabled, _GroupedWgrad.enabled, _SideStream.enabled)
         defer_reductions(True)
         group_wgrads(True)
         # (weight-gradient GEMMs on a second stream, joined in finish_backward, measured neutral-to-slower on MI355X under
@@ -155,10 +151,6 @@ class FlatTrainingState:
         # scan kernels slow each other down by more than the serial tail costs.  _SideStream stays off and the groups run
         # after the last block unless a caller switches them on)
         _SideStream.enabled = False
-        _GroupedWgrad.chunk, _GroupedWgrad.bg_wgs = 0, 0
-        if wgrad_overlap:
-            _SideStream.enabled = True
-            _GroupedWgrad.chunk, _GroupedWgrad.bg_wgs = int(wgrad_overlap[0]), int(wgrad_overlap[1])
 
     def close(self):
         """Issue whatever is queued and restore the wrappers' process-wide switches (deferred reductions, grouped weight
@@ -167,11 +159,10 @@ class FlatTrainingState:
         if self._saved_switches is None:
             return
         self.finish_backward()
-        d, g, s_, ch, bg = self._saved_switches
+        d, g, s_ = self._saved_switches
         defer_reductions(d)
         group_wgrads(g)
         _SideStream.enabled = s_
-        _GroupedWgrad.chunk, _GroupedWgrad.bg_wgs = ch, bg
         self._hook.remove()
         self._saved_switches = None
 

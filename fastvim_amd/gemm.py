@@ -174,12 +174,11 @@ def grouped_splits(Kd, target=None, M=None, N=None):
     return best
 
 
-def gemm_tn_grouped(jobs, reduce=True, max_wgs=0):
+def gemm_tn_grouped(jobs, reduce=True):
     """jobs: list of (x (Kd, M) bf16, y (Kd, N) bf16, out flat fp32 view of (M, N), splits).  ONE launch per 40
     problems computes every problem's split-K partials; the partials are then summed (deferred, fixed order) into
     ``out`` (accumulate).  ``reduce=False``: the sums are left to the caller -- returns [(partials, splits, out)] (a launch
-    on a second stream must be joined before anything reads the partials).  ``max_wgs`` > 0: throttled launches
-    (fv_gemm_bf16_tn_grouped_bg): at most that many workgroups walk the work, for a launch that runs beside other kernels."""
+    on a second stream must be joined before anything reads the partials)."""
     if not jobs:
         return []
     # one launch = one tile shape (the C side takes the shape that pads the launch's problems least: 128 x 192 for
@@ -200,9 +199,9 @@ def gemm_tn_grouped(jobs, reduce=True, max_wgs=0):
             else:
                 classes.setdefault(0, []).append(j)
         for c in sorted(classes):
-            todo += _gemm_tn_grouped_one(classes[c], reduce, c, max_wgs)
+            todo += _gemm_tn_grouped_one(classes[c], reduce, c)
         return todo
-    return _gemm_tn_grouped_one(jobs, reduce, next(iter(classes)), max_wgs)
+    return _gemm_tn_grouped_one(jobs, reduce, next(iter(classes)))
 
 
 _TILES = ((128, 128), (128, 192), (192, 128), (256, 256))
@@ -256,12 +255,11 @@ def fill_splits(jobs, c):
     return out_sp
 
 
-def _gemm_tn_grouped_one(jobs, reduce, c=None, max_wgs=0):
+def _gemm_tn_grouped_one(jobs, reduce, c=None):
     k = len(jobs)
     if c is None:
         c = _tile_class(jobs[0][0].shape[1], jobs[0][1].shape[1]) if k == 1 else 0
-    if not max_wgs:      # (a throttled launch does not try to fill the chip: its problems keep their own K slices)
-        jobs = [(x, y, out, s_) for (x, y, out, _), s_ in zip(jobs, fill_splits(jobs, c))]
+    jobs = [(x, y, out, s_) for (x, y, out, _), s_ in zip(jobs, fill_splits(jobs, c))]
     parts = []
     for x, y, out, sp in jobs:
         Kd, M = x.shape
@@ -280,8 +278,7 @@ def _gemm_tn_grouped_one(jobs, reduce, c=None, max_wgs=0):
     sps = (I * k)(*[j[3] for j in jobs])
     ldx = (I * k)(*[j[0].stride(0) for j in jobs])       # rows may be padded (a column slice of a wider buffer)
     ldy = (I * k)(*[j[1].stride(0) for j in jobs])
-    rc = L.lib().fv_gemm_bf16_tn_grouped_bg(xs, ys, ps, Kds, Ms, Ns, ldx, ldy, sps, L.i32(k), L.i32(max_wgs),
-                                            L.stream_of(jobs[0][0]))
+    rc = L.lib().fv_gemm_bf16_tn_grouped_ld(xs, ys, ps, Kds, Ms, Ns, ldx, ldy, sps, L.i32(k), L.stream_of(jobs[0][0]))
     L.check(rc, "gemm_bf16_tn_grouped")
     todo = [(part, sp, out) for (x, y, out, sp), part in zip(jobs, parts)]
     if not reduce:

@@ -89,10 +89,10 @@ def linear_dgrad(g2, w_c):
 
 
 class _SideStream:
-    """Weight-gradient GEMMs are off the critical path of backward: in flat-training mode they can be enqueued on a
-    second (lowest-priority) HIP stream -- fork after the producer, join in finish_backward -- so they overlap the
-    latency-bound row-walker / scan kernels of the main chain.  Operands are kept referenced until the join, so the
-    caching allocator cannot hand their memory to main-stream kernels."""
+    """Weight-gradient GEMMs are off the critical path of backward: in flat-training mode they are
+    enqueued on a second HIP stream (fork after the producer, join in finish_backward) so they overlap
+    the latency-bound row-walker / scan kernels of the main chain.  Operands are kept referenced
+    until the join, so the caching allocator cannot hand their memory to main-stream kernels."""
     enabled = False
     stream = None
     pending = []
@@ -103,8 +103,7 @@ class _SideStream:
             return fn()
         cur = torch.cuda.current_stream()
         if cls.stream is None:
-            least = torch.cuda.Stream.priority_range()[0] if hasattr(torch.cuda.Stream, "priority_range") else 0
-            cls.stream = torch.cuda.Stream(priority=least)
+            cls.stream = torch.cuda.Stream()
         cls.stream.wait_stream(cur)
         with torch.cuda.stream(cls.stream):
             out = fn()
@@ -127,11 +126,8 @@ class _GroupedWgrad:
     enabled = False
     jobs = []
     # chunk > 0: a group is launched as soon as it holds that many problems (on the weight-gradient stream when there is
-    # one) instead of after the last block.  As FULL launches beside the backward chain that measured slower at FastVim-T
-    # (flat.py); ``bg_wgs`` > 0 makes those early launches THROTTLED ones (fv_gemm_bf16_tn_grouped_bg: that many
-    # workgroups walk the group's work) -- the chain keeps the chip, the gradients trickle in behind it.
+    # one) instead of after the last block.  Measured slower at FastVim-T (flat.py), so off.
     chunk = 0
-    bg_wgs = 0
 
     @classmethod
     def add(cls, g2, a2, out):
@@ -148,15 +144,13 @@ class _GroupedWgrad:
     sums = []            # (partials, splits, out) of groups launched on the weight-gradient stream, not yet summed
 
     @classmethod
-    def flush(cls, final=False):
-        """``final``: the flush at the end of backward -- nothing runs beside it, so it takes the whole chip."""
+    def flush(cls):
         if cls.jobs:
             from .gemm import gemm_tn_grouped
             jobs, cls.jobs = cls.jobs, []
             if _SideStream.enabled:
                 # only the GEMM goes to the second stream; its partials are summed after the join (reduce())
-                wgs = 0 if final else cls.bg_wgs
-                cls.sums += _SideStream.run(lambda: gemm_tn_grouped(jobs, reduce=False, max_wgs=wgs), jobs)
+                cls.sums += _SideStream.run(lambda: gemm_tn_grouped(jobs, reduce=False), jobs)
             else:
                 gemm_tn_grouped(jobs)
 
@@ -164,9 +158,7 @@ class _GroupedWgrad:
     def reduce(cls):
         """After ``_SideStream.join()``: queue the fixed-order sums of the groups that ran on the second stream."""
         sums, cls.sums = cls.sums, []
-        cur = torch.cuda.current_stream() if sums else None
         for part, sp, out in sums:
-            part.record_stream(cur)      # allocated on the second stream, read (and then freed) on this one
             M.reduce_partials(part, sp, out=out, accumulate=True)
 
 
@@ -177,7 +169,7 @@ def group_wgrads(on):
 
 def flush_wgrads():
     """Launch the queued weight-gradient group, wait for the weight-gradient stream, queue the partial sums."""
-    _GroupedWgrad.flush(final=True)
+    _GroupedWgrad.flush()
     _SideStream.join()
     _GroupedWgrad.reduce()
 

@@ -362,14 +362,6 @@ int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* c
 int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
                                const int* M, const int* N, const int* ldx, const int* ldy, const int* splits, int count,
                                fv_stream_t stream);
-/* Same as a THROTTLED launch: max_workgroups > 0 caps the grid (multiple of 8) and the workgroups walk the work items in
- * a grid-stride loop -- for weight gradients issued on a second stream while the backward chain is still running (torch DDP
- * computes them inside backward as well, imagenet_classification/train.py:34-43; they are needed only before the
- * optimizer step): a few dozen workgroups finish a run of blocks' gradients under the next run's kernels and leave the
- * chip to them.  0: the full grid.  Values and summation order are those of the unthrottled launch. */
-int fv_gemm_bf16_tn_grouped_bg(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
-                               const int* M, const int* N, const int* ldx, const int* ldy, const int* splits, int count,
-                               int max_workgroups, fv_stream_t stream);
 
 /* x_proj of both directions, bf16: x_dbl (2, M, width) = xc (2, M, d_inner) @ x_proj_w2 (2, width, d_inner)^T, fp32
  * accumulate (mamba_simple_faster.py:321-327; the F.linear behind `self.x_proj` / `self.x_proj_b`).  M = batch*Lc,

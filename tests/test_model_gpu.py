@@ -475,63 +475,3 @@ def test_other_model_families_call_no_library_gemm(monkeypatch, which):
             loss.backward()
             opt.step()
             assert not hits and torch.isfinite(loss)
-
-
-@pytest.mark.parametrize("overlap", [(8, 16), (12, 0), (4, 8)])
-def test_background_weight_gradients_equal_end_of_backward_launch(monkeypatch, overlap):
-    """``FlatTrainingState(wgrad_overlap=(chunk, workgroups))``: weight gradients launched DURING backward, every `chunk`
-    problems, as throttled grouped launches on a second stream (fv_gemm_bf16_tn_grouped_bg: `workgroups` of them walk the
-    work in a grid-stride loop; 0 = full grids) compute the same partials in the same fixed order as the launch after the
-    last block: with the fill re-cut off, gradients and updated weights are bitwise equal, eagerly and under graph replay."""
-    import fastvim_amd.gemm as gemm_mod
-    monkeypatch.setattr(gemm_mod, "FILL", False)
-    from fastvim_amd.fastvim import VisionMamba
-    from fastvim_amd.flat import FlatAdamW, FlatTrainingState
-    from fastvim_amd.losses import SoftTargetCrossEntropy
-    x = torch.randn(32, 3, 224, 224, device="cuda")
-    tgt = torch.softmax(torch.randn(32, 100, device="cuda"), -1)
-    crit = SoftTargetCrossEntropy()
-
-    def run(ov, graph):
-        torch.manual_seed(0)
-        m = VisionMamba(img_size=224, depth=6, embed_dim=192, num_classes=100, rms_norm=True, residual_in_fp32=True,
-                        fused_add_norm=True, final_pool_type="mean", if_abs_pos_embed=True, drop_path_rate=0.1).cuda().train()
-        flat = FlatTrainingState(m, wgrad_overlap=ov)
-        opt = FlatAdamW(flat, m, lr=1e-3, weight_decay=0.05, no_decay=set())
-        torch.manual_seed(3)
-
-        def step():
-            flat.zero_grad()
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss = crit(m(x), tgt)
-            loss.backward()
-            flat.finish_backward()
-            opt.step()
-            return loss.detach()
-
-        if graph:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                lb = step()
-            losses = []
-            for _ in range(3):
-                g.replay()
-                losses.append(lb.item())
-        else:
-            losses = [step().item() for _ in range(4)]
-        torch.cuda.synchronize()
-        out = (losses[-3:], flat.grad_flat.clone(), flat.param_flat.clone())
-        flat.close()
-        return out
-
-    for graph in (False, True):
-        l0, g0, p0 = run(None, graph)
-        l1, g1, p1 = run(overlap, graph)
-        assert l0 == l1, (graph, l0, l1)
-        assert torch.equal(g0, g1) and torch.equal(p0, p1), graph

@@ -11,10 +11,6 @@ a = sys.argv[1:]
 model, img, batch, steps = a[0], int(a[1]), int(a[2]), int(a[3])
 if "--presum" in a:
     mixer_ops._XPROJ_PRESUM = int(a[a.index("--presum") + 1])
-ov = None
-if "--bg" in a:      # --bg CHUNK WGS: weight gradients as throttled background launches during backward
-    i = a.index("--bg")
-    ov = (int(a[i + 1]), int(a[i + 2]))
 torch.cuda.set_device(0)
-el, lv, ex = bench.run_training_steps(model, img, batch, 8, "bf16", steps, 3, 0, 1, torch.device("cuda", 0), wgrad_overlap=ov)
+el, lv, ex = bench.run_training_steps(model, img, batch, 8, "bf16", steps, 3, 0, 1, torch.device("cuda", 0))
 print(json.dumps({"ms_per_step": round(el / steps * 1e3, 3), "loss": round(lv, 4)}))
