@@ -735,7 +735,8 @@ def main():
                                    + (" (BASELINE configs[1])" if (args.model, args.img, args.batch) == ("T", 224, 128) else "")
                                    + (" (BASELINE configs[4], HCS off)" if (args.model, args.img, args.batch, args.channels) == ("C", 224, 64, 8) else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "hip_graph": use_graph, "optimizer_in_step": True, "final_loss": round(loss_val, 4)},
+                       "hip_graph": use_graph, "optimizer_in_step": True, "final_loss": round(loss_val, 4),
+                       "final_loss_hex": float(loss_val).hex()},
         }
         if "ddp" in extras:
             out["ddp"] = extras["ddp"]

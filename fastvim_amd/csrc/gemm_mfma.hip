@@ -32,6 +32,24 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 64;
 enum { KC = 0, KS = 1 };
 
+#ifdef FASTVIM_TUNING_HOOKS
+// Phase stamps of the fused projection + norm kernels (diagnostic build only; guide section 7 "In-kernel stamps"): wave 0 of
+// a workgroup stores s_memtime at its phase boundaries into a buffer nothing else reads.  Set with fv_debug_set_stamps().
+unsigned long long* g_fv_stamps = nullptr;
+__device__ __forceinline__ void fv_stamp(unsigned long long* buf, int slot) {
+  if (buf && threadIdx.x == 0) {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    buf[(size_t)blockIdx.x * 8 + slot] = t;
+  }
+}
+#define FV_STAMP(ne, slot) fv_stamp((ne)->stamps, slot)
+#else
+#define FV_STAMP(ne, slot) ((void)0)
+#endif
+
 struct GemmParams {
   const bf16_t* A;
   const bf16_t* B;
@@ -70,6 +88,9 @@ struct NormEpi {
   // rows of the output a workgroup owns (<= the tile height BM; 0 = BM): trimmed so that every resident workgroup gets the
   // same share of the rows -- M = 25 088 over 512 slots is 49 rows each instead of 392 tiles of 64 (1.53 per slot)
   int rpt;
+#ifdef FASTVIM_TUNING_HOOKS
+  unsigned long long* stamps;      // (workgroups, 8) phase stamps, nullable
+#endif
 };
 
 // KS tiles: rows (k) are EXT*2 bytes = a multiple of the 256-byte bank row, and a transposing read
@@ -360,6 +381,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
+  if constexpr (NORM_EPI != 0) FV_STAMP(ne, 0);
   f32x4 acc[NB][MB];   // [n tile][m tile]: rows = n (MFMA A slot = B operand), cols = m
 #pragma unroll
   for (int a = 0; a < NB; ++a)
@@ -439,6 +461,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     ga.issue(sA(0), kbeg, tid);
     gb.issue(sB(0), kbeg, tid);
     __syncthreads();
+    if constexpr (NORM_EPI != 0) FV_STAMP(ne, 1);      // first stage landed
     for (int t = 0; t < nt; ++t) {
       const int cur = t & 1;
 #ifdef FASTVIM_TUNING_HOOKS      // phase probe: dbg 1 = no multiply, 2 = no loads, 3 = loads of one K tile only (cache-resident)
@@ -478,6 +501,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     __syncthreads();
   }
   }
+  if constexpr (NORM_EPI != 0) FV_STAMP(ne, 2);        // K loop done
   // epilogue: acc[a][b][j] = C[m = m0 + wm*WMR + b*16 + (lane&15)][n = n0 + wn*WNC + a*16 + (lane>>4)*4 + j]
   const long zoff = (long)split * p.c_split_stride;
   if (p.bias && p.rb_period <= 0) {
@@ -507,6 +531,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
         *reinterpret_cast<uint2*>(smem + (wm * WMR + b * 16 + (lane & 15)) * RSB + (wn * WNC + a * 16 + (lane >> 4) * 4) * 2) = pk;
       }
     __syncthreads();
+    FV_STAMP(ne, 3);                                   // product tile in LDS
     const int lr = lane % LPR, gr = lane / LPR;
     const float inv_n = 1.f / (float)BN;
     float w[3][4], aw[3][4];
@@ -584,6 +609,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     }
     // d norm weight: the 4 row groups of a wave (permlane swaps), then the 4 waves through LDS, fixed order
     __syncthreads();
+    FV_STAMP(ne, 4);                                   // norm adjoint of the rows done (stores issued)
     float* s_acc = reinterpret_cast<float*>(smem + BM * RSB);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -599,12 +625,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     __syncthreads();
     float* dst = ne->pw + (size_t)block_id * BN;
     for (int c = tid; c < BN; c += NT) dst[c] = (s_acc[c] + s_acc[BN + c]) + (s_acc[2 * BN + c] + s_acc[3 * BN + c]);
+    FV_STAMP(ne, 5);                                   // partial d weight written
     if (ne->W2) {
       // ---- second phase: the previous block's out_proj data gradient d g = d x @ W_out from the tile in LDS
       __syncthreads();
       constexpr int O_B = (BM * RSB + 255) / 256 * 256, O_S = O_B + 2 * 128 * BK * 2;
       tile_times_w2<BM, RSB, KS>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, mlim, tid);
     }
+    FV_STAMP(ne, 6);                                   // second phase done (its stores issued)
     return;
   }
   if constexpr (NORM_EPI == 1) {
@@ -623,6 +651,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
         *reinterpret_cast<uint2*>(smem + (wm * WMR + b * 16 + (lane & 15)) * RSB + (wn * WNC + a * 16 + (lane >> 4) * 4) * 2) = pk;
       }
     __syncthreads();
+    FV_STAMP(ne, 3);
     const int lr = lane % LPR, gr = lane / LPR;
     const float inv_n = 1.f / (float)BN;
     float w[3][4];
@@ -696,12 +725,14 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
         }
       }
     }
+    FV_STAMP(ne, 4);
     if (ne->W2) {
       // ---- second phase: this block's in_proj, xz = y @ W_in^T, from the normalised tile in LDS
       __syncthreads();
       constexpr int O_B = (BM * RSB + 255) / 256 * 256, O_S = O_B + 2 * 128 * BK * 2;
       tile_times_w2<BM, RSB, KC>(smem, smem + O_B, smem + O_S, ne->W2, ne->ldw2, ne->N2, ne->C2, m0, mlim, tid);
     }
+    FV_STAMP(ne, 6);
     return;
   }
   if (!p.c_fp32) {
@@ -1526,6 +1557,9 @@ extern "C" int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* 
   }
   NormEpi ne{residual, norm_weight, row_scale, residual_out, (bf16_t*)y, rstd, rows_per_scale > 0 ? rows_per_scale : 1, eps,
              nullptr, nullptr, (const bf16_t*)W2, (bf16_t*)C2, ldw2, N2, fused_rpt(M)};
+#ifdef FASTVIM_TUNING_HOOKS
+  ne.stamps = g_fv_stamps;
+#endif
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto bm) {
     constexpr int BMR = decltype(bm)::value;
@@ -1551,6 +1585,11 @@ extern "C" int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* 
   FV_LAUNCH_CHECK();
   return FV_OK;
 }
+
+#ifdef FASTVIM_TUNING_HOOKS
+// diagnostic builds only: (workgroups, 8) uint64 device buffer the fused kernels stamp their phases into (NULL: off)
+extern "C" void fv_debug_set_stamps(unsigned long long* buf) { g_fv_stamps = buf; }
+#endif
 
 extern "C" int fv_gemm_bf16_dgrad_addnorm_blocks(int M) { return fv_cdiv(M, fused_rpt(M)); }
 
@@ -1586,6 +1625,9 @@ extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, con
   NormEpi ne{r, norm_weight, row_scale, dresidual_in, (bf16_t*)dx, const_cast<float*>(rstd),
              rows_per_scale > 0 ? rows_per_scale : 1, 0.f, dresidual_out, partial_dw,
              (const bf16_t*)W2, (bf16_t*)C2, ldw2, N2, fused_rpt(M)};
+#ifdef FASTVIM_TUNING_HOOKS
+  ne.stamps = g_fv_stamps;
+#endif
   auto go = [&](auto bm) {
     constexpr int BMR = decltype(bm)::value;
     // main loop: two (BMR + 192) x 64 stages; second phase: the d x tile, two 128 x 64 stages, four epilogue slabs
