@@ -53,15 +53,12 @@ t = raw[ok].double()
 slots = [0, 1, 2, 3, 4, 5, 6] if which == "bwd" else [0, 1, 2, 3, 4, 6]
 names = {0: "start", 1: "first stage landed", 2: "K loop done", 3: "product tile in LDS", 4: "norm rows done (stores issued)",
          5: "partial d weight written", 6: "second phase / end"}
-span = (t[:, 6].max() - t[:, 0].min()).item()
-tick_us = span / us                # ticks per microsecond, from the event-timed launch (includes launch overhead: approximate)
-print(f"{which}: launch {us:.1f} us (events), stamp span {span:.0f} ticks -> ~{tick_us:.0f} ticks/us; {nb} workgroups")
-t0 = t[:, 0].min()
-print(f"  workgroup start skew: median {((t[:, 0] - t0).median() / tick_us).item():.2f} us, max {((t[:, 0] - t0).max() / tick_us).item():.2f} us")
+life = t[:, 6] - t[:, 0]
+print(f"{which}: launch {us:.1f} us (events, incl. launch overhead); workgroup life median {life.median().item():.0f} ticks "
+      f"(min {life.min().item():.0f}, max {life.max().item():.0f}; s_memtime ticks, one counter per XCD: only differences inside a workgroup mean anything)")
 prev = 0
 for s_ in slots[1:]:
-    dlt = (t[:, s_] - t[:, prev]) / tick_us
-    print(f"  {names[prev]:34s} -> {names[s_]:34s}: median {dlt.median().item():6.2f} us  mean {dlt.mean().item():6.2f}  p90 {dlt.quantile(0.9).item():6.2f}")
+    dlt = t[:, s_] - t[:, prev]
+    print(f"  {names[prev]:34s} -> {names[s_]:34s}: median {dlt.median().item():8.0f} ticks ({100 * dlt.median().item() / life.median().item():5.1f} % of life)"
+          f"  p10 {dlt.quantile(0.1).item():8.0f}  p90 {dlt.quantile(0.9).item():8.0f}")
     prev = s_
-life = (t[:, 6] - t[:, 0]) / tick_us
-print(f"  workgroup life: median {life.median().item():.2f} us, max {life.max().item():.2f}; last end at {((t[:, 6].max() - t0) / tick_us).item():.2f} us")
