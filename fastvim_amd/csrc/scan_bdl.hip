@@ -503,12 +503,9 @@ __device__ __forceinline__ void tile_st(T* __restrict__ dst, int L, int w0, int 
   }
 }
 
-// TILED (L > 32): u, delta, z and out go through [channel][33] LDS tiles of 32 steps, filled and drained by
-// element-coalesced block-wide copies -- the per-lane loads of the un-tiled form are one 2-byte access per lane at a
-// stride of L, a memory round trip per 4 steps: 39.7 us at (8, 1536, 128, 16), 59.9 us at (64, 768, 112, 16) in round 2.
-template <typename T, bool TILED = false>
+template <typename T>
 __global__ __launch_bounds__(256) void scan_short_fwd_kernel(ScanParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [L][B(16) | C(16)] (+ 4 tiles when TILED)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [L][B(16) | C(16)]
   const int tid = threadIdx.x, q = tid & 3;
   const int cpg = p.dim / p.G, chunks = cpg / SCPB;
   const int g = blockIdx.x / chunks, cx = blockIdx.x - g * chunks, b = blockIdx.y;
@@ -524,40 +521,6 @@ __global__ __launch_bounds__(256) void scan_short_fwd_kernel(ScanParams p) {
   const T* dl = (const T*)p.delta + row;
   const T* z = p.z ? (const T*)p.z + row : nullptr;
   T* out = (T*)p.out + row;
-  if constexpr (TILED) {
-    float* s_u = smem + (size_t)p.L * 2 * SN;
-    float* s_d = s_u + SCPB * SWLP;
-    float* s_z = s_d + SCPB * SWLP;
-    float* s_o = s_z + SCPB * SWLP;
-    const int c = tid >> 2;                                              // channel of the block
-    const size_t row0 = ((size_t)b * p.dim + (d - c)) * p.L;             // the block's first channel
-    for (int w0 = 0; w0 < p.L; w0 += SWL) {
-      const int wl = min(SWL, p.L - w0);
-      tile_ld<T>((const T*)p.u + row0, p.L, w0, wl, s_u);
-      tile_ld<T>((const T*)p.delta + row0, p.L, w0, wl, s_d);
-      if (p.z) tile_ld<T>((const T*)p.z + row0, p.L, w0, wl, s_z);
-      __syncthreads();
-      for (int l = 0; l < wl; ++l) {
-        const float* r = smem + (w0 + l) * 2 * SN;
-        const float uu = s_u[c * SWLP + l];
-        float dt = s_d[c * SWLP + l] + bias;
-        if (p.softplus) dt = fv_softplus(dt);
-        const float du = dt * uu;
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], du * r[q * 4 + j]);
-          acc = fmaf(r[SN + q * 4 + j], st[j], acc);
-        }
-        float y = quad_sum(acc) + Dd * uu;
-        if (p.z) y *= fv_silu(s_z[c * SWLP + l]);
-        if (q == 0) s_o[c * SWLP + l] = y;
-      }
-      __syncthreads();
-      tile_st<T>((T*)p.out + row0, p.L, w0, wl, s_o);
-      __syncthreads();                                                   // the tiles are refilled next
-    }
-  } else
   for (int l0 = 0; l0 < p.L; l0 += 4) {
     float uv[4], dv[4], zv[4];
 #pragma unroll
@@ -856,10 +819,7 @@ int launch_short(const ScanParams& p, int bwd, hipStream_t st) {
   const dim3 grid(p.dim / SCPB, p.batch), block(256);
   FV_CHECK(p.batch <= 65535, "selective_scan: batch %d exceeds the launch grid", p.batch);
   if (!bwd) {
-    if (p.L > SWL)
-      hipLaunchKernelGGL((scan_short_fwd_kernel<T, true>), grid, block, ((size_t)p.L * 2 * SN + 4 * SCPB * SWLP) * 4, st, p);
-    else
-      hipLaunchKernelGGL((scan_short_fwd_kernel<T, false>), grid, block, (size_t)p.L * 2 * SN * 4, st, p);
+    hipLaunchKernelGGL((scan_short_fwd_kernel<T>), grid, block, (size_t)p.L * 2 * SN * 4, st, p);
   } else {
     const size_t smem = ((size_t)p.L * 2 * SN + SKS * 4 * 4 * 16 + 7 * SCPB * SWLP) * 4;
     static FvOncePerDevice done;   
