@@ -792,6 +792,14 @@ def main():
                 and (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16")):
             out["other_configs"] = other_configs_block(args.dtype, rank, dev)
             out["other_configs"]["f2_vim_vs_fastvim_2048px"] = vim_vs_fastvim_block(dev)
+            # forward-only (inference) throughput at 224 px, batch 128 -- eval mode, no_grad, bf16 autocast, HIP-graph replay
+            inf = {}
+            for key, mname in (("FastVim-T", "T"), ("FastVim-B", "B"), ("Vim-T", "V")):
+                try:
+                    inf[key] = inference_throughput(mname, 224, 128, dev, steps=10, warmup=3)
+                except Exception as e:
+                    inf[key] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            out["other_configs"]["inference_224px_bs128"] = inf
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
