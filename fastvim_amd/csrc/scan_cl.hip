@@ -48,6 +48,7 @@ struct ScanClParams {
   float* hend;           // (2, B, seg, d_in, N)  pass A out: state a segment reaches from a zero start
   float* sumdt;          // (2, B, seg, d_in)     pass A out: sum of delta over the segment (its decay is exp(A * sum))
   const float* hin;      // (2, B, seg, d_in, N)  pass C in: state entering the segment
+  int adj;               // combine kernel: 1 = the adjoint recurrence (segments walked last to first)
 };
 
 
@@ -822,8 +823,15 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
 
+  // segment-parallel backward (CK_GIVEN, long sequences on few batch elements; fv_mixer_scan_bwd_seg): grid.y = B * seg, this
+  // workgroup walks chunks [c_lo, c_hi) of one batch element, last first, from the adjoint state entering its segment (hin:
+  // pass A = scan_cl_fwd_chunked_kernel<.., 2>, pass B = scan_seg_combine_kernel with adj = 1); NBB is 1 then
+  const int nseg = (CK_GIVEN && p.seg > 1) ? p.seg : 1;
+  const int sgi = nseg > 1 ? (int)(blockIdx.y % nseg) : 0;
+  const int cps = (nchunk + nseg - 1) / nseg, c_lo = sgi * cps, c_hi = min(nchunk, c_lo + cps);
+  if (c_lo >= c_hi) return;
   for (int bi = 0; bi < p.NBB; ++bi) {
-    const int b = blockIdx.y * p.NBB + bi;
+    const int b = nseg > 1 ? (int)(blockIdx.y / nseg) : blockIdx.y * p.NBB + bi;
     const size_t bd = ((size_t)dir * p.B + b) * Lc;
     float* ck = p.ckpt + (((size_t)dir * p.B + b) * nchunk * p.d_in + dd) * N + q * 4;      // + c * d_in * N
     const size_t ck_c = (size_t)p.d_in * N;
@@ -868,7 +876,11 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
 
     // ---- backward over the chunks, last first
     sf2 dxa[2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int c = nchunk - 1; c >= 0; --c) {
+    if (nseg > 1 && act) {
+      const float4 h0 = *reinterpret_cast<const float4*>(p.hin + ((((size_t)dir * p.B + b) * nseg + sgi) * p.d_in + dd) * N + q * 4);
+      dxa[0].x = h0.x; dxa[0].y = h0.y; dxa[1].x = h0.z; dxa[1].y = h0.w;
+    }
+    for (int c = c_hi - 1; c >= c_lo; --c) {
       const int valid = min(LCT, Lc - c * LCT);
       // the state entering the chunk (requested first: it is needed after the staging barrier)
       float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1071,8 +1083,13 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
 //   B (scan_seg_combine_kernel): the states entering the segments, serially over the few segments, per (channel, state);
 //   C: every segment again from its true entry state -> y and the per-chunk checkpoints, exactly the serial kernel's.
 // Twice the arithmetic on seg times the workgroups.
-template <typename T, int RQ, bool STATE_ONLY = false>
+// MODE 0: the scan (y, checkpoints); 1: states only (pass A); 2: ADJOINT states only -- pass A of the segment-parallel
+// BACKWARD scan: the adjoint recurrence  dxa <- a_t (C_t dy_t + dxa)  walked high to low from a zero start, the same linear
+// structure with C dy in the place of B delta u (scan_cl_bwd_chunked_kernel then runs each segment from its true incoming
+// adjoint state).
+template <typename T, int RQ, int MODE = 0>
 __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p) {
+  constexpr bool STATE_ONLY = MODE != 0, ADJ = MODE == 2;
   constexpr int NWV = 4, CH = 64, LCT = 16, NTH = 256;
   constexpr int RQP = (RQ + 3) / 4 * 4, WP = 4 * RQP + 2 * N;
   constexpr int NST = (LCT * WP + NTH - 1) / NTH;           // staged values per thread and chunk
@@ -1108,6 +1125,7 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
   }
   const T* dbl = (const T*)p.xdbl + bd * W;
   const T* u = (const T*)p.xc + bd * p.d_in + ddm;
+  [[maybe_unused]] const float* gy = ADJ ? p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + ddm : nullptr;
   float* y = p.yc + bd * p.d_in + dd;
   float* ck = p.ckpt ? p.ckpt + (((size_t)dir * p.B + b) * nchunk * p.d_in + dd) * N + q * 4 : nullptr;
 
@@ -1133,7 +1151,8 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int sg = min(c * LCT + 4 * tg + r, Lc - 1), l = dir ? Lc - 1 - sg : sg;
-      um[r] = io<T>::ld(u + (size_t)l * p.d_in);
+      if constexpr (ADJ) um[r] = actm ? gy[(size_t)l * p.d_in] : 0.f;          // the output gradient of the step
+      else um[r] = io<T>::ld(u + (size_t)l * p.d_in);
     }
   };
   auto put = [&](int buf) {
@@ -1143,8 +1162,9 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
       if (e < LCT * WP) s_dbl[buf][e] = pre[i];
     }
   };
-  fetch(c0);
-  put(c0 & 1);
+  const int cfirst = ADJ ? c1 - 1 : c0, cstep = ADJ ? -1 : 1;      // the adjoint recurrence walks the chunks last to first
+  fetch(cfirst);
+  put(cfirst & 1);
   __syncthreads();
   sf2 st[2] = {{0.f, 0.f}, {0.f, 0.f}};
   const size_t sidx = (((size_t)dir * p.B + b) * nseg + sgi) * p.d_in + dd;      // (dir, b, segment, channel)
@@ -1153,7 +1173,9 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
     st[0].x = h0.x; st[0].y = h0.y; st[1].x = h0.z; st[1].y = h0.w;
   }
   float sdt = 0.f;
-  for (int c = c0; c < c1; ++c) {
+  for (int ci = 0; ci < c1 - c0; ++ci) {
+    const int c = cfirst + cstep * ci;
+    const bool more = ci + 1 < c1 - c0;
     const int buf = c & 1;
     const int valid = min(LCT, Lc - c * LCT);
     // delta of this chunk: its inputs are in registers / LDS
@@ -1166,10 +1188,11 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
       for (int r = 0; r < 4; ++r) {
         const int s = 4 * tg + r;
         const float dt = (actm && s < valid) ? fv_softplus(D[r] + bias_m) : 0.f;
-        *reinterpret_cast<float2*>(s_ch + ((size_t)s * CH + wv * 16 + cm) * 2) = make_float2(dt, dt * um[r]);
+        // {delta, delta * u}; adjoint pass: {delta, dy} (dy of a step past the sequence is masked: its C row is zero)
+        *reinterpret_cast<float2*>(s_ch + ((size_t)s * CH + wv * 16 + cm) * 2) = make_float2(dt, ADJ ? um[r] : dt * um[r]);
       }
     }
-    if (c + 1 < c1) fetch(c + 1);          // in flight under the recurrence
+    if (more) fetch(c + cstep);          // in flight under the recurrence
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();           // the table columns of this wave's 16 channels are read by this wave only
@@ -1177,13 +1200,18 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
     const float* my_bc = s_dbl[buf] + 4 * RQP + q * 4;
     const float* my_ch = s_ch + (size_t)ch * 2;
 #pragma unroll
-    for (int s = 0; s < LCT; ++s) {
+    for (int si = 0; si < LCT; ++si) {
+      const int s = ADJ ? LCT - 1 - si : si;
       if (s < valid) {          // uniform
         const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
         const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
         const float2 cv = *reinterpret_cast<const float2*>(my_ch + s * (CH * 2));
         const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
-        if constexpr (STATE_ONLY) {
+        if constexpr (ADJ) {
+          sdt += cv.x;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) st[h] = sexp2_2(A2[h] * cv.x) * sfma2(Cn[h], ssplat(cv.y), st[h]);      // a (C dy + dxa)
+        } else if constexpr (STATE_ONLY) {
           sdt += cv.x;
 #pragma unroll
           for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
@@ -1202,7 +1230,7 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
     }
     if (!STATE_ONLY && ck && c + 1 < nchunk && act)
       *reinterpret_cast<float4*>(ck + (size_t)(c + 1) * p.d_in * N) = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
-    if (c + 1 < c1) put(buf ^ 1);          // the other buffer's readers passed the barrier of the previous chunk
+    if (more) put(buf ^ 1);          // the other buffer's readers passed the barrier of the previous chunk
     __syncthreads();
   }
   if constexpr (STATE_ONLY) {
@@ -1225,7 +1253,8 @@ __global__ __launch_bounds__(256) void scan_seg_combine_kernel(ScanClParams p) {
   const float A = -__expf(p.Alog[dir][(size_t)d * N + n]);
   float* hin = const_cast<float*>(p.hin);
   float H = 0.f;
-  for (int s = 0; s < p.seg; ++s) {
+  for (int k = 0; k < p.seg; ++k) {
+    const int s = p.adj ? p.seg - 1 - k : k;      // the adjoint state flows from the last segment to the first
     const size_t sidx = (db * p.seg + s) * p.d_in + d;
     hin[sidx * N + n] = H;
     H = fmaf(__expf(A * p.sumdt[sidx]), H, p.hend[sidx * N + n]);
@@ -1432,12 +1461,17 @@ extern "C" int fv_mixer_scan_fwd_segments(int batch, int Lc, int d_inner, int dt
   static const int force = fv_tune("FASTVIM_SCAN_FWD_SEG", 0);   // tuning hook: > 0 fixed segment count (1 = serial)
   const int nchunk = (Lc + 15) / 16;
   if (Lc <= 16 || dt_rank > 48) return 1;
-  if (force > 0) return force < nchunk ? force : nchunk;
+  if (force > 0) {
+    const int f = force < nchunk ? force : nchunk, cps = (nchunk + f - 1) / f;
+    return (nchunk + cps - 1) / cps;
+  }
   const long wgs = (long)fv_cdiv(d_inner, CPB) * batch * 2;
   if (wgs >= 512 || nchunk < 16) return 1;
   long s = (1024 + wgs - 1) / wgs;
   if (s > nchunk / 8) s = nchunk / 8;
-  return (int)(s < 1 ? 1 : s);
+  if (s < 1) s = 1;
+  const long cps = (nchunk + s - 1) / s;          // chunks per segment
+  return (int)((nchunk + cps - 1) / cps);         // ... and no empty segment at the end
 }
 extern "C" size_t fv_mixer_scan_fwd_seg_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank) {
   const int S = fv_mixer_scan_fwd_segments(batch, Lc, d_inner, dt_rank);
@@ -1491,11 +1525,11 @@ extern "C" int fv_mixer_scan_fwd_seg(const void* xc, const void* x_dbl, const fl
       p.sumdt = seg_ws + nst * N;
       float* hin = seg_ws + nst * (N + 1);
       grid = dim3(fv_cdiv(d_inner, CPB), batch * S, 2);
-      if (dtype == FV_F32) FV_FC(float, true); else FV_FC(bf16_t, true);
+      if (dtype == FV_F32) FV_FC(float, 1); else FV_FC(bf16_t, 1);
       p.hin = hin;
       hipLaunchKernelGGL(scan_seg_combine_kernel, dim3(fv_cdiv((long)2 * batch * d_inner * N, 256)), dim3(256), 0, st, p);
     }
-    if (dtype == FV_F32) FV_FC(float, false); else FV_FC(bf16_t, false);
+    if (dtype == FV_F32) FV_FC(float, 0); else FV_FC(bf16_t, 0);
 #undef FV_FC
     FV_LAUNCH_CHECK();
     return FV_OK;
@@ -1646,11 +1680,33 @@ extern "C" int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const fl
                                 ckpt, 0, partials, batch, Lc, d_inner, dt_rank, d_state, dtype, stream);
 }
 
+// Segments of the segment-parallel BACKWARD scan (only with the forward launch's checkpoints): the forward rule, on the
+// model family's d_inner = 32 dt_rank so that the partial-row count depends on (batch, Lc, dt_rank) like its siblings.
+extern "C" int fv_mixer_scan_bwd_segments(int batch, int Lc, int dt_rank) {
+  return fv_mixer_scan_fwd_segments(batch, Lc, 32 * dt_rank, dt_rank);
+}
+extern "C" size_t fv_mixer_scan_bwd_seg_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank) {
+  const int S = fv_mixer_scan_bwd_segments(batch, Lc, dt_rank);
+  return S > 1 ? (size_t)2 * batch * S * d_inner * (2 * d_state + 1) : 0;
+}
+extern "C" int fv_mixer_scan_bwd_seg_partials(int batch, int Lc, int dt_rank) {
+  return batch * fv_mixer_scan_bwd_segments(batch, Lc, dt_rank);
+}
+
 extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
                                       const float* A_log, const float* dt_w_b, const float* dt_bias_b,
                                       const float* A_log_b, const float* dyc, int dyc_per_direction, float* dxc,
                                       float* dx_dbl, float* ckpt, int ckpt_given, float* partials, int batch, int Lc,
                                       int d_inner, int dt_rank, int d_state, int dtype, fv_stream_t stream) {
+  return fv_mixer_scan_bwd_seg(xc, x_dbl, dt_w, dt_bias, A_log, dt_w_b, dt_bias_b, A_log_b, dyc, dyc_per_direction, dxc, dx_dbl,
+                               ckpt, ckpt_given, partials, nullptr, batch, Lc, d_inner, dt_rank, d_state, dtype, stream);
+}
+
+extern "C" int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                     const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                     const float* A_log_b, const float* dyc, int dyc_per_direction, float* dxc,
+                                     float* dx_dbl, float* ckpt, int ckpt_given, float* partials, float* seg_ws, int batch,
+                                     int Lc, int d_inner, int dt_rank, int d_state, int dtype, fv_stream_t stream) {
   FV_CHECK(!ckpt_given || (ckpt && bwd_chunked(Lc, dt_rank)),
            "mixer_scan_bwd: checkpoints of the forward launch are only taken by the chunked kernel (fv_mixer_scan_ckpt_floats > 0)");
   FV_CHECK(batch > 0 && Lc > 0 && d_inner > 0 && dt_rank > 0, "mixer_scan_bwd: empty dimension");
@@ -1700,8 +1756,30 @@ extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const f
     return FV_OK;
   }
   if (bwd_chunked(Lc, dt_rank)) {
-    const int nwv = ck_waves(batch, d_inner);
+    const int S = (seg_ws && ckpt_given) ? fv_mixer_scan_bwd_segments(batch, Lc, dt_rank) : 1;
+    const int nwv = S > 1 ? 4 : ck_waves(batch, d_inner);      // (segments: the 64-channel workgroups the forward passes use)
     dim3 cgrid(fv_cdiv(d_inner, 16 * nwv), batch / p.NBB, 2), cblock(64 * nwv);
+    if (S > 1) {
+      // A: the adjoint state every segment reaches from zero (and its sum of delta); B: the adjoint states ENTERING the
+      // segments, last to first; then the backward kernel proper, every segment from its true incoming adjoint state
+      const size_t nst = (size_t)2 * batch * S * d_inner;
+      p.seg = S;
+      p.hend = seg_ws;
+      p.sumdt = seg_ws + nst * N;
+      p.hin = seg_ws + nst * (N + 1);
+      p.adj = 1;
+      const dim3 agrid(fv_cdiv(d_inner, CPB), batch * S, 2), ablock(256);
+#define FV_ADJ(TT)                                                                           \
+  do {                                                                                       \
+    if (RQ <= 3) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 3, 2>), agrid, ablock, 0, st, p);        \
+    else if (RQ <= 6) hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 6, 2>), agrid, ablock, 0, st, p);   \
+    else hipLaunchKernelGGL((scan_cl_fwd_chunked_kernel<TT, 12, 2>), agrid, ablock, 0, st, p);               \
+  } while (0)
+      if (dtype == FV_F32) FV_ADJ(float); else FV_ADJ(bf16_t);
+#undef FV_ADJ
+      hipLaunchKernelGGL(scan_seg_combine_kernel, dim3(fv_cdiv((long)2 * batch * d_inner * N, 256)), dim3(256), 0, st, p);
+      cgrid = dim3(fv_cdiv(d_inner, 16 * nwv), batch * S, 2);
+    }
 #define FV_CW(TT, RQQ, NWW)                                                                  \
   do {                                                                                       \
     size_t smem = (size_t)ChunkLds<RQQ, NWW>::floats * 4;                                    \

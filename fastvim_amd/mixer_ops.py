@@ -235,12 +235,18 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     if not given:
         nck = lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R))
         ckpt = torch.empty(nck, **f32o) if nck else None
-    nprt = lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc), L.i32(R))
+    # long sequences on few batch elements, with the forward launch's checkpoints: the segments side by side (one partial
+    # row of parameter gradients per batch element and segment)
+    nws = lib.fv_mixer_scan_bwd_seg_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R)) if given else 0
+    ws = torch.empty(nws, **f32o) if nws else None
+    nprt = lib.fv_mixer_scan_bwd_seg_partials(L.i32(B), L.i32(Lc), L.i32(R)) if nws else \
+        lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc), L.i32(R))
     part = torch.empty(nprt, 2 * d_in * (N + R + 1), **f32o)
-    rc = lib.fv_mixer_scan_bwd_ckpt(
+    rc = lib.fv_mixer_scan_bwd_seg(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b),
         L.ptr(A_log_b), L.ptr(dyc), L.i32(int(dyc_per_direction)), L.ptr(dxc), L.ptr(dx_dbl), L.ptr(ckpt), L.i32(int(given)),
-        L.ptr(part), L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
+        L.ptr(part), L.ptr(ws), L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)),
+        L.stream_of(xc))
     L.check(rc, "mixer_scan_bwd")
     if not keep_chunks:       # keep_chunks: the x_proj adjoint kernel sums the chunk partials itself
         dx_dbl = dx_dbl[0] if nchunks == 1 else reduce_partials(dx_dbl, nchunks)

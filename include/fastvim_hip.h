@@ -228,6 +228,19 @@ int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w,
                            const float* dyc, int dyc_per_direction, float* dxc, float* dx_dbl, float* ckpt,
                            int ckpt_given, float* partials, int batch, int Lc, int d_inner, int dt_rank, int d_state,
                            int dtype, fv_stream_t stream);
+/* Segment-parallel form of the same (long sequences on few batch elements, ckpt_given != 0 only: the un-pooled Vim baseline at
+ * high resolution): the adjoint recurrence is linear in the adjoint state like the forward one in the state, so the
+ * segments of fv_mixer_scan_fwd_seg are walked side by side here too -- adjoint states reached from zero, a serial combine
+ * last segment to first, then the backward kernel proper per segment.  seg_ws: fv_mixer_scan_bwd_seg_floats() fp32 (0: one
+ * segment, pass NULL); partials then has fv_mixer_scan_bwd_seg_partials() rows (one per batch element and segment). */
+int fv_mixer_scan_bwd_segments(int batch, int Lc, int dt_rank);
+size_t fv_mixer_scan_bwd_seg_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank);
+int fv_mixer_scan_bwd_seg_partials(int batch, int Lc, int dt_rank);
+int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias, const float* A_log,
+                          const float* dt_w_b, const float* dt_bias_b, const float* A_log_b, const float* dyc,
+                          int dyc_per_direction, float* dxc, float* dx_dbl, float* ckpt, int ckpt_given, float* partials,
+                          float* seg_ws, int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
+                          fv_stream_t stream);
 
 /* ---- MAE masked mixer: kept tokens <-> pooling rows --------------------------
  * Replaces compute_row_means_constantdivide (index_add_ over the kept tokens, divide by cols;

@@ -57,7 +57,11 @@ def test_host_side_launch_planning_functions():
     assert seg(128, 200, 384, 12) == 1                  # Vim-T 224 px batch 128: 1536 workgroups already
     assert seg(8, 128, 1536, 48) == 1                   # FastVim-B 2048 px: 8 chunks, nothing to cut
     assert seg(128, 14, 384, 12) == 1 and seg(1, 4104, 192, 80) == 1      # short; dt_rank > 48 (generic kernel)
-    assert seg(1, 4104, 192, 6) == 32                   # 257 chunks / 8
+    assert seg(1, 4104, 192, 6) == 29                   # 257 chunks: at most 32 segments -> 9 chunks each -> 29 non-empty ones
+    # the backward scan follows the forward rule on the model family's d_inner = 32 dt_rank; one partial row per (batch, segment)
+    assert lib.fv_mixer_scan_bwd_segments(i(8), i(16392), i(12)) == s_vim
+    assert lib.fv_mixer_scan_bwd_seg_partials(i(8), i(16392), i(12)) == 8 * s_vim
+    assert lib.fv_mixer_scan_bwd_seg_floats(i(128), i(200), i(384), i(16), i(12)) == 0
     n = lib.fv_mixer_scan_fwd_seg_floats(i(8), i(16392), i(384), i(16), i(12))
     assert n == 2 * 8 * s_vim * 384 * (2 * 16 + 1)
     assert lib.fv_mixer_scan_fwd_seg_floats(i(128), i(200), i(384), i(16), i(12)) == 0

@@ -250,7 +250,8 @@ def _scan_cl_case(Bsz, Lc, d_in, R, dtype, seed):
                                            (2, 17, 384, 12),        # a second chunk of one step
                                            (1, 197, 384, 12),       # unpooled Vim-T: 12 chunks + 5 steps
                                            (1, 4104, 192, 6),       # Lc >= 4096 (un-pooled Vim at 1024 px): 257 chunks; the
-                                                                    # forward launch runs segment-parallel (32 segments)
+                                                                    # forward (and, with its checkpoints, backward) launch
+                                                                    # runs segment-parallel (29 segments of 9 chunks)
                                            (2, 1000, 384, 12),      # 63 chunks in 7 segments of 9, ragged last chunk
                                            (64, 37, 384, 12),       # enough workgroups for the 12-wave form (192 channels)
                                            (64, 14, 1536, 48),      # short kernel walking 4 batch elements per workgroup
