@@ -179,6 +179,13 @@ def kernel_table(B, rows, cols, d, depth, dtype):
                                                     residual_in_fp32=True, is_rms_norm=True),
                             ("hid", "res"), B * L * d * (2 * e + 8), 1),
     }
+    # short pooled lengths in bf16 (configs 2 / 3 up to d_inner 768): the step runs x_proj + dt_proj + scan as ONE launch
+    # (fv_mixer_xproj_scan_fwd) -- time that launch under the scan_fwd name, as the step trace does
+    if dtype == torch.bfloat16:
+        Wx2c = (rn(2, R + 2 * N, d_in, dt=torch.float32) * d_in ** -0.5).to(dtype)
+        if M.xproj_scan_fwd(T["xc"], Wx2c, Wdt, bdt, A_log, Wdt, bdt, A_log) is not None:
+            table["scan_fwd"] = (lambda s: M.xproj_scan_fwd(s["xc"], Wx2c, Wdt, bdt, A_log, Wdt, bdt, A_log), ("xc",),
+                                 2 * (small * e + B * rows * (R + 2 * N) * e + small * 4) + Wx2c.numel() * e, 1)
     out = {}
     # the backward wrappers sum their per-block gradient partials right away when no flat gradient is attached; in
     # the training step those sums are deferred into reduce_partials_multi launches (timed by the step, not here), so
@@ -499,7 +506,8 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # (a live process group's watchdog thread polls events: "thread_local" keeps that legal during capture, pipeline.py)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
             loss_buf = fwd_bwd()
             if world == 1:
                 opt.step()

@@ -20,6 +20,7 @@ same sums are taken in another order and the two agree to rounding (tests/test_p
 import warnings
 
 import torch
+import torch.distributed as dist
 
 
 class SegmentedTrainStep:
@@ -139,17 +140,23 @@ class SegmentedTrainStep:
         self._restore(snap)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
+        # With a process group alive, its watchdog THREAD polls the events of finished collectives (hipEventQuery); under the
+        # default "global" capture mode any thread's event query while this thread captures is an error
+        # (hipErrorStreamCaptureUnsupported: "operation not permitted when stream is capturing" -- it took the whole process
+        # down, intermittently, in tests/test_pipeline_gpu.py::test_rccl_buckets_between_backward_graphs).  "thread_local"
+        # restricts the check to the capturing thread, which issues nothing but kernel launches.
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fwd, pool=pool):
+        with torch.cuda.graph(g_fwd, pool=pool, capture_error_mode=mode):
             self.loss = self._forward()
         g_bwd = []
         for k in range(self.K):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
                 self._backward(k)
             g_bwd.append(g)
         g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_opt, pool=pool):
+        with torch.cuda.graph(g_opt, pool=pool, capture_error_mode=mode):
             self.opt.step(grad_scale=self._gscale)
         self.graphs = (g_fwd, g_bwd, g_opt)
 
