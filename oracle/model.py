@@ -119,15 +119,20 @@ def patch_embed_oracle(sd, x, patch_size, cd):
 
 def fastvim_block_oracle(sd_layer, hidden, residual, layer_idx, token_size, *, norm_eps=1e-5,
                          rotate_every_block=True, row_scale=None, compute_dtype=torch.float64,
-                         mixer_kwargs=None):
+                         mixer_kwargs=None, storage_dtype=None):
     """models/fastvim.py:146-212 with fused_add_norm=True, rms_norm=True,
     residual_in_fp32=True.  ``row_scale`` is the DropPath per-sample scale applied to
-    ``hidden`` before the add (:182-190).  Returns (hidden_out, residual_out)."""
+    ``hidden`` before the add (:182-190).  Returns (hidden_out, residual_out).
+    ``storage_dtype``: the autocast mode of the HIP path -- the normalised rows and the mixer's tensors take a round trip
+    through it where the HIP path stores them (see ``fastvim_mixer_oracle``); the residual stream stays in ``compute_dtype``."""
     cd = compute_dtype
     h, res = fused_add_norm_oracle(hidden, sd_layer["norm.weight"], None, residual, norm_eps,
                                    prenorm=True, residual_in_fp32=True, is_rms_norm=True,
                                    row_scale=row_scale if residual is not None else None,
                                    compute_dtype=cd)
+    if storage_dtype is not None:
+        h = h.to(storage_dtype).to(cd)
+        mixer_kwargs = dict(mixer_kwargs or {}, storage_dtype=storage_dtype)
     T0, T1 = token_size
     Bsz, M, d = h.shape
     rot = rotate_every_block and layer_idx % 2 != 0
@@ -144,14 +149,28 @@ def fastvim_block_oracle(sd_layer, hidden, residual, layer_idx, token_size, *, n
 def fastvim_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, rotate_every_block=True,
                            final_pool_type="mean", row_scales=None, compute_dtype=torch.float64,
                            return_features=False, return_hidden=False, mixer_kwargs=None,
-                           scanpath_type="rowwise"):
+                           scanpath_type="rowwise", storage_dtype=None):
     """models/fastvim.py:484-557 (if_abs_pos_embed=True, fused_add_norm, rms_norm,
     residual_in_fp32).  ``row_scales``: optional list of depth+1 per-sample DropPath scales
     ((B,) tensors or None); entry i is applied inside block i, entry ``depth`` before norm_f.
     ``scanpath_type="colwise"`` (Pool_row): the patch grid is transposed before it is flattened and
-    the token grid is (gw, gh) (models/fastvim.py:45-51, 97-98)."""
+    the token grid is (gw, gh) (models/fastvim.py:45-51, 97-98).
+    ``storage_dtype`` (e.g. torch.bfloat16; rowwise path): same math in ``compute_dtype`` with a round trip through it at
+    every tensor the HIP path stores in it under autocast -- the unfolded patches and the projection weight, the patch
+    projection's product (bias and position table are added in fp32 after it), every block's normalised rows and mixer
+    tensors, the final norm's rows, the pooled feature, the head's weight and its logits.  For bf16 parity tests at a few
+    ulps instead of percent-level bounds."""
     cd = compute_dtype
-    h, token_size = patch_embed_oracle(sd, x, patch_size, cd)
+    rq = (lambda t: t) if storage_dtype is None else (lambda t: t.to(storage_dtype).to(cd))
+    if storage_dtype is None:
+        h, token_size = patch_embed_oracle(sd, x, patch_size, cd)
+    else:
+        Bsz, C, H, W = x.shape
+        ps = patch_size
+        gh, gw = H // ps, W // ps
+        patches = rq(x.to(cd)).reshape(Bsz, C, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(Bsz, gh * gw, C * ps * ps)
+        h = rq(patches @ rq(sd["patch_embed.proj.weight"].to(cd).reshape(-1, C * ps * ps)).t()) + sd["patch_embed.proj.bias"].to(cd)
+        token_size = (gh, gw)
     if scanpath_type == "colwise":
         gh, gw = token_size
         h = h.reshape(h.shape[0], gh, gw, -1).transpose(1, 2).reshape(h.shape[0], gh * gw, -1)
@@ -164,11 +183,18 @@ def fastvim_forward_oracle(sd, x, *, patch_size=16, depth=24, norm_eps=1e-5, rot
         rs = row_scales[i] if row_scales is not None else None
         h, residual = fastvim_block_oracle(_sub(sd, f"layers.{i}."), h, residual, i, token_size,
                                            norm_eps=norm_eps, rotate_every_block=rotate_every_block,
-                                           row_scale=rs, compute_dtype=cd, mixer_kwargs=mixer_kwargs)
+                                           row_scale=rs, compute_dtype=cd, mixer_kwargs=mixer_kwargs,
+                                           storage_dtype=storage_dtype)
         hiddens.append(h)
     rs = row_scales[depth] if row_scales is not None else None
     h = fused_add_norm_oracle(h, sd["norm_f.weight"], None, residual, norm_eps, prenorm=False,
                               residual_in_fp32=True, is_rms_norm=True, row_scale=rs, compute_dtype=cd)
+    if storage_dtype is not None and final_pool_type == "mean":
+        feat = rq(rq(h.to(cd)).mean(1))
+        if return_features:
+            return (feat, hiddens) if return_hidden else feat
+        logits = rq(feat @ rq(sd["head.weight"].to(cd)).t() + sd["head.bias"].to(cd))
+        return (logits, hiddens) if return_hidden else logits
     if final_pool_type == "mean":                                         # :541-542
         feat = h.to(cd).mean(1)
     elif final_pool_type == "none":

@@ -86,7 +86,32 @@ def test_fastvim_t_bf16_autocast_close_to_fp32_reference():
         logits = m(x.cuda())
     ref = c["logits"]
     rel = (logits.float().cpu() - ref).norm() / ref.norm()
-    assert rel <= 3e-2, rel   # 24 blocks of bf16 activations; fp32 residual stream keeps it ~1e-2
+    assert rel <= 1.5e-2, rel   # 24 blocks of bf16 activations; fp32 residual stream keeps it under 1e-2 (measured 8.6e-3)
+
+
+def test_fastvim_t_bf16_logits_vs_storage_rounded_oracle():
+    """bf16 at the MODEL level against the fp64 oracle with a bf16 round trip at every tensor the HIP path stores in bf16 under
+    autocast (patches, shadow weights, the patch projection's product, every block's normalised rows and mixer tensors, the
+    final norm, the pooled feature, the head's logits -- ``fastvim_forward_oracle(storage_dtype=torch.bfloat16)``; the
+    residual stream stays unrounded as in the HIP path).  At the mixer level that oracle pins the kernels to 2 ulps
+    (tests/test_config34_gpu.py); over 24 blocks the occasional one-ulp flip of an intermediate is carried and amplified
+    along the residual stream, so the model-level agreement is set by that, not by where the roundings sit: measured
+    7.2e-3 relative L2 / 2 ulps of the logit scale against this oracle and 8.6e-3 against the reference's fp32 logits.
+    Bounds: 1.2e-2 and 4 ulps here (the round-2 bound on the fp32 comparison was 3e-2; it is 1.5e-2 now)."""
+    from fastvim_amd.fastvim import FastVimT
+    from oracle import fastvim_forward_oracle, make_state_dict
+    c = load_golden("model_fastvim_t.pt")
+    sd = make_state_dict(seed=c["param_seed"], embed_dim=192, depth=24)
+    m = FastVimT(drop_path_rate=0.0).cuda().eval()
+    m.load_state_dict(sd, strict=True)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(c["x_seed"]))
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        logits = m(x.cuda())
+    ref = fastvim_forward_oracle(sd, x, compute_dtype=F64, storage_dtype=torch.bfloat16)
+    rel = ((logits.double().cpu() - ref).norm() / ref.norm()).item()
+    err, scale = _err(logits, ref), ref.abs().max().item()
+    assert rel <= 1.2e-2, rel
+    assert err <= 4 * 2.0 ** -8 * scale, (err, scale)
 
 
 def test_image_gradient_flows_through_patch_embed():
