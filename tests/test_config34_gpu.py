@@ -267,6 +267,8 @@ def test_scan_cl_kernels_vs_selective_scan_oracle(Bsz, Lc, d_in, R, dtype, given
     forward itself (long pooled lengths only; elsewhere the forward launch returns no checkpoints)."""
     from fastvim_amd import mixer_ops as M
     from oracle import selective_scan_oracle
+    if Lc >= 4000 and not given:
+        pytest.skip("the 4 104-step case runs once per dtype, in its training form (the fp64 oracle walks it in Python)")
     N = 16
     xc, x_dbl, Wdt, bdt, A_log, dyc = _scan_cl_case(Bsz, Lc, d_in, R, dtype, seed=Lc + d_in)
     dev = "cuda"
