@@ -108,13 +108,18 @@ def time_kernel(fns, iters=20, warm=3):
     torch.cuda.current_stream().wait_stream(side)
     g.replay()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    g.replay()
-    e.record()
-    torch.cuda.synchronize()
+    # median of three timed replays: one replay now and then catches a stall that is not the kernel's (a cfg-3 scan row
+    # once read 458 us against 52-54 us in every other run and 46.5 us in the step trace)
+    times = []
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        times.append(s.elapsed_time(e))
     del keep
-    return s.elapsed_time(e) * 1e-3 / iters   # seconds per launch (incl. its own reduce_partials, if any)
+    return sorted(times)[1] * 1e-3 / iters   # seconds per launch (incl. its own reduce_partials, if any)
 
 
 def rotating(fn, base, names, nbytes, cap=48):
