@@ -14,6 +14,34 @@ from . import _lib as L
 from .mixer_ops import reduce_partials
 
 
+def _conv_fwd(x, w32, b32, silu):
+    """The forward kernel launch: x (B, D, L) contiguous, w32 (D, W) / b32 (D,) fp32."""
+    B, D, Lq = x.shape
+    y = torch.empty_like(x)
+    rc = L.lib().fv_causal_conv1d_fwd(L.ptr(x), L.ptr(w32), L.ptr(b32), L.ptr(y), L.i32(B), L.i32(D), L.i32(Lq),
+                                      L.i32(w32.shape[1]), L.i32(silu), L.i32(L.dtype_code(x.dtype)), L.stream_of(x))
+    L.check(rc, "causal_conv1d_fwd")
+    return y
+
+
+def _conv_bwd(x, w32, b32, dy, silu):
+    """The backward kernel launch: (dx in x's dtype, dw (D, W) fp32, db (D,) fp32), the weight / bias sums over the batch
+    in fixed order."""
+    B, D, Lq = x.shape
+    W = w32.shape[1]
+    dy = dy.to(x.dtype)
+    if dy.stride(2) != 1 or dy.stride(1) != Lq or dy.stride(0) != D * Lq:
+        dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    part = torch.empty(B, D, 5, device=x.device, dtype=torch.float32)
+    rc = L.lib().fv_causal_conv1d_bwd(L.ptr(x), L.ptr(w32), L.ptr(b32), L.ptr(dy), L.ptr(dx), L.ptr(part), L.i32(B),
+                                      L.i32(D), L.i32(Lq), L.i32(W), L.i32(silu), L.i32(L.dtype_code(x.dtype)),
+                                      L.stream_of(x))
+    L.check(rc, "causal_conv1d_bwd")
+    red = reduce_partials(part.view(B, D * 5), B).view(D, 5)        # fixed-order sum over the batch
+    return dx, red[:, 4 - W:4], red[:, 4]
+
+
 class CausalConv1dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias=None, seq_idx=None, activation=None):
@@ -26,15 +54,10 @@ class CausalConv1dFn(torch.autograd.Function):
             raise RuntimeError(f"causal_conv1d_fn: x (B, D, L) / weight (D, W) expected, got {tuple(x.shape)} / {tuple(weight.shape)}")
         if x.stride(2) != 1 or x.stride(1) != x.shape[2]:
             x = x.contiguous()
-        B, D, Lq = x.shape
         w32 = weight.detach().float().contiguous()
         b32 = bias.detach().float().contiguous() if bias is not None else None
-        y = torch.empty_like(x)
         silu = activation in ("silu", "swish")
-        rc = L.lib().fv_causal_conv1d_fwd(L.ptr(x), L.ptr(w32), L.ptr(b32), L.ptr(y), L.i32(B), L.i32(D), L.i32(Lq),
-                                          L.i32(weight.shape[1]), L.i32(silu), L.i32(L.dtype_code(x.dtype)),
-                                          L.stream_of(x))
-        L.check(rc, "causal_conv1d_fwd")
+        y = _conv_fwd(x, w32, b32, silu)
         ctx.save_for_backward(x, w32, b32 if b32 is not None else x.new_empty(0))
         ctx.silu, ctx.has_bias = silu, bias is not None
         ctx.w_dtype = weight.dtype
@@ -44,21 +67,8 @@ class CausalConv1dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w32, b32 = ctx.saved_tensors
-        B, D, Lq = x.shape
-        W = w32.shape[1]
-        dy = dy.to(x.dtype)
-        if dy.stride(2) != 1 or dy.stride(1) != Lq or dy.stride(0) != D * Lq:
-            dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        part = torch.empty(B, D, 5, device=x.device, dtype=torch.float32)
-        rc = L.lib().fv_causal_conv1d_bwd(L.ptr(x), L.ptr(w32), L.ptr(b32 if ctx.has_bias else None), L.ptr(dy),
-                                          L.ptr(dx), L.ptr(part), L.i32(B), L.i32(D), L.i32(Lq), L.i32(W),
-                                          L.i32(ctx.silu), L.i32(L.dtype_code(x.dtype)), L.stream_of(x))
-        L.check(rc, "causal_conv1d_bwd")
-        red = reduce_partials(part.view(B, D * 5), B).view(D, 5)        # fixed-order sum over the batch
-        dw = red[:, 4 - W:4].to(ctx.w_dtype)
-        db = red[:, 4].to(ctx.b_dtype) if ctx.has_bias else None
-        return dx, dw, db, None, None
+        dx, dw, db = _conv_bwd(x, w32, b32 if ctx.has_bias else None, dy, ctx.silu)
+        return dx, dw.to(ctx.w_dtype), db.to(ctx.b_dtype) if ctx.has_bias else None, None, None
 
 
 def causal_conv1d_fn(x, weight, bias=None, seq_idx=None, activation=None):
