@@ -130,6 +130,24 @@ def rotating(fn, base, names, nbytes, cap=48):
     return [lambda s_=s_: fn(s_) for s_ in sets]
 
 
+def stream_floor(B, L, d_in, dtype):
+    """What PLAIN elementwise kernels get on HBM-cold tensors of the step's full-length size U = (B, L, d_in): a copy (1 read,
+    1 write) and an add (2 reads, 1 write), operand sets rotated exactly like the kernel rows.  The reference point for the
+    short HBM-bound kernels: at U = 19.3 MB a launch is 10-15 us long and its ramp and drain keep even a copy at 3.0-4.5
+    TB/s of the 8 TB/s peak (6.3 TB/s is what a long read-only stream reaches)."""
+    n = B * L * d_in
+    e = 2 if dtype == torch.bfloat16 else 4
+    base = {k: torch.randn(n, device="cuda").to(dtype) for k in ("a", "b", "c")}
+    out = {}
+    for name, fn, names, streams in (("copy_1r1w", lambda s: s["b"].copy_(s["a"]), ("a", "b"), 2),
+                                     ("add_2r1w", lambda s: torch.add(s["a"], s["b"], out=s["c"]), ("a", "b", "c"), 3)):
+        fns = rotating(fn, base, names, n * e * len(names))
+        t = time_kernel(fns)
+        out[name] = {"us": round(t * 1e6, 2), "MB": round(streams * n * e / 1e6, 2), "GBps": round(streams * n * e / t / 1e9, 1)}
+        del fns
+    return out
+
+
 def kernel_table(B, rows, cols, d, depth, dtype):
     """Time every hand-written full-length kernel of one mixer block at the benchmark shape and price it against its
     ALGORITHMIC bytes (formulas in DESIGN.md).  ``us`` is HBM-COLD (operand sets rotated past the Infinity Cache, as
@@ -781,6 +799,10 @@ def main():
                                "avg_us_warm": kt[dom].get("us_warm"),
                                "frac_warm": (round(kt[dom]["algorithmic_MB"] * 1e6 / (kt[dom]["us_warm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                                              if kt[dom].get("us_warm") else None)}
+            try:      # plain elementwise kernels on cold tensors of the same size: what a 10-15 us launch can reach at all
+                out["roofline"]["elementwise_floor_same_size_cold"] = stream_floor(args.batch, gs * gs, 2 * d, amp_dtype)
+            except Exception as e_:
+                out["roofline"]["elementwise_floor_same_size_cold"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
             if dom.startswith("scan"):
                 # the pooled scan moves 1/cols of a full-length tensor: it is bound by VALU issue, not by HBM
                 # (profiles/r01_pmc_scan_bwd.json: ~85 % of the SIMD issue slots busy at 4 waves/SIMD); the
