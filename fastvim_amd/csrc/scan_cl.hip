@@ -424,10 +424,11 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // the d delta_raw table's rows past Lc feed the K / M padding of the MFMAs: zero once
   for (int e = tid; e < 16 * SH_DRS; e += SH_THREADS) s_dr[e] = 0.f;
-  // dt_rank <= 12: this lane's dt_proj weights of both MFMA roles are loaded once per workgroup instead of once per batch
-  // element behind the staging barrier (an L2 round trip on every wave's critical path, twice per element); wider ranks
-  // have no registers left for them
-  constexpr bool HOIST = RQ <= 3;
+  // this lane's dt_proj weights of both MFMA roles are loaded once per workgroup instead of once per batch element behind
+  // the staging barrier (an L2 round trip on every wave's critical path, twice per element).  At dt_rank 48 they are 24
+  // registers and the kernel then spills 26 -- measured worth it all the same (same box, FastVim-B 224 px step 29.2 -> 28.5 ms,
+  // the kernel 139 -> 114 us; FastVim-S, dt_rank 24, 8 spills: 12.54 -> 12.51)
+  constexpr bool HOIST = RQ <= 12;
   float wt_h[HOIST ? RQP : 1], wa_h[HOIST ? 4 * RT : 1];
   if constexpr (HOIST) {
     const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv2 = t2 >> 6, dm = ch0 + wv2 * 16 + cm;
