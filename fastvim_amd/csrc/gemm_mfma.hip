@@ -1065,7 +1065,12 @@ __device__ __forceinline__ void p256_body(const GemmParams& p, int bid, int spli
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const int m = m0 + wr * 128 + b * 16 + (lane & 15), n = n0 + wc * 64 + a * 16 + (lane >> 4) * 4;
-        if (m < p.M) *reinterpret_cast<f32x4*>(Cf + (long)m * p.ldc + n) = acc[a][b];
+        if (m < p.M) {
+          f32x4* dst = reinterpret_cast<f32x4*>(Cf + (long)m * p.ldc + n);
+          // c_fp32 == 2: the one K slice of the problem is added to what C holds (a weight gradient accumulated in place:
+          // every element belongs to one workgroup, so the sum is as deterministic as the partial + reduction it replaces)
+          *dst = p.c_fp32 == 2 ? *dst + acc[a][b] : acc[a][b];
+        }
       }
     return;
   }
@@ -1663,9 +1668,15 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
   for (int base = 0; base < count; base += per_launch) {
     GroupedParams G{};
     const int n = count - base < per_launch ? count - base : per_launch;
+    bool any_direct = false;
     for (int i = 0; i < n; ++i) {
       const int q = base + i;
-      FV_CHECK(x[q] && y[q] && parts[q] && Kd[q] > 0 && M[q] > 0 && N[q] > 0 && splits[q] >= 1,
+      // splits[q] == -1: ONE K slice, ADDED to the (M, N) fp32 matrix parts[q] points at (large outputs of the phased
+      // 256 x 256 form only): no partial buffer, no reduction launch
+      const bool direct = splits[q] == -1;
+      const int nsl = direct ? 1 : splits[q];
+      any_direct = any_direct || direct;
+      FV_CHECK(x[q] && y[q] && parts[q] && Kd[q] > 0 && M[q] > 0 && N[q] > 0 && nsl >= 1,
                "gemm_bf16_tn_grouped: bad problem %d", q);
       const int la = ldx ? ldx[q] : M[q], lb = ldy ? ldy[q] : N[q];
       FV_CHECK(la >= M[q] && lb >= N[q] && la % 8 == 0 && lb % 8 == 0 && ((uintptr_t)x[q] & 15) == 0 &&
@@ -1673,11 +1684,11 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
                "gemm_bf16_tn_grouped: problem %d: operands must be 16-byte aligned, row strides multiples of 8", q);
       GemmParams& p = G.p[i];
       p.A = (const bf16_t*)x[q]; p.B = (const bf16_t*)y[q]; p.C = parts[q]; p.bias = nullptr;
-      p.M = M[q]; p.N = N[q]; p.K = Kd[q]; p.lda = la; p.ldb = lb; p.ldc = N[q]; p.c_fp32 = 1;
-      p.k_per_split = fv_cdiv(fv_cdiv(Kd[q], splits[q]), BK) * BK;
+      p.M = M[q]; p.N = N[q]; p.K = Kd[q]; p.lda = la; p.ldb = lb; p.ldc = N[q]; p.c_fp32 = direct ? 2 : 1;
+      p.k_per_split = fv_cdiv(fv_cdiv(Kd[q], nsl), BK) * BK;
       p.c_split_stride = (long)M[q] * N[q];
-      FV_CHECK(fv_cdiv(Kd[q], p.k_per_split) == splits[q],
-               "gemm_bf16_tn_grouped: problem %d: K=%d cannot be cut into %d slices of whole 64-deep tiles", q, Kd[q], splits[q]);
+      FV_CHECK(fv_cdiv(Kd[q], p.k_per_split) == nsl,
+               "gemm_bf16_tn_grouped: problem %d: K=%d cannot be cut into %d slices of whole 64-deep tiles", q, Kd[q], nsl);
     }
     G.count = n;
     static const int xcd_order = fv_tune("FASTVIM_WGRAD_GROUP_XCD", 1) | (fv_tune("FASTVIM_GEMM_DBG", 0) << 8);   // tuning hooks
@@ -1729,6 +1740,7 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
         static const int wg_phased = fv_tune("FASTVIM_WGRAD_P256", 1);   // tuning hook
         bool two_tiles = true;             // the phased loop wants at least two K tiles per slice
         for (int i = 0; i < n; ++i) two_tiles = two_tiles && G.p[i].k_per_split >= 2 * BK && G.p[i].K % G.p[i].k_per_split == 0;
+        FV_CHECK(!any_direct || (wg_phased && two_tiles), "gemm_bf16_tn_grouped: in-place accumulation (splits = -1) needs the phased 256 x 256 form");
         if (wg_phased && two_tiles)
           hipLaunchKernelGGL(gemm_p256_grouped_kernel, dim3(b2), dim3(512), (size_t)2 * (256 + 256) * BK * 2, st, G, xcd_order);
         else
@@ -1738,6 +1750,7 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
         continue;
       }
     }
+    FV_CHECK(!any_direct, "gemm_bf16_tn_grouped: in-place accumulation (splits = -1) is built for outputs that are multiples of 256 x 256 (>= 512 x 512) only");
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
       blocks += fv_cdiv(G.p[i].M, bm[cls]) * fv_cdiv(G.p[i].N, bn[cls]) * fv_cdiv(G.p[i].K, G.p[i].k_per_split);

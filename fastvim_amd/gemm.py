@@ -223,6 +223,7 @@ def _tile_class(M, N):
     return best
 
 
+DIRECT_ACC = True      # False: every grouped problem writes partials that a reduction launch adds to the gradient
 _SLOTS = (512, 512, 512, 256)     # workgroups of the grouped kernel the chip holds at once, per tile class (two per CU;
                                   # one of the 8-wave 256 x 256 tiles)
 FILL = True      # False: the factors of grouped_splits whatever the group (a segmented step then sums every weight
@@ -261,12 +262,18 @@ def _gemm_tn_grouped_one(jobs, reduce, c=None):
         c = _tile_class(jobs[0][0].shape[1], jobs[0][1].shape[1]) if k == 1 else 0
     jobs = [(x, y, out, s_) for (x, y, out, _), s_ in zip(jobs, fill_splits(jobs, c))]
     parts = []
+    direct = []
     for x, y, out, sp in jobs:
         Kd, M = x.shape
         N = y.shape[1]
         assert x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and x.stride(1) == 1 and y.stride(1) == 1
         assert out.numel() == M * N and out.dtype == torch.float32
-        parts.append(torch.empty(sp, M, N, device=x.device, dtype=torch.float32))
+        # one K slice of a large output (FastVim-B: 3072 x 768, 768 x 1536) is added to the gradient by the GEMM itself:
+        # the (1, M, N) partial and the launch that summed it were 1 GB of traffic per step for nothing
+        d = (DIRECT_ACC and c == 3 and sp == 1 and Kd % 64 == 0 and Kd >= 128 and out.is_contiguous()
+             and out.data_ptr() % 16 == 0)
+        direct.append(d)
+        parts.append(out.view(1, M, N) if d else torch.empty(sp, M, N, device=x.device, dtype=torch.float32))
     P = ctypes.c_void_p
     xs = (P * k)(*[j[0].data_ptr() for j in jobs])
     ys = (P * k)(*[j[1].data_ptr() for j in jobs])
@@ -275,12 +282,12 @@ def _gemm_tn_grouped_one(jobs, reduce, c=None):
     Kds = (I * k)(*[j[0].shape[0] for j in jobs])
     Ms = (I * k)(*[j[0].shape[1] for j in jobs])
     Ns = (I * k)(*[j[1].shape[1] for j in jobs])
-    sps = (I * k)(*[j[3] for j in jobs])
+    sps = (I * k)(*[-1 if d else j[3] for j, d in zip(jobs, direct)])
     ldx = (I * k)(*[j[0].stride(0) for j in jobs])       # rows may be padded (a column slice of a wider buffer)
     ldy = (I * k)(*[j[1].stride(0) for j in jobs])
     rc = L.lib().fv_gemm_bf16_tn_grouped_ld(xs, ys, ps, Kds, Ms, Ns, ldx, ldy, sps, L.i32(k), L.stream_of(jobs[0][0]))
     L.check(rc, "gemm_bf16_tn_grouped")
-    todo = [(part, sp, out) for (x, y, out, sp), part in zip(jobs, parts)]
+    todo = [(part, sp, out) for (x, y, out, sp), part, d in zip(jobs, parts, direct) if not d]
     if not reduce:
         return todo
     for part, sp, out in todo:

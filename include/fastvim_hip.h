@@ -367,7 +367,10 @@ int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* residual, c
 
 /* Several weight gradients in one launch (queued until the end of the backward pass): problem i is
  * x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32 partials (sum with fv_reduce_partials);
- * the same arithmetic, tiling and fixed split order as fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1). */
+ * the same arithmetic, tiling and fixed split order as fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1).
+ * splits_i == -1: one K slice ADDED in place to the (M_i, N_i) fp32 matrix parts_i points at (the gradient itself; no
+ * partial, nothing to reduce) -- for launches whose outputs are all multiples of 256 x 256 and at least 512 x 512, Kd_i a
+ * multiple of 64 and >= 128; an error otherwise. */
 int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
                             const int* M, const int* N, const int* splits, int count, fv_stream_t stream);
 /* Same with explicit row strides (elements) of x and y -- rows may be padded (ldx >= M, ldy >= N, multiples of 8; pad

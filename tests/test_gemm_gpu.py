@@ -175,6 +175,43 @@ def test_grouped_weight_gradients_tile_classes():
         assert torch.equal(got, single)
 
 
+def test_grouped_weight_gradients_accumulate_in_place():
+    """Large outputs with ONE K slice (FastVim-B: 3072 x 768, 768 x 1536) are added to the gradient by the grouped GEMM
+    itself (splits = -1 of fv_gemm_bf16_tn_grouped: no partial, no reduction launch): bit for bit what the partial +
+    fv_reduce_partials route gives, on a gradient that already holds a first backward pass, and mixed in one call with a
+    problem that keeps the partial route."""
+    from fastvim_amd import gemm as G
+    from fastvim_amd.mixer_ops import flush_reductions
+    torch.manual_seed(2)
+    shapes = [(1792, 3072, 768, 1), (1792, 768, 1536, 1), (1792, 768, 192, 7), (256, 512, 512, 1)]
+    xs = [(torch.randn(Kd, M_, device="cuda").bfloat16(), torch.randn(Kd, N_, device="cuda").bfloat16()) for Kd, M_, N_, _ in shapes]
+    first = [torch.randn(M_ * N_, device="cuda") for _, M_, N_, _ in shapes]
+    outs = {}
+    for mode in (True, False):
+        G.DIRECT_ACC = mode
+        try:
+            out = [f.clone() for f in first]
+            G.gemm_tn_grouped([(x, y, o, sp) for (x, y), o, (_, _, _, sp) in zip(xs, out, shapes)])
+            flush_reductions()
+            outs[mode] = out
+        finally:
+            G.DIRECT_ACC = True
+    for a, b, (x, y), f in zip(outs[True], outs[False], xs, first):
+        assert torch.equal(a, b)
+        ref = f.double() + (x.double().t() @ y.double()).reshape(-1)
+        assert (a.double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    # the C entry refuses the in-place form where it is not built (an output that is not a multiple of 256 x 256)
+    from fastvim_amd import _lib as L
+    import ctypes
+    x, y = torch.randn(256, 192, device="cuda").bfloat16(), torch.randn(256, 384, device="cuda").bfloat16()
+    o = torch.zeros(192 * 384, device="cuda")
+    P, I = ctypes.c_void_p, ctypes.c_int
+    rc = L.lib().fv_gemm_bf16_tn_grouped_ld((P * 1)(x.data_ptr()), (P * 1)(y.data_ptr()), (P * 1)(o.data_ptr()), (I * 1)(256),
+                                            (I * 1)(192), (I * 1)(384), (I * 1)(192), (I * 1)(384), (I * 1)(-1), L.i32(1),
+                                            L.stream_of(x))
+    assert rc != 0
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 768, 192), (392, 44, 384), (25088, 192, 384), (130, 72, 41),
                                    (7, 5, 3), (128, 1000, 192), (3584, 80, 1536), (8, 1000, 768)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -1,5 +1,5 @@
 """One configuration's step time with Python-side knobs set from the command line (C-side knobs: FASTVIM_* environment
-variables of a tuning build).  usage: python tools/probe/ab_step.py MODEL IMG BATCH STEPS [--presum N]"""
+variables of a tuning build).  usage: python tools/probe/ab_step.py MODEL IMG BATCH STEPS [--presum N] [--no-direct-acc]"""
 import json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
@@ -9,6 +9,9 @@ import bench
 from fastvim_amd import mixer_ops
 a = sys.argv[1:]
 model, img, batch, steps = a[0], int(a[1]), int(a[2]), int(a[3])
+if "--no-direct-acc" in a:
+    from fastvim_amd import gemm as _g
+    _g.DIRECT_ACC = False
 if "--presum" in a:
     mixer_ops._XPROJ_PRESUM = int(a[a.index("--presum") + 1])
 torch.cuda.set_device(0)
