@@ -101,8 +101,11 @@ def time_kernel(fns, iters=20, warm=3):
     side.wait_stream(torch.cuda.current_stream())
     g = torch.cuda.CUDAGraph()
     keep = []
+    # with a process group alive its watchdog thread polls events; a "global" capture turns that into a capture error
+    #  -- N > 1 runs time their kernel rows on rank 0 with the other ranks parked in a barrier
+    mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
     with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode=mode):
             for i in range(iters):
                 keep.append(fns[i % n]())
     torch.cuda.current_stream().wait_stream(side)
