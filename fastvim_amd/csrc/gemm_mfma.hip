@@ -1594,6 +1594,7 @@ extern "C" int fv_gemm_bf16_addnorm2(const void* A, const void* W, const float* 
 #ifdef FASTVIM_TUNING_HOOKS
 // diagnostic builds only: (workgroups, 8) uint64 device buffer the fused kernels stamp their phases into (NULL: off)
 extern "C" void fv_debug_set_stamps(unsigned long long* buf) { g_fv_stamps = buf; }
+extern "C" unsigned long long* fv_debug_get_stamps() { return g_fv_stamps; }      // for the other translation units' probes
 #endif
 
 extern "C" int fv_gemm_bf16_dgrad_addnorm_blocks(int M) { return fv_cdiv(M, fused_rpt(M)); }

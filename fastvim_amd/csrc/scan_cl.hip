@@ -49,6 +49,7 @@ struct ScanClParams {
   float* sumdt;          // (2, B, seg, d_in)     pass A out: sum of delta over the segment (its decay is exp(A * sum))
   const float* hin;      // (2, B, seg, d_in, N)  pass C in: state entering the segment
   int adj;               // combine kernel: 1 = the adjoint recurrence (segments walked last to first)
+  unsigned long long* stamps;   // tuning builds: phase stamps of the short backward kernel (fv_debug_set_stamps), else null
 };
 
 
@@ -387,6 +388,24 @@ __device__ __forceinline__ sf2 ssplat(float a) { sf2 o; o.x = a; o.y = a; return
 __device__ __forceinline__ sf2 sfma2(sf2 a, sf2 b, sf2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ sf2 sexp2_2(sf2 a) { sf2 o; o.x = fv_exp2(a.x); o.y = fv_exp2(a.y); return o; }
 
+#ifdef FASTVIM_TUNING_HOOKS
+extern "C" unsigned long long* fv_debug_get_stamps();
+// phase stamps (diagnostic build; tools/probe/scan_stamps.py): thread 0 stores s_memtime into [workgroup][element][8]
+__device__ __forceinline__ void sc_stamp(const ScanClParams& p, int bi, int slot) {
+  if (p.stamps && threadIdx.x == 0) {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    p.stamps[(wg * p.NBB + bi) * 8 + slot] = t;
+  }
+}
+#define SC_STAMP(bi, slot) sc_stamp(p, bi, slot)
+#else
+#define SC_STAMP(bi, slot) ((void)0)
+#endif
+
 template <typename T, int RQ, int LCT, bool EXACT>      // EXACT: Lc == LCT (the 14- and 16-row grids)
 __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -451,6 +470,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   for (int bi = 0; bi < p.NBB; ++bi) {
     const int b = blockIdx.y * p.NBB + bi;
     const size_t bd = ((size_t)dir * p.B + b) * Lc;
+    SC_STAMP(bi, 0);
     // matrix role: u and dy of this lane's 4 steps (requested before the staging barrier)
     float um[4], gm[4];
     float bias_m;
@@ -488,6 +508,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
       }
     }
     __syncthreads();      // rows staged; the previous element's readers of s_part / s_pd are done as well
+    SC_STAMP(bi, 1);
 
     // ---- delta_raw[t][ch] = sum_r dt_low[t][r] Wdt[ch][r] on the matrix cores (A: t x r, B: r x ch), then
     //      softplus / sigmoid once per (step, channel); the table row {delta, u, dy, sigmoid} goes to LDS
@@ -521,6 +542,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     __builtin_amdgcn_wave_barrier();       // the table rows of this wave's 16 channels are read by this wave only
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    SC_STAMP(bi, 2);
     // ---- forward recurrence, states kept
     const float* my_bc = s_dbl + 4 * RQP + q * 4;                   // this quad lane's B states of row 0 (C: + N)
     const float* my_ch = s_ch + (size_t)ch * 4;
@@ -545,6 +567,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
       }
     }
 
+    SC_STAMP(bi, 3);
     // ---- adjoint sweep, high to low
     sf2 dxa[2] = {{0.f, 0.f}, {0.f, 0.f}};
     float* my_part = s_part + (wv * 4 + q) * 8 + (lane >> 3);
@@ -597,6 +620,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    SC_STAMP(bi, 4);
     // ---- dt_proj adjoint on the matrix cores, from this wave's 16 columns of the d delta_raw table
     {
       const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv = t2 >> 6, dm = ch0 + wv * 16 + cm;
@@ -644,7 +668,9 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
         if (actm && s < Lc) p.dxc[(bd + l) * p.d_in + dm] = s_du[s * SH_CH + wv * 16 + cm];
       }
     }
+    SC_STAMP(bi, 5);
     __syncthreads();
+    SC_STAMP(bi, 6);
     // ---- sum the 12 waves in fixed order and scatter to the x_dbl column layout [dt_low | B | C]
     {
       const int tid = opaque_tid();
@@ -669,6 +695,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
         }
       }
     }
+    SC_STAMP(bi, 7);
   }   // batch elements of this block
   const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
   float* base = p.pP + ((size_t)blockIdx.y * 2 + dir) * per_dir;
@@ -1729,6 +1756,9 @@ extern "C" int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const fl
   const int RQ = rq_of(dt_rank);
   const bool ckl = ck_in_lds(Lc);
   p.NBB = scan_bwd_nbb(batch, Lc, dt_rank);
+#ifdef FASTVIM_TUNING_HOOKS
+  p.stamps = fv_debug_get_stamps();      // csrc/gemm_mfma.hip, set by fv_debug_set_stamps()
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (bwd_short(Lc, dt_rank)) {
     dim3 sgrid(fv_cdiv(d_inner, SH_CH), batch / p.NBB, 2), sblock(SH_THREADS);
