@@ -847,40 +847,50 @@ __device__ __forceinline__ u32x4 ds_read_b128_imm(uint32_t a) {
 
 // AMODE / BMODE: KC = operand K-contiguous, KS = K-slow (row-major as stored, transposing LDS reads).  <KC, KC> forward,
 // <KC, KS> data gradient, <KS, KS> weight gradient (CF32: fp32 partial of K slice `split`).  bid = tile of the problem.
-template <int AMODE, int BMODE, bool CF32>
-__device__ __forceinline__ void p256_body(const GemmParams& p, int bid, int split, char* smem) {
+// PERSIST (forward / data-gradient forms): the workgroup walks the tiles bid, bid + bid_stride, ... < bid_end.  The first
+// K tiles of the NEXT output tile are requested before this one's C leaves (the stage buffers are free once every wave
+// is past its last read; the C slabs of a persistent workgroup live in the 32 KiB above them, 16 rows at a time), so the
+// next K loop starts on landed data instead of behind a workgroup launch, its address set-up and a cold first fetch.
+template <int AMODE, int BMODE, bool CF32, bool PERSIST = false>
+__device__ __forceinline__ void p256_body(const GemmParams& p, int bid, int split, char* smem, int bid_stride = 0,
+                                          int bid_end = 0) {
   constexpr int HALF = 128 * BK * 2;            // bytes of a 128 x 64 half tile
   constexpr int PAR = 4 * HALF;                 // one K tile: A lo | A hi | B lo | B hi
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wv >> 2, wc = wv & 3;
   const int tiles_n = p.N / 256;
-  const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;
+  int m0, n0;
   const int kbeg = split * p.k_per_split;
   const int nt = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;
   // LDS-DMA sources: thread -> physical 16-byte slot e = tid + 512 i of a half tile (rows 8 slots wide, chunk ^= row & 7)
   const int sr = tid >> 3, sc = (tid & 7) ^ (sr & 7);
   const bf16_t* srcA[4];
   const bf16_t* srcB[4];        // KC: as A;  KS: [half][piece] sources of the K-slow image ([k][128 cols], chunk-swizzled)
+  auto set_tile = [&](int b_) {
+    m0 = (b_ / tiles_n) * 256;
+    n0 = (b_ % tiles_n) * 256;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {                 // row groups of 64: g = 2 half + i
-    if constexpr (AMODE == KC) srcA[g] = p.A + (long)min(m0 + g * 64 + sr, p.M - 1) * p.lda + sc * 8 + kbeg;
-    if constexpr (BMODE == KC) srcB[g] = p.B + (long)min(n0 + g * 64 + sr, p.N - 1) * p.ldb + sc * 8 + kbeg;
-  }
+    for (int g = 0; g < 4; ++g) {                 // row groups of 64: g = 2 half + i
+      if constexpr (AMODE == KC) srcA[g] = p.A + (long)min(m0 + g * 64 + sr, p.M - 1) * p.lda + sc * 8 + kbeg;
+      if constexpr (BMODE == KC) srcB[g] = p.B + (long)min(n0 + g * 64 + sr, p.N - 1) * p.ldb + sc * 8 + kbeg;
+    }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if constexpr (AMODE == KS) {
-      GldsPlan<KS, 128, 512> ga;
-      ga.init(p.A, p.lda, m0 + h * 128, p.M, tid);
-      srcA[2 * h] = ga.src[0] + (long)kbeg * p.lda;
-      srcA[2 * h + 1] = ga.src[1] + (long)kbeg * p.lda;
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (AMODE == KS) {
+        GldsPlan<KS, 128, 512> ga;
+        ga.init(p.A, p.lda, m0 + h * 128, p.M, tid);
+        srcA[2 * h] = ga.src[0] + (long)kbeg * p.lda;
+        srcA[2 * h + 1] = ga.src[1] + (long)kbeg * p.lda;
+      }
+      if constexpr (BMODE == KS) {
+        GldsPlan<KS, 128, 512> gb;
+        gb.init(p.B, p.ldb, n0 + h * 128, p.N, tid);
+        srcB[2 * h] = gb.src[0] + (long)kbeg * p.ldb;
+        srcB[2 * h + 1] = gb.src[1] + (long)kbeg * p.ldb;
+      }
     }
-    if constexpr (BMODE == KS) {
-      GldsPlan<KS, 128, 512> gb;
-      gb.init(p.B, p.ldb, n0 + h * 128, p.N, tid);
-      srcB[2 * h] = gb.src[0] + (long)kbeg * p.ldb;
-      srcB[2 * h + 1] = gb.src[1] + (long)kbeg * p.ldb;
-    }
-  }
+  };
+  set_tile(bid);
   typedef __attribute__((address_space(1))) const void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
   auto issueA = [&](int t) {
@@ -925,10 +935,6 @@ __device__ __forceinline__ void p256_body(const GemmParams& p, int bid, int spli
   }
 
   f32x4 acc[4][8];       // [n tile][m tile]
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   u32x4 fA[2][4], fB0[2][2], fB1[2][2];          // [ks][block]
   unsigned long long kB0[2][2][2], kB1[2][2][2];  // K-slow B: [ks][block][lo | hi], joined behind the wait
   unsigned long long kA[2][4][2];                 // K-slow A likewise
@@ -947,9 +953,19 @@ __device__ __forceinline__ void p256_body(const GemmParams& p, int bid, int spli
   constexpr int dbgf = 0;
 #endif
 
+  bool first_tile = true;
+  for (;;) {        // output tiles of a persistent workgroup (one pass otherwise)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // prologue: tiles 0 and 1 in flight, tile 0 landed
-  issueA(0); issueB(0);
-  if (nt > 1) { issueA(1); wait_vmc<4>(); } else wait_vmc<0>();
+  if (!PERSIST || first_tile) {
+    issueA(0); issueB(0);
+    if (nt > 1) { issueA(1); wait_vmc<4>(); } else wait_vmc<0>();
+  } else {
+    wait_vmc<0>();      // requested before the previous tile's C stores; those stores have completed as well
+  }
   __builtin_amdgcn_s_barrier();
   if (nt > 1) issueB(1);
   if (wr == 1) __builtin_amdgcn_s_barrier();      // the second row-half group runs one barrier behind
@@ -1076,8 +1092,42 @@ __device__ __forceinline__ void p256_body(const GemmParams& p, int bid, int spli
   }
   __syncthreads();
   constexpr int RS = 64 * 2 + 16;
-  char* my = smem + wv * (64 * RS);
   bf16_t* C = (bf16_t*)p.C;
+  if constexpr (PERSIST) {
+    const int m0e = m0, n0e = n0;
+    const bool more = bid + bid_stride < bid_end;
+    if (more) {          // the next tile's first K tiles go out under this tile's stores
+      bid += bid_stride;
+      set_tile(bid);
+      issueA(0); issueB(0);
+      if (nt > 1) issueA(1);
+    }
+    char* my = smem + 2 * PAR + wv * (16 * RS);        // above the stage buffers: 16 rows x 64 columns per wave and pass
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const f32x4 v = acc[a][bb];
+        uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<uint2*>(my + (lane & 15) * RS + (a * 16 + (lane >> 4) * 4) * 2) = pk;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = i * 64 + lane, r = idx >> 3, ch = idx & 7;
+        const int m = m0e + wr * 128 + bb * 16 + r, n = n0e + wc * 64 + ch * 8;
+#ifdef FASTVIM_TUNING_HOOKS
+        if (p.rb_period & 1) continue;
+#endif
+        if (m < p.M) *reinterpret_cast<u32x4*>(C + (long)m * p.ldc + n) = *reinterpret_cast<const u32x4*>(my + r * RS + ch * 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!more) break;
+    first_tile = false;
+    continue;
+  }
+  char* my = smem + wv * (64 * RS);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -1100,6 +1150,8 @@ __device__ __forceinline__ void p256_body(const GemmParams& p, int bid, int spli
     }
     __builtin_amdgcn_wave_barrier();
   }
+  break;
+  }      // output tiles
 }
 
 template <int BMODE>
@@ -1112,6 +1164,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(GemmParams p) {
     bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
   }
   p256_body<KC, BMODE, false>(p, bid, 0, smem);
+}
+
+// persistent form: gridDim.x (a multiple of 8: one workgroup per CU) workgroups; the one on XCD x, slot j walks the tiles
+// j, j + G/8, ... of that XCD's contiguous eighth of the tile order above
+template <int BMODE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256pp_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nblk = ((p.M + 255) / 256) * (p.N / 256);
+  const int w = blockIdx.x, per = gridDim.x / 8;
+  const int q8 = nblk / 8, r8 = nblk % 8, xcd = w % 8, j = w / 8;
+  const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, cnt = q8 + (xcd < r8 ? 1 : 0);
+  if (j >= cnt) return;
+  p256_body<KC, BMODE, false, true>(p, start + j, 0, smem, per, start + cnt);
 }
 
 // Several independent problems in ONE launch (the weight gradients of a whole backward pass, queued until its end):
@@ -1441,7 +1506,26 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
     }
     GemmParams q = p;
     q.rb_period = fv_tune("FASTVIM_GEMM_P256_DBG", 0);      // phase probe (tuning builds)
-    hipLaunchKernelGGL(gemm_nt256p_kernel<BMODE>, dim3(fv_cdiv(p.M, 256) * (p.N / 256)), dim3(512), 128 * 1024, st, q);
+    // persistent workgroups, one per CU (round 3): the next tile's first K tiles are requested before a tile's C leaves.
+    // Same C bit for bit; same box: FastVim-B 224 px 29.04 -> 28.75 ms per step, 2048 px 109.5 -> 107.9, FastChannelVim-S
+    // 44.48 -> 44.30; stand-alone 2-5 % per GEMM (profiles/r03_p256_persistent.log)
+    static const int persist = fv_tune("FASTVIM_GEMM_P256_PERSIST", 1);   // tuning hook: 0 = one workgroup per tile
+    const int ntile = fv_cdiv(p.M, 256) * (p.N / 256);
+    static int cus8 = 0;
+    static FvOncePerDevice attr2;
+    if (attr2.first()) {
+      int dev = 0, cus = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+      cus8 = cus / 8 * 8;
+      (void)hipFuncSetAttribute((const void*)gemm_nt256pp_kernel<BMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (persist && cus8 >= 8 && ntile > cus8) {
+      hipLaunchKernelGGL(gemm_nt256pp_kernel<BMODE>, dim3(cus8), dim3(512), 160 * 1024, st, q);
+      FV_LAUNCH_CHECK();
+      return FV_OK;
+    }
+    hipLaunchKernelGGL(gemm_nt256p_kernel<BMODE>, dim3(ntile), dim3(512), 128 * 1024, st, q);
     FV_LAUNCH_CHECK();
     return FV_OK;
   }

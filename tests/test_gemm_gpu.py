@@ -37,7 +37,8 @@ def test_gemm_nt_nn(M, N, K):
                                         ("nn", 70000, 1024, 512),     # ragged rows
                                         ("nn", 40000, 2048, 576)])    # odd number of K tiles
 def test_gemm_phased_256_form(kind, M, N, K):
-    """The phased 256 x 256 kernel (gemm_nt256p_kernel: LDS-DMA in flight across barriers, counted waits) takes forward
+    """The phased 256 x 256 kernel (gemm_nt256pp_kernel: persistent workgroups, LDS-DMA in flight across barriers and across
+    output tiles, counted waits) takes forward
     (K-contiguous weight) and data-gradient (weight as stored, transposing LDS reads) bf16 GEMMs of four rounds of tiles
     and more.  Against fp64 on the same inputs, against the fp32-output call of the same product (which runs the per-tile
     kernel; both accumulate in K order: the bf16 roundings must be equal), and bit-stable over repeated launches (a
