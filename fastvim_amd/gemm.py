@@ -158,10 +158,18 @@ def grouped_splits(Kd, target=None, M=None, N=None):
     (every slice writes and re-reads an (M, N) partial: at 7 slices 171 MB per FastVim-T step, 2.4 GB per FastVim-B
     step).  The largest divisor of the K tiles not above ``target``: 4 for outputs below 512 x 512 (FastVim-T: 5.90 ->
     5.87 ms per step against 7; 2 and 14 are slower, and so is a per-problem factor that evens out the workgroup
-    counts), 2 below 1024 x 1024, 1 above (FastVim-B: 32.5 -> 32.1 ms)."""
+    counts) -- 6 uneven slices for the projection-sized ones among them since round 3 --, 2 below 1024 x 1024, 1 above
+    (FastVim-B: 32.5 -> 32.1 ms)."""
     if target is None:
         if M is None or N is None or M * N < 512 * 512:
             target = 4
+            # round 3: SIX slices for the FastVim-T projections (768 x 192, 192 x 384), the last one shorter when six does
+            # not divide the K tiles (392 = 5 x 66 + 62) -- same box, three passes: 5.80 -> 5.72 ms per step (4 / 4: 5.80,
+            # 6 / 4: 5.74, 6 / 6: 5.72, 7 / 7: 5.84, 8 / 8: 5.80, 14 / 7: 5.93; profiles/r03_sweep_wgrad_splits_t.log)
+            if M is not None and N is not None and M * N >= 192 * 192 and Kd % 64 == 0 and Kd // 64 >= 6 * 14:
+                per = -(-(Kd // 64) // 6)
+                if -(-(Kd // 64) // per) == 6:
+                    return 6
         else:
             target = 2 if M * N < 1024 * 1024 else 1
     if Kd % 64:

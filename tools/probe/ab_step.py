@@ -12,6 +12,16 @@ model, img, batch, steps = a[0], int(a[1]), int(a[2]), int(a[3])
 if "--no-direct-acc" in a:
     from fastvim_amd import gemm as _g
     _g.DIRECT_ACC = False
+if "--wgrad-splits" in a:       # --wgrad-splits IN,OUT: split-K factors of the in_proj / out_proj weight gradients (uneven slices allowed)
+    from fastvim_amd import gemm as _g2
+    _si, _so = [int(v) for v in a[a.index("--wgrad-splits") + 1].split(",")]
+    _orig = _g2.grouped_splits
+    def _gs(Kd, target=None, M=None, N=None):
+        if M is not None and N is not None and M * N >= 192 * 192 and Kd >= 4096:
+            return _si if M > N else _so
+        return _orig(Kd, target, M, N)
+    _g2.grouped_splits = _gs
+    import fastvim_amd.mamba_simple_faster as _msf
 if "--presum" in a:
     mixer_ops._XPROJ_PRESUM = int(a[a.index("--presum") + 1])
 torch.cuda.set_device(0)
