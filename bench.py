@@ -344,8 +344,8 @@ TRACE_NAMES = {
     "add_rmsnorm_fwd": "add_norm_fwd3_kernel", "gemm_out_proj_addnorm_fwd": "gemm_addnorm_kernel",
     "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 4>",
 }
-PMC_TRAFFIC_JSON = "r03_v2_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
-STEP_TRACE_CSV = "r03_v2_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r03_v2 (profiles/README.md)
+PMC_TRAFFIC_JSON = "r03_v3_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
+STEP_TRACE_CSV = "r03_v3_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r03_v3 (profiles/README.md)
 
 
 def in_step_trace_us():
