@@ -1842,7 +1842,8 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
       G.blk_end[i] = blocks;
     }
     const size_t smem = (size_t)2 * (bm[cls] + bn[cls]) * BK * 2;
-    // (256 x 192 tiles on 8 waves for the first class, half the L2 traffic again: 310 vs 316 us in the step -- not taken)
+    // (256 x 192 tiles on 8 waves for the first class, half the L2 traffic again: 310 vs 316 us in the step in round 2 -- not
+    //  taken; again in round 3 with 6 / 8 / 12 / 14 K slices: step 5.73-5.84 against 5.68 ms, profiles/r03_ab_wgrad_t256_tiles.log)
     if (cls == 1) {
       static FvOncePerDevice attr;   
       if (attr.first()) {
