@@ -511,7 +511,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
         return loss.detach()
 
     seg = None
-    if use_graph and (world > 1 or force_segmented) and model_name in ("T", "S", "B") and buckets > 0:
+    if use_graph and (world > 1 or force_segmented) and model_name in ("T", "S", "B", "C") and buckets > 0:
         # N > 1: the step is a chain of graphs (forward | backward of K runs of blocks | optimizer) with the bucketed
         # gradient all-reduce launched between them, so that it overlaps the remaining backward (fastvim_amd/pipeline.py)
         from fastvim_amd.pipeline import SegmentedTrainStep
@@ -688,6 +688,29 @@ def vim_vs_fastvim_block(dev, img=2048, batch=8):
 
 
 # --------------------------------------------------------------------------- main
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: run ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`` as a CHILD process
+    (the reference's launcher equivalent: Lightning spawns one process per device, imagenet_classification/train.py:34-43)
+    and relay its output.  Called before anything in this process has initialised HIP: the parent never owns a GPU context,
+    and it never replaces itself (no exec) -- it waits for the child and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this image
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, cwd=os.getcwd(), stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:          # rank 0's one JSON line (and nothing else: stderr goes straight through)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -706,8 +729,9 @@ def main():
                     help="N > 1: gradient buckets = backward graph segments the all-reduce overlaps with (0: one all-reduce after backward)")
     ap.add_argument("--segmented", action="store_true",
                     help="use the segmented (N > 1) step also on one GPU: measures what the chain of graphs costs by itself")
-    ap.add_argument("--comm-dtype", default="auto", choices=["auto", "fp32", "bf16"],
-                    help="wire format of the gradient all-reduce (auto: bf16 for buckets of >= 100 MB of fp32 gradient, else fp32)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["auto", "fp32", "bf16"],
+                    help="wire format of the gradient all-reduce: fp32 (default, the reference's DDP), bf16, or auto "
+                         "(bf16 for buckets of >= 100 MB of fp32 gradient, else fp32) -- the compressed forms are opt-in")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
     ap.add_argument("--vim-2048", action="store_true", help="only the Vim-vs-FastVim block at 2048 px (SURVEY row f2), as JSON")
@@ -715,11 +739,15 @@ def main():
                     help="skip timing the reference-layout op selective_scan_fn at every config's (B, d_in, Lc, N)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU), BEFORE this process has
+        # touched the GPU in any way -- a fresh child, never an exec -- and pass its JSON line and exit code on
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # test hook: FASTVIM_BENCH_ONE_GPU=1 puts every rank on GPU 0 and exchanges gradients through gloo, so the
@@ -736,6 +764,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
+    if os.environ.get("FASTVIM_BENCH_FAIL_RANK") == str(rank):       # test hook: a rank that dies (tests/test_pipeline_gpu.py)
+        raise SystemExit(3)
     if args.vim_2048:
         print(json.dumps(vim_vs_fastvim_block(dev, args.img if args.img != 224 else 2048, args.batch if args.batch != 128 else 8)), flush=True)
         return

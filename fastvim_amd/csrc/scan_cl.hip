@@ -1711,17 +1711,26 @@ extern "C" int fv_mixer_scan_bwd_dir(const void* xc, const void* x_dbl, const fl
                                 ckpt, 0, partials, batch, Lc, d_inner, dt_rank, d_state, dtype, stream);
 }
 
-// Segments of the segment-parallel BACKWARD scan (only with the forward launch's checkpoints): the forward rule, on the
-// model family's d_inner = 32 dt_rank so that the partial-row count depends on (batch, Lc, dt_rank) like its siblings.
-extern "C" int fv_mixer_scan_bwd_segments(int batch, int Lc, int dt_rank) {
-  return fv_mixer_scan_fwd_segments(batch, Lc, 32 * dt_rank, dt_rank);
+// Segments of the segment-parallel BACKWARD scan (only with the forward launch's checkpoints): the forward rule on the
+// same (batch, Lc, d_inner, dt_rank) -- the REAL d_inner, not 32 dt_rank: an explicit dt_rank or expand != 2 makes the two
+// differ, and segment count, workspace, partial rows and dx_dbl slices must all describe the launch that is made.
+extern "C" int fv_mixer_scan_bwd_segments(int batch, int Lc, int d_inner, int dt_rank) {
+  return fv_mixer_scan_fwd_segments(batch, Lc, d_inner, dt_rank);
 }
 extern "C" size_t fv_mixer_scan_bwd_seg_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank) {
-  const int S = fv_mixer_scan_bwd_segments(batch, Lc, dt_rank);
+  const int S = fv_mixer_scan_bwd_segments(batch, Lc, d_inner, dt_rank);
   return S > 1 ? (size_t)2 * batch * S * d_inner * (2 * d_state + 1) : 0;
 }
-extern "C" int fv_mixer_scan_bwd_seg_partials(int batch, int Lc, int dt_rank) {
-  return batch * fv_mixer_scan_bwd_segments(batch, Lc, dt_rank);
+extern "C" int fv_mixer_scan_bwd_seg_partials(int batch, int Lc, int d_inner, int dt_rank) {
+  return batch * fv_mixer_scan_bwd_segments(batch, Lc, d_inner, dt_rank);
+}
+// channel chunks (= dx_dbl slices) of the launch fv_mixer_scan_bwd_seg makes: the segment-parallel form always walks
+// 64-channel workgroups (the forward passes' width), whatever ck_waves picks for the serial form
+static int bwd_chunks_of(int batch, int d_inner, int Lc, int dt_rank, int segments) {
+  return segments > 1 ? fv_cdiv(d_inner, 64) : fv_mixer_scan_bwd_chunks_b(batch, d_inner, Lc, dt_rank);
+}
+extern "C" int fv_mixer_scan_bwd_seg_chunks(int batch, int d_inner, int Lc, int dt_rank, int seg_ws_given) {
+  return bwd_chunks_of(batch, d_inner, Lc, dt_rank, seg_ws_given ? fv_mixer_scan_bwd_segments(batch, Lc, d_inner, dt_rank) : 1);
 }
 
 extern "C" int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
@@ -1790,9 +1799,11 @@ extern "C" int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const fl
     return FV_OK;
   }
   if (bwd_chunked(Lc, dt_rank)) {
-    const int S = (seg_ws && ckpt_given) ? fv_mixer_scan_bwd_segments(batch, Lc, dt_rank) : 1;
+    const int S = (seg_ws && ckpt_given) ? fv_mixer_scan_bwd_segments(batch, Lc, d_inner, dt_rank) : 1;
     const int nwv = S > 1 ? 4 : ck_waves(batch, d_inner);      // (segments: the 64-channel workgroups the forward passes use)
     dim3 cgrid(fv_cdiv(d_inner, 16 * nwv), batch / p.NBB, 2), cblock(64 * nwv);
+    // dx_dbl has one slice per channel chunk: what fv_mixer_scan_bwd_seg_chunks told the caller to allocate
+    FV_CHECK((int)cgrid.x == bwd_chunks_of(batch, d_inner, Lc, dt_rank, S), "mixer_scan_bwd: channel-chunk count mismatch");
     if (S > 1) {
       // A: the adjoint state every segment reaches from zero (and its sum of delta); B: the adjoint states ENTERING the
       // segments, last to first; then the backward kernel proper, every segment from its true incoming adjoint state

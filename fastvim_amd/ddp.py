@@ -16,12 +16,14 @@ contiguous BUCKETS of that buffer across ranks with RCCL (``torch.distributed`` 
 
 xGMI is point-to-point (7 links per GPU), so ring collectives are per-link bound: a few LARGE buckets (default:
 3 per step, tapered 10 : 8 : 6 blocks -- 12 / 9 / 7 MB at FastVim-T, 160 / 130 / 100 MB at FastVim-B -- so that the
-one nothing overlaps is the smallest; fastvim_amd/flat.py ``buckets``) instead of torch DDP's 25 MB default, and a
-bf16 wire format that halves the bytes per link: ``comm_dtype="auto"`` (the default of ``FlatTrainingState``) sends a
-bucket as bf16 when its fp32 size is at least ``bf16_min_bytes`` (100 MB: the FastVim-B buckets, where the exchange is
-bandwidth-bound) and as fp32 below (FastVim-T / -S, where it is latency-bound and the bytes do not matter).  The gradient
-itself stays fp32 on both sides of the wire: a bucket is rounded once to bf16, summed by RCCL, and written back into the
-fp32 buffer (relative error <= 2^-8 per addend, tests/test_ddp_cpu.py).  No BatchNorm exists in FastVim, so nothing else is
+one nothing overlaps is the smallest; fastvim_amd/flat.py ``buckets``) instead of torch DDP's 25 MB default.  The wire
+format is fp32 by default -- what the reference's DDP sums.  A bf16 wire that halves the bytes per link is an explicit
+opt-in (``comm_dtype=torch.bfloat16``, or ``"auto"``: bf16 for buckets whose fp32 size is at least ``bf16_min_bytes`` =
+100 MB, i.e. the FastVim-B buckets where the exchange is bandwidth-bound; ``bench.py --comm-dtype``), like the reference's
+detection-only fp16 hook (detection/vitdet/fp16_compression_hook.py:17-26).  With it the gradient stays fp32 on both sides
+of the wire: a bucket is rounded once to bf16, summed by RCCL IN bf16 (a ring of N ranks rounds once per hop: the error
+grows with N, tests/test_ddp_cpu.py bounds N = 2 and N = 8), and written back into the fp32 buffer.
+No BatchNorm exists in FastVim, so nothing else is
 exchanged.  The same class is the whole-buffer exchange (one bucket) used by
 ``FlatTrainingState.allreduce_mean_`` and by the CPU (gloo) tests.
 """

@@ -37,8 +37,11 @@ _MIXER_GROUPS = (
 
 
 class FlatTrainingState:
-    def __init__(self, model, shadow_dtype=torch.bfloat16, process_group=None, comm_dtype="auto",
+    def __init__(self, model, shadow_dtype=torch.bfloat16, process_group=None, comm_dtype=None,
                  chunk_bytes=256 << 20):
+        """``comm_dtype``: wire format of the gradient exchange.  None (default) = fp32, what the reference's DDP sums
+        (imagenet_classification/train.py:34-43); ``torch.bfloat16`` or ``"auto"`` (bf16 for buckets of >= 100 MB) are
+        explicit opt-ins, like the reference's detection-only fp16 hook (detection/vitdet/fp16_compression_hook.py:17-26)."""
         self.group = process_group
         self.comm_dtype = comm_dtype
         self.chunk = max(1, chunk_bytes // 4)

@@ -438,9 +438,21 @@ def out_proj_add_norm_ok(g, W_out, residual, norm_w, cdt):
 
 
 def _compute_dtype(t):
-    """bf16/fp16 under torch.autocast (reference: mamba_simple_faster.py:312-318), else the input dtype."""
+    """The autocast dtype under torch.autocast (reference: mamba_simple_faster.py:312-318), else the input dtype.
+    The module path (patch embed, blocks, mixers) is built for bf16 and fp32: the reference's other mixed precision,
+    ``--precision 16-mixed`` (imagenet_classification/train.py:17), is REFUSED here with one clear error instead of
+    running half the model through fallbacks -- the fused kernels keep fp32 statistics but store activations in the
+    compute dtype, and fp16's 5-bit exponent needs the loss scaling this build's fused backward does not carry.  The
+    op-level functions (``selective_scan_fn``, ``causal_conv1d_fn``, the compressed scan) do take fp16 tensors, like the
+    reference's kernels (selective_scan.cpp:328-332)."""
     if torch.is_autocast_enabled():
-        return torch.get_autocast_dtype('cuda')
+        dt = torch.get_autocast_dtype('cuda')
+        if dt == torch.float16:
+            raise RuntimeError("fastvim_amd: fp16 autocast is not supported by the HIP mixer path; "
+                               "use torch.autocast('cuda', dtype=torch.bfloat16) or run in fp32")
+        return dt
+    if t.dtype == torch.float16:
+        raise RuntimeError("fastvim_amd: fp16 activations are not supported by the HIP mixer path; use bf16 or fp32")
     return t.dtype
 
 

@@ -227,19 +227,20 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     W = R + 2 * N
     dev = xc.device
     lib = L.lib()
-    nchunks = lib.fv_mixer_scan_bwd_chunks_b(L.i32(B), L.i32(d_in), L.i32(Lc), L.i32(R))
     f32o = dict(device=dev, dtype=torch.float32)
+    given = ckpt is not None          # checkpoints of the forward launch (scan_fwd(want_ckpt=True))
+    # long sequences on few batch elements, with the forward launch's checkpoints: the segments side by side (one partial
+    # row of parameter gradients per batch element and segment).  Segment count, channel chunks and partial rows are all
+    # asked for the REAL d_inner (an explicit dt_rank / expand != 2 makes it differ from 32 dt_rank)
+    nws = lib.fv_mixer_scan_bwd_seg_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R)) if given else 0
+    nchunks = lib.fv_mixer_scan_bwd_seg_chunks(L.i32(B), L.i32(d_in), L.i32(Lc), L.i32(R), L.i32(int(nws > 0)))
     dxc = torch.empty(2, B, Lc, d_in, **f32o)
     dx_dbl = torch.empty(nchunks, 2, B * Lc, W, **f32o)
-    given = ckpt is not None          # checkpoints of the forward launch (scan_fwd(want_ckpt=True))
     if not given:
         nck = lib.fv_mixer_scan_bwd_ckpt_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R))
         ckpt = torch.empty(nck, **f32o) if nck else None
-    # long sequences on few batch elements, with the forward launch's checkpoints: the segments side by side (one partial
-    # row of parameter gradients per batch element and segment)
-    nws = lib.fv_mixer_scan_bwd_seg_floats(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(N), L.i32(R)) if given else 0
     ws = torch.empty(nws, **f32o) if nws else None
-    nprt = lib.fv_mixer_scan_bwd_seg_partials(L.i32(B), L.i32(Lc), L.i32(R)) if nws else \
+    nprt = lib.fv_mixer_scan_bwd_seg_partials(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(R)) if nws else \
         lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc), L.i32(R))
     part = torch.empty(nprt, 2 * d_in * (N + R + 1), **f32o)
     rc = lib.fv_mixer_scan_bwd_seg(

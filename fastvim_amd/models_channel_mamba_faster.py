@@ -294,19 +294,26 @@ class VisionMamba(nn.Module):
     def no_weight_decay(self):
         return {"pos_embed", "pos_embed_obj", "cls_token", "dist_token", "cls_token_head", "cls_token_tail"}
 
-    def forward_features(self, x, inference_params=None):
+    # forward_features (models_channel_mamba_faster.py:607-667) in the four pieces the segmented data-parallel step cuts at
+    # (fastvim_amd/pipeline.py: gradient buckets exchanged under the backward of the remaining runs of blocks)
+    def _embed(self, x):
         if self.if_abs_pos_embed:
             x, tokens_per_patch, h, w, _ = self.patch_embed(x, pos_embed=self.pos_embed)   # :617-627
             x = self.pos_drop(x)
         else:
             x, tokens_per_patch, h, w, _ = self.patch_embed(x)
-        residual = None
-        hidden_states = x
+        self._tokens_per_patch = tokens_per_patch       # what every block of this forward pass is called with
         if self.training:
             DropPath.predraw([l.drop_path for l in self.layers] + [self.drop_path], x.shape[0], x.device)
-        for layer in self.layers:
-            hidden_states, residual = layer(hidden_states, tokens_per_patch, residual,
+        return x, (h, w)
+
+    def _run_layers(self, hidden_states, residual, lo, hi, inference_params=None):
+        for layer in self.layers[lo:hi]:
+            hidden_states, residual = layer(hidden_states, self._tokens_per_patch, residual,
                                             inference_params=inference_params)
+        return hidden_states, residual
+
+    def _final(self, hidden_states, residual):
         is_rms = isinstance(self.norm_f, RMSNorm)
         if not self.fused_add_norm:
             residual = hidden_states if residual is None else residual + self.drop_path(hidden_states)
@@ -325,14 +332,22 @@ class VisionMamba(nn.Module):
             return hidden_states
         raise NotImplementedError
 
-    def forward(self, x, return_features=False, inference_params=None):
-        x = self.forward_features(x, inference_params)
-        if return_features:
-            return x
+    def _head(self, x):
         x = linear_module(self.head, x)
         if self.final_pool_type == "max":
             x = x.max(dim=1)[0]
         return x
+
+    def forward_features(self, x, inference_params=None):
+        hidden_states, _ = self._embed(x)
+        hidden_states, residual = self._run_layers(hidden_states, None, 0, len(self.layers), inference_params)
+        return self._final(hidden_states, residual)
+
+    def forward(self, x, return_features=False, inference_params=None):
+        x = self.forward_features(x, inference_params)
+        if return_features:
+            return x
+        return self._head(x)
 
 
 def channelvim_small_patch16_224_final_pool_mean_abs_pos_embed_with_noclstok_div2(

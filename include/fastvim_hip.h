@@ -233,9 +233,12 @@ int fv_mixer_scan_bwd_ckpt(const void* xc, const void* x_dbl, const float* dt_w,
  * segments of fv_mixer_scan_fwd_seg are walked side by side here too -- adjoint states reached from zero, a serial combine
  * last segment to first, then the backward kernel proper per segment.  seg_ws: fv_mixer_scan_bwd_seg_floats() fp32 (0: one
  * segment, pass NULL); partials then has fv_mixer_scan_bwd_seg_partials() rows (one per batch element and segment). */
-int fv_mixer_scan_bwd_segments(int batch, int Lc, int dt_rank);
+int fv_mixer_scan_bwd_segments(int batch, int Lc, int d_inner, int dt_rank);
 size_t fv_mixer_scan_bwd_seg_floats(int batch, int Lc, int d_inner, int d_state, int dt_rank);
-int fv_mixer_scan_bwd_seg_partials(int batch, int Lc, int dt_rank);
+int fv_mixer_scan_bwd_seg_partials(int batch, int Lc, int d_inner, int dt_rank);
+/* slices of dx_dbl (one per channel chunk) of the launch fv_mixer_scan_bwd_seg makes: with a segment workspace the
+ * 64-channel workgroups of the segment-parallel form, without it fv_mixer_scan_bwd_chunks_b() */
+int fv_mixer_scan_bwd_seg_chunks(int batch, int d_inner, int Lc, int dt_rank, int seg_ws_given);
 int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias, const float* A_log,
                           const float* dt_w_b, const float* dt_bias_b, const float* A_log_b, const float* dyc,
                           int dyc_per_direction, float* dxc, float* dx_dbl, float* ckpt, int ckpt_given, float* partials,

@@ -58,9 +58,18 @@ def test_host_side_launch_planning_functions():
     assert seg(8, 128, 1536, 48) == 1                   # FastVim-B 2048 px: 8 chunks, nothing to cut
     assert seg(128, 14, 384, 12) == 1 and seg(1, 4104, 192, 80) == 1      # short; dt_rank > 48 (generic kernel)
     assert seg(1, 4104, 192, 6) == 29                   # 257 chunks: at most 32 segments -> 9 chunks each -> 29 non-empty ones
-    # the backward scan follows the forward rule on the model family's d_inner = 32 dt_rank; one partial row per (batch, segment)
-    assert lib.fv_mixer_scan_bwd_segments(i(8), i(16392), i(12)) == s_vim
-    assert lib.fv_mixer_scan_bwd_seg_partials(i(8), i(16392), i(12)) == 8 * s_vim
+    # the backward scan follows the forward rule on the REAL d_inner; one partial row per (batch, segment)
+    assert lib.fv_mixer_scan_bwd_segments(i(8), i(16392), i(384), i(12)) == s_vim
+    assert lib.fv_mixer_scan_bwd_seg_partials(i(8), i(16392), i(384), i(12)) == 8 * s_vim
+    # d_inner != 32 dt_rank (explicit dt_rank / expand != 2): every size query describes the launch that is made --
+    # segment-parallel launches walk 64-channel workgroups, and dx_dbl has exactly one slice per workgroup column
+    for b, lc, d, r in ((32, 1000, 768, 4), (2, 1000, 768, 4), (8, 16392, 384, 12), (64, 37, 384, 12), (2, 4104, 1536, 8)):
+        S = lib.fv_mixer_scan_bwd_segments(i(b), i(lc), i(d), i(r))
+        assert S == seg(b, lc, d, r)
+        assert lib.fv_mixer_scan_bwd_seg_floats(i(b), i(lc), i(d), i(16), i(r)) == (2 * b * S * d * 33 if S > 1 else 0)
+        ch = lib.fv_mixer_scan_bwd_seg_chunks(i(b), i(d), i(lc), i(r), i(int(S > 1)))
+        assert ch == (-(-d // 64) if S > 1 else lib.fv_mixer_scan_bwd_chunks_b(i(b), i(d), i(lc), i(r)))
+    assert seg(32, 1000, 768, 4) == 1 and seg(2, 1000, 768, 4) > 1
     assert lib.fv_mixer_scan_bwd_seg_floats(i(128), i(200), i(384), i(16), i(12)) == 0
     n = lib.fv_mixer_scan_fwd_seg_floats(i(8), i(16392), i(384), i(16), i(12))
     assert n == 2 * 8 * s_vim * 384 * (2 * 16 + 1)

@@ -253,6 +253,8 @@ def _scan_cl_case(Bsz, Lc, d_in, R, dtype, seed):
                                                                     # forward (and, with its checkpoints, backward) launch
                                                                     # runs segment-parallel (29 segments of 9 chunks)
                                            (2, 1000, 384, 12),      # 63 chunks in 7 segments of 9, ragged last chunk
+                                           (2, 1000, 768, 4),       # d_inner != 32 dt_rank (explicit dt_rank), segment-parallel:
+                                                                    # segments / chunks / partial rows from the REAL d_inner
                                            (64, 37, 384, 12),       # enough workgroups for the 12-wave form (192 channels)
                                            (64, 14, 1536, 48),      # short kernel walking 4 batch elements per workgroup
                                            (2, 40, 1024, 64)])      # dt_rank > 48: the generic kernel (4-step segments)

@@ -139,6 +139,45 @@ def test_auto_wire_format_keeps_fp32_accumulation_error_bound(tmp_path):
     assert torch.equal(r["fp32_sum"] * 0.5, r["fp32_mean"])                         # grad_scale = 1 / 2 == the mean
 
 
+def _ring8_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastvim_amd.ddp import GradExchange
+    base = torch.randn(4096, generator=torch.Generator().manual_seed(40 + rank)) * torch.logspace(-6, 2, 4096)
+    ex = GradExchange(base.clone(), None, comm_dtype=torch.bfloat16)
+    ex.allreduce_(mean=False)
+    ex32 = GradExchange(base.clone(), None)              # the default wire: fp32
+    ex32.allreduce_(mean=False)
+    if rank == 0:
+        torch.save({"bf16": ex.flat, "fp32": ex32.flat, "wire32": ex32.wire_names()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_error_bound_with_eight_ranks(tmp_path):
+    """The opt-in bf16 wire at the node's full width: eight addends, each rounded once to bf16, summed IN bf16 (one more
+    rounding per partial sum, whatever order the backend takes them in) -- |error| <= 2^-8 * (sum |a_i| + 7 * sum |a_i|) per
+    element, and in practice a relative error of a few 2^-9 of sum |a_i|.  The default wire (fp32) differs from the fp64
+    sum only by fp32 rounding.  This is why bf16 is not the default: the reference's DDP sums fp32
+    (imagenet_classification/train.py:34-43)."""
+    import inspect
+    from fastvim_amd.flat import FlatTrainingState
+    assert inspect.signature(FlatTrainingState.__init__).parameters["comm_dtype"].default is None
+    out = str(tmp_path / "r8.pt")
+    mp.spawn(_ring8_worker, args=(8, _free_port(), out), nprocs=8, join=True)
+    r = torch.load(out)
+    sc = torch.logspace(-6, 2, 4096)
+    parts = [torch.randn(4096, generator=torch.Generator().manual_seed(40 + k)) * sc for k in range(8)]
+    exact = torch.stack(parts).double().sum(0)
+    mag = torch.stack(parts).double().abs().sum(0)
+    assert r["wire32"] == ["float32"]
+    assert ((r["fp32"].double() - exact).abs() <= 8 * 2.0 ** -24 * mag).all()
+    err = (r["bf16"].double() - exact).abs()
+    assert (err <= 8 * 2.0 ** -8 * mag).all() and err.max() > 0
+    assert (err / mag).mean() < 2.0 ** -8          # typical error: well inside the worst case
+
+
 def test_layer_major_buckets_tile_the_flat_gradient():
     """FlatTrainingState lays the gradient out block by block; buckets() cuts it into runs of whole blocks, last
     blocks first, that tile the buffer (CPU: no kernels involved)."""

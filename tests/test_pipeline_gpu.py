@@ -75,26 +75,46 @@ def test_segmented_step_equals_single_step(n_seg, graph, batch, fill, monkeypatc
     f1.close(); f2.close()
 
 
-@pytest.mark.parametrize("model,batch,total_mb,wire", [
-    ("T", 16, 28.7, ["float32"] * 3),                                # FastVim-T: 7.17 M fp32 gradients, 12 / 9 / 7 MB buckets
-    ("B", 8, 390.7, ["bfloat16", "bfloat16", "float32"]),            # FastVim-B: 97.7 M, 163 / 131 / 98 MB: bf16 from 100 MB on
+@pytest.mark.parametrize("model,batch,total_mb,wire,extra", [
+    ("T", 16, 28.7, ["float32"] * 3, []),                            # FastVim-T: 7.17 M fp32 gradients, 12 / 9 / 7 MB buckets
+    ("B", 8, 390.7, ["float32"] * 3, []),                            # FastVim-B: 97.7 M, 163 / 131 / 98 MB; fp32 wire by default
+    ("B", 8, 390.7, ["bfloat16", "bfloat16", "float32"], ["--comm-dtype", "auto"]),      # opt-in: bf16 from 100 MB on
+    ("C", 4, 102.6, ["float32"] * 3, ["--channels", "8"]),           # FastChannelVim-S/16 (BASELINE configs[4]): 25.6 M
 ])
-def test_two_rank_segmented_bench_line(model, batch, total_mb, wire):
-    """Two ranks on GPU 0 over gloo (FASTVIM_BENCH_ONE_GPU=1): the N > 1 bench path = segmented step with bucketed,
+def test_two_rank_segmented_bench_line(model, batch, total_mb, wire, extra):
+    """PLAIN ``python bench.py --gpus 2`` (no launcher: bench.py starts its own torch.distributed.run child before it touches
+    the GPU), two ranks on GPU 0 over gloo (FASTVIM_BENCH_ONE_GPU=1): the N > 1 bench path = segmented step with bucketed,
     asynchronously launched all-reduces, sums scaled by 1 / world inside the optimizer kernel; the line reports the
-    exchange (bucket sizes, wire format per bucket, exposed time).  FastVim-T and FastVim-B widths."""
-    env = dict(os.environ, FASTVIM_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541" if model == "T" else "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2",
-           "--model", model, "--steps", "3", "--warmup", "1", "--batch", str(batch), "--buckets", "3", "--no-cpu-baseline",
-           "--no-kernels", "--no-scan-op"]
+    exchange (backend, bucket sizes, wire format per bucket, exposed time).  FastVim-T / -B widths and the channel model."""
+    env = dict(os.environ, FASTVIM_BENCH_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", model, "--steps", "3", "--warmup", "1",
+           "--batch", str(batch), "--buckets", "3", "--no-cpu-baseline", "--no-kernels", "--no-scan-op"] + extra
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert out["n_gpus"] == 2 and out["ddp"]["overlapped"] and out["ddp"]["buckets"] == 3 and out["ddp"]["ranks"] == 2
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ddp"]["overlapped"] is True and out["ddp"]["buckets"] == 3 and out["ddp"]["ranks"] == 2
+    assert out["ddp"]["backend"] == "gloo"                                   # "nccl" (= RCCL) without the one-GPU test hook
     assert abs(sum(out["ddp"]["bucket_MB"]) - total_mb) < 0.5
     assert out["ddp"]["wire_dtype"] == wire
     assert out["ddp"]["allreduce_exposed_ms"] is not None and out["config"]["final_loss"] == out["config"]["final_loss"]
+    assert out["config"]["global_batch"] == 2 * batch and out["value"] > 0
+
+
+def test_self_launch_passes_the_childs_failure_on():
+    """``python bench.py --gpus 2`` relays the launcher child's exit code: a failing rank (test hook
+    FASTVIM_BENCH_FAIL_RANK) must not turn into rc 0, a JSON line or a hang."""
+    env = dict(os.environ, FASTVIM_BENCH_ONE_GPU="1", FASTVIM_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--batch", "2", "--no-cpu-baseline", "--no-kernels", "--no-scan-op"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 _RCCL_SCRIPT = r'''
