@@ -212,6 +212,19 @@ def kernel_table(B, rows, cols, d, depth, dtype):
         if M.xproj_scan_fwd(T["xc"], Wx2c, Wdt, bdt, A_log, Wdt, bdt, A_log) is not None:
             table["scan_fwd"] = (lambda s: M.xproj_scan_fwd(s["xc"], Wx2c, Wdt, bdt, A_log, Wdt, bdt, A_log), ("xc",),
                                  2 * (small * e + B * rows * (R + 2 * N) * e + small * 4) + Wx2c.numel() * e, 1)
+    # the x_proj adjoint as the step issues it (short pooled lengths: chunk sum + dxc += dx_dbl @ Wx + the bf16 dx_dbl rows
+    # the grouped weight-gradient launch reads; the weight gradient itself is in gemm_wgrad_grouped).  Algorithmic bytes:
+    # the scan backward's chunk partials read once, dxc read and written, the fp32 weight, the bf16 rows written
+    W_ = R + 2 * N
+    if dtype == torch.bfloat16 and W_ in M.XPROJ_WIDTHS:
+        Wx32 = rn(2, W_, d_in, dt=torch.float32) * d_in ** -0.5
+        _, T["dxdbl_chunks"], _ = M.scan_bwd(T["xc"], T["x_dbl"], Wdt, bdt, A_log, Wdt, bdt, A_log, T["dyc"], keep_chunks=True)
+        nch = T["dxdbl_chunks"].shape[0]
+        if nch < M._XPROJ_PRESUM:
+            table["xproj_bwd"] = (lambda s: M.xproj_bwd(s["dxdbl_chunks"], s["xc"], Wx32[0], Wx32[1], s["dxc"], dw=False),
+                                  ("dxdbl_chunks", "dxc"),
+                                  nch * 2 * B * rows * W_ * 4 + 2 * (2 * small * 4) + 2 * W_ * d_in * 4
+                                  + 2 * B * rows * ((W_ + 7) // 8 * 8) * 2, 1)
     out = {}
     # the backward wrappers sum their per-block gradient partials right away when no flat gradient is attached; in
     # the training step those sums are deferred into reduce_partials_multi launches (timed by the step, not here), so
@@ -343,6 +356,7 @@ TRACE_NAMES = {
     "combine_bwd": "combine_bwd_wave_kernel", "scan_bwd": "scan_cl_bwd_short_kernel", "conv_pool_bwd": "conv_pool_bwd_row_kernel",
     "add_rmsnorm_fwd": "add_norm_fwd3_kernel", "gemm_out_proj_addnorm_fwd": "gemm_addnorm_kernel",
     "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 4>",
+    "xproj_bwd": "xproj_bwd_kernel",
 }
 PMC_TRAFFIC_JSON = "r03_v3_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
 STEP_TRACE_CSV = "r03_v3_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r03_v3 (profiles/README.md)
@@ -363,6 +377,46 @@ def in_step_trace_us():
                 out[key] = round(float(r["AverageNs"]) / 1e3, 2)
                 break
     return out
+
+
+def step_roofline(kt, ms_per_step):
+    """Whole-step roofline from the kernel table: the ALGORITHMIC bytes of every row x its launches per step against the
+    step time (HBM fraction), and the flops of the GEMM rows against the dense bf16 MFMA peak.  Rows the table does not
+    carry (patch embed, head, loss, optimizer, reductions: ~3 % of the step) add bytes, so the fractions are slightly low."""
+    nbytes = sum(v["algorithmic_MB"] * 1e6 * v["launches_per_step"] for v in kt.values())
+    flops = sum(v["TFLOPs"] * 1e12 * v["us"] * 1e-6 * v["launches_per_step"] for v in kt.values() if "TFLOPs" in v)
+    t = ms_per_step * 1e-3
+    return {"algorithmic_GB": round(nbytes / 1e9, 3), "hbm_GBps": round(nbytes / t / 1e9, 1),
+            "hbm_frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "gemm_TFLOP": round(flops / 1e12, 4),
+            "gemm_TFLOPs": round(flops / t / 1e12, 1), "mfma_frac": round(flops / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "kernel_rows_us": round(sum(v["us_per_step"] for v in kt.values()), 1), "ms_per_step": round(ms_per_step, 3)}
+
+
+def profile_stamp():
+    """Where the committed-profile numbers of the line (roofline.traffic, us_in_step_trace) come from: file tags and the
+    commit that last touched them -- they are NOT measured in this run and go stale when a kernel changes."""
+    import subprocess
+    st = {"pmc_traffic": PMC_TRAFFIC_JSON, "step_trace": STEP_TRACE_CSV, "measured_in_this_run": False}
+    try:
+        r = subprocess.run(["git", "log", "-1", "--format=%h %cI", "--", os.path.join("profiles", PMC_TRAFFIC_JSON)],
+                           cwd=ROOT, capture_output=True, text=True, timeout=10)
+        h = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10)
+        st["profile_commit"] = r.stdout.strip() or None
+        st["head"] = h.stdout.strip() or None
+    except Exception:
+        st["profile_commit"] = st["head"] = None        # the GPU box's copy has no .git: the tags above still identify the files
+    return st
+
+
+def library_gemm_ceiling(M_, N_, K_, trans_b=True):
+    """The vendor library (hipBLASLt through torch) on the same operands: a same-box sanity ceiling for the build's GEMMs,
+    timed HERE only -- the product path never calls a library GEMM (tests/test_model_gpu.py::test_training_step_calls_no_library_gemm)."""
+    a = torch.randn(M_, K_, device="cuda").bfloat16()
+    sets = [{"a": a, "w": (torch.randn(N_, K_, device="cuda") if trans_b else torch.randn(K_, N_, device="cuda")).bfloat16()}]
+    fn = (lambda s: F.linear(s["a"], s["w"])) if trans_b else (lambda s: s["a"] @ s["w"])
+    fns = rotating(fn, sets[0], ("a",), 2 * (M_ * K_ + M_ * N_))
+    t = time_kernel(fns)
+    return round(2.0 * M_ * N_ * K_ / t / 1e12, 1)
 
 
 # --------------------------------------------------------------------------- CPU baseline
@@ -619,6 +673,17 @@ def other_configs_block(dtype, rank, dev, steps=5, warmup=2):
                                       **({"TFLOPs": kt[dom]["TFLOPs"], "mfma_frac": kt[dom]["mfma_frac"]} if "TFLOPs" in kt[dom] else {})}
             row["mfma_frac"] = {k[5:]: kt[k]["mfma_frac"] for k in kt if k.startswith("gemm_") and "mfma_frac" in kt[k]}
             row["kernel_us"] = {k: kt[k]["us"] for k in kt}
+            row["roofline_step"] = step_roofline(kt, el / steps * 1e3)
+            if d >= 384:      # the vendor library on the same shapes, same box, HBM-cold: how good is 0.4-0.5 of peak here?
+                Mt, d_in_ = batch * gs * gs, 2 * d
+                try:
+                    lib_tf = {"in_proj_fwd": library_gemm_ceiling(Mt, 2 * d_in_, d), "out_proj_fwd": library_gemm_ceiling(Mt, d, d_in_),
+                              "out_proj_dgrad": library_gemm_ceiling(Mt, d_in_, d, trans_b=False),
+                              "in_proj_dgrad": library_gemm_ceiling(Mt, d, 2 * d_in_, trans_b=False)}
+                    row["hipblaslt_TFLOPs"] = lib_tf
+                    row["build_TFLOPs"] = {k: kt["gemm_" + k]["TFLOPs"] for k in lib_tf}
+                except Exception as e_:
+                    row["hipblaslt_TFLOPs"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
             del kt
         out[key] = row
         gc.collect()
@@ -701,7 +766,6 @@ def self_launch(n):
         port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this image
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     child = subprocess.Popen(cmd, env=env, cwd=os.getcwd(), stdout=subprocess.PIPE, text=True)
@@ -732,6 +796,9 @@ def main():
     ap.add_argument("--comm-dtype", default="fp32", choices=["auto", "fp32", "bf16"],
                     help="wire format of the gradient all-reduce: fp32 (default, the reference's DDP), bf16, or auto "
                          "(bf16 for buckets of >= 100 MB of fp32 gradient, else fp32) -- the compressed forms are opt-in")
+    ap.add_argument("--mid-fusion", action="store_true",
+                    help="A/B: conv + pool / x_proj + scan / combine of the forward pass as ONE launch (csrc/mixer_mid_fwd.hip; "
+                         "measured neutral, off by default)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
     ap.add_argument("--vim-2048", action="store_true", help="only the Vim-vs-FastVim block at 2048 px (SURVEY row f2), as JSON")
@@ -743,6 +810,9 @@ def main():
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU), BEFORE this process has
         # touched the GPU in any way -- a fresh child, never an exec -- and pass its JSON line and exit code on
         raise SystemExit(self_launch(args.gpus))
+    if os.environ.get("FASTVIM_BENCH_HANG_DUMP"):      # debugging aid: python stacks of every thread after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["FASTVIM_BENCH_HANG_DUMP"]), exit=True)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -769,6 +839,9 @@ def main():
     if args.vim_2048:
         print(json.dumps(vim_vs_fastvim_block(dev, args.img if args.img != 224 else 2048, args.batch if args.batch != 128 else 8)), flush=True)
         return
+    if args.mid_fusion:
+        from fastvim_amd import mixer_ops as _M
+        _M.MID_FWD = True
     use_graph = not args.no_graph
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)
@@ -832,6 +905,8 @@ def main():
                                "avg_us_warm": kt[dom].get("us_warm"),
                                "frac_warm": (round(kt[dom]["algorithmic_MB"] * 1e6 / (kt[dom]["us_warm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                                              if kt[dom].get("us_warm") else None)}
+            out["roofline"]["committed_profile"] = profile_stamp()
+            out["roofline_step"] = step_roofline(kt, ms)
             try:      # plain elementwise kernels on cold tensors of the same size: what a 10-15 us launch can reach at all
                 out["roofline"]["elementwise_floor_same_size_cold"] = stream_floor(args.batch, gs * gs, 2 * d, amp_dtype)
             except Exception as e_:

@@ -482,14 +482,6 @@ class FastVimMixerFn(torch.autograd.Function):
             xz = xz.view(B, Ltok, 2 * d_in)                                                # (B, L, 2 d_in)
             cw2, cwb2 = cw.reshape(d_in, -1), cw_b.reshape(d_in, -1)
             amax = None
-            if pool_max:
-                xc, skip, amax = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
-                                                 D=D, D_b=D_b)
-            else:
-                xc, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
-                                           D=D, D_b=D_b)
-            if valid is not None and valid < rows * tpp:
-                xc[:, :, valid:].zero_()
             if fv is not None and "Wx2" in fv:          # x_proj / x_proj_b adjacent in the flat buffers
                 Wx2 = fv["Wx2"]
                 if fv["Wx2_shadow"].dtype == cdt:
@@ -500,17 +492,33 @@ class FastVimMixerFn(torch.autograd.Function):
             else:
                 Wx2 = torch.stack([Wx, Wx_b])                                           # (2, R+2N, d_in) fp32
                 Wx2_c = Wx2.to(cdt)
-            fused = M.xproj_scan_fwd(xc, Wx2_c, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)      # short pooled lengths, bf16
-            if fused is not None:
-                x_dbl, yc = fused
+            mid = None
+            if not pool_max and tpp == 1 and valid is None:
+                # conv + pool -> x_proj + scan -> combine as ONE launch where it is built (224 / 256 px grids, d_inner 384)
+                mid = M.mixer_mid_fwd(xz, cw2, cb, cwb2, cb_b, D, D_b, Wx2_c, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log,
+                                      ln_w, ln_b, ln_eps, rows, cols, transposed, scaling)
+            if mid is not None:
+                xc, skip, x_dbl, yc, g, mean, rstd = mid
             else:
-                x_dbl = M.xproj_fwd(xc, Wx2_c)                                           # (2, B*Lc, R+2N)
-                # long pooled lengths: when a backward pass will follow, the scan leaves the state entering every
-                # 16-step chunk behind and the backward kernel does not sweep forward again
-                nig = getattr(ctx, "needs_input_grad", None)
-                yc, ctx.scan_ckpt = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log,
-                                               want_ckpt=nig is None or any(nig))
-            g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
+                if pool_max:
+                    xc, skip, amax = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
+                                                     D=D, D_b=D_b)
+                else:
+                    xc, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
+                                               D=D, D_b=D_b)
+                if valid is not None and valid < rows * tpp:
+                    xc[:, :, valid:].zero_()
+                fused = M.xproj_scan_fwd(xc, Wx2_c, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)      # short pooled lengths, bf16
+                if fused is not None:
+                    x_dbl, yc = fused
+                else:
+                    x_dbl = M.xproj_fwd(xc, Wx2_c)                                           # (2, B*Lc, R+2N)
+                    # long pooled lengths: when a backward pass will follow, the scan leaves the state entering every
+                    # 16-step chunk behind and the backward kernel does not sweep forward again
+                    nig = getattr(ctx, "needs_input_grad", None)
+                    yc, ctx.scan_ckpt = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log,
+                                                   want_ckpt=nig is None or any(nig))
+                g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
             # W_out None: out_proj is the caller's (fused with the next block's add + norm, OutProjAddNormFn); the
             # gated activations g (B, L, d_in) are returned and their gradient comes back as ``dout``
             out = g if W_out is None else linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)

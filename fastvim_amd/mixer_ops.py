@@ -98,6 +98,57 @@ def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1):
     return g, mean, rstd
 
 
+MID_FWD = False       # opt-in (bench.py --mid-fusion): the fused forward launch of the mixer's middle instead of three launches.
+                      # Measured neutral (5.75-5.78 ms per FastVim-T step either way, profiles/r04_ab_mid_fwd_fusion.log), so off.
+_MID_FLAGS = {}       # (device index, stream handle) -> hand-off flags of the fused forward launch (zero between launches)
+
+
+def mixer_mid_fwd(xz, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, Wx2_c, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b,
+                  ln_w, ln_b, eps, rows, cols, transposed, scaling):
+    """conv_pool_fwd + xproj_scan_fwd + combine_fwd in ONE launch (csrc/mixer_mid_fwd.hip), same outputs bit for bit:
+    returns (xc, skip, x_dbl, yc, g, mean, rstd), or None when the shape is not covered (the caller then runs the three
+    launches).  Covered: bf16, mean pooling, tokens_per_patch 1, the 14 x 14 / 16 x 16 grids, d_inner 384, dt_rank <= 24,
+    2 * batch <= CUs (an image is carried by a PAIR of co-resident workgroups)."""
+    B, Ltok, two_d = xz.shape
+    d_in = two_d // 2
+    R, N = dt_w.shape[1], A_log.shape[1]
+    W = Wx2_c.shape[1]
+    lib = L.lib()
+    if (not MID_FWD or xz.dtype != torch.bfloat16 or Wx2_c.dtype != torch.bfloat16 or N != 16 or W != R + 2 * N
+            or conv_w.shape[-1] != 4 or D is None or D_b is None or not xz.is_contiguous() or not Wx2_c.is_contiguous() or xz.data_ptr() % 16
+            or Wx2_c.data_ptr() % 16
+            or not lib.fv_mixer_mid_fwd_ok(L.i32(B), L.i32(rows), L.i32(cols), L.i32(1), L.i32(d_in), L.i32(R),
+                                           L.i32(L.dtype_code(xz.dtype)), L.i32(0))):
+        return None
+    dev = xz.device
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B)
+    flags = _MID_FLAGS.get(key)
+    if flags is None:
+        flags = _MID_FLAGS[key] = torch.zeros(4 * B + 1, device=dev, dtype=torch.int32)
+    s_i, s_j = _geo(rows, cols, transposed)
+    xc = torch.empty(2, B, rows, d_in, device=dev, dtype=xz.dtype)
+    skip = torch.empty(B, Ltok, d_in, device=dev, dtype=xz.dtype)
+    x_dbl = torch.empty(2, B * rows, W, device=dev, dtype=xz.dtype)
+    yc = torch.empty(2, B, rows, d_in, device=dev, dtype=torch.float32)
+    g = torch.empty(B, Ltok, d_in, device=dev, dtype=xz.dtype)
+    mean = torch.empty(B * Ltok, device=dev, dtype=torch.float32) if ln_w is not None else None
+    rstd = torch.empty(B * Ltok, device=dev, dtype=torch.float32) if ln_w is not None else None
+    rc = lib.fv_mixer_mid_fwd(
+        L.ptr(xz), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(D), L.ptr(D_b), L.ptr(Wx2_c),
+        L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b), L.ptr(A_log_b), L.ptr(ln_w), L.ptr(ln_b),
+        L.ptr(xc), L.ptr(skip), L.ptr(x_dbl), L.ptr(yc), L.ptr(g), L.ptr(mean), L.ptr(rstd), L.ptr(flags), L.i32(B),
+        L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in), L.i32(R), L.i32(N), f32(scaling), f32(eps),
+        L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
+    L.check(rc, "mixer_mid_fwd")
+    return xc, skip, x_dbl, yc, g, mean, rstd
+
+
+def mixer_mid_errors():
+    """Number of fused forward launches' flag buffers whose error word is set (a bounded wait for the partner workgroup
+    ran out: that launch's outputs are invalid).  Synchronises; call it outside the hot loop."""
+    return sum(int(f[-1].item() != 0) for f in _MID_FLAGS.values())
+
+
 class _Deferred:
     """Gradient-partial reductions whose results are only needed before the optimizer step are queued
     (flat training state only) and issued up to 96 at a time by ONE launch (fv_reduce_partials_multi).

@@ -168,6 +168,27 @@ int fv_mixer_xproj_scan_fwd(const void* xc, const void* x_proj_w2, const float* 
                             void* x_dbl, float* yc, int batch, int Lc, int d_inner, int dt_rank, int d_state,
                             int dtype, fv_stream_t stream);
 
+/* The middle of the mixer's forward pass in ONE launch (reference: everything between in_proj and out_proj of
+ * Mamba.forward, mamba_simple_faster.py:272-444): fv_mixer_conv_pool_fwd + fv_mixer_xproj_scan_fwd + fv_mixer_combine_fwd
+ * with the same outputs, bit for bit.  An image is carried by a pair of workgroups (split by pooling rows for the conv and
+ * the combine, by scan direction for x_proj + scan) that exchange xc and yc through memory with agent-scope accesses; the
+ * launch is one workgroup per CU, so 2 * batch must not exceed the CU count.  Built for bf16, mean pooling, the 14 x 14 and
+ * 16 x 16 grids, d_inner == 384, dt_rank <= 24: ask fv_mixer_mid_fwd_ok (1 = covered) and take the three launches otherwise.
+ *   flags  (4 * batch + 1) int32, ZERO before the first launch and left zero by every launch (hand-off flags; the
+ *          last word is an error word: non-zero after a launch whose bounded wait for a partner workgroup ran out --
+ *          the outputs of that launch are then invalid).  One buffer per stream of launches.
+ * Outputs: xc (2, batch, rows, d_inner) bf16, skip (batch, L, d_inner) bf16, x_dbl (2, batch * rows, dt_rank + 2 * d_state)
+ * bf16, yc (2, batch, rows, d_inner) fp32, g (batch, L, d_inner) bf16, mean / rstd (batch * L) fp32 (ln_w != NULL). */
+int fv_mixer_mid_fwd_ok(int batch, int rows, int cols, int tokens_per_patch, int d_inner, int dt_rank, int dtype,
+                        int pool_max);
+int fv_mixer_mid_fwd(const void* xz, const float* conv_w, const float* conv_b, const float* conv_w_b,
+                     const float* conv_b_b, const float* D, const float* D_b, const void* x_proj_w2, const float* dt_w,
+                     const float* dt_bias, const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                     const float* A_log_b, const float* ln_w, const float* ln_b, void* xc, void* skip, void* x_dbl,
+                     float* yc, void* g, float* mean, float* rstd, int* flags, int batch, int rows, int cols, int s_i,
+                     int s_j, int d_inner, int dt_rank, int d_state, float scaling_factor, float eps, int dtype,
+                     fv_stream_t stream);
+
 /* g = LayerNorm((yc_f + yc_b + skip) / 2) * silu(z), the scan outputs expanded over `cols`; ln_w == NULL
  * skips the norm (use_norm_after_ssm=False).  mean/rstd (batch*L) fp32 are saved for backward, which
  * rebuilds the normalised value from skip, yc, mean, rstd. */
