@@ -17,16 +17,19 @@ def _opt_in(monkeypatch):
 
 
 def _close(name, a, b):
-    """bf16 outputs: at most one ulp apart, and in fewer than 1e-3 of the elements; fp32 ones: what one ulp of x_dbl does."""
+    """bf16 outputs: a rounding flip of an element (one bf16 ulp, two across a power of two; for x_dbl, a sum over 384
+    channels, a flip of the sum at the tensor's scale), in fewer than 1e-3 of the elements; fp32 ones (yc, mean, rstd):
+    what those flips do downstream -- 2^-7 of the tensor's scale."""
     assert a.dtype == b.dtype and a.shape == b.shape, name
     af, bf = a.float(), b.float()
     d = (af - bf).abs()
-    scale = torch.maximum(af.abs(), bf.abs()).clamp_min(2.0 ** -6)
+    gmax = bf.abs().max().item()
     if a.dtype == torch.bfloat16:
-        assert (d <= 2.0 ** -7 * scale * 1.01).all(), (name, d.max().item())
+        bound = torch.maximum(2.0 ** -6 * torch.maximum(af.abs(), bf.abs()), torch.full_like(d, 2.0 ** -8 * gmax))
+        assert (d <= bound).all(), (name, d.max().item(), gmax)
         assert (d != 0).float().mean().item() < 1e-3, (name, (d != 0).float().mean().item())
     else:
-        assert (d <= 2e-3 * torch.maximum(scale, bf.abs().max() * 1e-2)).all(), (name, d.max().item())
+        assert (d <= 2.0 ** -7 * gmax).all(), (name, d.max().item(), gmax)
 
 
 def _inputs(B, rows, d_in, R, seed, with_ln=True):
