@@ -5,6 +5,8 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/fastvim_hip.h"
 
 #define FV_WAVE 64
@@ -37,16 +39,27 @@ static inline int fv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // device (one bit each), so a process that drives several GPUs sets it on every one of them.  A race between two host
 // threads only repeats an idempotent call.
 struct FvOncePerDevice {
-  unsigned long long seen = 0;
+  std::atomic<unsigned long long> seen{0};
   bool first() {
     int d = 0;
     (void)hipGetDevice(&d);
     const unsigned long long bit = 1ull << (d & 63);
-    if (seen & bit) return false;
-    seen |= bit;
-    return true;
+    return (seen.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;     // exactly one caller per device sees "first"
   }
 };
+
+// CU count of the CURRENT device (kept per device: a process may drive several GPUs, and they need not be the same part)
+static inline int fv_cu_count() {
+  static std::atomic<int> cus[64];
+  int d = 0;
+  (void)hipGetDevice(&d);
+  int c = cus[d & 63].load(std::memory_order_relaxed);
+  if (c <= 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256;
+    cus[d & 63].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
 
 // A/B hooks of the kernel dispatchers.  The shipped library takes the measured default of every choice and reads NO
 // environment variable; a build with -DFASTVIM_TUNING_HOOKS (python -m fastvim_amd.build --tuning) reads FASTVIM_<NAME>

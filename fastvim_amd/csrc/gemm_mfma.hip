@@ -1427,15 +1427,11 @@ template <int BMODE, int WM, int WN, int NB, int MB, int S>
 int launch_stream(const GemmParams& p, hipStream_t st) {
   constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
   constexpr size_t smem = (size_t)S * (BM + BN) * BK * 2 + (size_t)WM * WN * 16 * (16 * NB * 2 + 16);
-  static int cus = 0;
+  const int cus = fv_cu_count();
   static FvOncePerDevice attr_set;
-  if (attr_set.first()) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  if (attr_set.first())
     (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<BMODE, WM, WN, NB, MB, S>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  }
   static const int per_cu_env = fv_tune("FASTVIM_GEMM_STREAM_WG", 0);   // tuning hook
   static const bool balance = (fv_tune("FASTVIM_GEMM_STREAM_BAL", 1) != 0);   // tuning hook
   const int fit = (int)((160 * 1024) / smem);
@@ -1511,15 +1507,10 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
     // 44.48 -> 44.30; stand-alone 2-5 % per GEMM (profiles/r03_p256_persistent.log)
     static const int persist = fv_tune("FASTVIM_GEMM_P256_PERSIST", 1);   // tuning hook: 0 = one workgroup per tile
     const int ntile = fv_cdiv(p.M, 256) * (p.N / 256);
-    static int cus8 = 0;
+    const int cus8 = fv_cu_count() / 8 * 8;
     static FvOncePerDevice attr2;
-    if (attr2.first()) {
-      int dev = 0, cus = 0;
-      (void)hipGetDevice(&dev);
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-      cus8 = cus / 8 * 8;
+    if (attr2.first())
       (void)hipFuncSetAttribute((const void*)gemm_nt256pp_kernel<BMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
     if (persist && cus8 >= 8 && ntile > cus8) {
       hipLaunchKernelGGL(gemm_nt256pp_kernel<BMODE>, dim3(cus8), dim3(512), 160 * 1024, st, q);
       FV_LAUNCH_CHECK();
@@ -1606,12 +1597,7 @@ static int gemm_entry(const void* A, const void* B, void* C, const float* bias, 
 static int fused_rpt(int M) {
   static const int force = fv_tune("FASTVIM_FUSED_RPT", 64);      // tuning hook
   if (force > 0) return force < 64 ? force : 64;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  }
+  const int cus = fv_cu_count();
   const long slots = 2L * cus, rounds = (M + 64 * slots - 1) / (64 * slots);
   long rpt = (M + slots * rounds - 1) / (slots * rounds);
   if (rpt < 16) rpt = 16;

@@ -271,6 +271,14 @@ def _gemm_tn_grouped_one(jobs, reduce, c=None):
     jobs = [(x, y, out, s_) for (x, y, out, _), s_ in zip(jobs, fill_splits(jobs, c))]
     parts = []
     direct = []
+
+    def _two_tiles(Kd, sp):      # the C side's rule for the phased 256 x 256 form: whole slices of at least two 64-deep K tiles
+        kps = -(-(-(-Kd // sp)) // 64) * 64
+        return kps >= 128 and Kd % kps == 0
+
+    # in-place accumulation exists in the phased 256 x 256 kernel only, and the C side picks the kernel for the LAUNCH: one
+    # problem whose slices are a single K tile sends the whole launch to the other kernel, so the flag is a launch property
+    launch_phased = c == 3 and all(_two_tiles(x.shape[0], sp) for x, _, _, sp in jobs)
     for x, y, out, sp in jobs:
         Kd, M = x.shape
         N = y.shape[1]
@@ -278,7 +286,7 @@ def _gemm_tn_grouped_one(jobs, reduce, c=None):
         assert out.numel() == M * N and out.dtype == torch.float32
         # one K slice of a large output (FastVim-B: 3072 x 768, 768 x 1536) is added to the gradient by the GEMM itself:
         # the (1, M, N) partial and the launch that summed it were 1 GB of traffic per step for nothing
-        d = (DIRECT_ACC and c == 3 and sp == 1 and Kd % 64 == 0 and Kd >= 128 and out.is_contiguous()
+        d = (DIRECT_ACC and launch_phased and sp == 1 and Kd % 64 == 0 and Kd >= 128 and out.is_contiguous()
              and out.data_ptr() % 16 == 0)
         direct.append(d)
         parts.append(out.view(1, M, N) if d else torch.empty(sp, M, N, device=x.device, dtype=torch.float32))

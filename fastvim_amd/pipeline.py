@@ -107,9 +107,12 @@ class SegmentedTrainStep:
 
     def _snapshot(self):
         f, o = self.flat, self.opt
-        bufs = [f.param_flat, f.shadow_flat] + [b for b in (getattr(o, "exp_avg", None), getattr(o, "exp_avg_sq", None),
-                                                            getattr(o, "ema", None), getattr(o, "step_t", None))
-                                                 if b is not None]
+        # every tensor attribute of the optimizer (moments, EMA, step count, lr, decay mask, ...) and the state's own buffers:
+        # whatever a warm-up step may advance is put back, not a hand-picked list
+        bufs = [f.param_flat, f.shadow_flat]
+        for v in vars(o).values():
+            if torch.is_tensor(v) and v.is_cuda and all(v is not b for b in bufs):
+                bufs.append(v)
         dev = f.param_flat.device
         return ([(b, b.clone()) for b in bufs], torch.get_rng_state(), torch.cuda.get_rng_state(dev), dev)
 
@@ -125,10 +128,13 @@ class SegmentedTrainStep:
     def _capture(self, warmup):
         from . import graph_capture_safe
         if not graph_capture_safe():
+            # known to replay some captured steps wrongly (non-finite after a few replays): do not capture at all
             warnings.warn("SegmentedTrainStep: HIP was initialised before `import fastvim_amd` could switch graph packet "
                           "capture off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): on ROCm 7.2 some captured training steps replay "
-                          "wrongly (DESIGN.md section 5).  Import fastvim_amd first, or export the variable.",
-                          RuntimeWarning, stacklevel=3)
+                          "wrongly (DESIGN.md section 5) -- running this step EAGERLY instead.  Import fastvim_amd first, or "
+                          "export the variable, to get graph replay.", RuntimeWarning, stacklevel=3)
+            self.use_graph = False
+            return
         snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
