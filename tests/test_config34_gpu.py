@@ -135,7 +135,12 @@ def test_mixer_bf16_forward_within_ulps_of_storage_rounded_oracle(d_model, grid)
     """Tight bf16 check: the fp64 oracle with a bf16 round trip at every tensor the HIP path stores
     in bf16 (input, shadow weights, xz, xc, x_dbl, skip, g, output) leaves only accumulation-order effects and the
     occasional one-ulp flip of an intermediate: the output must agree to 2 bf16 ulps of its scale in max-norm and to
-    2e-3 in relative L2 -- a 1 % error in any fused row kernel fails this by an order of magnitude."""
+    2e-3 in relative L2 -- a 1 % error in any fused row kernel fails this by an order of magnitude.
+
+    Role: this is a REGRESSION check, not the parity gate.  The storage-rounded oracle mirrors where the HIP path
+    rounds, so a misplaced rounding would be mirrored too; parity with the reference is the UNROUNDED fp64 oracle /
+    reference goldens with their looser bounds (``test_mixer_b_14x14_bf16_vs_oracle`` above at 1e-2 / 3e-2,
+    tests/test_mixer_gpu.py, tests/test_model_gpu.py)."""
     from fastvim_amd.mamba_simple_faster import Mamba
     from oracle import fastvim_mixer_oracle
     torch.manual_seed(d_model + grid[0])
@@ -162,7 +167,8 @@ def test_mixer_bf16_backward_within_ulps_of_storage_rounded_oracle(d_model, grid
     so what is left is accumulation order and the occasional one-ulp flip of an intermediate: d hidden must agree with the
     bf16-rounded oracle gradient to 2 bf16 ulps of its scale and 2e-3 in relative L2, every parameter gradient to 3e-3
     in relative L2 (sums over 784 tokens of values that each carry a 2^-9 rounding) -- an order of magnitude below the
-    3e-2 of the unrounded comparison above."""
+    3e-2 of the unrounded comparison above.  Like its forward twin a regression check on top of the unrounded gate: the
+    oracle's ``round_grads`` mode copies the build's own rounding points."""
     from fastvim_amd.mamba_simple_faster import Mamba
     from oracle import fastvim_mixer_oracle
     torch.manual_seed(7 * d_model + grid[0])
