@@ -303,6 +303,9 @@ class _Ctx:
         self.saved_tensors = tensors
 
 
+ADDNORM_RW = True       # out_proj + add + norm through the register-weight kernel where it is built (A/B switch)
+
+
 def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in=None):
     """``W_in`` (2 d_inner, d): also run this block's in_proj as a second phase of the launch; returns xz last."""
     B, Ltok, d_in = g.shape
@@ -326,7 +329,17 @@ def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in
     #  the kernel is even enqueued)
     W_out_c = _shadow(W_out, cdt)
     W_in_c = _shadow(W_in, cdt) if xz is not None else None
-    rc = L.lib().fv_gemm_bf16_addnorm2(
+    lib = L.lib()
+    if (ADDNORM_RW and xz is None and W_in is None
+            and lib.fv_gemm_bf16_addnorm_rw_ok(L.i32(Mrows), L.i32(d), L.i32(d_in)) and W_out_c.stride(0) % 8 == 0):
+        # the weight held in registers by persistent workgroups (csrc/gemm_rw.hip): same values bit for bit
+        rc = lib.fv_gemm_bf16_addnorm_rw(
+            L.ptr(g2), L.ptr(W_out_c), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
+            L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
+            ctypes.c_long(W_out_c.stride(0)), ctypes.c_float(eps), L.stream_of(g2))
+        L.check(rc, "gemm_bf16_addnorm_rw")
+        return y, res_out, rstd, w32, row_scale, rows_per_scale
+    rc = lib.fv_gemm_bf16_addnorm2(
         L.ptr(g2), L.ptr(W_out_c), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
         L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
         ctypes.c_long(d_in), ctypes.c_float(eps), L.ptr(W_in_c), L.ptr(xz),

@@ -381,6 +381,17 @@ int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, const float* d
                                     int K, long lda, long ldw, const void* W2, void* C2, int N2, long ldw2,
                                     fv_stream_t stream);
 
+/* fv_gemm_bf16_addnorm (out_proj + the next block's DropPath scale / residual add / RMSNorm; reference:
+ * mamba_simple_faster.py:435-444 + models/fastvim.py:168-190) with the WEIGHT HELD IN REGISTERS: one persistent 12-wave
+ * workgroup per CU, wave w keeps the K x 16 slice of W for output columns [16 w, 16 w + 16) in VGPRs for the whole launch
+ * and the workgroup's M / #CU rows stream through in 32-row tiles -- the weight is fetched once per CU instead of once per
+ * 64 rows.  Same arguments and, bit for bit, the same outputs as fv_gemm_bf16_addnorm.  Built for N == 192 and
+ * K in {192, 384}: ask fv_gemm_bf16_addnorm_rw_ok (1 = covered). */
+int fv_gemm_bf16_addnorm_rw_ok(int M, int N, int K);
+int fv_gemm_bf16_addnorm_rw(const void* A, const void* W, const float* residual, const float* norm_weight,
+                            const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd, int M,
+                            int N, int K, long lda, long ldw, float eps, fv_stream_t stream);
+
 /* fv_gemm_bf16_addnorm with a second GEMM phase: C2 (M, N2) bf16 = y @ W2^T, W2 (N2, N) bf16 row-major -- the block's
  * in_proj (mamba_simple_faster.py:189-193) computed from the normalised tile while it is still in LDS; bit-identical to
  * fv_gemm_bf16 on y.  W2 null: no second phase.  N2 % 128 == 0. */
