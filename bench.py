@@ -796,8 +796,8 @@ def main():
     ap.add_argument("--comm-dtype", default="fp32", choices=["auto", "fp32", "bf16"],
                     help="wire format of the gradient all-reduce: fp32 (default, the reference's DDP), bf16, or auto "
                          "(bf16 for buckets of >= 100 MB of fp32 gradient, else fp32) -- the compressed forms are opt-in")
-    ap.add_argument("--no-rw", action="store_true",
-                    help="A/B: the tiled fused projection + norm kernels instead of the register-weight ones (csrc/gemm_rw.hip)")
+    ap.add_argument("--rw", action="store_true",
+                    help="A/B: out_proj + add + norm through the register-weight kernel (csrc/gemm_rw.hip; measured equal, off by default)")
     ap.add_argument("--mid-fusion", action="store_true",
                     help="A/B: conv + pool / x_proj + scan / combine of the forward pass as ONE launch (csrc/mixer_mid_fwd.hip; "
                          "measured neutral, off by default)")
@@ -844,9 +844,9 @@ def main():
     if args.mid_fusion:
         from fastvim_amd import mixer_ops as _M
         _M.MID_FWD = True
-    if args.no_rw:
+    if args.rw:
         import fastvim_amd.mamba_simple_faster as _msf
-        _msf.ADDNORM_RW = False
+        _msf.ADDNORM_RW = True
     use_graph = not args.no_graph
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)

@@ -12,6 +12,13 @@
 // tile into the norm epilogue (lane mapping and operation order of add_norm_fwd3_kernel<16>, as in the kernel this
 // replaces), the next tile's rows and residual rows are in flight under the current tile's arithmetic.  Weight bytes per
 // launch: 256 x 147 KB = 38 MB once, and none of it through LDS.
+//
+// MEASURED (round 4, profiles/r04_ab_addnorm_register_weights.log): bit-identical to the tiled kernel and exactly as
+// fast -- 21.8 vs 21.3 us HBM-cold (3.1 vs 3.2 TB/s on the 67 MB both move), 18.8 vs 16.0 us cache-warm, FastVim-T step
+// 5.72-5.73 vs 5.71-5.73 ms.  The weight fill was not what bounds this launch: two designs with 58 MB and 0 MB of weight
+// traffic through LDS land on the same 21 us, which is what ANY launch moving 67 MB once gets on this chip (a plain 3-stream
+// add of that size: 3.0-4.5 TB/s, bench.py roofline.elementwise_floor_same_size_cold).  Kept as a tested opt-in
+// (mamba_simple_faster.ADDNORM_RW, bench.py --rw); the tiled kernel stays the default.
 #include <stdlib.h>
 
 #include "common.h"

@@ -303,7 +303,9 @@ class _Ctx:
         self.saved_tensors = tensors
 
 
-ADDNORM_RW = True       # out_proj + add + norm through the register-weight kernel where it is built (A/B switch)
+ADDNORM_RW = False      # opt-in A/B switch: out_proj + add + norm through the register-weight kernel (csrc/gemm_rw.hip).
+                        # Bit-identical and measured EQUAL (21.8 vs 21.3 us HBM-cold, step 5.72-5.73 vs 5.71-5.73 ms:
+                        # profiles/r04_ab_addnorm_register_weights.log), so the tiled kernel stays the default
 
 
 def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in=None):
