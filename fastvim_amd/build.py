@@ -34,7 +34,7 @@ def _file_flags(src):
 
 
 def _compile(src, obj, verbose):
-    cmd = [HIPCC, *FLAGS, *_file_flags(src), "-x", "hip", "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *os.environ.get("FASTVIM_EXTRA_FLAGS", "").split(), *_file_flags(src), "-x", "hip", "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -58,6 +58,9 @@ def build(force=False, verbose=False, tuning=False):
         FLAGS.append("-DFASTVIM_TUNING_HOOKS")
     if not tuning and "-DFASTVIM_TUNING_HOOKS" in FLAGS:
         FLAGS.remove("-DFASTVIM_TUNING_HOOKS")
+    extra = os.environ.get("FASTVIM_EXTRA_FLAGS", "").split()      # build-time A/B knobs (e.g. -DFV_BUF_STORE_AUX=16); forces a rebuild
+    if extra:
+        force = True
     hdr_m = _deps_mtime()
     jobs, objs = [], []
     for src in _sources():

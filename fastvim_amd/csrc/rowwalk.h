@@ -205,21 +205,27 @@ __device__ __forceinline__ void fv_buf_load_words(__amdgpu_buffer_rsrc_t r, int 
   }
 }
 
+// cache policy of the row kernels' bulk stores (aux operand of the buffer-store intrinsics: bit 0 = sc0, bit 1 = nt,
+// bit 4 = sc1).  0 = default.  A build-time A/B knob (FASTVIM_EXTRA_FLAGS=-DFV_BUF_STORE_AUX=<n> python -m fastvim_amd.build):
+// do write-through / non-temporal stores shorten the dirty-line flush at the kernel boundary?  Measured: see DESIGN.md.
+#ifndef FV_BUF_STORE_AUX
+#define FV_BUF_STORE_AUX 0
+#endif
 template <int W>
 __device__ __forceinline__ void fv_buf_store_words(__amdgpu_buffer_rsrc_t r, int voff, int soff, const uint32_t (&w)[W]) {
   if constexpr (W == 1) {
-    __builtin_amdgcn_raw_buffer_store_b32(w[0], r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(w[0], r, voff, soff, FV_BUF_STORE_AUX);
   } else if constexpr (W == 2) {
     fv_u32x2 t; t.x = w[0]; t.y = w[1];
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, FV_BUF_STORE_AUX);
   } else if constexpr (W == 3) {
     // as 8 + 4 bytes: the single buffer_store_dwordx3 form produced corrupt data here (gfx950, ROCm 7.2 hipcc)
     fv_u32x2 t; t.x = w[0]; t.y = w[1];
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(w[2], r, voff + 8, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, FV_BUF_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(w[2], r, voff + 8, soff, FV_BUF_STORE_AUX);
   } else if constexpr (W == 4) {
     fv_u32x4 t; t.x = w[0]; t.y = w[1]; t.z = w[2]; t.w = w[3];
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, FV_BUF_STORE_AUX);
   } else {
     static_assert(W % 2 == 0 && W <= 8, "unsupported vector width");
     uint32_t a[W / 2], b[W / 2];
