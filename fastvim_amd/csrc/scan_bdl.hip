@@ -555,6 +555,105 @@ __global__ __launch_bounds__(256) void scan_short_fwd_kernel(ScanParams p) {
   }
 }
 
+// Forward for 32 < L <= 128 (config 4: L = 128, config 5: L = 112): time-SEGMENTED.  The kernel above walks a row's L
+// steps serially in one lane; at (8, 1536, 128, 16) that is 768 waves -- fewer than one per SIMD -- each on a 128-step
+// dependent chain with per-lane 2-byte loads in front of every four steps: 40 us for 9.6 MB.  The recurrence is linear in
+// the state, so here a block's four waves are four consecutive SEGMENTS of the sequence for the same 16 channels:
+//   tables   the block computes, once per (channel, step) instead of once per quad lane, delta = softplus(delta + bias),
+//            delta u, D u and SiLU(z) into LDS tiles from coalesced operand loads;
+//   pass 1   every wave scans its segment from a ZERO state (no outputs) and leaves its end state and its sum of delta
+//            (the segment's decay is exp(A sum delta)) in LDS;
+//   combine  a wave folds the segments before it into the state entering its own (at most three steps);
+//   pass 2   every wave scans its segment again from that state, now with C, the skip and the gate; y leaves through an
+//            LDS tile in coalesced stores.
+// Twice the recurrence arithmetic, a quarter of the chain length, four times the waves (3 072 at that shape).
+constexpr int GCH = 16, GSEG = 4, GTHR = 64 * GSEG;      // channels per block, segments (= waves) per block
+
+template <typename T>
+__global__ __launch_bounds__(GTHR) void scan_short_fwd_seg_kernel(ScanParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6, q = lane & 3, cl = lane >> 2;
+  const int L = p.L, LP = L + 1;                              // tile row stride (bank spread)
+  const int cpg = p.dim / p.G, chunks = cpg / GCH;
+  const int g = blockIdx.x / chunks, cx = blockIdx.x - g * chunks, b = blockIdx.y;
+  const int d0 = g * cpg + cx * GCH, d = d0 + cl;
+  float* s_bc = smem;                                         // [L][B(16) | C(16)]
+  float* s_dt = smem + (size_t)L * 2 * SN;                    // [16][LP] delta
+  float* s_du = s_dt + GCH * LP;                              // delta * u
+  float* s_sk = s_du + GCH * LP;                              // D * u, then y
+  float* s_gz = s_sk + GCH * LP;                              // SiLU(z) (present only with a gate)
+  float* s_end = s_gz + (p.z ? GCH * LP : 0);                 // [GSEG][16][16] end states, [GSEG][16] sums of delta
+  float* s_sum = s_end + GSEG * GCH * SN;
+  const size_t row0 = ((size_t)b * p.dim + d0) * L;
+  const T* U = (const T*)p.u + row0;
+  const T* DL = (const T*)p.delta + row0;
+  const T* Z = p.z ? (const T*)p.z + row0 : nullptr;
+  // ---- tables: 16 x L (channel, step) pairs over 256 threads, element-coalesced along the rows
+  for (int e = tid; e < GCH * L; e += GTHR) {
+    const int c = e / L, l = e - c * L;
+    const float uv = io<T>::ld(U + e);
+    float dt = io<T>::ld(DL + e) + (p.delta_bias ? p.delta_bias[d0 + c] : 0.f);
+    if (p.softplus) dt = fv_softplus(dt);
+    s_dt[c * LP + l] = dt;
+    s_du[c * LP + l] = dt * uv;
+    s_sk[c * LP + l] = p.D ? p.D[d0 + c] * uv : 0.f;
+    if (Z) s_gz[c * LP + l] = fv_silu(io<T>::ld(Z + e));
+  }
+  stage_bc<T>(p, b, g, s_bc);
+  float A2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) A2[j] = p.A[(size_t)d * SN + q * 4 + j] * FV_LOG2E;
+  __syncthreads();
+  const int ls = (L + GSEG - 1) / GSEG, l0 = seg * ls, l1 = min(L, l0 + ls);
+  const float* my_dt = s_dt + cl * LP;
+  const float* my_du = s_du + cl * LP;
+  // ---- pass 1: end state of the segment from zero, and its sum of delta
+  float st[4] = {0.f, 0.f, 0.f, 0.f}, sdt = 0.f;
+  for (int l = l0; l < l1; ++l) {
+    const float* r = s_bc + (size_t)l * 2 * SN + q * 4;
+    const float dt = my_dt[l], du = my_du[l];
+    sdt += dt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], du * r[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s_end[(seg * GCH + cl) * SN + q * 4 + j] = st[j];
+  if (q == 0) s_sum[seg * GCH + cl] = sdt;
+  __syncthreads();
+  // ---- combine: the state entering this segment = the earlier segments folded in order
+#pragma unroll
+  for (int j = 0; j < 4; ++j) st[j] = 0.f;
+  for (int s2 = 0; s2 < seg; ++s2) {
+    const float sd = s_sum[s2 * GCH + cl];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(sd * A2[j]), st[j], s_end[(s2 * GCH + cl) * SN + q * 4 + j]);
+  }
+  // ---- pass 2: the segment again from its true entry state, with outputs
+  for (int l = l0; l < l1; ++l) {
+    const float* r = s_bc + (size_t)l * 2 * SN + q * 4;
+    const float dt = my_dt[l], du = my_du[l];
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], du * r[j]);
+      acc = fmaf(r[SN + j], st[j], acc);
+    }
+    float y = quad_sum(acc) + s_sk[cl * LP + l];
+    if (Z) y *= s_gz[cl * LP + l];
+    if (q == 0) s_sk[cl * LP + l] = y;             // (the D u entry of this (channel, step) is consumed: y takes its place)
+  }
+  if (p.last_state && seg == GSEG - 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.last_state[((size_t)b * p.dim + d) * SN + q * 4 + j] = st[j];
+  }
+  __syncthreads();
+  T* OUT = (T*)p.out + row0;
+  for (int e = tid; e < GCH * L; e += GTHR) {
+    const int c = e / L, l = e - c * L;
+    io<T>::st(OUT + e, s_sk[c * LP + l]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scan_short_bwd_kernel(ScanParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -819,7 +918,16 @@ int launch_short(const ScanParams& p, int bwd, hipStream_t st) {
   const dim3 grid(p.dim / SCPB, p.batch), block(256);
   FV_CHECK(p.batch <= 65535, "selective_scan: batch %d exceeds the launch grid", p.batch);
   if (!bwd) {
-    hipLaunchKernelGGL((scan_short_fwd_kernel<T>), grid, block, (size_t)p.L * 2 * SN * 4, st, p);
+    static const bool seg_on = (fv_tune("FASTVIM_SCAN_SHORT_SEG", 1) != 0);   // tuning hook
+    // 32 < L <= 128 on FEW rows (config 4: 8 x 1536 rows = 768 serial waves, under one per SIMD): four time segments per
+    // block, 27 instead of 40 us there.  With two or more serial waves per SIMD already (config 5: 64 x 768 rows) the
+    // second pass costs more than the shorter chain gives (82 vs 61 us): the serial kernel stays.
+    if (seg_on && p.L > SWL && (long)(p.dim / GCH) * p.batch < 2 * 4 * fv_cu_count()) {
+      const size_t smem = ((size_t)p.L * 2 * SN + (p.z ? 4 : 3) * GCH * (p.L + 1) + GSEG * GCH * SN + GSEG * GCH) * 4;
+      hipLaunchKernelGGL((scan_short_fwd_seg_kernel<T>), dim3(p.dim / GCH, p.batch), dim3(GTHR), smem, st, p);
+    } else {
+      hipLaunchKernelGGL((scan_short_fwd_kernel<T>), grid, block, (size_t)p.L * 2 * SN * 4, st, p);
+    }
   } else {
     const size_t smem = ((size_t)p.L * 2 * SN + SKS * 4 * 4 * 16 + 7 * SCPB * SWLP) * 4;
     static FvOncePerDevice done;   

@@ -189,3 +189,40 @@ def test_scan_errors():
         selective_scan_fn(u, u, A, torch.randn(2, 300, 8, device="cuda"), torch.randn(2, 300, 8, device="cuda"))
     with pytest.raises(RuntimeError):
         selective_scan_fn(u.cpu(), u.cpu(), A[:, :8].cpu(), torch.randn(2, 8, 8), torch.randn(2, 8, 8))
+
+
+@pytest.mark.parametrize("Bsz,D,L", [(2, 64, 33), (2, 128, 37), (1, 64, 128), (3, 64, 112), (2, 96, 100), (2, 64, 64)])
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
+def test_short_scan_segmented_forward_vs_oracle(Bsz, D, L, itype):
+    """32 < L <= 128 with d_state 16 takes the time-segmented forward kernel (scan_short_fwd_seg_kernel: a block's four
+    waves scan four consecutive segments -- end states from zero, a fold over the earlier segments, a second scan from
+    the true entry state; ragged last segment when L % 4 != 0): output, gate, skip, bias, softplus and last state against
+    the fp64 oracle, and the gradients through the (unchanged) backward kernel."""
+    from fastvim_amd.selective_scan_interface import selective_scan_fn
+    from oracle import selective_scan_oracle
+    g = torch.Generator().manual_seed(Bsz * 1000 + D + L)
+    N = 16
+    cpu = dict(u=torch.randn(Bsz, D, L, generator=g).to(itype), delta=(0.5 * torch.rand(Bsz, D, L, generator=g)).to(itype),
+               A=-0.5 * torch.rand(D, N, generator=g), B=torch.randn(Bsz, N, L, generator=g).to(itype),
+               C=torch.randn(Bsz, N, L, generator=g).to(itype), D=torch.randn(D, generator=g),
+               z=torch.randn(Bsz, D, L, generator=g).to(itype), delta_bias=0.5 * torch.rand(D, generator=g))
+    lc = {k: v.clone().requires_grad_() for k, v in cpu.items()}
+    lg = {k: v.clone().cuda().requires_grad_() for k, v in cpu.items()}
+    order = ("u", "delta", "A", "B", "C", "D", "z", "delta_bias")
+    oref, lref = selective_scan_oracle(*[lc[k] for k in order], True, True, compute_dtype=F64, out_dtype=F64)
+    out, last = selective_scan_fn(*[lg[k] for k in order[:6]], z=lg["z"], delta_bias=lg["delta_bias"], delta_softplus=True,
+                                  return_last_state=True)
+    assert out.dtype == itype
+    ftol = {torch.float32: 2e-5, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[itype]
+    assert _maxerr(out, oref) <= ftol * max(1.0, oref.abs().max().item())
+    assert _maxerr(last, lref) <= 2e-5 * max(1.0, lref.abs().max().item())
+    out2, _ = selective_scan_fn(*[lg[k] for k in order[:6]], z=lg["z"], delta_bias=lg["delta_bias"], delta_softplus=True,
+                                return_last_state=True)
+    assert torch.equal(out, out2)
+    go = torch.randn(Bsz, D, L, generator=torch.Generator().manual_seed(1))
+    oref.backward(go.double())
+    out.backward(go.cuda().to(itype))
+    gtol = {torch.float32: 5e-4, torch.bfloat16: 3e-2, torch.float16: 4e-3}[itype]
+    for k in cpu:
+        gr, gg = lc[k].grad, lg[k].grad
+        assert _maxerr(gg, gr) <= gtol * max(1.0, gr.abs().max().item()), (k, _maxerr(gg, gr), gr.abs().max().item())
