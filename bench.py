@@ -397,6 +397,10 @@ def profile_stamp():
     commit that last touched them -- they are NOT measured in this run and go stale when a kernel changes."""
     import subprocess
     st = {"pmc_traffic": PMC_TRAFFIC_JSON, "step_trace": STEP_TRACE_CSV, "measured_in_this_run": False}
+    try:      # the commit the profiled tree was at, recorded in the file itself (the GPU box's copy of the repo has no .git)
+        st["taken_at_commit"] = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_JSON))).get("taken_at_commit")
+    except (OSError, ValueError):
+        st["taken_at_commit"] = None
     try:
         r = subprocess.run(["git", "log", "-1", "--format=%h %cI", "--", os.path.join("profiles", PMC_TRAFFIC_JSON)],
                            cwd=ROOT, capture_output=True, text=True, timeout=10)
