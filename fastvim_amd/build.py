@@ -11,8 +11,11 @@ OBJ = os.path.join(PKG, "csrc", "_obj")
 LIB = os.path.join(PKG, "libfastvim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
+# -fgpu-flush-denormals-to-zero: fp32 denormals are flushed, as in the reference's kernels (its extension is built with
+# nvcc --use_fast_math, which implies --ftz=true: mamba-1p1p1/setup.py:102-153); the expansions of exp / log / rcp / rsqrt lose
+# their denormal-range scaling code: FastVim-T step 5.736 -> 5.708 ms on one box (profiles/r04_ab_flush_denormals.log)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffast-math", "-fno-finite-math-only",
-         "-Wno-unused-result", "-DNDEBUG"]
+         "-fgpu-flush-denormals-to-zero", "-Wno-unused-result", "-DNDEBUG"]
 
 
 def _sources():
