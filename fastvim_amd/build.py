@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "csrc", "_obj")
 LIB = os.path.join(PKG, "libfastvim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-ARCH = "gfx950"
+ARCH = os.environ.get("FASTVIM_ARCH", "gfx950")      # build-time A/B knob: e.g. gfx950:xnack-
 # -fgpu-flush-denormals-to-zero: fp32 denormals are flushed, as in the reference's kernels (its extension is built with
 # nvcc --use_fast_math, which implies --ftz=true: mamba-1p1p1/setup.py:102-153); the expansions of exp / log / rcp / rsqrt lose
 # their denormal-range scaling code: FastVim-T step 5.736 -> 5.708 ms on one box (profiles/r04_ab_flush_denormals.log)
