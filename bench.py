@@ -800,11 +800,8 @@ def main():
     ap.add_argument("--comm-dtype", default="fp32", choices=["auto", "fp32", "bf16"],
                     help="wire format of the gradient all-reduce: fp32 (default, the reference's DDP), bf16, or auto "
                          "(bf16 for buckets of >= 100 MB of fp32 gradient, else fp32) -- the compressed forms are opt-in")
-    ap.add_argument("--rw", action="store_true",
-                    help="A/B: out_proj + add + norm through the register-weight kernel (csrc/gemm_rw.hip; measured equal, off by default)")
-    ap.add_argument("--mid-fusion", action="store_true",
-                    help="A/B: conv + pool / x_proj + scan / combine of the forward pass as ONE launch (csrc/mixer_mid_fwd.hip; "
-                         "measured neutral, off by default)")
+    ap.add_argument("--no-xproj-fold", action="store_true",
+                    help="A/B: the x_proj adjoint as its own launch instead of inside the short scan backward (round 5)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
     ap.add_argument("--vim-2048", action="store_true", help="only the Vim-vs-FastVim block at 2048 px (SURVEY row f2), as JSON")
@@ -845,12 +842,9 @@ def main():
     if args.vim_2048:
         print(json.dumps(vim_vs_fastvim_block(dev, args.img if args.img != 224 else 2048, args.batch if args.batch != 128 else 8)), flush=True)
         return
-    if args.mid_fusion:
-        from fastvim_amd import mixer_ops as _M
-        _M.MID_FWD = True
-    if args.rw:
+    if args.no_xproj_fold:
         import fastvim_amd.mamba_simple_faster as _msf
-        _msf.ADDNORM_RW = True
+        _msf.XPROJ_IN_SCAN = False
     use_graph = not args.no_graph
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)

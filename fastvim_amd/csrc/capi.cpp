@@ -14,4 +14,4 @@ void fv_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fv_last_error(void) { return g_err; }
-extern "C" int fv_version(void) { return 1; }
+extern "C" int fv_version(void) { return FV_ABI_VERSION; }

@@ -71,7 +71,9 @@ struct RowSrc {
   int b;
 };
 
-template <typename T, int NT>
+// X2: the pooled gradient is dxc + dxc2 (dxc2 in the storage dtype: the other channel chunk's x_proj term, written by
+// fv_mixer_scan_bwd_xproj); the second addend travels packed, one row ahead like the first, and is added at first use
+template <typename T, int NT, bool X2 = false>
 __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_pool_bwd_row_kernel(BwdParams p, int nch, int RG) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 12 * d_in accumulator
   typedef PairVec<T, 1> P;
@@ -90,6 +92,12 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
   const int tok_x = 2 * p.d_in * (int)sizeof(T), tok_d = p.d_in * (int)sizeof(T);   // bytes per token
   const int voff = c0 * (int)sizeof(T);
   const __amdgpu_buffer_rsrc_t bp = fv_make_buf(p.dxc, 2 * dstride * 4);    // both directions' pooled gradients
+  const __amdgpu_buffer_rsrc_t bp2 = fv_make_buf(X2 ? p.dxc2 : p.dxc, X2 ? 2 * dstride * sizeof(T) : 0);
+  struct Pooled {          // a pooled gradient as loaded: fp32 pair + (X2) the packed second addend
+    f2 a;
+    P b;
+    __device__ __forceinline__ f2 sum() const { if constexpr (X2) return a + b.get(0); else return a; }
+  };
   auto locate = [&](int row) {
     const bool ok = row < nrows;
     const int r = ok ? row : 0;
@@ -122,10 +130,12 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
   auto pooled = [&](const RowSrc& s, int r, bool backward) {
     const bool ok = r == 1 || (r == 0 ? s.up : s.down);
     uint32_t w[2];
-    fv_buf_load_words<2>(bp, c0 * 4, s.pooled_off + (ok ? (r - 1) * p.d_in * 4 : 0) + (backward ? (int)dstride * 4 : 0), w);
-    f2 o;
-    o.x = __uint_as_float(w[0]);
-    o.y = __uint_as_float(w[1]);
+    const int eoff = s.pooled_off / 4 + (ok ? (r - 1) * p.d_in : 0) + (backward ? (int)dstride : 0);     // element offset
+    fv_buf_load_words<2>(bp, c0 * 4, eoff * 4, w);
+    Pooled o;
+    o.a.x = __uint_as_float(w[0]);
+    o.a.y = __uint_as_float(w[1]);
+    if constexpr (X2) o.b.load(bp2, voff, eoff * (int)sizeof(T));
     return o;
   };
   auto row_of = [&](int it) { return (it * gridDim.x + blockIdx.x) * RG + rg; };
@@ -146,13 +156,13 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
   // first use -- here exactly as in the loop, so that the waits the compiler places at the top of the loop body (one
   // count for both ways in) find them oldest: row i's pair at the top of the previous iteration, row i-1's after its
   // last use (step -1), row i+1's at the end.
-  f2 cf_mid_raw = pooled(cur, 1, false), cb_mid_raw = pooled(cur, 1, true);
-  f2 cb_up = pooled(cur, 0, true);
+  Pooled cf_mid_raw = pooled(cur, 1, false), cb_mid_raw = pooled(cur, 1, true);
+  Pooled cb_up_raw = pooled(cur, 0, true);
   __builtin_amdgcn_sched_barrier(0);      // (the scheduler would issue these last)
 #pragma unroll
   for (int k = 0; k < NT + 6; ++k) fetch(cur, k);
   __builtin_amdgcn_sched_barrier(0);
-  f2 cf_dn = pooled(cur, 2, false);
+  Pooled cf_dn_raw = pooled(cur, 2, false);
   __builtin_amdgcn_sched_barrier(0);
   const f2 bf = bf_raw * (p.bf ? 1.f : 0.f), bb = bb_raw * (p.bb ? 1.f : 0.f);
   const f2 Dfh = Df_raw * (p.Df ? 0.5f : 0.f), Dbh = Db_raw * (p.Db ? 0.5f : 0.f);
@@ -162,10 +172,11 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
     const __amdgpu_buffer_rsrc_t bo = fv_make_buf((T*)p.dxz + (size_t)cur.b * g.L * 2 * p.d_in, (size_t)g.L * tok_x);
     const bool up = cur.up, down = cur.down;
     const int m_row = cur.m_row;
-    const f2 cf_mid = cf_mid_raw * p.pool_scale, cb_mid = cb_mid_raw * p.pool_scale;
+    const f2 cf_mid = cf_mid_raw.sum() * p.pool_scale, cb_mid = cb_mid_raw.sum() * p.pool_scale;
     cf_mid_raw = pooled(nxt, 1, false);
     cb_mid_raw = pooled(nxt, 1, true);
-    cb_up *= cur.up ? p.pool_scale : 0.f;
+    const f2 cb_up = cb_up_raw.sum() * (cur.up ? p.pool_scale : 0.f);
+    f2 cf_dn = splat(0.f);
     f2 x[NT + 6], dov[NT + 6], dpf[NT + 6], dpb[NT + 6];   // index q + 3; live ranges are 4 steps (full unroll)
     const float m_up = up ? 1.f : 0.f, m_dn = down ? 1.f : 0.f;
 #pragma unroll
@@ -193,10 +204,10 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
       const f2 dsf = sgf * fma2(pf, 1.f - sgf, splat(1.f)), dsb = sgb * fma2(pb, 1.f - sgb, splat(1.f));
       // position n+3 / n missing (outside the sequence): its gradient is zero
       const float e3 = q3 < NT ? 1.f : m_dn, e0 = n >= 0 ? 1.f : m_up;
-      if (q3 == NT) cf_dn *= cur.down ? p.pool_scale : 0.f;
+      if (q3 == NT) cf_dn = cf_dn_raw.sum() * (cur.down ? p.pool_scale : 0.f);
       const f2 nf = fma2(Dfh, dov[k3], q3 >= NT ? cf_dn : cf_mid) * dsf * e3;
       const f2 nb = fma2(Dbh, dov[k0], n < 0 ? cb_up : cb_mid) * dsb * e0;
-      if (n == -1) cb_up = pooled(nxt, 0, true);
+      if (n == -1) cb_up_raw = pooled(nxt, 0, true);
       dpf[k3] = nf;
       dpb[k0] = nb;
       if (q3 < NT) {        // position n+3 belongs to this row: its parameter gradients are accumulated here
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(sizeof(T) == 2 && NT <= 14 ? 768 : 512) void conv_p
       // iteration to its end (shorter live ranges) and the next iteration starts by waiting for all of them
       __builtin_amdgcn_sched_barrier(0);
     }
-    cf_dn = pooled(nxt, 2, false);
+    cf_dn_raw = pooled(nxt, 2, false);
     cur = nxt;
   }
   flush_partials(p, smem, c0, c_lo, nch * 128, rg, RG, a_wf, a_wb, a_bf, a_bb, a_Df * 0.5f, a_Db * 0.5f);
@@ -434,18 +445,23 @@ int launch_chan(const BwdParams& p, int nch, int rgr, int grid, int groups, size
   return FV_OK;
 }
 
-template <typename T, int NT>
-int launch_row(const BwdParams& p, int nch, int rgr, int grid, int groups, size_t smem, hipStream_t st) {
+template <typename T, int NT, bool X2>
+int launch_row2(const BwdParams& p, int nch, int rgr, int grid, int groups, size_t smem, hipStream_t st) {
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
-    static FvOncePerDevice done;   
+    static FvOncePerDevice done;
     if (done.first()) {
-      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_row_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)0;     
+      (void)hipFuncSetAttribute((const void*)conv_pool_bwd_row_kernel<T, NT, X2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)0;
     }
   }
-  hipLaunchKernelGGL((conv_pool_bwd_row_kernel<T, NT>), dim3(grid, groups), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
+  hipLaunchKernelGGL((conv_pool_bwd_row_kernel<T, NT, X2>), dim3(grid, groups), dim3(64 * nch * rgr), smem, st, p, nch, rgr);
   FV_LAUNCH_CHECK();
   return FV_OK;
+}
+template <typename T, int NT>
+int launch_row(const BwdParams& p, int nch, int rgr, int grid, int groups, size_t smem, hipStream_t st) {
+  return p.dxc2 ? launch_row2<T, NT, true>(p, nch, rgr, grid, groups, smem, st)
+                : launch_row2<T, NT, false>(p, nch, rgr, grid, groups, smem, st);
 }
 
 }  // namespace
@@ -464,6 +480,7 @@ int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t
   // <= 768 (168) for the bf16 14-token whole-row kernel, i.e. fewer row groups per block than the generic kernel, over
   // the same persistent grid
   const bool long_rows = chan8 || dense8;
+  if (p.dxc2 && (long_rows || p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16))) return FV_ERR_UNSUPPORTED;
   const int wmax = (long_rows || dtype == FV_F32 || p.geo.cols > 14) ? 8 : 12;
   const int cap = wmax / nchg < 1 ? 1 : wmax / nchg;
   const int rgr = rg < cap ? rg : cap;

@@ -567,6 +567,8 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
     int rc = fvi::conv_pool_bwd_row(p, nch, rg, (int)grid.x, smem, sizeof(T) == 4 ? FV_F32 : FV_BF16, st);
     if (rc != FV_ERR_UNSUPPORTED) return rc;
   }
+  FV_CHECK(!p.dxc2, "mixer_conv_pool_bwd2: a second pooled-gradient addend is taken by the whole-row kernel only "
+                    "(mean pooling, tokens_per_patch 1, 14 or 16 columns, d_inner a multiple of 128)");
   if (p.amax) {      // max pooling: generic kernels only
     if (smem > 64 * 1024) {
       static FvOncePerDevice done_pm;   
@@ -653,6 +655,21 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
                                       int rows, int cols, int tok_stride_row, int tok_stride_col,
                                       int tokens_per_patch, int d_inner, int d_conv, int pool_max,
                                       float scaling_factor, int dtype, fv_stream_t stream) {
+  return fv_mixer_conv_pool_bwd2(xz, d_o, dxc, nullptr, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, amax, dxz, partials, batch,
+                                 rows, cols, tok_stride_row, tok_stride_col, tokens_per_patch, d_inner, d_conv, pool_max,
+                                 scaling_factor, dtype, stream);
+}
+
+extern "C" int fv_mixer_conv_pool_bwd2_ok(int rows, int cols, int tokens_per_patch, int d_inner, int pool_max) {
+  return !pool_max && tokens_per_patch == 1 && (cols == 14 || cols == 16) && rows > 0 && d_inner % 128 == 0 && d_inner <= 1024;
+}
+
+extern "C" int fv_mixer_conv_pool_bwd2(const void* xz, const void* d_o, const float* dxc, const void* dxc2,
+                                       const float* conv_w, const float* conv_b, const float* conv_w_b,
+                                       const float* conv_b_b, const float* D, const float* D_b, const void* amax,
+                                       void* dxz, float* partials, int batch, int rows, int cols, int tok_stride_row,
+                                       int tok_stride_col, int tokens_per_patch, int d_inner, int d_conv, int pool_max,
+                                       float scaling_factor, int dtype, fv_stream_t stream) {
   int rc = check_geo_b(batch, rows, cols, tok_stride_row, tok_stride_col, d_inner, dtype);
   FV_CHECK(tokens_per_patch > 0, "mixer_conv_pool_bwd: tokens_per_patch must be positive");
   if (rc) return rc;
@@ -661,8 +678,10 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
   FV_CHECK(cols * tokens_per_patch >= 3, "mixer_conv_pool_bwd: needs at least 3 tokens per pooling row (got %d)", cols * tokens_per_patch);
   FV_CHECK(xz && d_o && dxc && conv_w && conv_w_b && D && D_b && dxz && partials, "mixer_conv_pool_bwd: null pointer");
   BwdParams p{};
-  p.xz = xz; p.dob_in = d_o; p.dxc = dxc; p.wf = conv_w; p.bf = conv_b; p.wb = conv_w_b; p.bb = conv_b_b;
+  p.xz = xz; p.dob_in = d_o; p.dxc = dxc; p.dxc2 = dxc2; p.wf = conv_w; p.bf = conv_b; p.wb = conv_w_b; p.bb = conv_b_b;
   p.Df = D; p.Db = D_b; p.dxz = dxz; p.part = partials;
+  FV_CHECK(!dxc2 || fv_mixer_conv_pool_bwd2_ok(rows, cols, tokens_per_patch, d_inner, pool_max),
+           "mixer_conv_pool_bwd2: shape does not take a second pooled-gradient addend (fv_mixer_conv_pool_bwd2_ok)");
   p.geo = make_geo(rows, cols, tok_stride_row, tok_stride_col, tokens_per_patch);
   p.B = batch; p.d_in = d_inner;
   p.pool_scale = pool_max ? 1.f : scaling_factor / (float)cols;

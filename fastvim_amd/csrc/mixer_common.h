@@ -8,6 +8,8 @@ struct BwdParams {
   const void *xz, *dg, *skip, *dob_in;
   const float *wf, *bf, *wb, *bb, *Df, *Db, *lnw, *lnb, *mean, *rstd, *dxc, *yc;
   const void* amax;                     // max pooling: argmax columns saved by the forward (else null)
+  const void* dxc2;                     // conv_pool_bwd, nullable: second addend of the pooled gradient, storage dtype (the
+                                        // other channel chunk's x_proj term of fv_mixer_scan_bwd_xproj); whole-row kernel only
   void *dxz, *dob;
   float *dyc, *part;
   Geo geo;

@@ -50,6 +50,11 @@ struct ScanClParams {
   const float* hin;      // (2, B, seg, d_in, N)  pass C in: state entering the segment
   int adj;               // combine kernel: 1 = the adjoint recurrence (segments walked last to first)
   unsigned long long* stamps;   // tuning builds: phase stamps of the short backward kernel (fv_debug_set_stamps), else null
+  // short backward kernel with the x_proj adjoint folded in (fv_mixer_scan_bwd_xproj; two 192-channel chunks): each
+  // workgroup multiplies ITS chunk's partial d x_dbl rows by the whole x_proj weight -- the own-channel half of the
+  // product is added to dxc, the other chunk's half goes to dxc2 (storage dtype) and is added by the consumer
+  const float* Wx[2];    // (R+2N, d_in) fp32
+  void* dxc2;            // (2, B, Lc, d_in)
 };
 
 
@@ -357,6 +362,7 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
 #endif
 constexpr int SH_NWV = SH_WAVES, SH_CH = 16 * SH_NWV, SH_THREADS = 64 * SH_NWV;
 constexpr int SH_DRS = SH_CH + 2;      // row stride of the d delta_raw table: = 2 (mod 32), MFMA operand reads conflict-free
+constexpr int SH_XS = 68;              // row stride of the summed d x_dbl rows: = 4 (mod 64), the 16 x 4 operand reads of a k step hit 64 banks
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -371,7 +377,14 @@ struct ShortLds {
   static constexpr int o_du = o_dr + 16 * SH_DRS;                  // LCT * 192       d u
   static constexpr int o_part = o_du + LCT * SH_CH;                // LCT * 12 * 4 * 8   dB / dC wave partials
   static constexpr int o_pd = o_part + LCT * SH_NWV * 4 * 8;       // 12 * 16 * 16 * RT  d dt_low wave partials
-  static constexpr int floats = o_pd + SH_NWV * 16 * 16 * RT;
+  static constexpr int o_x = o_pd + SH_NWV * 16 * 16 * RT;         // 16 * SH_XS  summed d x_dbl rows (x_proj adjoint fold)
+  static constexpr int floats = o_x;
+  // x_proj weight fragments of a wave (XPJ, LDS-DMA form): k rows 0..27 go into the wave's own slab of the {delta, u, dy,
+  // sigmoid} table (dead once the wave's adjoint sweep is over: 14 pieces of 64 floats), k rows 28.. into o_xw
+  static constexpr int XCH = 2 * ((4 * RQ + 2 * N + 3) / 4);       // 64-float pieces: 2 k rows x (16 own + 16 other channels)
+  static constexpr int XCH_T = LCT < XCH ? LCT : XCH;              // pieces that fit the table slab
+  static constexpr int o_xw = o_x + 16 * SH_XS;                    // 12 waves x (XCH - XCH_T) x 64
+  static constexpr int floats_x = o_xw + SH_NWV * (XCH - XCH_T) * 64;
 };
 
 // An index the compiler cannot relate to earlier copies of itself: the address arithmetic of a late section (output
@@ -406,7 +419,9 @@ __device__ __forceinline__ void sc_stamp(const ScanClParams& p, int bi, int slot
 #define SC_STAMP(bi, slot) ((void)0)
 #endif
 
-template <typename T, int RQ, int LCT, bool EXACT>      // EXACT: Lc == LCT (the 14- and 16-row grids)
+// XPJ: the x_proj adjoint's data half (dxc += d x_dbl @ Wx, selective_scan_interface.py:726-734) runs here as well, on the
+// fp32 matrix cores, from the workgroup's own partial d x_dbl rows (two channel chunks: see ScanClParams::dxc2)
+template <typename T, int RQ, int LCT, bool EXACT, bool XPJ = false>      // EXACT: Lc == LCT (the 14- and 16-row grids)
 __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef ShortLds<RQ, LCT> LD;
@@ -417,6 +432,10 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   float* s_du = smem + LD::o_du;
   float* s_part = smem + LD::o_part;
   float* s_pd = smem + LD::o_pd;
+  float* s_x = smem + LD::o_x;
+  float* s_xw = smem + LD::o_xw;
+  constexpr int XKS = XPJ ? (4 * RQ + 2 * N + 3) / 4 : 1;      // k steps (4 x_dbl columns each) of the x_proj adjoint
+  static_assert(!XPJ || 4 * XKS <= SH_XS, "summed d x_dbl rows wider than their LDS stride");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int dir = blockIdx.z, ch0 = blockIdx.x * SH_CH;
   const int W = p.R + 2 * N;
@@ -443,6 +462,8 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // the d delta_raw table's rows past Lc feed the K / M padding of the MFMAs: zero once
   for (int e = tid; e < 16 * SH_DRS; e += SH_THREADS) s_dr[e] = 0.f;
+  if constexpr (XPJ)       // columns past R + 2N pad the K dimension of the x_proj adjoint (rows past Lc are never stored)
+    for (int e = tid; e < 16 * SH_XS; e += SH_THREADS) s_x[e] = 0.f;
   // this lane's dt_proj weights of both MFMA roles are loaded once per workgroup instead of once per batch element behind
   // the staging barrier (an L2 round trip on every wave's critical path, twice per element).  At dt_rank 48 they are 24
   // registers and the kernel then spills 26 -- measured worth it all the same (same box, FastVim-B 224 px step 29.2 -> 28.5 ms,
@@ -621,6 +642,28 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     SC_STAMP(bi, 4);
+    // x_proj adjoint: this wave's B operand fragments -- Wx[k][its 16 channels of this chunk | its 16 of the other one],
+    // 44 x 32 floats -- are fetched by LDS-DMA (no register destination: the recurrence sits at the register limit) into
+    // the wave's own slab of the step table, which nothing reads after the wave's adjoint sweep, and a small tail region;
+    // they arrive under the dt_proj adjoint, the two barriers and the 12-wave sums.  One piece = 2 k rows x 32 channels =
+    // 64 dwords = one wave instruction (LDS address M0 + 4 lane).  Issued as asm: through the builtin the compiler
+    // would make every LDS read that follows wait for the DMA (it cannot tell the regions apart).
+    if constexpr (XPJ) {
+      const int t2 = opaque_tid(), ln = t2 & 63, wv2 = t2 >> 6;
+      const int slot = ln & 31, kr = ln >> 5;
+      const int chx = (slot < 16 ? ch0 : SH_CH - ch0) + wv2 * 16 + (slot & 15);
+      const float* wbase = p.Wx[dir];
+      const uint32_t tab = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(s_ch + wv2 * 64);
+      const uint32_t ext = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(s_xw + wv2 * ((LD::XCH - LD::XCH_T) * 64));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the sweep's last reads of the slab have returned
+#pragma unroll
+      for (int c = 0; c < LD::XCH; ++c) {
+        const int k = min(2 * c + kr, W - 1);                  // rows past W = R + 2N meet zero columns of A: any finite value
+        const uint32_t voff = (uint32_t)(k * p.d_in + chx) * 4u;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(c < LD::XCH_T ? tab + (uint32_t)c * (SH_CH * 16) : ext + (uint32_t)(c - LD::XCH_T) * 256);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(wbase), "s"(dst) : "memory");
+      }
+    }
     // ---- dt_proj adjoint on the matrix cores, from this wave's 16 columns of the d delta_raw table
     {
       const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv = t2 >> 6, dm = ch0 + wv * 16 + cm;
@@ -660,12 +703,14 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
           accW[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, accW[rt], 0, 0, 0);
         }
       }
-      // d u of this lane's 4 steps
+      // d u of this lane's 4 steps (XPJ: stored below, with the x_proj term)
+      if constexpr (!XPJ) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int s = 4 * tg + r;
-        const int l = dir ? Lc - 1 - s : s;
-        if (actm && s < Lc) p.dxc[(bd + l) * p.d_in + dm] = s_du[s * SH_CH + wv * 16 + cm];
+        for (int r = 0; r < 4; ++r) {
+          const int s = 4 * tg + r;
+          const int l = dir ? Lc - 1 - s : s;
+          if (actm && s < Lc) p.dxc[(bd + l) * p.d_in + dm] = s_du[s * SH_CH + wv * 16 + cm];
+        }
       }
     }
     SC_STAMP(bi, 5);
@@ -683,6 +728,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
         for (int w = 0; w < SH_NWV; ++w) t += s_part[((s * SH_NWV + w) * 4 + qq) * 8 + v];
         const int l = dir ? Lc - 1 - s : s;
         out[l * W + col] = t;
+        if constexpr (XPJ) s_x[s * SH_XS + col] = t;
       }
       for (int e = tid; e < Lc * (16 * RT); e += SH_THREADS) {       // (step, r) with r < 16 RT; no run-time division
         const int s = e / (16 * RT), r = e - s * (16 * RT);
@@ -692,6 +738,37 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
           for (int w = 0; w < SH_NWV; ++w) t += s_pd[(w * 16 + s) * (16 * RT) + r];
           const int l = dir ? Lc - 1 - s : s;
           out[l * W + r] = t;
+          if constexpr (XPJ) s_x[s * SH_XS + r] = t;
+        }
+      }
+    }
+    if constexpr (XPJ) {
+      // ---- x_proj adjoint, data half: (16 steps x W) @ (W x 16 channels) per wave and chunk on the fp32 matrix cores;
+      //      result lane = (channel cm, steps 4 tg .. 4 tg + 3) -- the layout d u is stored from
+      __syncthreads();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's weight fragments have landed (wave-private)
+      const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv = t2 >> 6;
+      f32x4_t Do = {0.f, 0.f, 0.f, 0.f}, Dx = {0.f, 0.f, 0.f, 0.f};
+      const float* ftab = s_ch + wv * 64 + (tg & 1) * 32 + cm;
+      const float* fext = s_xw + wv * ((LD::XCH - LD::XCH_T) * 64) + (tg & 1) * 32 + cm;
+#pragma unroll
+      for (int ks = 0; ks < XKS; ++ks) {
+        const float a = s_x[cm * SH_XS + 4 * ks + tg];          // A[step cm][k = 4 ks + tg]
+        // k row 4 ks + tg sits in piece 2 ks + (tg >> 1), row tg & 1 of it
+        const float* f = 2 * ks + 1 < LD::XCH_T ? ftab + (2 * ks + (tg >> 1)) * (SH_CH * 4)
+                                                 : fext + (2 * ks + (tg >> 1) - LD::XCH_T) * 64;
+        Do = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f[0], Do, 0, 0, 0);
+        Dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f[16], Dx, 0, 0, 0);
+      }
+      T* x2 = (T*)p.dxc2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s = 4 * tg + r;
+        const int l = dir ? Lc - 1 - s : s;
+        if (s < Lc) {
+          const size_t o = (bd + l) * p.d_in + wv * 16 + cm;
+          p.dxc[o + ch0] = s_du[s * SH_CH + wv * 16 + cm] + Do[r];
+          io<T>::st(x2 + o + (SH_CH - ch0), Dx[r]);
         }
       }
     }
@@ -1693,6 +1770,45 @@ extern "C" size_t fv_mixer_scan_bwd_ckpt_floats(int batch, int Lc, int d_inner, 
   return (size_t)2 * batch * ((Lc + 3) / 4) * d_inner * d_state;
 }
 
+
+// the register-resident short kernel; xpj: with the x_proj adjoint folded in (p.Wx / p.dxc2 set, two channel chunks)
+static int launch_bwd_short(const ScanClParams& p, int batch, int Lc, int d_inner, int RQ, int dtype, bool xpj, hipStream_t st) {
+  dim3 sgrid(fv_cdiv(d_inner, SH_CH), batch / p.NBB, 2), sblock(SH_THREADS);
+#define FV_S(TT, RQQ, LCC, EXX, XPP)                                                         \
+  do {                                                                                       \
+    size_t smem = (size_t)(XPP ? ShortLds<RQQ, LCC>::floats_x : ShortLds<RQQ, LCC>::floats) * 4; \
+    static FvOncePerDevice done;                                                             \
+    if (smem > 64 * 1024 && done.first()) {                                                  \
+      (void)hipFuncSetAttribute((const void*)scan_cl_bwd_short_kernel<TT, RQQ, LCC, EXX, XPP>, \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      (void)0;                                                                               \
+    }                                                                                        \
+    hipLaunchKernelGGL((scan_cl_bwd_short_kernel<TT, RQQ, LCC, EXX, XPP>), sgrid, sblock, smem, st, p); \
+  } while (0)
+  if (xpj) {      // built for the whole 14- and 16-row grids at dt_rank <= 12 (FastVim-T and the small test models)
+    if (RQ > 3 || (Lc != 14 && Lc != 16)) return FV_ERR_UNSUPPORTED;
+    if (dtype == FV_F32) { if (Lc == 14) FV_S(float, 3, 14, true, true); else FV_S(float, 3, 16, true, true); }
+    else { if (Lc == 14) FV_S(bf16_t, 3, 14, true, true); else FV_S(bf16_t, 3, 16, true, true); }
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
+#define FV_SL(TT, RQQ)                                                                       \
+  do {                                                                                       \
+    if (Lc == 14) FV_S(TT, RQQ, 14, true, false); else if (Lc < 14) FV_S(TT, RQQ, 14, false, false);       \
+    else if (Lc == 16) FV_S(TT, RQQ, 16, true, false); else FV_S(TT, RQQ, 16, false, false);               \
+  } while (0)
+#define FV_SD(TT)                                                                            \
+  do {                                                                                       \
+    if (RQ <= 3) FV_SL(TT, 3); else if (RQ <= 6) FV_SL(TT, 6); else FV_SL(TT, 12);           \
+  } while (0)
+  if (dtype == FV_F32) FV_SD(float); else FV_SD(bf16_t);
+#undef FV_SD
+#undef FV_SL
+#undef FV_S
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
 extern "C" int fv_mixer_scan_bwd(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
                                  const float* A_log, const float* dt_w_b, const float* dt_bias_b,
                                  const float* A_log_b, const float* dyc, float* dxc, float* dx_dbl, float* ckpt,
@@ -1769,35 +1885,7 @@ extern "C" int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const fl
   p.stamps = fv_debug_get_stamps();      // csrc/gemm_mfma.hip, set by fv_debug_set_stamps()
 #endif
   hipStream_t st = (hipStream_t)stream;
-  if (bwd_short(Lc, dt_rank)) {
-    dim3 sgrid(fv_cdiv(d_inner, SH_CH), batch / p.NBB, 2), sblock(SH_THREADS);
-#define FV_S(TT, RQQ, LCC, EXX)                                                              \
-  do {                                                                                       \
-    size_t smem = (size_t)ShortLds<RQQ, LCC>::floats * 4;                                    \
-    static FvOncePerDevice done;                                                                   \
-    if (smem > 64 * 1024 && done.first()) {                                                         \
-      (void)hipFuncSetAttribute((const void*)scan_cl_bwd_short_kernel<TT, RQQ, LCC, EXX>,    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      (void)0;                                                                                \
-    }                                                                                        \
-    hipLaunchKernelGGL((scan_cl_bwd_short_kernel<TT, RQQ, LCC, EXX>), sgrid, sblock, smem, st, p); \
-  } while (0)
-#define FV_SL(TT, RQQ)                                                                       \
-  do {                                                                                       \
-    if (Lc == 14) FV_S(TT, RQQ, 14, true); else if (Lc < 14) FV_S(TT, RQQ, 14, false);       \
-    else if (Lc == 16) FV_S(TT, RQQ, 16, true); else FV_S(TT, RQQ, 16, false);               \
-  } while (0)
-#define FV_SD(TT)                                                                            \
-  do {                                                                                       \
-    if (RQ <= 3) FV_SL(TT, 3); else if (RQ <= 6) FV_SL(TT, 6); else FV_SL(TT, 12);           \
-  } while (0)
-    if (dtype == FV_F32) FV_SD(float); else FV_SD(bf16_t);
-#undef FV_SD
-#undef FV_SL
-#undef FV_S
-    FV_LAUNCH_CHECK();
-    return FV_OK;
-  }
+  if (bwd_short(Lc, dt_rank)) return launch_bwd_short(p, batch, Lc, d_inner, RQ, dtype, false, st);
   if (bwd_chunked(Lc, dt_rank)) {
     const int S = (seg_ws && ckpt_given) ? fv_mixer_scan_bwd_segments(batch, Lc, d_inner, dt_rank) : 1;
     const int nwv = S > 1 ? 4 : ck_waves(batch, d_inner);      // (segments: the 64-channel workgroups the forward passes use)
@@ -1885,4 +1973,38 @@ extern "C" int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const fl
 #undef FV_B
   FV_LAUNCH_CHECK();
   return FV_OK;
+}
+
+// ---- short backward scan with the x_proj adjoint's data half folded in.  Replaces, for the 14- / 16-row grids at
+// d_inner = 384 (two 192-channel chunks), fv_mixer_scan_bwd + fv_mixer_xproj_bwd2: dxc receives the through-the-scan
+// gradient PLUS this chunk's (d x_dbl partial) @ Wx for its own channels, dxc2 (storage dtype) the same product for the
+// other chunk's channels -- the consumer (fv_mixer_conv_pool_bwd2) adds the two.  dx_dbl still receives the per-chunk
+// fp32 partial rows: their sum is the x_proj weight gradient's operand (fv_chunk_rows_bf16).
+extern "C" int fv_mixer_scan_bwd_xproj_ok(int batch, int Lc, int d_inner, int dt_rank, int dtype) {
+  return bwd_short(Lc, dt_rank) && (Lc == 14 || Lc == 16) && rq_of(dt_rank) <= 3 && d_inner == 2 * SH_CH && batch > 0 &&
+         (dtype == FV_F32 || dtype == FV_BF16);
+}
+
+extern "C" int fv_mixer_scan_bwd_xproj(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
+                                       const float* A_log, const float* dt_w_b, const float* dt_bias_b,
+                                       const float* A_log_b, const float* dyc, const float* x_proj_w,
+                                       const float* x_proj_w_b, float* dxc, void* dxc2, float* dx_dbl, float* partials,
+                                       int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
+                                       fv_stream_t stream) {
+  FV_CHECK(d_state == N, "mixer_scan_bwd_xproj: only d_state == 16 is built (got %d)", d_state);
+  FV_CHECK(fv_mixer_scan_bwd_xproj_ok(batch, Lc, d_inner, dt_rank, dtype),
+           "mixer_scan_bwd_xproj: shape (Lc %d, d_inner %d, dt_rank %d) is not built (fv_mixer_scan_bwd_xproj_ok)", Lc, d_inner, dt_rank);
+  FV_CHECK(xc && x_dbl && dt_w && dt_bias && A_log && dt_w_b && dt_bias_b && A_log_b && dyc && x_proj_w && x_proj_w_b &&
+               dxc && dxc2 && dx_dbl && partials, "mixer_scan_bwd_xproj: null pointer");
+  ScanClParams p{};
+  p.xc = xc; p.xdbl = x_dbl; p.dyc = dyc; p.dxc = dxc; p.dxdbl = dx_dbl; p.pP = partials;
+  p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
+  p.Alog[0] = A_log; p.Alog[1] = A_log_b;
+  p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.dxc2 = dxc2;
+  p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
+  p.NBB = scan_bwd_nbb(batch, Lc, dt_rank);
+#ifdef FASTVIM_TUNING_HOOKS
+  p.stamps = fv_debug_get_stamps();
+#endif
+  return launch_bwd_short(p, batch, Lc, d_inner, rq_of(dt_rank), dtype, true, (hipStream_t)stream);
 }

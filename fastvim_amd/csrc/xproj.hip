@@ -156,7 +156,57 @@ __global__ __launch_bounds__(64 * NWV) void xproj_fwd_kernel(const bf16_t* __res
   }
 }
 
+// ---- summed d x_dbl rows as the bf16 operand of the x_proj weight gradient, for up to 64 mixers in ONE launch: where
+// the x_proj adjoint's data half runs inside the scan backward (fv_mixer_scan_bwd_xproj), nothing else has summed the
+// channel-chunk partials.  out[row][c] = bf16(sum_chunk in[chunk][row][c]) for c < W, zero in the pad columns (the
+// rows fv_mixer_xproj_bwd2 publishes, bit for bit: same summation order).
+constexpr int CRJ_MAX = 64;
+struct ChunkRowJobs {
+  const float* in[CRJ_MAX];
+  bf16_t* out[CRJ_MAX];
+  int nchunks, W, WP;
+  long rows;
+};
+__global__ __launch_bounds__(256) void chunk_rows_bf16_kernel(ChunkRowJobs J) {
+  const float* __restrict__ in = J.in[blockIdx.y];
+  bf16_t* __restrict__ out = J.out[blockIdx.y];
+  const long n = J.rows * J.WP;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const long r = e / J.WP;
+    const int c = (int)(e - r * J.WP);
+    float t = 0.f;
+    if (c < J.W) {
+      const float* src = in + r * J.W + c;
+      const size_t cs = (size_t)J.rows * J.W;
+      for (int c0 = 0; c0 < J.nchunks; c0 += 6) {
+        float v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) v[u] = c0 + u < J.nchunks ? src[(size_t)(c0 + u) * cs] : 0.f;
+        t += ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
+      }
+    }
+    out[e] = __float2bfloat16(t);
+  }
+}
+
 }  // namespace
+
+extern "C" int fv_chunk_rows_bf16(const float* const* partials, void* const* outs, int njobs, int nchunks, long rows,
+                                  int width, fv_stream_t stream) {
+  FV_CHECK(partials && outs && njobs > 0 && njobs <= CRJ_MAX, "chunk_rows_bf16: 1..%d jobs", CRJ_MAX);
+  FV_CHECK(nchunks > 0 && rows > 0 && width > 0, "chunk_rows_bf16: empty dimension");
+  ChunkRowJobs J{};
+  for (int j = 0; j < njobs; ++j) {
+    FV_CHECK(partials[j] && outs[j], "chunk_rows_bf16: null pointer in job %d", j);
+    J.in[j] = partials[j];
+    J.out[j] = (bf16_t*)outs[j];
+  }
+  J.nchunks = nchunks; J.W = width; J.WP = (width + 7) / 8 * 8; J.rows = rows;
+  const int bx = fv_cdiv(rows * J.WP, 256 * 4) < 1 ? 1 : fv_cdiv(rows * J.WP, 256 * 4);
+  hipLaunchKernelGGL(chunk_rows_bf16_kernel, dim3(bx, njobs), dim3(256), 0, (hipStream_t)stream, J);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
 
 static int xproj_rows() {
   static const int r = fv_tune("FASTVIM_XPROJ_ROWS", 16);   // tuning hook

@@ -186,6 +186,7 @@ class FlatTrainingState:
         if n:
             _GroupedWgrad.jobs = []
             _GroupedWgrad.sums = []
+            _GroupedWgrad.rows_jobs = []
             drop_reductions()
             warnings.warn(f"FlatTrainingState.zero_grad(): {n} queued gradient jobs of an unfinished backward pass "
                           "were discarded -- call finish_backward() (or allreduce_mean_() / optimizer.step()) after "

@@ -117,6 +117,9 @@ class _SideStream:
         cls.pending = []
 
 
+XPROJ_IN_SCAN = True      # the x_proj adjoint's data half inside the short scan backward where it is built (A/B switch)
+
+
 class _GroupedWgrad:
     """Weight gradients are only needed before the optimizer step.  With the flat training state they are queued
     (operands kept alive) and computed by grouped launches (fv_gemm_bf16_tn_grouped, up to 40 problems each) at the end of
@@ -142,9 +145,15 @@ class _GroupedWgrad:
             cls.flush()
 
     sums = []            # (partials, splits, out) of groups launched on the weight-gradient stream, not yet summed
+    # operands that still have to be MADE before the group runs: (d x_dbl chunk partials fp32, bf16 rows) of the mixers
+    # whose x_proj adjoint ran inside the scan backward (fv_mixer_scan_bwd_xproj) -- one launch for all of them
+    rows_jobs = []
 
     @classmethod
     def flush(cls):
+        if cls.rows_jobs:
+            rj, cls.rows_jobs = cls.rows_jobs, []
+            M.chunk_rows_bf16(rj)
         if cls.jobs:
             from .gemm import gemm_tn_grouped
             jobs, cls.jobs = cls.jobs, []
@@ -303,11 +312,6 @@ class _Ctx:
         self.saved_tensors = tensors
 
 
-ADDNORM_RW = False      # opt-in A/B switch: out_proj + add + norm through the register-weight kernel (csrc/gemm_rw.hip).
-                        # Bit-identical and measured EQUAL (21.8 vs 21.3 us HBM-cold, step 5.72-5.73 vs 5.71-5.73 ms:
-                        # profiles/r04_ab_addnorm_register_weights.log), so the tiled kernel stays the default
-
-
 def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in=None):
     """``W_in`` (2 d_inner, d): also run this block's in_proj as a second phase of the launch; returns xz last."""
     B, Ltok, d_in = g.shape
@@ -332,15 +336,6 @@ def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in
     W_out_c = _shadow(W_out, cdt)
     W_in_c = _shadow(W_in, cdt) if xz is not None else None
     lib = L.lib()
-    if (ADDNORM_RW and xz is None and W_in is None
-            and lib.fv_gemm_bf16_addnorm_rw_ok(L.i32(Mrows), L.i32(d), L.i32(d_in)) and W_out_c.stride(0) % 8 == 0):
-        # the weight held in registers by persistent workgroups (csrc/gemm_rw.hip): same values bit for bit
-        rc = lib.fv_gemm_bf16_addnorm_rw(
-            L.ptr(g2), L.ptr(W_out_c), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
-            L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
-            ctypes.c_long(W_out_c.stride(0)), ctypes.c_float(eps), L.stream_of(g2))
-        L.check(rc, "gemm_bf16_addnorm_rw")
-        return y, res_out, rstd, w32, row_scale, rows_per_scale
     rc = lib.fv_gemm_bf16_addnorm2(
         L.ptr(g2), L.ptr(W_out_c), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
         L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
@@ -507,33 +502,25 @@ class FastVimMixerFn(torch.autograd.Function):
             else:
                 Wx2 = torch.stack([Wx, Wx_b])                                           # (2, R+2N, d_in) fp32
                 Wx2_c = Wx2.to(cdt)
-            mid = None
-            if not pool_max and tpp == 1 and valid is None:
-                # conv + pool -> x_proj + scan -> combine as ONE launch where it is built (224 / 256 px grids, d_inner 384)
-                mid = M.mixer_mid_fwd(xz, cw2, cb, cwb2, cb_b, D, D_b, Wx2_c, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log,
-                                      ln_w, ln_b, ln_eps, rows, cols, transposed, scaling)
-            if mid is not None:
-                xc, skip, x_dbl, yc, g, mean, rstd = mid
+            if pool_max:
+                xc, skip, amax = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
+                                                 D=D, D_b=D_b)
             else:
-                if pool_max:
-                    xc, skip, amax = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
-                                                     D=D, D_b=D_b)
-                else:
-                    xc, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
-                                               D=D, D_b=D_b)
-                if valid is not None and valid < rows * tpp:
-                    xc[:, :, valid:].zero_()
-                fused = M.xproj_scan_fwd(xc, Wx2_c, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)      # short pooled lengths, bf16
-                if fused is not None:
-                    x_dbl, yc = fused
-                else:
-                    x_dbl = M.xproj_fwd(xc, Wx2_c)                                           # (2, B*Lc, R+2N)
-                    # long pooled lengths: when a backward pass will follow, the scan leaves the state entering every
-                    # 16-step chunk behind and the backward kernel does not sweep forward again
-                    nig = getattr(ctx, "needs_input_grad", None)
-                    yc, ctx.scan_ckpt = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log,
-                                                   want_ckpt=nig is None or any(nig))
-                g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
+                xc, skip = M.conv_pool_fwd(xz, cw2, cb, cwb2, cb_b, rows, cols, transposed, pool_max, scaling, tpp,
+                                           D=D, D_b=D_b)
+            if valid is not None and valid < rows * tpp:
+                xc[:, :, valid:].zero_()
+            fused = M.xproj_scan_fwd(xc, Wx2_c, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log)      # short pooled lengths, bf16
+            if fused is not None:
+                x_dbl, yc = fused
+            else:
+                x_dbl = M.xproj_fwd(xc, Wx2_c)                                           # (2, B*Lc, R+2N)
+                # long pooled lengths: when a backward pass will follow, the scan leaves the state entering every
+                # 16-step chunk behind and the backward kernel does not sweep forward again
+                nig = getattr(ctx, "needs_input_grad", None)
+                yc, ctx.scan_ckpt = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log,
+                                               want_ckpt=nig is None or any(nig))
+            g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
             # W_out None: out_proj is the caller's (fused with the next block's add + norm, OutProjAddNormFn); the
             # gated activations g (B, L, d_in) are returned and their gradient comes back as ``dout``
             out = g if W_out is None else linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
@@ -570,13 +557,31 @@ class FastVimMixerFn(torch.autograd.Function):
                                          grad_out=fv.get("ln_grad") if ln_w is not None else None, tpp=tpp)
             W_ = x_dbl.shape[-1]
             fused_xproj = W_ in M.XPROJ_WIDTHS
-            dxc, dx_dbl, ps = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
-                                         grad_out=fv.get("scan_grad"), keep_chunks=fused_xproj,
-                                         ckpt=getattr(ctx, "scan_ckpt", None))
-            # x_proj adjoint (selective_scan_interface.py:726-734), both directions
             Mrows = B * rows * tpp
-            if (fused_xproj and _GroupedWgrad.enabled and "Wx2_grad" in fv and xc.dtype == torch.bfloat16
-                    and Mrows % 64 == 0 and d_in % 8 == 0):
+            grouped_x = (fused_xproj and _GroupedWgrad.enabled and "Wx2_grad" in fv and xc.dtype == torch.bfloat16
+                         and Mrows % 64 == 0 and d_in % 8 == 0)
+            dxc2 = None
+            if (grouped_x and XPROJ_IN_SCAN and amax is None and getattr(ctx, "scan_ckpt", None) is None
+                    and M.scan_bwd_xproj_ok(xc, Wdt, pool_max, rows, cols, tpp)):
+                # FastVim-T: the x_proj adjoint's data half runs inside the scan backward (one launch less per block); the
+                # pooled gradient arrives as two addends, the bf16 d x_dbl rows of the weight gradient are made by one
+                # launch for all blocks right before the grouped weight-gradient GEMMs
+                dxc, dxc2, dx_dbl, ps = M.scan_bwd_xproj(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
+                                                         Wx2[0], Wx2[1], grad_out=fv.get("scan_grad"))
+                dxb = torch.empty(2, Mrows, (W_ + 7) // 8 * 8, device=xc.device, dtype=torch.bfloat16)
+                _GroupedWgrad.rows_jobs.append((dx_dbl, dxb))
+                xc2 = xc.view(2, Mrows, d_in)
+                for k_ in range(2):
+                    _GroupedWgrad.add(dxb[k_][:, :W_], xc2[k_], fv["Wx2_grad"][k_].reshape(-1))
+                dWx2 = (None, None)
+            else:
+                dxc, dx_dbl, ps = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
+                                             grad_out=fv.get("scan_grad"), keep_chunks=fused_xproj,
+                                             ckpt=getattr(ctx, "scan_ckpt", None))
+            # x_proj adjoint (selective_scan_interface.py:726-734), both directions
+            if dxc2 is not None:
+                pass
+            elif grouped_x:
                 # the weight gradient dx_dbl^T xc joins the grouped launch at the end of backward (bf16 dx_dbl, as in
                 # the reference's autocast backward); the kernel only adds dx_dbl @ Wx to dxc
                 dxb = M.xproj_bwd(dx_dbl, xc, Wx2[0], Wx2[1], dxc, dw=False)
@@ -598,7 +603,7 @@ class FastVimMixerFn(torch.autograd.Function):
                 dxc = dxc.view(2, B * rows * tpp, d_in) + gemm_any_bnn(dx_dbl, Wx2.float(), out_dtype=torch.float32)   # + dx_dbl @ Wx
             p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
                                  pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None,
-                                 tpp=tpp, amax=amax)
+                                 tpp=tpp, amax=amax, dxc2=dxc2)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
             fused_dgrad = getattr(ctx, "fused_in_dgrad", None)
             if fused_dgrad is not None:

@@ -98,57 +98,6 @@ def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1):
     return g, mean, rstd
 
 
-MID_FWD = False       # opt-in (bench.py --mid-fusion): the fused forward launch of the mixer's middle instead of three launches.
-                      # Measured neutral (5.75-5.78 ms per FastVim-T step either way, profiles/r04_ab_mid_fwd_fusion.log), so off.
-_MID_FLAGS = {}       # (device index, stream handle) -> hand-off flags of the fused forward launch (zero between launches)
-
-
-def mixer_mid_fwd(xz, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, Wx2_c, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b,
-                  ln_w, ln_b, eps, rows, cols, transposed, scaling):
-    """conv_pool_fwd + xproj_scan_fwd + combine_fwd in ONE launch (csrc/mixer_mid_fwd.hip), same outputs bit for bit:
-    returns (xc, skip, x_dbl, yc, g, mean, rstd), or None when the shape is not covered (the caller then runs the three
-    launches).  Covered: bf16, mean pooling, tokens_per_patch 1, the 14 x 14 / 16 x 16 grids, d_inner 384, dt_rank <= 24,
-    2 * batch <= CUs (an image is carried by a PAIR of co-resident workgroups)."""
-    B, Ltok, two_d = xz.shape
-    d_in = two_d // 2
-    R, N = dt_w.shape[1], A_log.shape[1]
-    W = Wx2_c.shape[1]
-    lib = L.lib()
-    if (not MID_FWD or xz.dtype != torch.bfloat16 or Wx2_c.dtype != torch.bfloat16 or N != 16 or W != R + 2 * N
-            or conv_w.shape[-1] != 4 or D is None or D_b is None or not xz.is_contiguous() or not Wx2_c.is_contiguous() or xz.data_ptr() % 16
-            or Wx2_c.data_ptr() % 16
-            or not lib.fv_mixer_mid_fwd_ok(L.i32(B), L.i32(rows), L.i32(cols), L.i32(1), L.i32(d_in), L.i32(R),
-                                           L.i32(L.dtype_code(xz.dtype)), L.i32(0))):
-        return None
-    dev = xz.device
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B)
-    flags = _MID_FLAGS.get(key)
-    if flags is None:
-        flags = _MID_FLAGS[key] = torch.zeros(4 * B + 1, device=dev, dtype=torch.int32)
-    s_i, s_j = _geo(rows, cols, transposed)
-    xc = torch.empty(2, B, rows, d_in, device=dev, dtype=xz.dtype)
-    skip = torch.empty(B, Ltok, d_in, device=dev, dtype=xz.dtype)
-    x_dbl = torch.empty(2, B * rows, W, device=dev, dtype=xz.dtype)
-    yc = torch.empty(2, B, rows, d_in, device=dev, dtype=torch.float32)
-    g = torch.empty(B, Ltok, d_in, device=dev, dtype=xz.dtype)
-    mean = torch.empty(B * Ltok, device=dev, dtype=torch.float32) if ln_w is not None else None
-    rstd = torch.empty(B * Ltok, device=dev, dtype=torch.float32) if ln_w is not None else None
-    rc = lib.fv_mixer_mid_fwd(
-        L.ptr(xz), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b), L.ptr(D), L.ptr(D_b), L.ptr(Wx2_c),
-        L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b), L.ptr(A_log_b), L.ptr(ln_w), L.ptr(ln_b),
-        L.ptr(xc), L.ptr(skip), L.ptr(x_dbl), L.ptr(yc), L.ptr(g), L.ptr(mean), L.ptr(rstd), L.ptr(flags), L.i32(B),
-        L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(d_in), L.i32(R), L.i32(N), f32(scaling), f32(eps),
-        L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))
-    L.check(rc, "mixer_mid_fwd")
-    return xc, skip, x_dbl, yc, g, mean, rstd
-
-
-def mixer_mid_errors():
-    """Number of fused forward launches' flag buffers whose error word is set (a bounded wait for the partner workgroup
-    ran out: that launch's outputs are invalid).  Synchronises; call it outside the hot loop."""
-    return sum(int(f[-1].item() != 0) for f in _MID_FLAGS.values())
-
-
 class _Deferred:
     """Gradient-partial reductions whose results are only needed before the optimizer step are queued
     (flat training state only) and issued up to 96 at a time by ONE launch (fv_reduce_partials_multi).
@@ -308,16 +257,68 @@ def scan_bwd(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, grad_ou
     return dxc, dx_dbl, reduce_partials(part, nprt).view(2, d_in * (N + R + 1))
 
 
+def scan_bwd_xproj_ok(xc, dt_w, pool_max, rows, cols, tpp):
+    """Is the short backward scan with the x_proj adjoint folded in built for this shape (and does the conv + pool
+    adjoint that consumes its two-part pooled gradient take it)?"""
+    _, B, Lc, d_in = xc.shape
+    lib = L.lib()
+    return bool(xc.dtype in (torch.float32, torch.bfloat16)
+                and lib.fv_mixer_scan_bwd_xproj_ok(L.i32(B), L.i32(Lc), L.i32(d_in), L.i32(dt_w.shape[1]), L.i32(L.dtype_code(xc.dtype)))
+                and lib.fv_mixer_conv_pool_bwd2_ok(L.i32(rows), L.i32(cols), L.i32(tpp), L.i32(d_in), L.i32(int(bool(pool_max)))))
+
+
+def scan_bwd_xproj(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, Wx, Wx_b, grad_out=None):
+    """The short backward scan with the x_proj adjoint's data half folded in (fv_mixer_scan_bwd_xproj): returns
+    (dxc, dxc2, dx_dbl_chunks, pr).  dxc (2, B, Lc, d_in) fp32 + dxc2 (same shape, storage dtype) is the TOTAL gradient of
+    the pooled conv output (through the scan and through x_proj); ``conv_pool_bwd(..., dxc2=dxc2)`` adds the two.
+    dx_dbl_chunks (2, 2, B * Lc, W) fp32: the per-chunk partial rows (their sum is the x_proj weight gradient's operand)."""
+    _, B, Lc, d_in = xc.shape
+    R, N = dt_w.shape[1], A_log.shape[1]
+    W = R + 2 * N
+    lib = L.lib()
+    f32o = dict(device=xc.device, dtype=torch.float32)
+    dxc = torch.empty(2, B, Lc, d_in, **f32o)
+    dxc2 = torch.empty(2, B, Lc, d_in, device=xc.device, dtype=xc.dtype)
+    dx_dbl = torch.empty(2, 2, B * Lc, W, **f32o)
+    nprt = lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc), L.i32(R))
+    part = torch.empty(nprt, 2 * d_in * (N + R + 1), **f32o)
+    rc = lib.fv_mixer_scan_bwd_xproj(
+        L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b), L.ptr(A_log_b),
+        L.ptr(dyc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(dxc), L.ptr(dxc2), L.ptr(dx_dbl), L.ptr(part), L.i32(B), L.i32(Lc),
+        L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
+    L.check(rc, "mixer_scan_bwd_xproj")
+    if grad_out is not None:
+        reduce_partials(part, nprt, out=grad_out, accumulate=True)
+        return dxc, dxc2, dx_dbl, None
+    return dxc, dxc2, dx_dbl, reduce_partials(part, nprt).view(2, d_in * (N + R + 1))
+
+
+def chunk_rows_bf16(jobs):
+    """jobs: [(dx_dbl_chunks (nchunks, 2, M, W) fp32, out (2, M, WP) bf16)], all of one shape: out = bf16(sum over the
+    chunks), pad columns zero -- ONE launch for up to 64 mixers (fv_chunk_rows_bf16)."""
+    lib = L.lib()
+    for lo in range(0, len(jobs), 64):
+        grp = jobs[lo:lo + 64]
+        nchunks, _, Mrows, W = grp[0][0].shape
+        assert all(j[0].shape == grp[0][0].shape and j[1].dtype == torch.bfloat16 and j[1].is_contiguous() for j in grp)
+        k = len(grp)
+        ins = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in grp])
+        outs = (ctypes.c_void_p * k)(*[j[1].data_ptr() for j in grp])
+        rc = lib.fv_chunk_rows_bf16(ins, outs, L.i32(k), L.i32(nchunks), ctypes.c_long(2 * Mrows), L.i32(W), L.stream_of(grp[0][0]))
+        L.check(rc, "chunk_rows_bf16")
+
+
 def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed,
-                  pool_max, scaling, grad_out=None, tpp=1, amax=None):
+                  pool_max, scaling, grad_out=None, tpp=1, amax=None, dxc2=None):
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
     lib = L.lib()
     nb = lib.fv_mixer_bwd_blocks(L.i32(B), L.i32(rows), L.i32(d_in), L.i32(tpp), L.i32(1))
     part = torch.empty(nb, 12 * d_in, device=xz.device, dtype=torch.float32)
-    rc = lib.fv_mixer_conv_pool_bwd(
-        L.ptr(xz), L.ptr(d_o), L.ptr(dxc), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
+    assert dxc2 is None or (dxc2.dtype == xz.dtype and dxc2.shape == dxc.shape and dxc2.is_contiguous())
+    rc = lib.fv_mixer_conv_pool_bwd2(
+        L.ptr(xz), L.ptr(d_o), L.ptr(dxc), L.ptr(dxc2), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
         L.ptr(D), L.ptr(D_b), L.ptr(amax), L.ptr(dxz), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i),
         L.i32(s_j), L.i32(tpp), L.i32(d_in), L.i32(conv_w.shape[-1]), L.i32(pool_max), f32(scaling),
         L.i32(L.dtype_code(xz.dtype)), L.stream_of(xz))

@@ -32,6 +32,14 @@ enum { FV_F32 = 0, FV_BF16 = 1, FV_F16 = 2 };
 enum { FV_OK = 0, FV_ERR_INVALID = -1, FV_ERR_HIP = -2, FV_ERR_UNSUPPORTED = -3 };
 
 const char* fv_last_error(void);
+/* ABI version of this header; fv_version() returns the one the library was built with -- a caller compiled against
+ * another value must not call anything else.  History:
+ *   1  rounds 1-3.
+ *   2  round 4 changed fv_mixer_scan_bwd_segments / fv_mixer_scan_bwd_seg_partials (a d_inner argument was inserted)
+ *      without bumping the number; round 5 bumps it for that break, removes the opt-in fv_mixer_mid_fwd(_ok) and
+ *      fv_gemm_bf16_addnorm_rw(_ok), and adds fv_mixer_scan_bwd_xproj(_ok), fv_mixer_conv_pool_bwd2(_ok),
+ *      fv_chunk_rows_bf16. */
+#define FV_ABI_VERSION 2
 int fv_version(void);
 
 /* ------------------------------------------------------------------------
@@ -168,27 +176,6 @@ int fv_mixer_xproj_scan_fwd(const void* xc, const void* x_proj_w2, const float* 
                             void* x_dbl, float* yc, int batch, int Lc, int d_inner, int dt_rank, int d_state,
                             int dtype, fv_stream_t stream);
 
-/* The middle of the mixer's forward pass in ONE launch (reference: everything between in_proj and out_proj of
- * Mamba.forward, mamba_simple_faster.py:272-444): fv_mixer_conv_pool_fwd + fv_mixer_xproj_scan_fwd + fv_mixer_combine_fwd
- * with the same outputs, bit for bit.  An image is carried by a pair of workgroups (split by pooling rows for the conv and
- * the combine, by scan direction for x_proj + scan) that exchange xc and yc through memory with agent-scope accesses; the
- * launch is one workgroup per CU, so 2 * batch must not exceed the CU count.  Built for bf16, mean pooling, the 14 x 14 and
- * 16 x 16 grids, d_inner == 384, dt_rank <= 24: ask fv_mixer_mid_fwd_ok (1 = covered) and take the three launches otherwise.
- *   flags  (4 * batch + 1) int32, ZERO before the first launch and left zero by every launch (hand-off flags; the
- *          last word is an error word: non-zero after a launch whose bounded wait for a partner workgroup ran out --
- *          the outputs of that launch are then invalid).  One buffer per stream of launches.
- * Outputs: xc (2, batch, rows, d_inner) bf16, skip (batch, L, d_inner) bf16, x_dbl (2, batch * rows, dt_rank + 2 * d_state)
- * bf16, yc (2, batch, rows, d_inner) fp32, g (batch, L, d_inner) bf16, mean / rstd (batch * L) fp32 (ln_w != NULL). */
-int fv_mixer_mid_fwd_ok(int batch, int rows, int cols, int tokens_per_patch, int d_inner, int dt_rank, int dtype,
-                        int pool_max);
-int fv_mixer_mid_fwd(const void* xz, const float* conv_w, const float* conv_b, const float* conv_w_b,
-                     const float* conv_b_b, const float* D, const float* D_b, const void* x_proj_w2, const float* dt_w,
-                     const float* dt_bias, const float* A_log, const float* dt_w_b, const float* dt_bias_b,
-                     const float* A_log_b, const float* ln_w, const float* ln_b, void* xc, void* skip, void* x_dbl,
-                     float* yc, void* g, float* mean, float* rstd, int* flags, int batch, int rows, int cols, int s_i,
-                     int s_j, int d_inner, int dt_rank, int d_state, float scaling_factor, float eps, int dtype,
-                     fv_stream_t stream);
-
 /* g = LayerNorm((yc_f + yc_b + skip) / 2) * silu(z), the scan outputs expanded over `cols`; ln_w == NULL
  * skips the norm (use_norm_after_ssm=False).  mean/rstd (batch*L) fp32 are saved for backward, which
  * rebuilds the normalised value from skip, yc, mean, rstd. */
@@ -266,6 +253,27 @@ int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const float* dt_w, 
                           float* seg_ws, int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
                           fv_stream_t stream);
 
+/* fv_mixer_scan_bwd for the short pooled lengths WITH the data half of the x_proj adjoint folded in (reference:
+ * selective_scan_interface.py:679-696 + 726-734, `dx = dx_dbl @ x_proj.weight` added to the scan's d u).  Built for
+ * Lc in {14, 16}, d_inner == 384 (two 192-channel chunks), dt_rank <= 12: ask fv_mixer_scan_bwd_xproj_ok.
+ *   x_proj_w, x_proj_w_b (dt_rank + 2 * d_state, d_inner) fp32: the weights as stored
+ *   dxc  (2, batch, Lc, d_inner) fp32: d u through the scan + (this chunk's partial d x_dbl) @ Wx, own channels
+ *   dxc2 (2, batch, Lc, d_inner) storage dtype: the same product for the OTHER chunk's channels; the total gradient of
+ *        the pooled conv output is dxc + dxc2 (fv_mixer_conv_pool_bwd2 adds them)
+ *   dx_dbl (2, 2, batch * Lc, W) fp32: per-chunk partial rows (fv_chunk_rows_bf16 sums them for the weight gradient)
+ *   partials: fv_mixer_scan_bwd_partials() rows, as for fv_mixer_scan_bwd.  Deterministic. */
+int fv_mixer_scan_bwd_xproj_ok(int batch, int Lc, int d_inner, int dt_rank, int dtype);
+int fv_mixer_scan_bwd_xproj(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias, const float* A_log,
+                            const float* dt_w_b, const float* dt_bias_b, const float* A_log_b, const float* dyc,
+                            const float* x_proj_w, const float* x_proj_w_b, float* dxc, void* dxc2, float* dx_dbl,
+                            float* partials, int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
+                            fv_stream_t stream);
+/* outs[j] (rows, WP) bf16 = sum over nchunks of partials[j] (nchunks, rows, width) fp32, WP = width rounded up to 8, pad
+ * columns zero; up to 64 jobs of one shape in one launch (host arrays of device pointers).  The rows
+ * fv_mixer_xproj_bwd2 publishes, bit for bit. */
+int fv_chunk_rows_bf16(const float* const* partials, void* const* outs, int njobs, int nchunks, long rows, int width,
+                       fv_stream_t stream);
+
 /* ---- MAE masked mixer: kept tokens <-> pooling rows --------------------------
  * Replaces compute_row_means_constantdivide (index_add_ over the kept tokens, divide by cols;
  * mamba_simple_masked_faster.py:376-416) and the torch.gather that expands the scan output back to the kept tokens
@@ -293,6 +301,16 @@ int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const float* dxc, co
                            const float* D_b, const void* amax, void* dxz, float* partials, int batch, int rows,
                            int cols, int tok_stride_row, int tok_stride_col, int tokens_per_patch, int d_inner,
                            int d_conv, int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
+
+/* Same, with the pooled gradient given as two addends: dxc (fp32) + dxc2 (storage dtype, nullable) -- the form
+ * fv_mixer_scan_bwd_xproj produces.  dxc2 is taken by the whole-row kernel only: mean pooling, tokens_per_patch 1,
+ * 14 or 16 columns, d_inner a multiple of 128 (fv_mixer_conv_pool_bwd2_ok). */
+int fv_mixer_conv_pool_bwd2_ok(int rows, int cols, int tokens_per_patch, int d_inner, int pool_max);
+int fv_mixer_conv_pool_bwd2(const void* xz, const void* d_o, const float* dxc, const void* dxc2, const float* conv_w,
+                            const float* conv_b, const float* conv_w_b, const float* conv_b_b, const float* D,
+                            const float* D_b, const void* amax, void* dxz, float* partials, int batch, int rows,
+                            int cols, int tok_stride_row, int tok_stride_col, int tokens_per_patch, int d_inner,
+                            int d_conv, int pool_max, float scaling_factor, int dtype, fv_stream_t stream);
 
 /* out[i] (+)= sum_{s < n_partials} partials[s*n + i], fixed order (deterministic); accumulate != 0
  * adds into `out` (gradient accumulation straight into a parameter's .grad). */
@@ -380,17 +398,6 @@ int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, const float* d
                                     int rows_per_scale, void* dx, float* dresidual_in, float* partial_dw, int M, int N,
                                     int K, long lda, long ldw, const void* W2, void* C2, int N2, long ldw2,
                                     fv_stream_t stream);
-
-/* fv_gemm_bf16_addnorm (out_proj + the next block's DropPath scale / residual add / RMSNorm; reference:
- * mamba_simple_faster.py:435-444 + models/fastvim.py:168-190) with the WEIGHT HELD IN REGISTERS: one persistent 12-wave
- * workgroup per CU, wave w keeps the K x 16 slice of W for output columns [16 w, 16 w + 16) in VGPRs for the whole launch
- * and the workgroup's M / #CU rows stream through in 32-row tiles -- the weight is fetched once per CU instead of once per
- * 64 rows.  Same arguments and, bit for bit, the same outputs as fv_gemm_bf16_addnorm.  Built for N == 192 and
- * K in {192, 384}: ask fv_gemm_bf16_addnorm_rw_ok (1 = covered). */
-int fv_gemm_bf16_addnorm_rw_ok(int M, int N, int K);
-int fv_gemm_bf16_addnorm_rw(const void* A, const void* W, const float* residual, const float* norm_weight,
-                            const float* row_scale, int rows_per_scale, void* y, float* residual_out, float* rstd, int M,
-                            int N, int K, long lda, long ldw, float eps, fv_stream_t stream);
 
 /* fv_gemm_bf16_addnorm with a second GEMM phase: C2 (M, N2) bf16 = y @ W2^T, W2 (N2, N) bf16 row-major -- the block's
  * in_proj (mamba_simple_faster.py:189-193) computed from the normalised tile while it is still in LDS; bit-identical to

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), f"{s} declared in include/fastvim_hip.h but not exported"
     assert sorted(_lib.C_ABI_SYMBOLS) == declared
-    assert lib.fv_version() >= 1
+    # the library and the header it was built from agree on the ABI version (bumped with every signature change)
+    hdr = open(os.path.join(ROOT, "include", "fastvim_hip.h")).read()
+    assert lib.fv_version() == int(re.search(r"#define\s+FV_ABI_VERSION\s+(\d+)", hdr).group(1)) == 2
 
 
 def test_no_cpu_fallback():

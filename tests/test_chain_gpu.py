@@ -110,31 +110,3 @@ def test_second_gemm_phases_bitwise(M):
                                              ctypes.c_long(d), L.ptr(W_out), L.ptr(dg), L.i32(d_in), ctypes.c_long(d_in), L.stream_of(dxz))
     L.check(rc, "dgrad_addnorm_bwd2")
     assert torch.equal(dg, gemm_nn(dx, W_out))
-
-
-@pytest.mark.parametrize("M,K,with_scale", [(25088, 384, True), (25088, 384, False), (100, 384, True), (33, 192, False),
-                                            (8 * 196, 192, True), (25089, 384, True)])
-def test_register_weight_addnorm_equals_the_tiled_kernel(M, K, with_scale, monkeypatch):
-    """fv_gemm_bf16_addnorm_rw (csrc/gemm_rw.hip: persistent workgroups, the weight slice of a wave in registers) against
-    fv_gemm_bf16_addnorm (64-row tiles, weight streamed through LDS per tile): every output bit for bit, whole and ragged
-    row counts (the last workgroup's last tile is partial), with and without the DropPath row scale."""
-    import fastvim_amd.mamba_simple_faster as msf
-    from fastvim_amd import _lib as L_
-    assert L_.lib().fv_gemm_bf16_addnorm_rw_ok(L_.i32(M), L_.i32(192), L_.i32(K)) == 1
-    gen = torch.Generator(device="cuda").manual_seed(M + K)
-    rn = lambda *s: torch.randn(*s, device=_dev(), generator=gen)
-    nimg = 8 if M % 8 == 0 else 1
-    g = rn(nimg, M // nimg, K).bfloat16()
-    W = (rn(192, K) * K ** -0.5)
-    res = rn(nimg, M // nimg, 192)
-    nw = 1 + 0.1 * rn(192)
-    scale = (torch.rand(nimg, device=_dev(), generator=gen) > 0.3).float() / 0.7 if with_scale else None
-    outs = []
-    for rw in (True, False):
-        monkeypatch.setattr(msf, "ADDNORM_RW", rw)
-        y, ro, rstd = msf._out_proj_add_norm_fwd(g, W, res, nw, 1e-5, scale, torch.bfloat16)[:3]
-        outs.append((y.clone(), ro.clone(), rstd.clone()))
-    torch.cuda.synchronize()
-    for n, a, b in zip(("normed", "residual_out", "rstd"), *outs):
-        assert torch.equal(a, b), f"{n}: max |diff| {(a.float() - b.float()).abs().max().item():.3e}"
-    assert torch.isfinite(outs[0][0].float()).all()
