@@ -800,6 +800,8 @@ def main():
     ap.add_argument("--comm-dtype", default="fp32", choices=["auto", "fp32", "bf16"],
                     help="wire format of the gradient all-reduce: fp32 (default, the reference's DDP), bf16, or auto "
                          "(bf16 for buckets of >= 100 MB of fp32 gradient, else fp32) -- the compressed forms are opt-in")
+    ap.add_argument("--no-combine-fusion", action="store_true",
+                    help="A/B: combine as its own launch instead of inside the out_proj + add + norm launch (round 5)")
     ap.add_argument("--no-xproj-fold", action="store_true",
                     help="A/B: the x_proj adjoint as its own launch instead of inside the short scan backward (round 5)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -845,6 +847,9 @@ def main():
     if args.no_xproj_fold:
         import fastvim_amd.mamba_simple_faster as _msf
         _msf.XPROJ_IN_SCAN = False
+    if args.no_combine_fusion:
+        import fastvim_amd.mamba_simple_faster as _msf
+        _msf.COMBINE_IN_OUT_PROJ = False
     use_graph = not args.no_graph
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)

@@ -11,11 +11,14 @@ OBJ = os.path.join(PKG, "csrc", "_obj")
 LIB = os.path.join(PKG, "libfastvim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = os.environ.get("FASTVIM_ARCH", "gfx950")      # build-time A/B knob: e.g. gfx950:xnack-
-# -fgpu-flush-denormals-to-zero: fp32 denormals are flushed, as in the reference's kernels (its extension is built with
-# nvcc --use_fast_math, which implies --ftz=true: mamba-1p1p1/setup.py:102-153); the expansions of exp / log / rcp / rsqrt lose
-# their denormal-range scaling code: FastVim-T step 5.736 -> 5.708 ms on one box (profiles/r04_ab_flush_denormals.log)
+# Per-source flags come from a source's first line (``// hipcc-flags: ...``).  -fgpu-flush-denormals-to-zero is one of
+# them: fp32 denormals are flushed in the scan / conv / mixer kernels only -- the code that replaces the reference's own
+# CUDA extension, which is built with nvcc --use_fast_math (implies --ftz=true: mamba-1p1p1/setup.py:102-153); the expansions
+# of exp / log / rcp / rsqrt lose their denormal-range scaling code (FastVim-T step 5.736 -> 5.708 ms on one box,
+# profiles/r04_ab_flush_denormals.log).  The optimizer, the loss, the norms, the GEMMs and the glue kernels stand in for
+# stock PyTorch / Triton code that does not flush, and are built without it (round 5, advisor).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffast-math", "-fno-finite-math-only",
-         "-fgpu-flush-denormals-to-zero", "-Wno-unused-result", "-DNDEBUG"]
+         "-Wno-unused-result", "-DNDEBUG"]
 
 
 def _sources():
@@ -61,9 +64,14 @@ def build(force=False, verbose=False, tuning=False):
         FLAGS.append("-DFASTVIM_TUNING_HOOKS")
     if not tuning and "-DFASTVIM_TUNING_HOOKS" in FLAGS:
         FLAGS.remove("-DFASTVIM_TUNING_HOOKS")
-    extra = os.environ.get("FASTVIM_EXTRA_FLAGS", "").split()      # build-time A/B knobs (e.g. -DFV_BUF_STORE_AUX=16); forces a rebuild
-    if extra:
+    extra = os.environ.get("FASTVIM_EXTRA_FLAGS", "").split()      # build-time A/B knobs (e.g. -DFV_BUF_STORE_AUX=16)
+    # what the objects were compiled with: a change of target, flags or A/B knobs -- in either direction -- rebuilds all
+    sig = " ".join([ARCH, *FLAGS, "|", *extra])
+    fstamp = os.path.join(OBJ, ".flags")
+    if not os.path.exists(fstamp) or open(fstamp).read() != sig:
         force = True
+        with open(fstamp, "w") as f:
+            f.write(sig)
     hdr_m = _deps_mtime()
     jobs, objs = [], []
     for src in _sources():

@@ -1,4 +1,4 @@
-// hipcc-flags: -fno-slp-vectorize
+// hipcc-flags: -fno-slp-vectorize -fgpu-flush-denormals-to-zero
 // Wave-per-token combine kernels (expand + skip + average + LayerNorm + gate, and the adjoint) for d_inner = 384 or 768
 // (mamba_simple_faster.py:356, 412-414, 434-441; channel path mamba_simple_channel_faster.py:333-340, 452-478).
 //

@@ -1,3 +1,4 @@
+// hipcc-flags: -fgpu-flush-denormals-to-zero
 // Causal depthwise conv1d (+ optional SiLU) in the reference op layout (batch, dim, seqlen), seqlen
 // contiguous.  Replaces causal_conv1d_cuda.causal_conv1d_fwd / causal_conv1d_bwd of the PyPI
 // package causal-conv1d 1.1.3.post1 (not vendored in the reference; call sites

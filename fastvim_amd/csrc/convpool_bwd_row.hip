@@ -1,4 +1,4 @@
-// hipcc-flags: -fno-slp-vectorize
+// hipcc-flags: -fno-slp-vectorize -fgpu-flush-denormals-to-zero
 // Whole-row conv + pool backward for short pooling rows (cols == 14 or 16, tokens_per_patch == 1,
 // d_inner a multiple of 128): the adjoint of the D-skip, mean-pool, SiLU and both depthwise convs
 // (mamba_simple_faster.py:270-305, 356-358, 412-416; FastVim_MambaInnerFnNoOutProj_withoutZ.backward,

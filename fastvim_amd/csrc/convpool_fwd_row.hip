@@ -1,4 +1,4 @@
-// hipcc-flags: -fno-slp-vectorize
+// hipcc-flags: -fno-slp-vectorize -fgpu-flush-denormals-to-zero
 // Whole-row conv + pool (+ skip) forward for short pooling rows (cols == 14 or 16, tokens_per_patch == 1):
 // both depthwise convs + SiLU, the pooling over the row and skip = D*conv_f + D_b*conv_b
 // (mamba_simple_faster.py:272-305, 356-358, 412-416).  Written for instruction count like

@@ -1,3 +1,4 @@
+// hipcc-flags: -fgpu-flush-denormals-to-zero
 // Kept tokens <-> pooling rows for the MAE masked mixer: a deterministic segment sum
 // (replaces compute_row_means_constantdivide, mamba_simple_masked_faster.py:376-416: index_add_ over the kept
 // tokens, divided by cols) and a row gather (replaces the torch.gather expansions, :281-283, 311-314).  Each is the

@@ -1,3 +1,4 @@
+// hipcc-flags: -fgpu-flush-denormals-to-zero
 // Backward kernels of the fused FastVim mixer "middle" (channel-last).  Hand-written adjoint of
 // csrc/mixer_fwd.hip; replaces the autograd graph of mamba_simple_faster.py:270-444 and the
 // hand-written backward of FastVim_MambaInnerFnNoOutProj_withoutZ

@@ -1,3 +1,4 @@
+// hipcc-flags: -fgpu-flush-denormals-to-zero
 // Forward kernels of the fused FastVim mixer "middle" (everything between the in_proj GEMM
 // output xz and the out_proj GEMM input), channel-last.  Replaces, for one bidirectional
 // block, the ~35 launches of mamba_simple_faster.py:270-444:

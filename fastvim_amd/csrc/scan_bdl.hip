@@ -1,3 +1,4 @@
+// hipcc-flags: -fgpu-flush-denormals-to-zero
 // Selective scan in the reference layout (B, D, L), L contiguous -- the drop-in for
 // selective_scan_cuda.fwd/bwd (mamba-1p1p1/csrc/selective_scan/selective_scan.cpp:226-492).
 //

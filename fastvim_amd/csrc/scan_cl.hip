@@ -1,3 +1,4 @@
+// hipcc-flags: -fgpu-flush-denormals-to-zero
 // dt_proj + softplus + selective scan over the POOLED rows, channel-last, forward and backward,
 // both scan directions in one launch.  Replaces selective_scan_cuda.fwd/bwd as used by the FastVim
 // mixer (mamba_simple_faster.py:328-354, 390-410; selective_scan_interface.py:558-568, 679-696)

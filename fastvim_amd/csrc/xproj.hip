@@ -1,3 +1,4 @@
+// hipcc-flags: -fgpu-flush-denormals-to-zero
 // Adjoint of the x_proj linear layer of both scan directions, fused with the sum over the scan
 // backward's channel-chunk partials.  Replaces, per block and per step, the einsum / addmm chain of
 // selective_scan_interface.py:698-734:

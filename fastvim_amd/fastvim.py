@@ -21,6 +21,7 @@ from torch import Tensor
 
 from .layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
 from . import glue_ops as G
+from . import mamba_simple_faster as msf
 from .mamba_simple_faster import (ChainedBlockFn, LinearFn, Mamba, OutProjAddNormFn, _compute_dtype, _direct_grad, _shadow,
                                   linear_dgrad, linear_wgrad, out_proj_add_norm_ok)
 from .mixer_ops import reduce_partials
@@ -451,6 +452,10 @@ class VisionMamba(nn.Module):
         cdt = _compute_dtype(hidden_states if pend is None else pend[0])
         # pend: (gated activations, out_proj weight) of the previous block -- None at the start of a chain, or carried in
         # from the previous run of blocks (``_run_layers_open``: the segmented training step cuts there)
+        # pack: the previous block's gated activations have NOT been computed yet -- their combine (expand + LayerNorm +
+        # gate) is deferred into the next block's out_proj + add + norm launch (``fv_mixer_combine_out_proj_addnorm``);
+        # whoever else consumes them (the end of the run, a cut, a block the fused launch is not built for) resolves it
+        pack = None
         for layer_idx in range(lo, hi):
             blk = self.layers[layer_idx]
             scale = None
@@ -460,17 +465,26 @@ class VisionMamba(nn.Module):
             if pend is not None and out_proj_add_norm_ok(pend[0], pend[1], residual, blk.norm.weight, cdt):
                 # previous out_proj + this block's add + norm + mixer as ONE autograd node: its backward can hand the
                 # in_proj data gradient straight to the norm's adjoint
-                g, residual = ChainedBlockFn.apply(pend[0], pend[1], residual, blk.norm.weight, float(blk.norm.eps), scale,
-                                                   *blk.mixer.mixer_fn_args(cdt, rot, defer_out_proj=True))
+                ChainedBlockFn.pending_in = pack
+                ChainedBlockFn.defer = msf.COMBINE_IN_OUT_PROJ
+                try:
+                    g, residual = ChainedBlockFn.apply(pend[0], pend[1], residual, blk.norm.weight, float(blk.norm.eps), scale,
+                                                       *blk.mixer.mixer_fn_args(cdt, rot, defer_out_proj=True))
+                finally:
+                    ChainedBlockFn.pending_in, ChainedBlockFn.defer = None, False
+                pack, ChainedBlockFn.pending_out = ChainedBlockFn.pending_out, None
                 pend = (g, blk.mixer.out_proj.weight)
                 continue
             else:
+                msf.resolve_combine(pack)
+                pack = None
                 if pend is not None:
                     hidden_states = LinearFn.apply(pend[0], pend[1], cdt)
                 hidden_states, residual = layer_norm_fn(
                     hidden_states, blk.norm.weight, blk.norm.bias, residual=residual, eps=blk.norm.eps, prenorm=True,
                     residual_in_fp32=blk.residual_in_fp32, is_rms_norm=True, row_scale=scale, out_dtype=cdt)
             pend = (blk.mixer(hidden_states, transposed_grid=rot, defer_out_proj=True), blk.mixer.out_proj.weight)
+        msf.resolve_combine(pack)      # the run ends (or is cut) here: the last block's combine as its own launch
         if not close:
             return None, residual, pend
         return LinearFn.apply(pend[0], pend[1], cdt), residual
@@ -542,10 +556,16 @@ class VisionMamba(nn.Module):
         return self._final(hidden_states, residual)
 
     def forward(self, x, return_features=False, inference_params=None):
+        half = msf.half_io(x) or self.pos_embed_dtype_is_half()
         x = self.forward_features(x, inference_params)
-        if return_features:
-            return x
-        return self._head(x)
+        if not return_features:
+            x = self._head(x)
+        # fp16 regime (fp16 autocast / a .half() model): computed in fp32 inside, fp16 at the boundary like the reference
+        return x.to(torch.float16) if half and torch.is_tensor(x) and x.is_floating_point() else x
+
+    def pos_embed_dtype_is_half(self):
+        p = next(self.parameters(), None)
+        return p is not None and p.dtype == torch.float16
 
 
 class MM_FastVim(VisionMamba):

@@ -11,7 +11,7 @@ FastVim against (README.md:15) is thus measured on the same code path.
 """
 import torch.nn.functional as F
 
-from .mamba_simple_faster import FastVimMixerFn, Mamba as _FastVimMamba, _compute_dtype
+from .mamba_simple_faster import FastVimMixerFn, Mamba as _FastVimMamba, _compute_dtype, mixer_apply
 
 
 def _split_rows_exact(L):
@@ -68,8 +68,8 @@ class Mamba(_FastVimMamba):
         ln_w = self.layernorm.weight if self.use_norm_after_ssm else None
         ln_b = self.layernorm.bias if self.use_norm_after_ssm else None
         ln_eps = self.layernorm.eps if self.use_norm_after_ssm else 0.0
-        out = FastVimMixerFn.apply(
-            hidden_states, self.in_proj.weight, self.in_proj.bias,
+        out = mixer_apply(
+            FastVimMixerFn, hidden_states, self.in_proj.weight, self.in_proj.bias,
             self.conv1d.weight, self.conv1d.bias, self.conv1d_b.weight, self.conv1d_b.bias,
             self.x_proj.weight, self.x_proj_b.weight,
             self.dt_proj.weight, self.dt_proj.bias, self.dt_proj_b.weight, self.dt_proj_b.bias,

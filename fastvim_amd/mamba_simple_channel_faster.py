@@ -13,7 +13,7 @@ Spatial-First order (:226-241, 259-274, 325-331, 376-382): position ``(channel*r
 group ``(channel, row)`` -- exactly the FastVim mixer on a ``(tokens_per_patch*rows) x cols`` grid, which is how it
 runs here (no ``tokens_per_patch`` in the kernels; the channel ``Block`` transposes rotated layers physically).
 """
-from .mamba_simple_faster import FastVimMixerFn, Mamba as _FastVimMamba, _compute_dtype
+from .mamba_simple_faster import FastVimMixerFn, Mamba as _FastVimMamba, _compute_dtype, mixer_apply
 
 
 class Mamba(_FastVimMamba):
@@ -53,8 +53,8 @@ class Mamba(_FastVimMamba):
         rows, cols, tpp = self._geometry(int(tokens_per_patch))
         if self.scan_order == "Spatial-First" and transposed_grid:
             raise RuntimeError("Spatial-First mixers take physically transposed tokens (the channel Block does that)")
-        out = FastVimMixerFn.apply(
-            hidden_states, self.in_proj.weight, self.in_proj.bias,
+        out = mixer_apply(
+            FastVimMixerFn, hidden_states, self.in_proj.weight, self.in_proj.bias,
             self.conv1d.weight, self.conv1d.bias, self.conv1d_b.weight, self.conv1d_b.bias,
             self.x_proj.weight, self.x_proj_b.weight,
             self.dt_proj.weight, self.dt_proj.bias, self.dt_proj_b.weight, self.dt_proj_b.bias,

@@ -312,8 +312,19 @@ class _Ctx:
         self.saved_tensors = tensors
 
 
-def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in=None):
-    """``W_in`` (2 d_inner, d): also run this block's in_proj as a second phase of the launch; returns xz last."""
+COMBINE_IN_OUT_PROJ = True      # combine (expand + LayerNorm + gate) as the A-tile producer of the out_proj + add + norm launch (A/B switch)
+
+
+def resolve_combine(pack):
+    """Run a deferred combine as its own launch (the chain ends, is cut, or meets a consumer that cannot produce it)."""
+    if pack is not None:
+        M.combine_fwd(pack["xz"], pack["skip"], pack["yc"], pack["ln_w"], pack["ln_b"], pack["eps"], pack["rows"],
+                      pack["cols"], pack["transposed"], out=pack["out"])
+
+
+def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in=None, pack=None):
+    """``W_in`` (2 d_inner, d): also run this block's in_proj as a second phase of the launch; returns xz last.
+    ``pack``: g has not been computed yet -- its combine runs inside this launch (``fv_mixer_combine_out_proj_addnorm``)."""
     B, Ltok, d_in = g.shape
     d = W_out.shape[0]
     Mrows = B * Ltok
@@ -336,6 +347,13 @@ def _out_proj_add_norm_fwd(g, W_out, residual, norm_w, eps, row_scale, cdt, W_in
     W_out_c = _shadow(W_out, cdt)
     W_in_c = _shadow(W_in, cdt) if xz is not None else None
     lib = L.lib()
+    if pack is not None:
+        if xz is None and W_out_c.stride(1) == 1 and W_out_c.stride(0) % 8 == 0 and W_out_c.data_ptr() % 16 == 0:
+            y, res_out, rstd = M.combine_out_proj_addnorm(pack["xz"], pack["skip"], pack["yc"], pack["ln_w"], pack["ln_b"],
+                                                          pack["eps"], pack["rows"], pack["cols"], pack["transposed"],
+                                                          pack["out"], W_out_c, res2, w32, row_scale, rows_per_scale, eps)
+            return y, res_out, rstd, w32, row_scale, rows_per_scale
+        resolve_combine(pack)
     rc = lib.fv_gemm_bf16_addnorm2(
         L.ptr(g2), L.ptr(W_out_c), L.ptr(res2), L.ptr(w32), L.ptr(row_scale), L.i32(rows_per_scale),
         L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.i32(Mrows), L.i32(d), L.i32(d_in), ctypes.c_long(g2.stride(0)),
@@ -362,6 +380,11 @@ class ChainedBlockFn(torch.autograd.Function):
     # faster stand-alone (32.3 vs 36.3 us), but 0.07 ms SLOWER per FastVim-T step (5.94 vs 5.87 ms, same box): the
     # 38 MB of xz stores at the end of a 392-workgroup launch cost more than the launch they save.  Off.
     in_proj_in_launch = False
+    # side channel of the chained run (single-threaded, set and consumed around one ``apply``): ``pending_in`` = the
+    # deferred combine of g_prev (its buffers are g_prev's storage), ``pending_out`` = this block's own deferred combine
+    pending_in = None
+    pending_out = None
+    defer = False
 
     @staticmethod
     def forward(ctx, g_prev, W_out_prev, residual, norm_w, eps, row_scale, *mixer_args):
@@ -370,8 +393,14 @@ class ChainedBlockFn(torch.autograd.Function):
         d = W_out_prev.shape[0]
         cdt = mixer_args[26]            # FastVimMixerFn.forward(ctx, hidden, <26 arguments>, cdt, fv, tpp, valid)
         W_in, b_in = mixer_args[0], mixer_args[1]
+        pack, ChainedBlockFn.pending_in = ChainedBlockFn.pending_in, None
+        assert pack is None or pack["out"][0].data_ptr() == g_prev.data_ptr()
         with torch.autocast("cuda", enabled=False):
-            if ChainedBlockFn.in_proj_in_launch and b_in is None:
+            if pack is not None:
+                y, res_out, rstd, w32, rs, rps = _out_proj_add_norm_fwd(g_prev, W_out_prev, residual, norm_w, eps, row_scale,
+                                                                      cdt, pack=pack)
+                xz = None
+            elif ChainedBlockFn.in_proj_in_launch and b_in is None:
                 y, res_out, rstd, w32, rs, rps, xz = _out_proj_add_norm_fwd(g_prev, W_out_prev, residual, norm_w, eps,
                                                                           row_scale, cdt, W_in=W_in)
             else:
@@ -379,9 +408,12 @@ class ChainedBlockFn(torch.autograd.Function):
                 xz = None
         fctx = _Ctx()
         fctx.precomputed_xz = xz
+        fctx.defer_combine = ChainedBlockFn.defer
         g = FastVimMixerFn.forward(fctx, y.view(B, Ltok, d), *mixer_args)
         mixer_saved = fctx.__dict__.pop("saved_tensors")
         fctx.__dict__.pop("precomputed_xz", None)
+        fctx.__dict__.pop("defer_combine", None)
+        ChainedBlockFn.pending_out = fctx.__dict__.pop("pending_combine", None)
         ctx.save_for_backward(g_prev, W_out_prev, res_out, w32, rstd, rs, *mixer_saved)
         ctx.mixer_attrs = fctx.__dict__
         ctx.rows_per_scale = rps
@@ -448,22 +480,37 @@ def out_proj_add_norm_ok(g, W_out, residual, norm_w, cdt):
 
 
 def _compute_dtype(t):
-    """The autocast dtype under torch.autocast (reference: mamba_simple_faster.py:312-318), else the input dtype.
-    The module path (patch embed, blocks, mixers) is built for bf16 and fp32: the reference's other mixed precision,
-    ``--precision 16-mixed`` (imagenet_classification/train.py:17), is REFUSED here with one clear error instead of
-    running half the model through fallbacks -- the fused kernels keep fp32 statistics but store activations in the
-    compute dtype, and fp16's 5-bit exponent needs the loss scaling this build's fused backward does not carry.  The
-    op-level functions (``selective_scan_fn``, ``causal_conv1d_fn``, the compressed scan) do take fp16 tensors, like the
-    reference's kernels (selective_scan.cpp:328-332)."""
+    """The dtype the kernels compute and store activations in: the autocast dtype under torch.autocast (reference:
+    mamba_simple_faster.py:312-318), else the input dtype -- except fp16, which is UPCAST: the module path (patch embed,
+    blocks, mixers) is built for bf16 and fp32, so the reference's other mixed precision, ``--precision 16-mixed``
+    (imagenet_classification/train.py:17), and a ``model.half()`` run in fp32 with fp16 at the model's boundary
+    (``half_io``): same function, fp32 (not fp16) rounding inside, loss scaling passes through untouched because no
+    intermediate is ever stored in fp16.  The op-level functions (``selective_scan_fn``, ``causal_conv1d_fn``, the compressed
+    scan) take fp16 tensors natively, like the reference's kernels (selective_scan.cpp:328-332)."""
     if torch.is_autocast_enabled():
         dt = torch.get_autocast_dtype('cuda')
-        if dt == torch.float16:
-            raise RuntimeError("fastvim_amd: fp16 autocast is not supported by the HIP mixer path; "
-                               "use torch.autocast('cuda', dtype=torch.bfloat16) or run in fp32")
-        return dt
-    if t.dtype == torch.float16:
-        raise RuntimeError("fastvim_amd: fp16 activations are not supported by the HIP mixer path; use bf16 or fp32")
-    return t.dtype
+        return torch.float32 if dt == torch.float16 else dt
+    return torch.float32 if t.dtype == torch.float16 else t.dtype
+
+
+def half_io(t):
+    """Is this call in the fp16 regime (fp16 autocast, or fp16 activations / a ``.half()`` model)?  Module outputs are
+    then cast to fp16, what the reference returns there."""
+    if torch.is_autocast_enabled():
+        return torch.get_autocast_dtype('cuda') == torch.float16
+    return t.dtype == torch.float16
+
+
+def mixer_apply(fn, hidden, *args):
+    """``fn.apply`` for the mixer Functions with fp16 PARAMETERS (a ``model.half()``) upcast first: the kernels read fp32
+    masters through raw pointers.  The casts are autograd nodes, so a fp16 parameter still gets its (fp16) gradient."""
+    if any(torch.is_tensor(a) and a.dtype == torch.float16 for a in args):
+        args = tuple(a.float() if torch.is_tensor(a) and a.dtype == torch.float16 else a for a in args)
+    out = fn.apply(hidden, *args)
+    # fp16 activations in, fp16 out.  (Under fp16 AUTOCAST with fp32 activations -- what the blocks of this build's models
+    # hand over -- the result stays fp32: the norm kernels between blocks take fp32 / bf16 rows, and the model casts once
+    # at its boundary.)
+    return out.to(torch.float16) if hidden.dtype == torch.float16 else out
 
 
 class FastVimMixerFn(torch.autograd.Function):
@@ -520,7 +567,15 @@ class FastVimMixerFn(torch.autograd.Function):
                 nig = getattr(ctx, "needs_input_grad", None)
                 yc, ctx.scan_ckpt = M.scan_fwd(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log,
                                                want_ckpt=nig is None or any(nig))
-            g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
+            if (getattr(ctx, "defer_combine", False) and W_out is None and not pool_max and valid is None
+                    and M.combine_out_proj_addnorm_ok(xz, rows, cols, tpp, d)):
+                # the caller (ChainedBlockFn of the NEXT block) gates the activations inside its out_proj + add + norm
+                # launch: the buffers exist (they are this node's output / saved tensors), their contents come later
+                g, mean, rstd = M.combine_buffers(xz, ln_w)
+                ctx.pending_combine = dict(xz=xz, skip=skip, yc=yc, ln_w=ln_w, ln_b=ln_b, eps=ln_eps, rows=rows, cols=cols,
+                                           transposed=transposed, out=(g, mean, rstd))
+            else:
+                g, mean, rstd = M.combine_fwd(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, tpp=tpp)
             # W_out None: out_proj is the caller's (fused with the next block's add + norm, OutProjAddNormFn); the
             # gated activations g (B, L, d_in) are returned and their gradient comes back as ``dout``
             out = g if W_out is None else linear_fwd(g.view(B * Ltok, d_in), W_out_c, b_out).view(B, Ltok, d)
@@ -742,8 +797,8 @@ class Mamba(nn.Module):
         ln_w = self.layernorm.weight if self.use_norm_after_ssm else None
         ln_b = self.layernorm.bias if self.use_norm_after_ssm else None
         ln_eps = self.layernorm.eps if self.use_norm_after_ssm else 0.0
-        out = FastVimMixerFn.apply(
-            hidden_states, self.in_proj.weight, self.in_proj.bias,
+        out = mixer_apply(
+            FastVimMixerFn, hidden_states, self.in_proj.weight, self.in_proj.bias,
             self.conv1d.weight, self.conv1d.bias, self.conv1d_b.weight, self.conv1d_b.bias,
             self.x_proj.weight, self.x_proj_b.weight,
             self.dt_proj.weight, self.dt_proj.bias, self.dt_proj_b.weight, self.dt_proj_b.bias,

@@ -23,7 +23,7 @@ from . import _lib as L
 from . import mixer_ops as M
 from .mamba_simple import _split_rows_exact as _split_rows
 from .gemm import gemm_any_bnn, gemm_any_btn
-from .mamba_simple_faster import (Mamba as _FastVimMamba, _compute_dtype, _shadow, linear_dgrad, linear_fwd,
+from .mamba_simple_faster import (Mamba as _FastVimMamba, _compute_dtype, _shadow, mixer_apply, linear_dgrad, linear_fwd,
                                   linear_wgrad)
 
 
@@ -138,8 +138,8 @@ class Mamba_masked(_FastVimMamba):
         ln_w = self.layernorm.weight if self.use_norm_after_ssm else None
         ln_b = self.layernorm.bias if self.use_norm_after_ssm else None
         ln_eps = self.layernorm.eps if self.use_norm_after_ssm else 0.0
-        out = MaskedFastVimMixerFn.apply(
-            hidden_states, ids_keep, self.in_proj.weight, self.in_proj.bias,
+        out = mixer_apply(
+            MaskedFastVimMixerFn, hidden_states, ids_keep, self.in_proj.weight, self.in_proj.bias,
             self.conv1d.weight, self.conv1d.bias, self.conv1d_b.weight, self.conv1d_b.bias,
             self.x_proj.weight, self.x_proj_b.weight,
             self.dt_proj.weight, self.dt_proj.bias, self.dt_proj_b.weight, self.dt_proj_b.bias,

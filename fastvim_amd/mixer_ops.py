@@ -79,17 +79,22 @@ def xproj_scan_fwd(xc, Wx2_c, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b):
     return x_dbl, yc
 
 
-def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1):
-    """g (B, L, d_in) = LayerNorm((yc_f + yc_b + skip) / 2) * silu(z); also returns mean, rstd (B*L) fp32."""
+def combine_buffers(xz, ln_w):
+    """The outputs of ``combine_fwd``, unwritten: g (B, L, d_in), mean, rstd (B*L) fp32 (None without a LayerNorm)."""
+    B, Ltok, two_d = xz.shape
+    g = torch.empty(B, Ltok, two_d // 2, device=xz.device, dtype=xz.dtype)
+    if ln_w is not None:
+        return g, torch.empty(B * Ltok, device=xz.device, dtype=torch.float32), torch.empty(B * Ltok, device=xz.device, dtype=torch.float32)
+    return g, None, None
+
+
+def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1, out=None):
+    """g (B, L, d_in) = LayerNorm((yc_f + yc_b + skip) / 2) * silu(z); also returns mean, rstd (B*L) fp32.
+    ``out``: (g, mean, rstd) buffers of ``combine_buffers`` to write instead of fresh ones."""
     B, Ltok, two_d = xz.shape
     d_in = two_d // 2
     s_i, s_j = _geo(rows, cols, transposed)
-    g = torch.empty(B, Ltok, d_in, device=xz.device, dtype=xz.dtype)
-    if ln_w is not None:
-        mean = torch.empty(B * Ltok, device=xz.device, dtype=torch.float32)
-        rstd = torch.empty(B * Ltok, device=xz.device, dtype=torch.float32)
-    else:
-        mean = rstd = None
+    g, mean, rstd = out if out is not None else combine_buffers(xz, ln_w)
     rc = L.lib().fv_mixer_combine_fwd(
         L.ptr(xz), L.ptr(skip), L.ptr(yc), L.ptr(ln_w), L.ptr(ln_b), f32(eps), L.ptr(g), L.ptr(mean), L.ptr(rstd),
         L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.i32(tpp), L.i32(d_in),
@@ -193,6 +198,35 @@ def reduce_partials(part, n_partials, out=None, accumulate=False, defer=True):
                                     L.i32(accumulate), L.stream_of(part))
     L.check(rc, "reduce_partials")
     return out
+
+
+def combine_out_proj_addnorm_ok(xz, rows, cols, tpp, d_model):
+    B, Ltok, two_d = xz.shape
+    return bool(xz.dtype == torch.bfloat16 and xz.is_contiguous() and
+                L.lib().fv_mixer_combine_out_proj_addnorm_ok(L.i32(B), L.i32(rows), L.i32(cols), L.i32(tpp), L.i32(two_d // 2),
+                                                             L.i32(d_model), L.i32(L.FV_BF16)))
+
+
+def combine_out_proj_addnorm(xz, skip, yc, ln_w, ln_b, ln_eps, rows, cols, transposed, out, W_out_c, residual2, norm_w32,
+                             row_scale, rows_per_scale, eps):
+    """``combine_fwd`` into the buffers ``out`` = (g, mean, rstd) AND out_proj + DropPath scale + residual add + RMSNorm
+    of the result (``fv_gemm_bf16_addnorm``) in one launch; returns (normed (M, d) bf16, residual_out (M, d) fp32,
+    rstd (M))."""
+    B, Ltok, two_d = xz.shape
+    d = W_out_c.shape[0]
+    Mrows = B * Ltok
+    s_i, s_j = _geo(rows, cols, transposed)
+    g, mean, rstd_ln = out
+    y = torch.empty(Mrows, d, device=xz.device, dtype=torch.bfloat16)
+    res_out = torch.empty(Mrows, d, device=xz.device, dtype=torch.float32)
+    rstd = torch.empty(Mrows, device=xz.device, dtype=torch.float32)
+    rc = L.lib().fv_mixer_combine_out_proj_addnorm(
+        L.ptr(xz), L.ptr(skip), L.ptr(yc), L.ptr(ln_w), L.ptr(ln_b), f32(ln_eps), L.ptr(g), L.ptr(mean), L.ptr(rstd_ln),
+        L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j), L.ptr(W_out_c), ctypes.c_long(W_out_c.stride(0)),
+        L.ptr(residual2), L.ptr(norm_w32), L.ptr(row_scale), L.i32(rows_per_scale), L.ptr(y), L.ptr(res_out), L.ptr(rstd),
+        f32(eps), L.stream_of(xz))
+    L.check(rc, "mixer_combine_out_proj_addnorm")
+    return y, res_out, rstd
 
 
 def combine_bwd(dg, xz, skip, yc, ln_w, ln_b, mean, rstd, dxz, rows, cols, transposed, grad_out=None, tpp=1):

@@ -399,6 +399,21 @@ int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, const float* d
                                     int K, long lda, long ldw, const void* W2, void* C2, int N2, long ldw2,
                                     fv_stream_t stream);
 
+/* fv_mixer_combine_fwd + fv_gemm_bf16_addnorm in ONE launch (round 5): the gated activations g of a block are produced
+ * tile by tile inside the out_proj GEMM that also does the NEXT block's DropPath scale + residual add + RMSNorm
+ * (reference: mamba_simple_faster.py:356, 412-414, 434-444; models/fastvim.py:168-190).  g (batch, L, 384) bf16, mean /
+ * rstd_ln (batch * L) are written for the backward pass exactly as fv_mixer_combine_fwd writes them; y / residual_out /
+ * rstd exactly as fv_gemm_bf16_addnorm does from that g.  Built for bf16, d_inner 384, d_model 192, tokens_per_patch 1
+ * (fv_mixer_combine_out_proj_addnorm_ok); W (192, ldw) bf16 row-major = out_proj.weight. */
+int fv_mixer_combine_out_proj_addnorm_ok(int batch, int rows, int cols, int tokens_per_patch, int d_inner, int d_model,
+                                         int dtype);
+int fv_mixer_combine_out_proj_addnorm(const void* xz, const void* skip, const float* yc, const float* ln_w,
+                                      const float* ln_b, float ln_eps, void* g, float* mean, float* rstd_ln, int batch,
+                                      int rows, int cols, int tok_stride_row, int tok_stride_col, const void* W, long ldw,
+                                      const float* residual, const float* norm_weight, const float* row_scale,
+                                      int rows_per_scale, void* y, float* residual_out, float* rstd, float eps,
+                                      fv_stream_t stream);
+
 /* fv_gemm_bf16_addnorm with a second GEMM phase: C2 (M, N2) bf16 = y @ W2^T, W2 (N2, N) bf16 row-major -- the block's
  * in_proj (mamba_simple_faster.py:189-193) computed from the normalised tile while it is still in LDS; bit-identical to
  * fv_gemm_bf16 on y.  W2 null: no second phase.  N2 % 128 == 0. */

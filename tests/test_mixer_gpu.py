@@ -204,3 +204,35 @@ def test_mixer_wide_models_vs_oracle(d_model, grid):
         for n, q in m.named_parameters():
             e = _err(q.grad, p[n].grad)
             assert e <= 2e-4 * max(1.0, p[n].grad.abs().max().item()), (d_model, transposed, n, e, p[n].grad.abs().max().item())
+
+
+def test_mixer_denormal_range_activations_vs_oracle():
+    """Mixer-level twin of tests/test_scan_gpu.py::test_scan_denormal_range_inputs_vs_oracle: the fused row / scan kernels
+    are built with fp32 denormals flushed (fastvim_amd/build.py).  A d_model = 192 mixer whose input has half of its images
+    scaled into the 1e-18 ... 1e-22 range -- the pooled conv output, delta * B * u, the scan states and their adjoints are
+    then fp32 denormals for those images -- against the fp64 oracle, forward and input gradient, at the usual fp32 bounds
+    on the output scale; the O(1) images of the same batch must be unaffected."""
+    from fastvim_amd.mamba_simple_faster import Mamba
+    from oracle import fastvim_mixer_oracle
+    torch.manual_seed(3)
+    m = Mamba(192, token_size=[14, 14]).cuda()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    h = torch.randn(4, 196, 192)
+    h[1] *= 1e-18
+    h[3] *= 1e-22
+    hg = h.cuda().requires_grad_()
+    y = m(hg)
+    p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    hc = h.clone().requires_grad_()
+    yref = fastvim_mixer_oracle(p, hc, (14, 14), compute_dtype=F64, out_dtype=F64)
+    assert torch.isfinite(y).all()
+    assert _err(y, yref) <= 1e-5 * max(1.0, yref.abs().max().item()), _err(y, yref)
+    for b in (0, 2):        # the ordinary images on their own scale
+        assert _err(y[b], yref[b]) <= 1e-5 * max(1.0, yref[b].abs().max().item())
+    g = torch.randn_like(h)
+    y.backward(g.cuda()); yref.backward(g.double())
+    assert torch.isfinite(hg.grad).all()
+    assert _err(hg.grad, hc.grad) <= 2e-5 * max(1.0, hc.grad.abs().max().item())
+    for n, q in m.named_parameters():
+        e = _err(q.grad, p[n].grad)
+        assert e <= 1e-4 * max(1.0, p[n].grad.abs().max().item()), (n, e)

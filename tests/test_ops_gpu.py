@@ -121,25 +121,57 @@ def test_compressed_scan_backward_vs_oracle(dtype):
         assert e <= tg * max(1.0, r[k].grad.abs().max().item()), (k, e)
 
 
-def test_fp16_autocast_is_refused_by_the_module_path():
-    """The reference's other mixed precision (``--precision 16-mixed``, imagenet_classification/train.py:17) is not built for
-    the fused module path: ONE clear error at the first block, not a library GEMM followed by a kernel's dtype complaint.
-    bf16 autocast and fp32 run (every other test); the op-level functions take fp16 tensors (tests above)."""
+def test_fp16_autocast_and_half_models_run_through_the_module_path():
+    """The reference's other mixed precision (``--precision 16-mixed``, imagenet_classification/train.py:17) and a
+    ``model.half()`` (its kernels dispatch fp16: selective_scan.cpp:328-332): the module path computes them in fp32 with
+    fp16 at the model boundary (``mamba_simple_faster._compute_dtype``) -- same function as the fp32 run up to the fp16
+    rounding of inputs / parameters / outputs, gradients flow (GradScaler-style scaled loss included), no library GEMM is
+    involved (the fp32-MFMA kernels run)."""
     from fastvim_amd.fastvim import VisionMamba
     from fastvim_amd.mamba_simple_faster import Mamba
     torch.manual_seed(0)
     m = VisionMamba(img_size=64, patch_size=16, depth=2, embed_dim=64, num_classes=10, rms_norm=True, residual_in_fp32=True,
-                    fused_add_norm=True, final_pool_type="mean").cuda()
+                    fused_add_norm=True, final_pool_type="mean", drop_path_rate=0.0).cuda()
     x = torch.randn(2, 3, 64, 64, device="cuda")
-    with pytest.raises(RuntimeError, match="fp16 autocast is not supported"):
-        with torch.autocast("cuda", dtype=torch.float16):
-            m(x)
+    ref = m(x)                                                  # fp32 run
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = m(x)
+    assert y.dtype == torch.float16 and torch.isfinite(y.float()).all()
+    assert (y.float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    # training under fp16 autocast with a scaled loss: finite gradients equal to the fp32 run's (x the scale)
+    m.zero_grad()
+    ref.float().square().mean().backward()
+    g32 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = m(x).float().square().mean()
+    (loss * 1024.0).backward()
+    for n, p in m.named_parameters():
+        assert torch.isfinite(p.grad).all(), n
+        s_ = max(g32[n].abs().max().item(), 1e-6)
+        assert (p.grad / 1024.0 - g32[n]).abs().max().item() <= 2e-2 * s_, n
+    # a .half() model on fp16 images (inference): fp16 out, close to the fp32 model evaluated on the same rounded inputs
+    import copy
+    mh = copy.deepcopy(m).half().eval()
+    mr = copy.deepcopy(mh).float().eval()                        # fp16-rounded parameters, fp32 arithmetic
+    with torch.no_grad():
+        yh = mh(x.half())
+        yr = mr(x.half().float())
+    assert yh.dtype == torch.float16
+    assert (yh.float() - yr).abs().max().item() <= 2e-3 * max(1.0, yr.abs().max().item())
+    # the mixer on its own: fp16 activations in -> fp16 out; fp16 parameters get fp16 gradients
     mx = Mamba(64, token_size=(4, 4)).cuda()
-    with pytest.raises(RuntimeError, match="fp16 autocast is not supported"):
-        with torch.autocast("cuda", dtype=torch.float16):
-            mx(torch.randn(2, 16, 64, device="cuda"))
-    with pytest.raises(RuntimeError, match="fp16 activations are not supported"):
-        mx.half()(torch.randn(2, 16, 64, device="cuda").half())
+    h = torch.randn(2, 16, 64, device="cuda")
+    y32 = mx(h)
+    mxh = copy.deepcopy(mx).half()
+    hh = h.half().requires_grad_()
+    yh = mxh(hh)
+    assert yh.dtype == torch.float16 and (yh.float() - y32).abs().max().item() <= 1e-2 * max(1.0, y32.abs().max().item())
+    yh.float().sum().backward()
+    assert hh.grad.dtype == torch.float16 and all(p.grad is not None and p.grad.dtype == torch.float16 for p in mxh.parameters())
+    with torch.autocast("cuda", dtype=torch.float16):
+        ya = mx(h)
+    assert (ya.float() - y32).abs().max().item() <= 1e-5 * max(1.0, y32.abs().max().item())      # fp32 inside
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert torch.isfinite(m(x).float()).all()
 

@@ -226,3 +226,46 @@ def test_short_scan_segmented_forward_vs_oracle(Bsz, D, L, itype):
     for k in cpu:
         gr, gg = lc[k].grad, lg[k].grad
         assert _maxerr(gg, gr) <= gtol * max(1.0, gr.abs().max().item()), (k, _maxerr(gg, gr), gr.abs().max().item())
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("seqlen", [14, 200])
+def test_scan_denormal_range_inputs_vs_oracle(itype, seqlen):
+    """The scan / conv / mixer kernels are built with -fgpu-flush-denormals-to-zero (fastvim_amd/build.py; the reference's
+    extension is built with nvcc --use_fast_math, which flushes as well: mamba-1p1p1/setup.py:131-149).  Feed the kernel
+    inputs whose intermediate products live in the fp32 denormal range -- tiny steps delta in [1e-6, 1e-3], A in [-16, -1],
+    and u a mixture of O(1) values and values of 1e-20 ... 1e-30, so that delta * B * u and C * x are denormal for part of
+    the channels -- and hold it to the same bound as everywhere else: 1e-5 * max(1, max|y|) against the fp64 oracle (fp32
+    I/O; one storage ulp for the 16-bit types).  A flushed denormal is an absolute error below 1.2e-38 per term, so the bound
+    holds iff nothing ELSE depends on denormal arithmetic (e.g. a scaled exp / log expansion)."""
+    from fastvim_amd.selective_scan_interface import selective_scan_fn
+    from oracle import selective_scan_oracle
+    g = torch.Generator().manual_seed(seqlen)
+    Bsz, D, N = 2, 64, 16
+    u = torch.randn(Bsz, D, seqlen, generator=g)
+    tiny = 10.0 ** (-20.0 - 10.0 * torch.rand(Bsz, D, 1, generator=g))
+    u = torch.where(torch.rand(Bsz, D, 1, generator=g) < 0.5, u * tiny, u)            # half of the channels: 1e-20 .. 1e-30
+    delta = 10.0 ** (-6.0 + 3.0 * torch.rand(Bsz, D, seqlen, generator=g))            # [1e-6, 1e-3]
+    A = -(1.0 + 15.0 * torch.rand(D, N, generator=g))                                 # [-16, -1]
+    Bm = torch.randn(Bsz, 1, N, seqlen, generator=g)
+    Cm = torch.randn(Bsz, 1, N, seqlen, generator=g)
+    Dv = torch.randn(D, generator=g)
+    z = torch.randn(Bsz, D, seqlen, generator=g)
+    if itype != torch.float32:       # the inputs as the 16-bit kernel sees them (fp16 flushes 1e-20 itself: keep those exact zeros)
+        u, delta, Bm, Cm, z = (t.to(itype).float() for t in (u, delta, Bm, Cm, z))
+    dev = lambda t, act=True: t.cuda().to(itype) if act else t.cuda()
+    out, last = selective_scan_fn(dev(u), dev(delta), dev(A, False), dev(Bm), dev(Cm), dev(Dv, False), z=dev(z),
+                                  delta_bias=None, delta_softplus=False, return_last_state=True)
+    oref, lref = selective_scan_oracle(u, delta, A, Bm, Cm, Dv, z, None, False, True, compute_dtype=F64, out_dtype=F64)
+    scale = max(1.0, oref.abs().max().item())
+    if itype == torch.float32:
+        assert _maxerr(out, oref) <= 1e-5 * scale, (_maxerr(out, oref), scale)
+        # the tiny channels on their own scale as well: relative error of what is NOT denormal stays small
+        big = oref.abs() > 1e-30
+        rel = ((out.double().cpu() - oref).abs() / oref.abs().clamp_min(1e-300))[big]
+        assert rel.max().item() <= 1e-3, rel.max().item()
+    else:
+        ulp = 2.0 ** (-8 if itype == torch.bfloat16 else -11)
+        assert ((out.double().cpu() - oref).abs() <= ulp * oref.abs() + 1e-5 * scale).all()
+    assert _maxerr(last, lref) <= 1e-5 * max(1.0, lref.abs().max().item())
+    assert torch.isfinite(out.float()).all()
