@@ -4,14 +4,15 @@
 // d_inner = 384, d_model = 192, bf16 (FastVim-T).  Reference: mamba_simple_faster.py:356, 412-414, 434-444 and
 // models/fastvim.py:168-190.
 //
-// Why the two fit without a hand-off: both are partitioned by tokens.  A workgroup owns 64 consecutive memory tokens;
-//   phase 1  each of its four waves gates 16 of them with combine_fwd_wave's per-token arithmetic (a wave owns a whole
-//            token: LayerNorm sums are DPP reductions), stores g to HBM once -- backward needs it -- and into a
-//            64 x 384 bf16 A panel in LDS;
+// Why the two fit without a hand-off: both are partitioned by tokens.  A workgroup owns four pooling rows of one image
+// (up to 64 tokens: tile row 16 w + j = column j of pooling row i0 + w);
+//   phase 1  each of its four waves gates ONE pooling row with combine_fwd_wave's per-token arithmetic (a wave owns a
+//            whole token: LayerNorm sums are DPP reductions; one yc row per wave), stores g to HBM once -- backward
+//            needs it -- and into a 64 x 384 bf16 A panel in LDS;
 //   phase 2  the panel never moves again: the K loop has no barrier and no A traffic; wave w owns output columns
 //            [48 w, 48 w + 48) and streams ITS quarter of W_out straight from L2 into MFMA operand registers (a lane's
-//            fragment is 16 contiguous bytes of one weight row), three 32-deep k steps ahead -- the first three are
-//            requested at kernel entry and arrive under phase 1;
+//            fragment is 16 contiguous bytes of one weight row), six 32-deep k steps ahead in line pairs -- the first six
+//            are requested at kernel entry and arrive under phase 1;
 //   phase 3  the epilogue of gemm_addnorm_kernel<64>, lane for lane: product rounded to bf16 into an LDS tile, then
 //            residual add + RMSNorm of whole 192-wide rows (the residual rows are requested at kernel entry too).
 // g is read back by nobody in the forward pass: 19.3 MB of reads and one launch boundary per block go away.
@@ -141,9 +142,11 @@ __global__ __launch_bounds__(CG_NT, 2) void combine_out_proj_addnorm_kernel(CgPa
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) wrow[nb] = p.W + (long)(wv * 48 + nb * 16 + fn) * p.ldw + fk * 8;
 #pragma unroll
-    for (int s = 0; s < CG_PD; ++s)
+    for (int s = 0; s < CG_PD; s += 2)
 #pragma unroll
-      for (int nb = 0; nb < 3; ++nb) fb[s][nb] = *reinterpret_cast<const cg_bf16x8*>(wrow[nb] + s * 32);
+      for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fb[s + h][nb] = *reinterpret_cast<const cg_bf16x8*>(wrow[nb] + (s + h) * 32);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 3; ++q) ysum[q] = ysf[q] + ysb[q];
@@ -252,26 +255,37 @@ __global__ __launch_bounds__(CG_NT, 2) void combine_out_proj_addnorm_kernel(CgPa
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (cg_f32x4){0.f, 0.f, 0.f, 0.f};
   const char* afrag = smem + (lane & 15) * CG_RSA + (lane >> 4) * 16;
+  // k steps go in PAIRS: a lane's fragments of steps 2 j and 2 j + 1 are the two halves of one 128-byte line of its weight
+  // row, and a wave's load instruction touches 16 such rows -- refilled one step at a time, every line was pulled from L2
+  // twice (the 32 KB L1 does not keep it for a step: 8 waves x 6 KB pass through in between)
+  static_assert(CG_PD % 2 == 0 && CG_KS % 2 == 0, "the weight ring is refilled in line pairs");
 #pragma unroll
-  for (int ks = 0; ks < (CG_DBG == 2 ? 0 : CG_KS); ++ks) {
-    const int s = ks % CG_PD;
-    cg_bf16x8 cur[3];
+  for (int kp = 0; kp < (CG_DBG == 2 ? 0 : CG_KS); kp += 2) {
+    cg_bf16x8 cur[2][3];
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb) cur[nb] = fb[s][nb];
-    if (ks + CG_PD < CG_KS) {
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int nb = 0; nb < 3; ++nb) fb[s][nb] = *reinterpret_cast<const cg_bf16x8*>(wrow[nb] + (ks + CG_PD) * 32);
+      for (int nb = 0; nb < 3; ++nb) cur[h][nb] = fb[(kp + h) % CG_PD][nb];
+    if (kp + CG_PD < CG_KS) {
+#pragma unroll
+      for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          fb[(kp + h) % CG_PD][nb] = *reinterpret_cast<const cg_bf16x8*>(wrow[nb] + (kp + h + CG_PD) * 32);
     }
     // the refill stays HERE: left alone, the scheduler sinks every load to its first use (shorter live ranges) and each
-    // k step then waits out a full L2 round trip -- 33 of them in a row
+    // k step then waits out a full L2 round trip
     __builtin_amdgcn_sched_barrier(0);
-    cg_bf16x8 fa[4];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) fa[mb] = *reinterpret_cast<const cg_bf16x8*>(afrag + mb * 16 * CG_RSA + ks * 64);
+    for (int h = 0; h < 2; ++h) {
+      cg_bf16x8 fa[4];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+      for (int mb = 0; mb < 4; ++mb) fa[mb] = *reinterpret_cast<const cg_bf16x8*>(afrag + mb * 16 * CG_RSA + (kp + h) * 64);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[a], fa[b], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[h][a], fa[b], acc[a][b], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();       // every wave is done reading the panel: the product tile overlays it

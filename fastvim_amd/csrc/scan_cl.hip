@@ -404,7 +404,7 @@ __device__ __forceinline__ sf2 sexp2_2(sf2 a) { sf2 o; o.x = fv_exp2(a.x); o.y =
 
 #ifdef FASTVIM_TUNING_HOOKS
 extern "C" unsigned long long* fv_debug_get_stamps();
-// phase stamps (diagnostic build; tools/probe/scan_stamps.py): thread 0 stores s_memtime into [workgroup][element][8]
+// phase stamps (diagnostic build; tools/probe/scan_stamps.py): thread 0 stores s_memtime into [workgroup][element][12]
 __device__ __forceinline__ void sc_stamp(const ScanClParams& p, int bi, int slot) {
   if (p.stamps && threadIdx.x == 0) {
     unsigned long long t;
@@ -412,7 +412,7 @@ __device__ __forceinline__ void sc_stamp(const ScanClParams& p, int bi, int slot
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     __builtin_amdgcn_sched_barrier(0);
     const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    p.stamps[(wg * p.NBB + bi) * 8 + slot] = t;
+    p.stamps[(wg * p.NBB + bi) * 12 + slot] = t;
   }
 }
 #define SC_STAMP(bi, slot) sc_stamp(p, bi, slot)
@@ -728,8 +728,8 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
 #pragma unroll
         for (int w = 0; w < SH_NWV; ++w) t += s_part[((s * SH_NWV + w) * 4 + qq) * 8 + v];
         const int l = dir ? Lc - 1 - s : s;
-        out[l * W + col] = t;
-        if constexpr (XPJ) s_x[s * SH_XS + col] = t;
+        if constexpr (XPJ) s_x[s * SH_XS + col] = t;      // (its global copy is stored after the x_proj phase, below)
+        else out[l * W + col] = t;
       }
       for (int e = tid; e < Lc * (16 * RT); e += SH_THREADS) {       // (step, r) with r < 16 RT; no run-time division
         const int s = e / (16 * RT), r = e - s * (16 * RT);
@@ -738,16 +738,18 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
 #pragma unroll
           for (int w = 0; w < SH_NWV; ++w) t += s_pd[(w * 16 + s) * (16 * RT) + r];
           const int l = dir ? Lc - 1 - s : s;
-          out[l * W + r] = t;
           if constexpr (XPJ) s_x[s * SH_XS + r] = t;
+          else out[l * W + r] = t;
         }
       }
     }
+    SC_STAMP(bi, 7);
     if constexpr (XPJ) {
       // ---- x_proj adjoint, data half: (16 steps x W) @ (W x 16 channels) per wave and chunk on the fp32 matrix cores;
       //      result lane = (channel cm, steps 4 tg .. 4 tg + 3) -- the layout d u is stored from
       __syncthreads();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's weight fragments have landed (wave-private)
+      SC_STAMP(bi, 8);
       const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv = t2 >> 6;
       f32x4_t Do = {0.f, 0.f, 0.f, 0.f}, Dx = {0.f, 0.f, 0.f, 0.f};
       const float* ftab = s_ch + wv * 64 + (tg & 1) * 32 + cm;
@@ -761,6 +763,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
         Do = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f[0], Do, 0, 0, 0);
         Dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f[16], Dx, 0, 0, 0);
       }
+      SC_STAMP(bi, 9);
       T* x2 = (T*)p.dxc2;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -772,8 +775,17 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
           io<T>::st(x2 + o + (SH_CH - ch0), Dx[r]);
         }
       }
+      // the chunk's partial d x_dbl rows go out LAST, from their LDS copy: stored in the sums phase they sat between the
+      // weight fragments' LDS-DMA and the wait for it, and every wave then waited out a store's round trip per element
+      float* out = p.dxdbl + (((size_t)blockIdx.x * 2 + dir) * p.B + b) * Lc * W;
+      for (int e = t2; e < Lc * W; e += SH_THREADS) {
+        const int s = e / W, c = e - s * W;
+        const int l = dir ? Lc - 1 - s : s;
+        out[l * W + c] = s_x[s * SH_XS + c];
+      }
+      SC_STAMP(bi, 10);
     }
-    SC_STAMP(bi, 7);
+    SC_STAMP(bi, 11);
   }   // batch elements of this block
   const size_t per_dir = (size_t)p.d_in * (N + p.R + 1);
   float* base = p.pP + ((size_t)blockIdx.y * 2 + dir) * per_dir;
