@@ -151,7 +151,44 @@ def stream_floor(B, L, d_in, dtype):
     return out
 
 
-def kernel_table(B, rows, cols, d, depth, dtype):
+def floor_curve(dtype, sizes_mb=(8, 16, 32, 64, 112, 160)):
+    """[(traffic MB, us)] of a PLAIN copy kernel (1 read + 1 write) on HBM-cold operands, total traffic as given: the
+    price of merely moving a kernel row's algorithmic bytes in one launch on this box, same timing method as the rows."""
+    e = 2 if dtype == torch.bfloat16 else 4
+    pts = []
+    for mb in sizes_mb:
+        n = int(mb * 1e6 / 2 / e)
+        base = {k: torch.randn(n, device="cuda").to(dtype) for k in ("a", "b")}
+        fns = rotating(lambda s: s["b"].copy_(s["a"]), base, ("a", "b"), 2 * n * e)
+        pts.append((2 * n * e / 1e6, time_kernel(fns) * 1e6))
+        del fns, base
+    return pts
+
+
+def floor_us(curve, mb):
+    """Linear interpolation of ``floor_curve`` (extrapolated with the end slopes)."""
+    if mb <= curve[0][0]:
+        return curve[0][1] * max(mb / curve[0][0], 0.5)          # small launches: the fixed part dominates
+    for (x0, y0), (x1, y1) in zip(curve[:-1], curve[1:]):
+        if mb <= x1:
+            return y0 + (y1 - y0) * (mb - x0) / (x1 - x0)
+    (x0, y0), (x1, y1) = curve[-2], curve[-1]
+    return y1 + (y1 - y0) * (mb - x1) / (x1 - x0)
+
+
+def add_floors(kt, dtype):
+    """Per kernel row: ``floor_us`` = a plain copy moving the row's own algorithmic bytes (HBM-cold, this run) and
+    ``floor_ratio`` = us / floor_us (1.0 = the row costs what moving its bytes costs; the verdict's bar is 1.25)."""
+    curve = floor_curve(dtype)
+    for v in kt.values():
+        if "algorithmic_MB" in v and v.get("launches_per_step", 1) >= 1 and "us" in v:
+            f = floor_us(curve, v["algorithmic_MB"])
+            v["floor_us"] = round(f, 2)
+            v["floor_ratio"] = round(v["us"] / f, 2)
+    return [(round(a, 1), round(b, 2)) for a, b in curve]
+
+
+def kernel_table(B, rows, cols, d, depth, dtype, tpp=1):
     """Time every hand-written full-length kernel of one mixer block at the benchmark shape and price it against its
     ALGORITHMIC bytes (formulas in DESIGN.md).  ``us`` is HBM-COLD (operand sets rotated past the Infinity Cache, as
     inside the step); ``us_warm`` is the same launch repeated on one operand set (cache-resident: an upper bound on
@@ -159,7 +196,8 @@ def kernel_table(B, rows, cols, d, depth, dtype):
     from fastvim_amd import mixer_ops as M
     from fastvim_amd.layernorm import layer_norm_fn
     dev = "cuda"
-    d_in, L, R, N = 2 * d, rows * cols, -(-d // 16), 16
+    d_in, L, R, N = 2 * d, rows * cols * tpp, -(-d // 16), 16
+    prow = rows * tpp                        # pooled rows per image (channel-wise tokenization: one per channel token slot)
     e = 2 if dtype == torch.bfloat16 else 4
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s, dt=dtype: torch.randn(*s, device=dev, generator=g).to(dt)
@@ -171,35 +209,35 @@ def kernel_table(B, rows, cols, d, depth, dtype):
     Wdt = rn(d_in, R, dt=torch.float32) * R ** -0.5
     bdt = torch.full((d_in,), -4.0, device=dev)
     A_log = torch.log(torch.arange(1, N + 1, device=dev, dtype=torch.float32)).repeat(d_in, 1).contiguous()
-    T["xc"], T["skip"] = M.conv_pool_fwd(T["xz"], cw, cb, cwb, cbb, rows, cols, False, 0, 1.0, D=D, D_b=Db)
-    T["x_dbl"] = rn(2, B * rows, R + 2 * N)
+    T["xc"], T["skip"] = M.conv_pool_fwd(T["xz"], cw, cb, cwb, cbb, rows, cols, False, 0, 1.0, tpp, D=D, D_b=Db)
+    T["x_dbl"] = rn(2, B * prow, R + 2 * N)
     T["yc"] = M.scan_fwd(T["xc"], T["x_dbl"], Wdt, bdt, A_log, Wdt, bdt, A_log)
-    _, T["mean"], T["rstd"] = M.combine_fwd(T["xz"], T["skip"], T["yc"], lnw, lnb, 1e-5, rows, cols, False)
+    _, T["mean"], T["rstd"] = M.combine_fwd(T["xz"], T["skip"], T["yc"], lnw, lnb, 1e-5, rows, cols, False, tpp=tpp)
     T["dg"] = rn(B, L, d_in)
     T["dxz"] = torch.empty_like(T["xz"])
     T["d_o"], T["dyc"], _ = M.combine_bwd(T["dg"], T["xz"], T["skip"], T["yc"], lnw, lnb, T["mean"], T["rstd"], T["dxz"],
-                                          rows, cols, False)
-    T["dxc"] = torch.randn(2, B, rows, d_in, device=dev, generator=g)
+                                          rows, cols, False, tpp=tpp)
+    T["dxc"] = torch.randn(2, B, prow, d_in, device=dev, generator=g)
     T["hid"], T["res"] = rn(B, L, d), torch.randn(B, L, d, device=dev, generator=g)
     nw = torch.ones(d, device=dev)
     U = B * L * d_in * e                      # one full-length (B, L, d_in) tensor
-    small = B * rows * d_in
+    small = B * prow * d_in
     table = {      # name: (launch on an operand set, the set's tensors that rotate, algorithmic bytes, launches per block)
-        "conv_pool_fwd": (lambda s: M.conv_pool_fwd(s["xz"], cw, cb, cwb, cbb, rows, cols, False, 0, 1.0, D=D, D_b=Db),
+        "conv_pool_fwd": (lambda s: M.conv_pool_fwd(s["xz"], cw, cb, cwb, cbb, rows, cols, False, 0, 1.0, tpp, D=D, D_b=Db),
                           ("xz",), 2 * U + 2 * small * e, 1),            # x read, skip written, xc written
         "scan_fwd": (lambda s: M.scan_fwd(s["xc"], s["x_dbl"], Wdt, bdt, A_log, Wdt, bdt, A_log),
-                     ("xc", "x_dbl"), 2 * (small * e + B * rows * (R + 2 * N) * e + small * 4), 1),
-        "combine_fwd": (lambda s: M.combine_fwd(s["xz"], s["skip"], s["yc"], lnw, lnb, 1e-5, rows, cols, False),
+                     ("xc", "x_dbl"), 2 * (small * e + B * prow * (R + 2 * N) * e + small * 4), 1),
+        "combine_fwd": (lambda s: M.combine_fwd(s["xz"], s["skip"], s["yc"], lnw, lnb, 1e-5, rows, cols, False, tpp=tpp),
                         ("xz", "skip", "yc"), 3 * U + 2 * small * 4 + 2 * B * L * 4, 1),    # skip, z read; g written
         "combine_bwd": (lambda s: M.combine_bwd(s["dg"], s["xz"], s["skip"], s["yc"], lnw, lnb, s["mean"], s["rstd"],
-                                                s["dxz"], rows, cols, False),
+                                                s["dxz"], rows, cols, False, tpp=tpp),
                         ("dg", "xz", "skip", "yc", "mean", "rstd", "dxz"),
                         5 * U + 3 * small * 4 + 2 * B * L * 4, 1),   # dg, z, skip read; dz, do written
         "scan_bwd": (lambda s: M.scan_bwd(s["xc"], s["x_dbl"], Wdt, bdt, A_log, Wdt, bdt, A_log, s["dyc"]),
                      ("xc", "x_dbl", "dyc"),
-                     2 * (small * e + B * rows * (R + 2 * N) * (e + 4) + small * 4) + small * 4, 1),
+                     2 * (small * e + B * prow * (R + 2 * N) * (e + 4) + small * 4) + small * 4, 1),
         "conv_pool_bwd": (lambda s: M.conv_pool_bwd(s["xz"], s["d_o"], s["dxc"], cw, cb, cwb, cbb, D, Db, s["dxz"], rows, cols,
-                                                    False, 0, 1.0),
+                                                    False, 0, 1.0, tpp=tpp),
                           ("xz", "d_o", "dxc", "dxz"), 3 * U + 2 * small * 4, 1),
         "add_rmsnorm_fwd": (lambda s: layer_norm_fn(s["hid"], nw, None, residual=s["res"], eps=1e-5, prenorm=True,
                                                     residual_in_fp32=True, is_rms_norm=True),
@@ -211,20 +249,34 @@ def kernel_table(B, rows, cols, d, depth, dtype):
         Wx2c = (rn(2, R + 2 * N, d_in, dt=torch.float32) * d_in ** -0.5).to(dtype)
         if M.xproj_scan_fwd(T["xc"], Wx2c, Wdt, bdt, A_log, Wdt, bdt, A_log) is not None:
             table["scan_fwd"] = (lambda s: M.xproj_scan_fwd(s["xc"], Wx2c, Wdt, bdt, A_log, Wdt, bdt, A_log), ("xc",),
-                                 2 * (small * e + B * rows * (R + 2 * N) * e + small * 4) + Wx2c.numel() * e, 1)
+                                 2 * (small * e + B * prow * (R + 2 * N) * e + small * 4) + Wx2c.numel() * e, 1)
     # the x_proj adjoint as the step issues it (short pooled lengths: chunk sum + dxc += dx_dbl @ Wx + the bf16 dx_dbl rows
     # the grouped weight-gradient launch reads; the weight gradient itself is in gemm_wgrad_grouped).  Algorithmic bytes:
     # the scan backward's chunk partials read once, dxc read and written, the fp32 weight, the bf16 rows written
     W_ = R + 2 * N
-    if dtype == torch.bfloat16 and W_ in M.XPROJ_WIDTHS:
+    folded = (dtype == torch.bfloat16 and tpp == 1 and M.scan_bwd_xproj_ok(T["xc"], Wdt, False, rows, cols, 1))
+    if folded:
+        # FastVim-T: the x_proj adjoint's data half runs INSIDE the scan backward (round 5) and the conv + pool adjoint
+        # takes the pooled gradient as two addends -- timed as the step issues them.  Bytes: the scan row's + the second
+        # addend (storage dtype) written once and read once + the fp32 x_proj weight
+        Wx32 = rn(2, W_, d_in, dt=torch.float32) * d_in ** -0.5
+        _, T["dxc2"], _, _ = M.scan_bwd_xproj(T["xc"], T["x_dbl"], Wdt, bdt, A_log, Wdt, bdt, A_log, T["dyc"], Wx32[0], Wx32[1])
+        sb = table["scan_bwd"]
+        table["scan_bwd"] = (lambda s: M.scan_bwd_xproj(s["xc"], s["x_dbl"], Wdt, bdt, A_log, Wdt, bdt, A_log, s["dyc"], Wx32[0], Wx32[1]),
+                             sb[1], sb[2] + 2 * small * e + 2 * W_ * d_in * 4, 1)
+        cb_ = table["conv_pool_bwd"]
+        table["conv_pool_bwd"] = (lambda s: M.conv_pool_bwd(s["xz"], s["d_o"], s["dxc"], cw, cb, cwb, cbb, D, Db, s["dxz"], rows, cols,
+                                                            False, 0, 1.0, dxc2=s["dxc2"]),
+                                  cb_[1] + ("dxc2",), cb_[2] + 2 * small * e, 1)
+    elif dtype == torch.bfloat16 and W_ in M.XPROJ_WIDTHS:
         Wx32 = rn(2, W_, d_in, dt=torch.float32) * d_in ** -0.5
         _, T["dxdbl_chunks"], _ = M.scan_bwd(T["xc"], T["x_dbl"], Wdt, bdt, A_log, Wdt, bdt, A_log, T["dyc"], keep_chunks=True)
         nch = T["dxdbl_chunks"].shape[0]
         if nch < M._XPROJ_PRESUM:
             table["xproj_bwd"] = (lambda s: M.xproj_bwd(s["dxdbl_chunks"], s["xc"], Wx32[0], Wx32[1], s["dxc"], dw=False),
                                   ("dxdbl_chunks", "dxc"),
-                                  nch * 2 * B * rows * W_ * 4 + 2 * (2 * small * 4) + 2 * W_ * d_in * 4
-                                  + 2 * B * rows * ((W_ + 7) // 8 * 8) * 2, 1)
+                                  nch * 2 * B * prow * W_ * 4 + 2 * (2 * small * 4) + 2 * W_ * d_in * 4
+                                  + 2 * B * prow * ((W_ + 7) // 8 * 8) * 2, 1)
     out = {}
     # the backward wrappers sum their per-block gradient partials right away when no flat gradient is attached; in
     # the training step those sums are deferred into reduce_partials_multi launches (timed by the step, not here), so
@@ -334,8 +386,23 @@ def kernel_table(B, rows, cols, d, depth, dtype):
                                                              L_.i32(2 * d_in), ctypes.c_long(2 * d_in), ctypes.c_long(d),
                                                              L_.ptr(W_out), L_.ptr(s["dg"]), L_.i32(d_in), ctypes.c_long(d_in),
                                                              L_.stream_of(s["xz2"])), "dgrad_addnorm_bwd")
+            fuse_c = tpp == 1 and M.combine_out_proj_addnorm_ok(T["xz"], rows, cols, 1, d)
+            if fuse_c:
+                # round 5: combine is the A-tile producer of this launch from the third block on (fastvim._run_layers_chained)
+                C_ = dict(T, resid=F_["resid"])
+                C_["gbuf"], C_["mbuf"], C_["rbuf"] = M.combine_buffers(T["xz"], lnw)
+                sc_b = torch.ones(B, device=dev)
+
+                def fused_cfwd(s):
+                    return M.combine_out_proj_addnorm(s["xz"], s["skip"], s["yc"], lnw, lnb, 1e-5, rows, cols, False,
+                                                      (s["gbuf"], s["mbuf"], s["rbuf"]), W_out, s["resid"], nw_, sc_b, L, 1e-5)
+                gemm_row("combine_out_proj_addnorm_fwd", fused_cfwd, ("xz", "skip", "yc", "resid", "gbuf"), C_,
+                         3 * U + 2 * small * 4 + 2 * B * L * 4 + Mt * (d * (4 + 4 + e) + 4), 2.0 * Mt * d * d_in, depth - 2)
+                out["combine_fwd"]["launches_per_step"] = 2
+                out["combine_fwd"]["us_per_step"] = round(out["combine_fwd"]["us"] * 2, 1)
+                del C_
             gemm_row("gemm_out_proj_addnorm_fwd", fused_fwd, ("g2", "resid", "y", "ro", "rs"), F_,
-                     Mt * (d_in * e + d * (4 + 4 + e) + 4), 2.0 * Mt * d * d_in, depth - 1)
+                     Mt * (d_in * e + d * (4 + 4 + e) + 4), 2.0 * Mt * d * d_in, 1 if fuse_c else depth - 1)
             gemm_row("gemm_in_proj_dgrad_addnorm_bwd", fused_bwd, ("xz2", "gg", "resid", "rstd", "y", "ro", "pw", "dg"), F_,
                      Mt * (2 * d_in * e + d * (4 + 4 + 4 + e) + 4 + d_in * e), 2.0 * Mt * d * 3 * d_in, depth - 1)
             del F_
@@ -356,7 +423,7 @@ TRACE_NAMES = {
     "combine_bwd": "combine_bwd_wave_kernel", "scan_bwd": "scan_cl_bwd_short_kernel", "conv_pool_bwd": "conv_pool_bwd_row_kernel",
     "add_rmsnorm_fwd": "add_norm_fwd3_kernel", "gemm_out_proj_addnorm_fwd": "gemm_addnorm_kernel",
     "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 4>",
-    "xproj_bwd": "xproj_bwd_kernel",
+    "xproj_bwd": "xproj_bwd_kernel", "combine_out_proj_addnorm_fwd": "combine_out_proj_addnorm_kernel",
 }
 PMC_TRAFFIC_JSON = "r04_v1_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
 STEP_TRACE_CSV = "r04_v1_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r04_v1 (profiles/README.md)
@@ -619,6 +686,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     torch.cuda.synchronize()
     if seg is not None:
         timing["on"] = True
+        seg.exchange.timing = world > 1          # per-bucket launch-to-completion events (fastvim_amd/ddp.py)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
@@ -641,7 +709,12 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
             "buckets": len(ex.bounds) if ex is not None else 1,
             "bucket_MB": [round((b - a) * 4 / 1e6, 2) for a, b in ex.bounds] if ex is not None else None,
             "wire_dtype": ex.wire_names() if ex is not None else None,
-            "allreduce_exposed_ms": None if seg is None else round(seg.exposed_ms(), 3)}
+            # per bucket, in the order backward completes them: launch -> completion of its all-reduce (events on the
+            # exchange's own stream); only the wait after the LAST backward graph is exposed to the step
+            "bucket_allreduce_ms": (seg.exchange.bucket_ms() if seg is not None else None),
+            "allreduce_exposed_ms": None if seg is None else round(seg.exposed_ms(), 3),
+            "launcher_env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "MASTER_ADDR", "MASTER_PORT",
+                                                              "OMP_NUM_THREADS", "NCCL_DEBUG", "FASTVIM_BENCH_ONE_GPU")}}
     flat.close()
     return elapsed, loss_val, extras
 
@@ -667,19 +740,27 @@ def other_configs_block(dtype, rank, dev, steps=5, warmup=2):
             continue
         row = {"ms_per_step": round(el / steps * 1e3, 3), "images_per_sec": round(batch * steps / el, 1), "steps": steps,
                "warmup": warmup, "final_loss": round(lv, 4), "finite": lv == lv, "params_M": round(ex["params"] / 1e6, 2)}
-        if mname in ("T", "S", "B"):
+        if mname in ("T", "S", "B", "C"):
             gs = img // 16
-            d = {"T": 192, "S": 384, "B": 768}[mname]
-            kt = kernel_table(batch, gs, gs, d, 24, torch.bfloat16 if dtype == "bf16" else torch.float32)
+            d = {"T": 192, "S": 384, "B": 768, "C": 384}[mname]
+            adt = torch.bfloat16 if dtype == "bf16" else torch.float32
+            # (channel model: tokens_per_patch = channels, Channel-First -- the cell-walking conv kernels, pooled length rows x channels)
+            kt = kernel_table(batch, gs, gs, d, 24, adt, tpp=ch if mname == "C" else 1)
+            try:
+                add_floors(kt, adt)
+            except Exception as e_:
+                row["floor_error"] = f"{type(e_).__name__}: {e_}"[:200]
             dom = max(kt, key=lambda k: kt[k]["us_per_step"])
             row["dominant_kernel"] = {"kernel": dom, "avg_us": kt[dom]["us"], "us_per_step": kt[dom]["us_per_step"],
                                       "GBps": kt[dom]["GBps"], "hbm_frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
                                       **({"TFLOPs": kt[dom]["TFLOPs"], "mfma_frac": kt[dom]["mfma_frac"]} if "TFLOPs" in kt[dom] else {})}
             row["mfma_frac"] = {k[5:]: kt[k]["mfma_frac"] for k in kt if k.startswith("gemm_") and "mfma_frac" in kt[k]}
             row["kernel_us"] = {k: kt[k]["us"] for k in kt}
+            row["kernel_floor_ratio"] = {k: kt[k]["floor_ratio"] for k in kt if "floor_ratio" in kt[k]}
+            row["kernel_hbm_frac"] = {k: round(kt[k]["GBps"] / HBM_PEAK_GBS, 3) for k in kt}
             row["roofline_step"] = step_roofline(kt, el / steps * 1e3)
             if d >= 384:      # the vendor library on the same shapes, same box, HBM-cold: how good is 0.4-0.5 of peak here?
-                Mt, d_in_ = batch * gs * gs, 2 * d
+                Mt, d_in_ = batch * gs * gs * (ch if mname == "C" else 1), 2 * d
                 try:
                     lib_tf = {"in_proj_fwd": library_gemm_ceiling(Mt, 2 * d_in_, d), "out_proj_fwd": library_gemm_ceiling(Mt, d, d_in_),
                               "out_proj_dgrad": library_gemm_ceiling(Mt, d_in_, d, trans_b=False),
@@ -793,6 +874,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--kernels", action="store_true",
+                    help="N > 1: time the kernel table as well (rank 0, after the timed region, the other ranks parked in a "
+                         "barrier -- off by default there: the scaling run stays short and no rank idles next to a busy one)")
     ap.add_argument("--buckets", type=int, default=3,
                     help="N > 1: gradient buckets = backward graph segments the all-reduce overlaps with (0: one all-reduce after backward)")
     ap.add_argument("--segmented", action="store_true",
@@ -810,6 +894,10 @@ def main():
     ap.add_argument("--no-scan-op", action="store_true",
                     help="skip timing the reference-layout op selective_scan_fn at every config's (B, d_in, Lc, N)")
     args = ap.parse_args()
+    if args.gpus > 1 and not args.kernels:
+        args.no_kernels = True
+        args.no_other_configs = True
+        args.no_scan_op = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU), BEFORE this process has
@@ -887,8 +975,12 @@ def main():
             out["ddp"] = extras["ddp"]
         if args.segmented:
             out["config"]["segmented_step"] = args.buckets
-        if not args.no_kernels and args.model not in ("C", "V", "M"):
-            kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype)
+        if not args.no_kernels and args.model not in ("V", "M"):
+            kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype, tpp=args.channels if args.model == "C" else 1)
+            try:      # per row: what a plain copy of the row's own bytes costs on this box (floor_us) and us / floor_us
+                out["floor_curve_copy_MB_us"] = add_floors(kt, amp_dtype)
+            except Exception as e_:
+                out["floor_curve_copy_MB_us"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
             dom = max(kt, key=lambda k: kt[k]["us_per_step"])     # the kernel that costs the most time per step
             if (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16"):
                 for k_, v_ in in_step_trace_us().items():         # the same kernel inside the step (committed rocprofv3 trace)
@@ -904,7 +996,8 @@ def main():
                 pass
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kt[dom]["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(kt[dom]["GBps"] / HBM_PEAK_GBS, 4),
-                               "traffic": traffic, "avg_us": kt[dom]["us"],
+                               "traffic": traffic, "avg_us": kt[dom]["us"], "floor_us": kt[dom].get("floor_us"),
+                               "floor_ratio": kt[dom].get("floor_ratio"),
                                "algorithmic_bytes": int(kt[dom]["algorithmic_MB"] * 1e6),
                                # avg_us is HBM-cold (operand sets rotated past the 256 MB Infinity Cache, as the step sees
                                # the kernel); the cache-resident repeat of one operand set is kept beside it
@@ -916,7 +1009,7 @@ def main():
             out["roofline"]["committed_profile"] = profile_stamp()
             out["roofline_step"] = step_roofline(kt, ms)
             try:      # plain elementwise kernels on cold tensors of the same size: what a 10-15 us launch can reach at all
-                out["roofline"]["elementwise_floor_same_size_cold"] = stream_floor(args.batch, gs * gs, 2 * d, amp_dtype)
+                out["roofline"]["elementwise_floor_same_size_cold"] = stream_floor(args.batch, gs * gs * (args.channels if args.model == "C" else 1), 2 * d, amp_dtype)
             except Exception as e_:
                 out["roofline"]["elementwise_floor_same_size_cold"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
             if dom.startswith("scan"):

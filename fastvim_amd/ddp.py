@@ -57,6 +57,12 @@ class GradExchange:
             all(a[1] == b[0] for a, b in zip(covered[:-1], covered[1:])), "buckets must tile the gradient buffer"
         self._pending = []          # (work handle, view, wire buffer or None)
         self._wire = {}             # persistent wire buffers (graph-safe addresses, no per-step allocation)
+        # per-bucket timing (bench.py --gpus N): events bracketing each bucket's collective ON A STREAM OF ITS OWN -- the
+        # first waits for the producer (the backward segment), the second for the collective's completion -- so the
+        # duration is launch-to-completion of the exchange itself, whatever the compute stream does meanwhile
+        self.timing = False
+        self._cs = None
+        self._timed = []            # (bucket, start event, end event)
 
     @property
     def world_size(self):
@@ -67,6 +73,8 @@ class GradExchange:
         if self.world_size == 1:
             return
         lo, hi = self.bounds[k]
+        if self.timing and self.flat.is_cuda:
+            return self._launch_timed(k)
         for s in range(lo, hi, self.chunk):
             e = min(hi, s + self.chunk)
             view = self.flat[s:e]
@@ -82,6 +90,42 @@ class GradExchange:
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._pending.append((work, view, None))
 
+    def _launch_timed(self, k):
+        """``launch`` with the bucket's collective bracketed by events on a side stream (see ``timing``)."""
+        if self._cs is None:
+            self._cs = torch.cuda.Stream(self.flat.device)
+        cur = torch.cuda.current_stream(self.flat.device)
+        self._cs.wait_stream(cur)
+        lo, hi = self.bounds[k]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self._cs):
+            e0.record()
+            for s in range(lo, hi, self.chunk):
+                e = min(hi, s + self.chunk)
+                view = self.flat[s:e]
+                wire = self.wire_dtypes[k]
+                buf = None
+                if wire is not None:
+                    buf = self._wire.get((s, e))
+                    if buf is None:
+                        buf = self._wire[(s, e)] = torch.empty(e - s, device=view.device, dtype=wire)
+                    buf.copy_(view)
+                work = dist.all_reduce(buf if buf is not None else view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work.wait()                      # (stream-wise: the side stream waits for the collective)
+                if buf is not None:
+                    view.copy_(buf)
+            e1.record()
+        self._timed.append((k, e0, e1))
+        self._pending.append((None, None, None))      # finish() joins the side stream
+
+    def bucket_ms(self):
+        """Per bucket: mean launch-to-completion time of its collective over the timed steps (after a synchronize)."""
+        out = {}
+        for k, e0, e1 in self._timed:
+            out.setdefault(k, []).append(e0.elapsed_time(e1))
+        self._timed = []
+        return [round(sum(out[k]) / len(out[k]), 3) if k in out else None for k in range(len(self.bounds))]
+
     def finish(self, mean=True):
         """Wait (stream-wise on GPUs) for every launched bucket; ``mean``: turn the sums into means (one more pass over
         the buffer -- pass False when the optimizer applies ``1 / world_size`` itself)."""
@@ -90,6 +134,9 @@ class GradExchange:
             return
         pending, self._pending = self._pending, []
         for work, view, buf in pending:
+            if work is None:                     # timed launch: everything happened on the side stream
+                torch.cuda.current_stream(self.flat.device).wait_stream(self._cs)
+                continue
             work.wait()
             if buf is not None:
                 view.copy_(buf)

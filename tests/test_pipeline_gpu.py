@@ -102,6 +102,32 @@ def test_two_rank_segmented_bench_line(model, batch, total_mb, wire, extra):
     assert out["ddp"]["wire_dtype"] == wire
     assert out["ddp"]["allreduce_exposed_ms"] is not None and out["config"]["final_loss"] == out["config"]["final_loss"]
     assert out["config"]["global_batch"] == 2 * batch and out["value"] > 0
+    ms = out["ddp"]["bucket_allreduce_ms"]                                   # launch -> completion of each bucket's all-reduce
+    assert len(ms) == 3 and all(m is not None and m > 0 for m in ms)
+    assert out["ddp"]["launcher_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and out["ddp"]["launcher_env"]["MASTER_ADDR"] == "127.0.0.1"
+
+
+@pytest.mark.parametrize("buckets", [0, 1, 3, 6])
+def test_eight_rank_bench_line_on_one_gpu(buckets):
+    """``python bench.py --gpus 8`` as the driver's scaling run issues it, eight ranks on GPU 0 over gloo
+    (FASTVIM_BENCH_ONE_GPU=1), batch 2 per rank: everything that depends on the rank COUNT -- eight children on one port,
+    per-rank seeds, bucket bounds, rank 0's stdout relay, the barrier-bracketed timing -- and every legal --buckets value
+    (0: one all-reduce after a single-graph backward; 1 / 3 / 6: the chain of graphs).  No kernel table under N > 1 by
+    default: the line stays short and no rank idles beside a busy one."""
+    env = dict(os.environ, FASTVIM_BENCH_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "2", "--steps", "2", "--warmup", "1",
+           "--buckets", str(buckets), "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ddp"]["ranks"] == 8 and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
+    assert out["ddp"]["overlapped"] is (buckets > 0) and out["ddp"]["buckets"] == max(buckets, 1)
+    assert "kernels" not in out and "other_configs" not in out
+    assert out["config"]["final_loss"] == out["config"]["final_loss"] and out["value"] > 0
 
 
 def test_self_launch_passes_the_childs_failure_on():
