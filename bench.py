@@ -44,6 +44,13 @@ def build_model(name, img_size, drop_path, channels=8):
     if name == "V":      # Vim-T baseline (models/vim.py): un-pooled scan, middle class token -- the paper's comparison point
         from fastvim_amd.vim import vim_tiny_patch16_224_final_pool_mean_abs_pos_embed_with_midclstok_div2 as vim_t
         return vim_t(img_size=img_size, drop_path_rate=drop_path)
+    if name == "CV":     # ChannelVim-S/16, the un-pooled channel baseline with a middle class token (cell_imaging/config/ChannelVimS.yaml:24)
+        from fastvim_amd.models_channel_mamba import (
+            channelvim_small_patch16_224_final_pool_mean_abs_pos_embed_with_midclstok_div2 as cvim_s)
+        return cvim_s(img_size=img_size, channels=channels, hcs=False, drop_path_rate=drop_path)
+    if name == "MV":     # Vim-B masked autoencoder, the un-pooled MAE baseline (mae/config/pretrain_VimB.yaml:22)
+        from fastvim_amd.fastvim_mae import mae_vim_base_dec512d2b
+        return mae_vim_base_dec512d2b(img_size=img_size)
     if name == "M":      # FastVim-B masked autoencoder, the reference's MAE pre-training model (mae/config/pretrain_FastVimB.yaml:25)
         from fastvim_amd.models_mae import mae_FastVim_base_dec512d2b
         return mae_FastVim_base_dec512d2b(img_size=img_size)
@@ -605,10 +612,11 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     from fastvim_amd.losses import SoftTargetCrossEntropy
 
     torch.manual_seed(1234)                    # identical init on every rank (DDP broadcast equivalent)
-    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1, "V": 0.05, "M": 0.0}[model_name]   # imagenet_classification/config/FastVim*.yaml:15
+    drop_path = {"T": 0.05, "S": 0.15, "B": 0.4, "C": 0.1, "V": 0.05, "M": 0.0, "MV": 0.0, "CV": 0.1}[model_name]   # imagenet_classification/config/FastVim*.yaml:15
     model = build_model(model_name, img, drop_path, channels).to(dev).train()
     gen = torch.Generator().manual_seed(100 + rank)
-    in_ch = channels if model_name == "C" else 3
+    in_ch = channels if model_name in ("C", "CV") else 3
+    is_mae = model_name in ("M", "MV")
     x = torch.randn(batch, in_ch, img, img, generator=gen).to(dev)
     tgt = soft_targets(batch, 1000, gen, dev)
     flat = FlatTrainingState(model, comm_dtype=comm_dtype)      # flat fp32 params / grads + bf16 shadow weights
@@ -617,7 +625,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     # one fused kernel: AdamW (the reference recipe's two param groups) + ModelEmaV2 lerp + bf16 shadow refresh
     # MAE pre-training recipe: lr = blr * batch / 256 with blr 1.5e-4, betas (0.9, 0.95) (mae/config/pretrain_FastVimB.yaml:20,
     # mae/mae_imagenet.py); the classification recipe's 1e-3 without warm-up diverges on it within ~10 steps
-    lr, betas = (1.5e-4 * batch * world / 256, (0.9, 0.95)) if model_name == "M" else (1e-3, (0.9, 0.999))
+    lr, betas = (1.5e-4 * batch * world / 256, (0.9, 0.95)) if is_mae else (1e-3, (0.9, 0.999))
     opt = FlatAdamW(flat, model, lr=lr, betas=betas, weight_decay=0.05, no_decay=no_decay, ema_decay=0.9999)
     torch.manual_seed(5678 + rank)             # per-rank DropPath streams
     criterion = SoftTargetCrossEntropy()
@@ -625,11 +633,11 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     def fwd_bwd():
         flat.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == "bf16"):
-            if model_name == "M":
+            if is_mae:
                 loss = model(x, mask_ratio=0.75)[0]      # norm-pix MSE on the 75 % removed patches (mae_imagenet.py SSLModule)
             else:
                 logits = model(x)
-        if model_name != "M":
+        if not is_mae:
             loss = criterion(logits, tgt)      # SoftTargetCrossEntropy (supervised_imagenet.py:83), fused value + gradient
         loss.backward()
         flat.finish_backward()
@@ -813,6 +821,29 @@ def inference_throughput(model_name, img, batch, dev, steps=5, warmup=2):
     return {"ms_per_batch": round(el / steps * 1e3, 3), "images_per_sec": round(batch * steps / el, 2), "finite": ok}
 
 
+def baselines_block(dev, steps=3, warmup=1):
+    """SURVEY row f2 for the other two task families: the pooled model against its un-pooled baseline at the shape the
+    reference's configs train -- MAE pre-training (FastVim-B vs Vim-B encoder, 224 px, batch 128, mask 0.75:
+    mae/config/pretrain_{FastVimB,VimB}.yaml) and JUMP-CP-shaped classification (FastChannelVim-S/16 vs ChannelVim-S/16,
+    8 channels, 224 px, batch 64: cell_imaging/config/{FastChannelVimS,ChannelVimS}.yaml).  Training steps on the same
+    kernels; the baselines scan every (kept) token instead of the pooled rows."""
+    out = {}
+    for key, fast, base, batch, ch in (("mae_pretrain_224px_bs128", "M", "MV", 128, 3),
+                                       ("channel_8ch_224px_bs64", "C", "CV", 64, 8)):
+        row = {}
+        for tag, name in (("pooled", fast), ("unpooled_baseline", base)):
+            try:
+                el, lv, ex = run_training_steps(name, 224, batch, ch, "bf16", steps, warmup, 0, 1, dev)
+                row[tag] = {"model": name, "ms_per_step": round(el / steps * 1e3, 2), "images_per_sec": round(batch * steps / el, 1),
+                            "finite": lv == lv, "params_M": round(ex["params"] / 1e6, 2)}
+            except Exception as e:
+                row[tag] = {"model": name, "error": f"{type(e).__name__}: {e}"[:300]}
+        if all("ms_per_step" in row[t] for t in ("pooled", "unpooled_baseline")):
+            row["train_speedup_pct"] = round((row["unpooled_baseline"]["ms_per_step"] / row["pooled"]["ms_per_step"] - 1.0) * 100.0, 1)
+        out[key] = row
+    return out
+
+
 def vim_vs_fastvim_block(dev, img=2048, batch=8):
     """the un-pooled Vim baseline against FastVim at the resolution of the paper's headline claim ("up to
     72.5 % speedup in inference speed ... on high resolution (2048x2048) images", /root/reference README.md:15).  Same
@@ -865,7 +896,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C", "V", "M"],
+    ap.add_argument("--model", default="T", choices=["T", "S", "B", "C", "V", "M", "MV", "CV"],
                     help="FastVim-T/S/B, C = FastChannelVim-S/16 (use --batch 64 for BASELINE configs[4]), V = Vim-T baseline")
     ap.add_argument("--channels", type=int, default=8, help="input channels of the channel model (--model C)")
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
@@ -953,10 +984,12 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         gs = args.img // 16
-        d = {"T": 192, "S": 384, "B": 768, "C": 384, "V": 192, "M": 768}[args.model]
+        d = {"T": 192, "S": 384, "B": 768, "C": 384, "V": 192, "M": 768, "MV": 768, "CV": 384}[args.model]
         mname = (f"FastChannelVim-S/16 {args.channels}ch" if args.model == "C" else
                  "Vim-T (un-pooled baseline)" if args.model == "V" else
-                 "FastVim-B MAE pre-training (mask 0.75, decoder 512x2)" if args.model == "M" else f"FastVim-{args.model}")
+                 "FastVim-B MAE pre-training (mask 0.75, decoder 512x2)" if args.model == "M" else
+                 "Vim-B MAE pre-training (un-pooled baseline, mask 0.75, decoder 512x2)" if args.model == "MV" else
+                 f"ChannelVim-S/16 {args.channels}ch (un-pooled baseline)" if args.model == "CV" else f"FastVim-{args.model}")
         out = {
             "metric": "images/sec %s %dpx bs=%d/GPU fwd+bwd (+all-reduce +AdamW +EMA), whole job" % (mname, args.img, args.batch),
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -975,7 +1008,7 @@ def main():
             out["ddp"] = extras["ddp"]
         if args.segmented:
             out["config"]["segmented_step"] = args.buckets
-        if not args.no_kernels and args.model not in ("V", "M"):
+        if not args.no_kernels and args.model not in ("V", "M", "MV", "CV"):
             kt = kernel_table(args.batch, gs, gs, d, 24, amp_dtype, tpp=args.channels if args.model == "C" else 1)
             try:      # per row: what a plain copy of the row's own bytes costs on this box (floor_us) and us / floor_us
                 out["floor_curve_copy_MB_us"] = add_floors(kt, amp_dtype)
@@ -1028,7 +1061,7 @@ def main():
                 "largest_gemm": {"kernel": gm, "bound": "mfma", "achieved": kt[gm]["TFLOPs"], "peak": 2500.0,
                                  "unit": "TFLOP/s", "frac": kt[gm]["mfma_frac"], "hbm_GBps": kt[gm]["GBps"],
                                  "avg_us": kt[gm]["us"]}}
-        if not args.no_cpu_baseline and world == 1 and args.model not in ("C", "V", "M"):
+        if not args.no_cpu_baseline and world == 1 and args.model not in ("C", "V", "M", "MV", "CV"):
             out["cpu_baseline"] = cpu_baseline()
         if not args.no_scan_op and not args.no_kernels and world == 1 and args.model == "T":
             out["scan_op"] = scan_op_table(cpu=not args.no_cpu_baseline)
@@ -1036,6 +1069,7 @@ def main():
                 and (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16")):
             out["other_configs"] = other_configs_block(args.dtype, rank, dev)
             out["other_configs"]["f2_vim_vs_fastvim_2048px"] = vim_vs_fastvim_block(dev)
+            out["other_configs"]["f2_baselines_mae_and_channel"] = baselines_block(dev)
             # forward-only (inference) throughput at 224 px, batch 128 -- eval mode, no_grad, bf16 autocast, HIP-graph replay
             inf = {}
             for key, mname in (("FastVim-T", "T"), ("FastVim-B", "B"), ("Vim-T", "V")):

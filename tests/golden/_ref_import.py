@@ -182,13 +182,17 @@ def load_reference():
     from mamba_ssm.modules import mamba_simple_channel_faster_2dcompress as mscf2    # 2-D compress channel mixer / model
     chan2 = importlib.import_module("models.channel_wise_tokenization.models_channel_mamba_faster_2dcompress")
 
-    for m in (fastvim, msf, chan, mscf, mae, chan2, mscf2):
+    # the two un-pooled baselines of the other task families (round 5): Vim-encoder MAE, ChannelVim with a middle class token
+    mae_vim = importlib.import_module("models.mae.fastvim_mae")
+    chan_vim = importlib.import_module("models.channel_wise_tokenization.models_channel_mamba")
+
+    for m in (fastvim, msf, chan, mscf, mae, chan2, mscf2, mae_vim, chan_vim):
         m.rms_norm_fn = rms_norm_fn
         m.layer_norm_fn = layer_norm_fn
         m.RMSNorm = RMSNorm
 
     ns = types.SimpleNamespace(
-        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, mscf2=mscf2, chan2=chan2, ms=ms, vim=vim, msmf=msmf, mae=mae, rms_norm_fn=rms_norm_fn,
+        ssi=ssi, ln=ln, msf=msf, fastvim=fastvim, mscf=mscf, chan=chan, mscf2=mscf2, chan2=chan2, ms=ms, vim=vim, msmf=msmf, mae=mae, mae_vim=mae_vim, chan_vim=chan_vim, rms_norm_fn=rms_norm_fn,
         layer_norm_fn=layer_norm_fn, RMSNorm=RMSNorm, causal_conv1d_fn=causal_conv1d_fn,
     )
     _loaded = ns

@@ -436,6 +436,81 @@ def gen_mae():
     save("mae.pt", cases)
 
 
+def gen_baselines():
+    """The two un-pooled baselines of the other task families (round 5, verdict item 8): the Vim-encoder MAE
+    (models/mae/fastvim_mae.py: class token in the middle of the kept tokens, appended in the decoder) and ChannelVim
+    (models/channel_wise_tokenization/models_channel_mamba.py: Channel-First tokens, middle class token).  Tiny models,
+    reference path use_fast_path=False (causal_conv1d_fn + selective_scan_ref)."""
+    cases = {}
+    for name, img, seed in (("mae_vim_64_keep4", 64, 61), ("mae_vim_96_keep9", 96, 62)):
+        torch.manual_seed(seed)
+        m = ref.mae_vim.MaskedAutoencoderViM(img_size=img, patch_size=16, depth=4, embed_dim=32, decoder_embed_dim=32,
+                                             decoder_depth=2, rms_norm=True, residual_in_fp32=True, fused_add_norm=True,
+                                             ssm_cfg={"use_fast_path": False})
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith((".D", ".D_b", "layernorm.weight", "norm.weight", "norm_f.weight", "decoder_norm.weight")):
+                    p.add_(0.1 * torch.randn_like(p))
+                elif n.endswith("bias") and p.requires_grad:
+                    p.add_(0.05 * torch.randn_like(p))
+        x = torch.randn(2, 3, img, img)
+        L = (img // 16) ** 2
+        noise = torch.rand(2, L)
+        rand = torch.rand
+        torch.rand = lambda *a, **k: noise.clone()     # random_masking draws torch.rand(N, L, device=...) (fastvim_mae.py:551)
+        try:
+            loss, pred, mask = m(x, mask_ratio=0.75)
+        finally:
+            torch.rand = rand
+        loss.backward()
+        keep = ("patch_embed.proj.weight", "cls_token", "layers.0.mixer.in_proj.weight", "layers.1.mixer.A_b_log",
+                "layers.3.mixer.D", "layers.2.mixer.conv1d_b.weight", "norm_f.weight", "decoder_embed.weight", "mask_token",
+                "decoder_blocks.1.mixer.x_proj.weight", "decoder_pred.bias")
+        cases[name] = dict(x=x, noise=noise, loss=loss.detach(), pred=pred.detach(), mask=mask,
+                           grads={n: p.grad.clone() for n, p in m.named_parameters() if n in keep},
+                           state_dict={k: v.clone() for k, v in m.state_dict().items()},
+                           cfg=dict(img_size=img, patch_size=16, depth=4, embed_dim=32, decoder_embed_dim=32, decoder_depth=2))
+    torch.manual_seed(78)        # initialisation contract
+    m = ref.mae_vim.MaskedAutoencoderViM(img_size=64, patch_size=16, depth=2, embed_dim=32, decoder_embed_dim=32,
+                                         decoder_depth=1, rms_norm=True, residual_in_fp32=True, fused_add_norm=True,
+                                         ssm_cfg={"use_fast_path": False})
+    cases["mae_vim_init_seed78"] = dict(state_dict={k: v.clone() for k, v in m.state_dict().items()},
+                                        cfg=dict(img_size=64, patch_size=16, depth=2, embed_dim=32, decoder_embed_dim=32,
+                                                 decoder_depth=1))
+    # ---- ChannelVim, eval mode (HCS off) and one Spatial-First variant
+    for name, img, chans, order in (("channelvim_64_c3", 64, 3, "Channel-First"), ("channelvim_32_c5_spatial", 32, 5, "Spatial-First")):
+        torch.manual_seed(71)
+        model = ref.chan_vim.VisionMamba(img_size=img, patch_size=16, depth=4, embed_dim=32, channels=chans, num_classes=10,
+                                         rms_norm=True, residual_in_fp32=True, fused_add_norm=True, final_pool_type="mean",
+                                         if_abs_pos_embed=True, if_cls_token=True, drop_path_rate=0.0, scan_order=order,
+                                         ssm_cfg={"use_fast_path": False})
+        init_sd = {k: v.clone() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith(("D", "D_b", "norm.weight", "layernorm.weight", "norm_f.weight")):
+                    p.add_(0.2 * torch.randn_like(p))
+                elif n.endswith(("layernorm.bias", "head.bias", "patch_embed.proj.bias")):
+                    p.add_(0.1 * torch.randn_like(p))
+        model.eval()
+        x = torch.randn(2, chans, img, img)
+        logits = model(x)
+        g = torch.randn_like(logits)
+        logits.backward(g)
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()
+                 if n in ("pos_embed", "cls_token", "head.weight", "layers.0.mixer.in_proj.weight", "layers.1.mixer.A_b_log",
+                          "layers.3.mixer.x_proj_b.weight", "layers.2.norm.weight", "patch_embed.proj.bias",
+                          "patch_embed.proj.weight", "patch_embed.channel_embed.weight", "norm_f.weight",
+                          "layers.1.mixer.conv1d.weight", "layers.2.mixer.dt_proj.bias")}
+        cases[name] = dict(img=img, channels=chans, scan_order=order, init_seed=71,
+                           init_probe={k: init_sd[k] for k in ("cls_token", "layers.0.mixer.in_proj.weight",
+                                                               "layers.3.mixer.dt_proj.bias", "pos_embed",
+                                                               "patch_embed.channel_embed.weight")},
+                           state_dict={k: v.clone() for k, v in model.state_dict().items()},
+                           x=x, logits=logits.detach(), g=g, grads=grads,
+                           cfg=dict(patch_size=16, depth=4, embed_dim=32, num_classes=10))
+    save("baselines.pt", cases)
+
+
 def gen_channel_variants():
     """Remaining channel-model variants: scan_order="Spatial-First" of the channel model and the
     "2-D compress" model (row-wise -> column-wise -> channel-wise scan cycle).  Tiny backbones, eval mode (HCS off)."""
@@ -525,6 +600,6 @@ def gen_config34():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked", "mae", "config34", "channel_variants"]
+    which = sys.argv[1:] or ["scan", "compressed_scan", "conv", "norm", "mixer", "model", "channel", "vim", "masked", "mae", "config34", "channel_variants", "baselines"]
     for w in which:
         globals()["gen_" + w]()
