@@ -55,6 +55,7 @@ struct ScanClParams {
   // workgroup multiplies ITS chunk's partial d x_dbl rows by the whole x_proj weight -- the own-channel half of the
   // product is added to dxc, the other chunk's half goes to dxc2 (storage dtype) and is added by the consumer
   const float* Wx[2];    // (R+2N, d_in) fp32
+  const void* Wxb;       // (2, R+2N, d_in) bf16 shadow of the two: the bf16 instantiation multiplies in bf16 (see XB below)
   void* dxc2;            // (2, B, Lc, d_in)
 };
 
@@ -436,6 +437,9 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   float* s_x = smem + LD::o_x;
   float* s_xw = smem + LD::o_xw;
   constexpr int XKS = XPJ ? (4 * RQ + 2 * N + 3) / 4 : 1;      // k steps (4 x_dbl columns each) of the x_proj adjoint
+  constexpr bool XB = XPJ && sizeof(T) == 2;                  // bf16 storage: the x_proj adjoint on the bf16 matrix cores
+  constexpr int XNB = XKS;                                    // its weight pieces of 4 k rows (K = 4 XKS <= 64)
+  static_assert(!XB || (4 * XKS <= 64 && 16 - LD::XCH_T <= LD::XCH - LD::XCH_T), "bf16 x_proj adjoint: K <= 64, tail pieces fit");
   static_assert(!XPJ || 4 * XKS <= SH_XS, "summed d x_dbl rows wider than their LDS stride");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int dir = blockIdx.z, ch0 = blockIdx.x * SH_CH;
@@ -463,8 +467,11 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // the d delta_raw table's rows past Lc feed the K / M padding of the MFMAs: zero once
   for (int e = tid; e < 16 * SH_DRS; e += SH_THREADS) s_dr[e] = 0.f;
-  if constexpr (XPJ)       // columns past R + 2N pad the K dimension of the x_proj adjoint (rows past Lc are never stored)
+  if constexpr (XPJ) {     // columns past R + 2N pad the K dimension of the x_proj adjoint (rows past Lc are never stored)
     for (int e = tid; e < 16 * SH_XS; e += SH_THREADS) s_x[e] = 0.f;
+    if constexpr (XB)      // ... and so do the weight rows behind it: the tail pieces are never written again
+      for (int e = tid; e < SH_NWV * (LD::XCH - LD::XCH_T) * 64; e += SH_THREADS) s_xw[e] = 0.f;
+  }
   // this lane's dt_proj weights of both MFMA roles are loaded once per workgroup instead of once per batch element behind
   // the staging barrier (an L2 round trip on every wave's critical path, twice per element).  At dt_rank 48 they are 24
   // registers and the kernel then spills 26 -- measured worth it all the same (same box, FastVim-B 224 px step 29.2 -> 28.5 ms,
@@ -649,7 +656,30 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     // they arrive under the dt_proj adjoint, the two barriers and the 12-wave sums.  One piece = 2 k rows x 32 channels =
     // 64 dwords = one wave instruction (LDS address M0 + 4 lane).  Issued as asm: through the builtin the compiler
     // would make every LDS read that follows wait for the DMA (it cannot tell the regions apart).
-    if constexpr (XPJ) {
+    if constexpr (XB) {
+      // bf16 storage: the product is taken on the bf16 matrix cores (4 instead of 22 instructions per wave; with twelve
+      // waves at once the fp32 ones made this phase MFMA-throughput bound, 2 500 ticks per element) from bf16(d x_dbl) and
+      // the bf16 shadow weight -- the operands the reference's autocast backward multiplies (selective_scan_interface.py:
+      // 726-734).  One piece = 4 k rows x (16 own + 16 other channels) bf16 = 64 dwords; the K padding (rows up to 63)
+      // must be finite: the table pieces behind the weights are zeroed, the two tail pieces stay zero from kernel entry.
+      const int t2 = opaque_tid(), ln = t2 & 63, wv2 = t2 >> 6;
+      const int row4 = ln >> 4, seg = (ln >> 3) & 1, dd = ln & 7;
+      const int chb = (seg ? SH_CH - ch0 : ch0) + wv2 * 16 + 2 * dd;
+      const bf16_t* wbase = (const bf16_t*)p.Wxb + (size_t)dir * W * p.d_in;
+      const uint32_t tab = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(s_ch + wv2 * 64);
+      const uint32_t ext = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(s_xw + wv2 * ((LD::XCH - LD::XCH_T) * 64));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the sweep's last reads of the slab have returned
+#pragma unroll
+      for (int c = 0; c < XNB; ++c) {
+        const int k = min(4 * c + row4, W - 1);                // rows past W meet zero columns of A: any finite value
+        const uint32_t voff = (uint32_t)(k * p.d_in + chb) * 2u;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(c < LD::XCH_T ? tab + (uint32_t)c * (SH_CH * 16) : ext + (uint32_t)(c - LD::XCH_T) * 256);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(wbase), "s"(dst) : "memory");
+      }
+#pragma unroll
+      for (int c = XNB; c < (LD::XCH_T < 16 ? LD::XCH_T : 16); ++c)       // table pieces behind the weights: K padding
+        s_ch[wv2 * 64 + c * (SH_CH * 4) + ln] = 0.f;
+    } else if constexpr (XPJ) {
       const int t2 = opaque_tid(), ln = t2 & 63, wv2 = t2 >> 6;
       const int slot = ln & 31, kr = ln >> 5;
       const int chx = (slot < 16 ? ch0 : SH_CH - ch0) + wv2 * 16 + (slot & 15);
@@ -752,10 +782,38 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
       SC_STAMP(bi, 8);
       const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, wv = t2 >> 6;
       f32x4_t Do = {0.f, 0.f, 0.f, 0.f}, Dx = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (XB) {
+        typedef __bf16 xb16x8 __attribute__((ext_vector_type(8)));
+        const int q4 = cm >> 2, pp = cm & 3;
+        const uint32_t tabb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(s_ch + wv * 64);
+        const uint32_t extb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(s_xw + wv * ((LD::XCH - LD::XCH_T) * 64));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          // A[step cm][k = 32 ks + 8 tg .. + 7] from the fp32 sums, rounded to bf16
+          const float* ar = s_x + cm * SH_XS + ks * 32 + tg * 8;
+          const float4 a0 = *reinterpret_cast<const float4*>(ar), a1 = *reinterpret_cast<const float4*>(ar + 4);
+          typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+          const u32x4v ap = {pack_bf16x2(a0.x, a0.y), pack_bf16x2(a0.z, a0.w), pack_bf16x2(a1.x, a1.y), pack_bf16x2(a1.z, a1.w)};
+          const xb16x8 af = __builtin_bit_cast(xb16x8, ap);
+          // B[k][channel]: k rows 32 ks + 8 tg + {0..3} sit in piece 8 ks + 2 tg, + {4..7} in the next one; a transposing
+          // read hands lane (channel cm) the four rows of its column
+          const int c0 = ks * 8 + 2 * tg;
+          const uint32_t b0 = (c0 < LD::XCH_T ? tabb + (uint32_t)c0 * (SH_CH * 16) : extb + (uint32_t)(c0 - LD::XCH_T) * 256) + q4 * 64 + pp * 8;
+          const uint32_t b1 = (c0 + 1 < LD::XCH_T ? tabb + (uint32_t)(c0 + 1) * (SH_CH * 16) : extb + (uint32_t)(c0 + 1 - LD::XCH_T) * 256) + q4 * 64 + pp * 8;
+          unsigned long long lo_o, hi_o, lo_x, hi_x;
+          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %4 offset:32\n\t"
+                       "ds_read_b64_tr_b16 %3, %5 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(lo_o), "=&v"(hi_o), "=&v"(lo_x), "=&v"(hi_x) : "v"(b0), "v"(b1) : "memory");
+          typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
+          const u64x2v bo = {lo_o, hi_o}, bx = {lo_x, hi_x};
+          Do = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(xb16x8, bo), Do, 0, 0, 0);
+          Dx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(xb16x8, bx), Dx, 0, 0, 0);
+        }
+      }
       const float* ftab = s_ch + wv * 64 + (tg & 1) * 32 + cm;
       const float* fext = s_xw + wv * ((LD::XCH - LD::XCH_T) * 64) + (tg & 1) * 32 + cm;
 #pragma unroll
-      for (int ks = 0; ks < XKS; ++ks) {
+      for (int ks = 0; ks < (XB ? 0 : XKS); ++ks) {
         const float a = s_x[cm * SH_XS + 4 * ks + tg];          // A[step cm][k = 4 ks + tg]
         // k row 4 ks + tg sits in piece 2 ks + (tg >> 1), row tg & 1 of it
         const float* f = 2 * ks + 1 < LD::XCH_T ? ftab + (2 * ks + (tg >> 1)) * (SH_CH * 4)
@@ -2001,7 +2059,8 @@ extern "C" int fv_mixer_scan_bwd_xproj_ok(int batch, int Lc, int d_inner, int dt
 extern "C" int fv_mixer_scan_bwd_xproj(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias,
                                        const float* A_log, const float* dt_w_b, const float* dt_bias_b,
                                        const float* A_log_b, const float* dyc, const float* x_proj_w,
-                                       const float* x_proj_w_b, float* dxc, void* dxc2, float* dx_dbl, float* partials,
+                                       const float* x_proj_w_b, const void* x_proj_w2_bf16, float* dxc, void* dxc2,
+                                       float* dx_dbl, float* partials,
                                        int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
                                        fv_stream_t stream) {
   FV_CHECK(d_state == N, "mixer_scan_bwd_xproj: only d_state == 16 is built (got %d)", d_state);
@@ -2013,7 +2072,8 @@ extern "C" int fv_mixer_scan_bwd_xproj(const void* xc, const void* x_dbl, const 
   p.xc = xc; p.xdbl = x_dbl; p.dyc = dyc; p.dxc = dxc; p.dxdbl = dx_dbl; p.pP = partials;
   p.Wdt[0] = dt_w; p.Wdt[1] = dt_w_b; p.dtb[0] = dt_bias; p.dtb[1] = dt_bias_b;
   p.Alog[0] = A_log; p.Alog[1] = A_log_b;
-  p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.dxc2 = dxc2;
+  FV_CHECK(dtype != FV_BF16 || x_proj_w2_bf16, "mixer_scan_bwd_xproj: bf16 storage needs the bf16 x_proj weights (2, W, d_inner)");
+  p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.Wxb = x_proj_w2_bf16; p.dxc2 = dxc2;
   p.B = batch; p.Lc = Lc; p.d_in = d_inner; p.R = dt_rank;
   p.NBB = scan_bwd_nbb(batch, Lc, dt_rank);
 #ifdef FASTVIM_TUNING_HOOKS

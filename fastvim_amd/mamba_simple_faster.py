@@ -621,8 +621,10 @@ class FastVimMixerFn(torch.autograd.Function):
                 # FastVim-T: the x_proj adjoint's data half runs inside the scan backward (one launch less per block); the
                 # pooled gradient arrives as two addends, the bf16 d x_dbl rows of the weight gradient are made by one
                 # launch for all blocks right before the grouped weight-gradient GEMMs
+                wsh = fv.get("Wx2_shadow")
                 dxc, dxc2, dx_dbl, ps = M.scan_bwd_xproj(xc, x_dbl, Wdt, bdt, A_log, Wdt_b, bdt_b, A_b_log, dyc,
-                                                         Wx2[0], Wx2[1], grad_out=fv.get("scan_grad"))
+                                                         Wx2[0], Wx2[1], grad_out=fv.get("scan_grad"),
+                                                         Wx2_bf16=wsh if wsh is not None and wsh.dtype == torch.bfloat16 else None)
                 dxb = torch.empty(2, Mrows, (W_ + 7) // 8 * 8, device=xc.device, dtype=torch.bfloat16)
                 _GroupedWgrad.rows_jobs.append((dx_dbl, dxb))
                 xc2 = xc.view(2, Mrows, d_in)

@@ -301,7 +301,7 @@ def scan_bwd_xproj_ok(xc, dt_w, pool_max, rows, cols, tpp):
                 and lib.fv_mixer_conv_pool_bwd2_ok(L.i32(rows), L.i32(cols), L.i32(tpp), L.i32(d_in), L.i32(int(bool(pool_max)))))
 
 
-def scan_bwd_xproj(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, Wx, Wx_b, grad_out=None):
+def scan_bwd_xproj(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, Wx, Wx_b, grad_out=None, Wx2_bf16=None):
     """The short backward scan with the x_proj adjoint's data half folded in (fv_mixer_scan_bwd_xproj): returns
     (dxc, dxc2, dx_dbl_chunks, pr).  dxc (2, B, Lc, d_in) fp32 + dxc2 (same shape, storage dtype) is the TOTAL gradient of
     the pooled conv output (through the scan and through x_proj); ``conv_pool_bwd(..., dxc2=dxc2)`` adds the two.
@@ -316,9 +316,12 @@ def scan_bwd_xproj(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, W
     dx_dbl = torch.empty(2, 2, B * Lc, W, **f32o)
     nprt = lib.fv_mixer_scan_bwd_partials(L.i32(B), L.i32(Lc), L.i32(R))
     part = torch.empty(nprt, 2 * d_in * (N + R + 1), **f32o)
+    if xc.dtype == torch.bfloat16 and Wx2_bf16 is None:      # (2, W, d_in) bf16: the shadow weights where the caller has them
+        Wx2_bf16 = torch.stack([Wx, Wx_b]).to(torch.bfloat16)
+    assert Wx2_bf16 is None or (Wx2_bf16.dtype == torch.bfloat16 and Wx2_bf16.is_contiguous() and Wx2_bf16.shape == (2, W, d_in))
     rc = lib.fv_mixer_scan_bwd_xproj(
         L.ptr(xc), L.ptr(x_dbl), L.ptr(dt_w), L.ptr(dt_b), L.ptr(A_log), L.ptr(dt_w_b), L.ptr(dt_b_b), L.ptr(A_log_b),
-        L.ptr(dyc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(dxc), L.ptr(dxc2), L.ptr(dx_dbl), L.ptr(part), L.i32(B), L.i32(Lc),
+        L.ptr(dyc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(Wx2_bf16), L.ptr(dxc), L.ptr(dxc2), L.ptr(dx_dbl), L.ptr(part), L.i32(B), L.i32(Lc),
         L.i32(d_in), L.i32(R), L.i32(N), L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
     L.check(rc, "mixer_scan_bwd_xproj")
     if grad_out is not None:

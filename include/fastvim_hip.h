@@ -257,6 +257,9 @@ int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const float* dt_w, 
  * selective_scan_interface.py:679-696 + 726-734, `dx = dx_dbl @ x_proj.weight` added to the scan's d u).  Built for
  * Lc in {14, 16}, d_inner == 384 (two 192-channel chunks), dt_rank <= 12: ask fv_mixer_scan_bwd_xproj_ok.
  *   x_proj_w, x_proj_w_b (dt_rank + 2 * d_state, d_inner) fp32: the weights as stored
+ *   x_proj_w2_bf16 (2, dt_rank + 2 * d_state, d_inner) bf16: the two, rounded -- required for bf16 storage, where the
+ *        product is taken on the bf16 matrix cores from bf16(d x_dbl) and these (the operands of the reference's autocast
+ *        backward); fp32 storage multiplies the fp32 weights exactly and ignores it (may be NULL)
  *   dxc  (2, batch, Lc, d_inner) fp32: d u through the scan + (this chunk's partial d x_dbl) @ Wx, own channels
  *   dxc2 (2, batch, Lc, d_inner) storage dtype: the same product for the OTHER chunk's channels; the total gradient of
  *        the pooled conv output is dxc + dxc2 (fv_mixer_conv_pool_bwd2 adds them)
@@ -265,9 +268,9 @@ int fv_mixer_scan_bwd_seg(const void* xc, const void* x_dbl, const float* dt_w, 
 int fv_mixer_scan_bwd_xproj_ok(int batch, int Lc, int d_inner, int dt_rank, int dtype);
 int fv_mixer_scan_bwd_xproj(const void* xc, const void* x_dbl, const float* dt_w, const float* dt_bias, const float* A_log,
                             const float* dt_w_b, const float* dt_bias_b, const float* A_log_b, const float* dyc,
-                            const float* x_proj_w, const float* x_proj_w_b, float* dxc, void* dxc2, float* dx_dbl,
-                            float* partials, int batch, int Lc, int d_inner, int dt_rank, int d_state, int dtype,
-                            fv_stream_t stream);
+                            const float* x_proj_w, const float* x_proj_w_b, const void* x_proj_w2_bf16, float* dxc,
+                            void* dxc2, float* dx_dbl, float* partials, int batch, int Lc, int d_inner, int dt_rank,
+                            int d_state, int dtype, fv_stream_t stream);
 /* outs[j] (rows, WP) bf16 = sum over nchunks of partials[j] (nchunks, rows, width) fp32, WP = width rounded up to 8, pad
  * columns zero; up to 64 jobs of one shape in one launch (host arrays of device pointers).  The rows
  * fv_mixer_xproj_bwd2 publishes, bit for bit. */
