@@ -55,6 +55,7 @@ struct CgParams {
   float* rstd;             // (M)
   float eps;
   int M;
+  int d_in;                // = 384, as a RUN-TIME value: 1 / d_in must come out of the same v_rcp_f32 as in combine_fwd_wave_kernel
 };
 
 __device__ __forceinline__ float cg_hsum(f2 v) { return v.x + v.y; }
@@ -88,10 +89,12 @@ __global__ __launch_bounds__(CG_NT, 2) void combine_out_proj_addnorm_kernel(CgPa
   float4 ne_r[2][2][3], ne_w[3];
   float ne_sc[2][2];
   {
+    // (source-order arithmetic, as in combine_fwd_wave_kernel: the two gate tokens bit for bit alike)
+#pragma clang fp reassociate(off) contract(off)
     const int lc = lane * 6, voff = lc * 2;
     const int tok_x = 2 * CG_K * 2, tok_s = CG_K * 2;
     const bool has_ln = p.lnw != nullptr;
-    const float inv_d = 1.f / (float)CG_K;
+    const float inv_d = 1.f / (float)p.d_in;      // (a compile-time 1 / 384 is the exactly rounded quotient: one ulp off the stand-alone kernel's)
     const size_t ydir = (size_t)p.B * g.rows * CG_K;
     const __amdgpu_buffer_rsrc_t bz = fv_make_buf((const bf16_t*)p.xz + CG_K, (size_t)p.M * tok_x - tok_s);
     const __amdgpu_buffer_rsrc_t bs = fv_make_buf(p.skip, (size_t)p.M * tok_s);
@@ -406,6 +409,7 @@ extern "C" int fv_mixer_combine_out_proj_addnorm(const void* xz, const void* ski
   p.W = (const bf16_t*)W; p.ldw = ldw; p.residual = residual; p.nw = norm_weight; p.row_scale = row_scale;
   p.rows_per_scale = rows_per_scale; p.res_out = residual_out; p.y = (bf16_t*)y; p.rstd = rstd; p.eps = eps;
   p.M = batch * rows * cols;
+  p.d_in = CG_K;
   const size_t smem = (size_t)CG_BM * CG_RSA;
   hipLaunchKernelGGL(combine_out_proj_addnorm_kernel, dim3(batch * fv_cdiv(rows, 4)), dim3(CG_NT), smem, (hipStream_t)stream, p);
   FV_LAUNCH_CHECK();

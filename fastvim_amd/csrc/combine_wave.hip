@@ -23,6 +23,9 @@ __device__ __forceinline__ float hsum(f2 v) { return v.x + v.y; }
 
 template <typename T, int NP, int NCK, int TT>
 __global__ __launch_bounds__(64 * NW) void combine_fwd_wave_kernel(FwdParams p) {
+  // source-order arithmetic (no reassociation, no contraction beyond the explicit fmas): csrc/combine_gemm.hip gates tokens
+  // with the same expressions inside the out_proj launch, and the two must agree bit for bit whatever surrounds them
+#pragma clang fp reassociate(off) contract(off)
   typedef PairVec<T, NP> P;
   constexpr int CHK = 128 * NP, CHKB = CHK * (int)sizeof(T);
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -15,14 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("kernel_rows", [False, True])
 def test_two_rank_bench_line(kernel_rows):
-    """kernel_rows: as the driver runs it -- rank 0 times its kernel table (graph captures of its own) while the process
-    group is alive and the other rank waits in the closing barrier."""
+    """kernel_rows: ``--kernels`` -- rank 0 times its kernel table (graph captures of its own) while the process group is
+    alive and the other rank waits in the closing barrier.  Without the flag an N > 1 line carries no kernel table (round
+    5: the scaling run stays short and no rank idles beside a busy one)."""
     env = dict(os.environ, FASTVIM_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29538" if kernel_rows else "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2",
            "--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-scan-op"]
-    if not kernel_rows:
-        cmd.append("--no-kernels")
+    if kernel_rows:
+        cmd.append("--kernels")
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -31,5 +32,6 @@ def test_two_rank_bench_line(kernel_rows):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]      # finite
+    assert ("kernels" in out) == kernel_rows
     if kernel_rows:
         assert out["roofline"]["frac"] > 0 and out["roofline"]["elementwise_floor_same_size_cold"]["add_2r1w"]["us"] > 0

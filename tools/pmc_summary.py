@@ -7,8 +7,11 @@ import json
 import re
 import sys
 
-KEYS = (("conv_pool_fwd", "conv_pool_fwd"), ("scan_fwd", "scan_cl_fwd"), ("combine_fwd", "combine_fwd"),
-        ("combine_bwd", "combine_bwd"), ("scan_bwd", "scan_cl_bwd"), ("conv_pool_bwd", "conv_pool_bwd"),
+KEYS = (("conv_pool_fwd", "conv_pool_fwd"), ("scan_fwd", "scan_cl_fwd"), ("combine_out_proj_addnorm_fwd", "combine_out_proj_addnorm_kernel"),
+        ("combine_fwd", "combine_fwd"),
+        ("combine_bwd", "combine_bwd"), ("scan_bwd_xproj", "14, true, true>"), ("scan_bwd", "scan_cl_bwd"),
+        ("conv_pool_bwd_two_addends", "conv_pool_bwd_row_kernel<__hip_bfloat16, 14, true>"), ("conv_pool_bwd", "conv_pool_bwd"),
+        ("chunk_rows_bf16", "chunk_rows_bf16"),
         ("xproj_bwd", "xproj_bwd"), ("add_norm_fwd", "add_norm_fwd"), ("add_norm_bwd", "add_norm_bwd"),
         ("gemm_out_proj_addnorm_fwd", "gemm_addnorm_kernel"), ("gemm_in_proj_dgrad_addnorm_bwd", "gemm_dgrad_addnorm_bwd_kernel"),
         ("gemm", "gemm_bf16_kernel"))

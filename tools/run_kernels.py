@@ -30,6 +30,13 @@ for _ in range(n):
     d_o, dyc, _ = M.combine_bwd(dg, xz, skip, yc, lnw, lnb, mean, rstd, dxz, rows, cols, False)
     dxc, dxd, _ = M.scan_bwd(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc, keep_chunks=True)
     M.conv_pool_bwd(xz, d_o, dxc, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 0, 1.0)
+    # round 5, as the FastVim-T step issues them: the scan backward with the x_proj adjoint folded in, the conv + pool
+    # adjoint on the two-addend pooled gradient, the rows of the x_proj weight gradient
+    Wx32 = rn(2, R_ + 2 * N, d_in, dt=torch.float32) * d_in ** -0.5
+    if M.scan_bwd_xproj_ok(xc, Wdt, False, rows, cols, 1):
+        dxc_a, dxc_b, dxd2, _ = M.scan_bwd_xproj(xc, x_dbl, Wdt, bdt, A_log, Wdt, bdt, A_log, dyc, Wx32[0], Wx32[1])
+        M.conv_pool_bwd(xz, d_o, dxc_a, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 0, 1.0, dxc2=dxc_b)
+        M.chunk_rows_bf16([(dxd2, torch.empty(2, B * rows, (R_ + 2 * N + 7) // 8 * 8, device=dev, dtype=torch.bfloat16))])
     hid, res = rn(B, L, d), torch.randn(B, L, d, device=dev, generator=g)
     nw = torch.ones(d, device=dev, requires_grad=True)
     hid.requires_grad_(); res.requires_grad_()
@@ -56,6 +63,9 @@ for _ in range(n):
     L_.check(lib.fv_gemm_bf16_addnorm(L_.ptr(g2), L_.ptr(W_out), L_.ptr(resid), L_.ptr(nw_), L_.ptr(sc_), L_.i32(L), L_.ptr(y_),
                                       L_.ptr(ro_), L_.ptr(rs_), L_.i32(Mtok), L_.i32(d), L_.i32(d_in), ctypes.c_long(d_in),
                                       ctypes.c_long(d_in), ctypes.c_float(1e-5), L_.stream_of(g2)), "addnorm")
+    # round 5: combine as the A-tile producer of that launch
+    if M.combine_out_proj_addnorm_ok(xz, rows, cols, 1, d):
+        M.combine_out_proj_addnorm(xz, skip, yc, lnw, lnb, 1e-5, rows, cols, False, M.combine_buffers(xz, lnw), W_out, resid, nw_, sc_, L, 1e-5)
     dg_ = torch.empty(Mtok, d_in, device=dev, dtype=dtype)
     L_.check(lib.fv_gemm_bf16_dgrad_addnorm_bwd2(L_.ptr(xz2), L_.ptr(W_in), L_.ptr(gg_), L_.ptr(resid), L_.ptr(rstd_), L_.ptr(nw_),
                                                  L_.ptr(sc_), L_.i32(L), L_.ptr(y_), L_.ptr(ro_), L_.ptr(pw_), L_.i32(Mtok), L_.i32(d),
