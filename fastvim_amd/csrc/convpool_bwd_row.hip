@@ -473,17 +473,28 @@ int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t
   if ((size_t)p.B * p.geo.rows * p.d_in * 8 > 0x7ffff000ull) return FV_ERR_UNSUPPORTED;   // pooled gradients: one descriptor, int offsets
   const bool chan8 = p.geo.tpp == 8 && p.geo.pcols >= 2;
   const bool dense8 = p.geo.tpp == 1 && p.geo.cols % 8 == 0 && p.geo.cols >= 24;      // 512 / 1024 / 2048 px grids
-  int groups = (nch + 7) / 8;                   // channel groups of at most 8 waves over blockIdx.y
-  while (nch % groups) ++groups;
-  const int nchg = nch / groups;
-  // rows live in registers: blocks of <= 512 threads (256 VGPRs per wave) for the long-row kernels and fp32 storage,
-  // <= 768 (168) for the bf16 14-token whole-row kernel, i.e. fewer row groups per block than the generic kernel, over
-  // the same persistent grid
   const bool long_rows = chan8 || dense8;
   if (p.dxc2 && (long_rows || p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16))) return FV_ERR_UNSUPPORTED;
-  const int wmax = (long_rows || dtype == FV_F32 || p.geo.cols > 14) ? 8 : 12;
+  // channel groups over blockIdx.y.  Whole-row kernels: at most 8 waves of channels per block.  Long-row kernels (201
+  // VGPRs: 8 waves per CU): blocks of FOUR waves -- at most two waves of channels x two or four rows -- so that two
+  // blocks share a CU and the dispatcher has 2-6x as many, lighter blocks to balance (six-wave blocks left a quarter of
+  // the wave slots empty): FastChannelVim-S 200.5 -> 173 us, FastVim-B at 2048 px 448.7 -> 385 us
+  // (profiles/r05_ab_chan_block_shapes.log)
+  static const int t_groups = fv_tune("FASTVIM_BWD_CHAN_GROUPS", 0), t_rg = fv_tune("FASTVIM_BWD_CHAN_RG", 0);   // tuning hooks
+  int groups = long_rows ? (nch + 1) / 2 : (nch + 7) / 8;
+  while (nch % groups) ++groups;
+  if (long_rows && t_groups > 0 && nch % t_groups == 0) groups = t_groups;
+  const int nchg = nch / groups;
+  // rows live in registers: blocks of <= 512 threads (256 VGPRs per wave) for fp32 storage and 16-token rows,
+  // <= 768 (168) for the bf16 14-token whole-row kernel, i.e. fewer row groups per block than the generic kernel, over
+  // the same persistent grid
+  const int wmax = (dtype == FV_F32 || p.geo.cols > 14) ? 8 : 12;
   const int cap = wmax / nchg < 1 ? 1 : wmax / nchg;
-  const int rgr = rg < cap ? rg : cap;
+  int rgr = rg < cap ? rg : cap;
+  if (long_rows) {
+    rgr = t_rg > 0 ? t_rg : 4 / nchg;
+    smem = (size_t)12 * nchg * 128 * 4;           // a block accumulates its own channels only
+  }
   if (chan8 || dense8) {
     static const bool chan = (fv_tune("FASTVIM_BWD_CHAN", 1) != 0);   // tuning hook
     if (!chan) return FV_ERR_UNSUPPORTED;

@@ -205,17 +205,22 @@ __global__ __launch_bounds__(512) void conv_pool_fwd_chan_kernel(FwdParams p) {
   }
 }
 
-// channel groups: the smallest split of d_in / 128 waves into blocks of at most 8 waves
+// channel groups: the smallest split of d_in / 128 waves into blocks of at most 2 waves.  The waves of a block share
+// nothing (each owns 128 channels of the row), so small blocks only help the dispatcher fill the CUs: FastChannelVim-S
+// (6 waves of channels) 101.1 us with one 6-wave block per row, 86.9 with three 2-wave blocks; FastVim-B at 2048 px
+// (12 waves) 239.6 -> 195.7 us (profiles/r05_ab_chan_block_shapes.log)
 inline int chan_groups(int d_in) {
   const int nw = d_in / 128;
-  int gq = (nw + 7) / 8;
+  int gq = (nw + 1) / 2;
   while (nw % gq) ++gq;
   return gq;
 }
 
 template <typename T, int TPP, bool CHAN>
 int launch_chan(const FwdParams& p, int pool_max, hipStream_t st) {
-  const int gq = chan_groups(p.d_in), nch = p.d_in / 128 / gq;
+  static const int t_gq = fv_tune("FASTVIM_FWD_CHAN_GROUPS", 0);   // tuning hook
+  const int nw = p.d_in / 128;
+  const int gq = (t_gq > 0 && nw % t_gq == 0) ? t_gq : chan_groups(p.d_in), nch = nw / gq;
   dim3 grid(p.geo.rows, p.B, gq), block(64 * nch);
   if (pool_max) hipLaunchKernelGGL((conv_pool_fwd_chan_kernel<T, TPP, true, CHAN>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((conv_pool_fwd_chan_kernel<T, TPP, false, CHAN>), grid, block, 0, st, p);
