@@ -475,25 +475,36 @@ int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t
   const bool dense8 = p.geo.tpp == 1 && p.geo.cols % 8 == 0 && p.geo.cols >= 24;      // 512 / 1024 / 2048 px grids
   const bool long_rows = chan8 || dense8;
   if (p.dxc2 && (long_rows || p.geo.tpp != 1 || (p.geo.cols != 14 && p.geo.cols != 16))) return FV_ERR_UNSUPPORTED;
-  // channel groups over blockIdx.y.  Whole-row kernels: at most 8 waves of channels per block.  Long-row kernels (201
-  // VGPRs: 8 waves per CU): blocks of FOUR waves -- at most two waves of channels x two or four rows -- so that two
+  // channel groups over blockIdx.y.  Long-row kernels (201 VGPRs: 8 waves per CU): blocks of FOUR waves -- at most two waves of channels x two or four rows -- so that two
   // blocks share a CU and the dispatcher has 2-6x as many, lighter blocks to balance (six-wave blocks left a quarter of
   // the wave slots empty): FastChannelVim-S 200.5 -> 173 us, FastVim-B at 2048 px 448.7 -> 385 us
   // (profiles/r05_ab_chan_block_shapes.log)
   static const int t_groups = fv_tune("FASTVIM_BWD_CHAN_GROUPS", 0), t_rg = fv_tune("FASTVIM_BWD_CHAN_RG", 0);   // tuning hooks
-  int groups = long_rows ? (nch + 1) / 2 : (nch + 7) / 8;
-  while (nch % groups) ++groups;
-  if (long_rows && t_groups > 0 && nch % t_groups == 0) groups = t_groups;
-  const int nchg = nch / groups;
-  // rows live in registers: blocks of <= 512 threads (256 VGPRs per wave) for fp32 storage and 16-token rows,
-  // <= 768 (168) for the bf16 14-token whole-row kernel, i.e. fewer row groups per block than the generic kernel, over
-  // the same persistent grid
-  const int wmax = (dtype == FV_F32 || p.geo.cols > 14) ? 8 : 12;
-  const int cap = wmax / nchg < 1 ? 1 : wmax / nchg;
-  int rgr = rg < cap ? rg : cap;
+  // rows live in registers: whole-row blocks of <= 512 threads (256 VGPRs per wave) for fp32 storage and 16-token rows,
+  // <= 768 (168) for the bf16 14-token kernel, i.e. fewer row groups per block than the generic kernel, over the same
+  // persistent grid.  The split must not leave wave slots of the CU empty (FastVim-B, 12 waves of channels: two
+  // 6-wave blocks 99.5 us, one 12-wave block 73.4, three 4-wave blocks 75.6)
+  const int wmax = (long_rows || dtype == FV_F32 || p.geo.cols > 14) ? 8 : 12;
+  int groups = 1, nchg = nch, rgr = 1;
   if (long_rows) {
+    groups = (nch + 1) / 2;
+    while (nch % groups) ++groups;
+    if (t_groups > 0 && nch % t_groups == 0) groups = t_groups;
+    nchg = nch / groups;
     rgr = t_rg > 0 ? t_rg : 4 / nchg;
     smem = (size_t)12 * nchg * 128 * 4;           // a block accumulates its own channels only
+  } else {
+    static const int r_groups = fv_tune("FASTVIM_BWD_ROW_GROUPS", 0), r_rg = fv_tune("FASTVIM_BWD_ROW_RG", 0);   // tuning hooks
+    for (groups = 1; groups <= nch; ++groups) {
+      if (nch % groups) continue;
+      nchg = nch / groups;
+      if (nchg > wmax) continue;
+      rgr = rg < wmax / nchg ? rg : wmax / nchg;
+      if (wmax % (nchg * rgr) == 0) break;
+    }
+    if (groups > nch) { groups = nch; nchg = 1; rgr = 1; }
+    if (r_groups > 0 && nch % r_groups == 0) { groups = r_groups; nchg = nch / groups; rgr = rg < wmax / nchg ? rg : (wmax / nchg < 1 ? 1 : wmax / nchg); }
+    if (r_rg > 0) rgr = r_rg;
   }
   if (chan8 || dense8) {
     static const bool chan = (fv_tune("FASTVIM_BWD_CHAN", 1) != 0);   // tuning hook
