@@ -1822,6 +1822,39 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
       }
     }
     FV_CHECK(!any_direct, "gemm_bf16_tn_grouped: in-place accumulation (splits = -1) is built for outputs that are multiples of 256 x 256 (>= 512 x 512) only");
+    // S-width outputs (d_model 384: in_proj 1536 x 384, out_proj 384 x 768 -- FastVim-S, FastChannelVim-S): 256 x 192 /
+    // 192 x 256 tiles on 8 waves, one workgroup per CU.  The launch is bound by the L2 -> LDS fill (see above): a 128 x 128
+    // tile moves 32 KB per 2.1 MFLOP of K step, these 56 KB per 6.3 -- 0.59 x the fill (gemm.py puts the two shapes in
+    // launches of their own)
+    {
+      static const int wide8 = fv_tune("FASTVIM_WGRAD_WIDE8", 1);   // tuning hook
+      bool c4 = dma && wide8 && tile_env != 1, c5 = c4;
+      for (int i = 0; i < n; ++i) {
+        const GemmParams& q = G.p[i];
+        c4 = c4 && q.M % 256 == 0 && q.N % 192 == 0 && q.N % 256 != 0 && (long)q.M * q.N >= 1024 * 384;
+        c5 = c5 && q.M % 192 == 0 && q.N % 256 == 0 && q.M % 256 != 0 && (long)q.M * q.N >= 384 * 768;
+      }
+      if (c4 || c5) {
+        const int tm = c4 ? 256 : 192, tn = c4 ? 192 : 256;
+        int b2 = 0;
+        for (int i = 0; i < n; ++i) {
+          b2 += (G.p[i].M / tm) * (G.p[i].N / tn) * fv_cdiv(G.p[i].K, G.p[i].k_per_split);
+          G.blk_end[i] = b2;
+        }
+        const size_t sm8 = (size_t)2 * (256 + 192) * BK * 2;
+        static FvOncePerDevice attr8;
+        if (attr8.first()) {
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 4, 2, true, 6, 4>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8);
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_grouped_kernel<KS, KS, 2, 4, true, 4, 6>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8);
+        }
+        if (c4) hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 4, 2, true, 6, 4>), dim3(b2), dim3(512), sm8, st, G, xcd_order);
+        else hipLaunchKernelGGL((gemm_bf16_grouped_kernel<KS, KS, 2, 4, true, 4, 6>), dim3(b2), dim3(512), sm8, st, G, xcd_order);
+        FV_LAUNCH_CHECK();
+        continue;
+      }
+    }
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
       blocks += fv_cdiv(G.p[i].M, bm[cls]) * fv_cdiv(G.p[i].N, bn[cls]) * fv_cdiv(G.p[i].K, G.p[i].k_per_split);

@@ -195,13 +195,13 @@ def gemm_tn_grouped(jobs, reduce=True):
     # joins the largest 128-row group it ties with
     classes = {}
     for j in jobs:
-        classes.setdefault(_tile_class(j[0].shape[1], j[1].shape[1]), []).append(j)
+        classes.setdefault(_tile_class(j[0].shape[1], j[1].shape[1], j[0].shape[0]), []).append(j)
     if len(classes) > 1:
         todo = []
         loose = classes.pop(0, [])
         for j in loose:
             M, N = j[0].shape[1], j[1].shape[1]
-            ties = [c for c in classes if c != 3 and _padded(M, N, c) == _padded(M, N, 0)]
+            ties = [c for c in classes if c < 3 and _padded(M, N, c) == _padded(M, N, 0)]
             if ties:
                 classes[max(ties, key=lambda c: len(classes[c]))].append(j)
             else:
@@ -212,7 +212,7 @@ def gemm_tn_grouped(jobs, reduce=True):
     return _gemm_tn_grouped_one(jobs, reduce, next(iter(classes)))
 
 
-_TILES = ((128, 128), (128, 192), (192, 128), (256, 256))
+_TILES = ((128, 128), (128, 192), (192, 128), (256, 256), (256, 192), (192, 256))
 
 
 def _padded(M, N, c):
@@ -220,10 +220,17 @@ def _padded(M, N, c):
     return -(-M // bm) * bm * -(-N // bn) * bn
 
 
-def _tile_class(M, N):
-    """Index into _TILES of the tile shape that pads an (M, N) output least; ties go to 128 x 128."""
+def _tile_class(M, N, Kd=None):
+    """Index into _TILES of the tile shape that pads an (M, N) output least; ties go to 128 x 128.  ``Kd`` (tokens): the
+    8-wave S-width tiles pay from long K loops on (FastChannelVim-S, 100 352 tokens: step 44.35 -> 43.51 ms; FastVim-S at
+    224 px, 25 088 tokens: 12.55 -> 12.62, stays on 128 x 128; profiles/r05_ab_wgrad_s_width_tiles.log)."""
     if M % 256 == 0 and N % 256 == 0 and M * N >= 512 * 512:
         return 3          # large outputs (FastVim-B: 3072 x 768, 768 x 1536): 256 x 256 tiles on 8 waves halve the L2 traffic
+    if WIDE8 and (Kd is None or Kd >= WIDE8_MIN_K):             # S-width outputs (1536 x 384, 384 x 768): 256 x 192 / 192 x 256 tiles on 8 waves (csrc/gemm_mfma.hip)
+        if M % 256 == 0 and N % 192 == 0 and N % 256 and M * N >= 1024 * 384:
+            return 4
+        if M % 192 == 0 and N % 256 == 0 and M % 256 and M * N >= 384 * 768:
+            return 5
     best = 0
     for c in (1, 2):
         if _padded(M, N, c) < _padded(M, N, best):
@@ -232,7 +239,9 @@ def _tile_class(M, N):
 
 
 DIRECT_ACC = True      # False: every grouped problem writes partials that a reduction launch adds to the gradient
-_SLOTS = (512, 512, 512, 256)     # workgroups of the grouped kernel the chip holds at once, per tile class (two per CU;
+WIDE8 = True           # False: S-width weight gradients on 128 x 128 tiles (A/B knob)
+WIDE8_MIN_K = 50000    # tokens from which the 8-wave S-width tiles are used
+_SLOTS = (512, 512, 512, 256, 256, 256)     # workgroups of the grouped kernel the chip holds at once, per tile class (two per CU;
                                   # one of the 8-wave 256 x 256 tiles)
 FILL = True      # False: the factors of grouped_splits whatever the group (a segmented step then sums every weight
                  # gradient in the order of the single-graph step: tests/test_pipeline_gpu.py)
@@ -247,6 +256,8 @@ def fill_splits(jobs, c):
     not go below that (and not below 14 tiles).  Measured, 6 blocks at FastVim-T: in_proj problems 156 -> 97 us,
     out_proj + x_proj 152 -> 102 us (tools/probe/wgrad_fill.py)."""
     bm, bn = _TILES[c]
+    if c >= 4 and FILL:
+        return _fill_splits_wide8(jobs, bm, bn)
     work = 0
     for x, y, out, sp in jobs:
         if x.shape[0] % 64 or not FILL:
@@ -264,10 +275,33 @@ def fill_splits(jobs, c):
     return out_sp
 
 
+def _fill_splits_wide8(jobs, bm, bn):
+    """One split-K factor for a launch of 8-wave tiles (one workgroup per CU, 256 slots): the launch runs in whole rounds
+    of 256 workgroups, so the factor is the divisor of the K tiles that minimises  rounds x K tiles per workgroup  plus the
+    partial traffic it adds (one K tile of a 256 x 192 tile ~ 1.95 us on a CU; an (M, N) fp32 partial written and re-read
+    ~ M N 8 bytes at 4.5 TB/s).  FastChannelVim-S in_proj (24 problems x 12 tiles, 1568 K tiles): 2 slices = 2.25 rounds
+    (3 paid), 8 slices = 9 rounds exactly."""
+    kts = {x.shape[0] // 64 for x, _, _, _ in jobs}
+    if len(kts) != 1 or any(x.shape[0] % 64 for x, _, _, _ in jobs):
+        return [j[3] for j in jobs]
+    kt = kts.pop()
+    tiles = sum(-(-x.shape[1] // bm) * -(-y.shape[1] // bn) for x, y, _, _ in jobs)
+    part_us = sum(x.shape[1] * y.shape[1] * 8 for x, y, _, _ in jobs) / 4.5e6
+    base = min(j[3] for j in jobs)
+    best, best_cost = base, None
+    for s_ in range(1, kt // 14 + 1):
+        if kt % s_:
+            continue
+        cost = -(-tiles * s_ // 256) * (kt // s_) * 1.95 + part_us * s_
+        if best_cost is None or cost < best_cost:
+            best, best_cost = s_, cost
+    return [best for _ in jobs]
+
+
 def _gemm_tn_grouped_one(jobs, reduce, c=None):
     k = len(jobs)
     if c is None:
-        c = _tile_class(jobs[0][0].shape[1], jobs[0][1].shape[1]) if k == 1 else 0
+        c = _tile_class(jobs[0][0].shape[1], jobs[0][1].shape[1], jobs[0][0].shape[0]) if k == 1 else 0
     jobs = [(x, y, out, s_) for (x, y, out, _), s_ in zip(jobs, fill_splits(jobs, c))]
     parts = []
     direct = []

@@ -176,6 +176,44 @@ def test_grouped_weight_gradients_tile_classes():
         assert torch.equal(got, single)
 
 
+def test_grouped_weight_gradients_s_width_tiles():
+    """S-width outputs (in_proj 1536 x 384, out_proj 384 x 768: FastVim-S, FastChannelVim-S) run on 256 x 192 / 192 x 256
+    tiles of 8 waves, each shape in a launch of its own with ONE split-K factor that fills whole rounds of workgroups
+    (gemm.fill_splits): against fp64 and, bit for bit, against the single-launch split-K GEMM at that factor."""
+    from fastvim_amd import gemm as G
+    from fastvim_amd.mixer_ops import flush_reductions
+    torch.manual_seed(2)
+    shapes = [(3584, 1536, 384), (3584, 384, 768), (3584, 56, 768)]
+    assert [G._tile_class(M_, N_) for _, M_, N_ in shapes] == [4, 5, 0]
+    assert G._tile_class(1536, 384, 25088) == 0 and G._tile_class(1536, 384, 100352) == 4      # long K loops only
+    min_k, G.WIDE8_MIN_K = G.WIDE8_MIN_K, 0
+    jobs, refs = [], []
+    for Kd, M_, N_ in shapes * 3:
+        x = torch.randn(Kd, M_, device="cuda").bfloat16()
+        y = torch.randn(Kd, N_, device="cuda").bfloat16()
+        jobs.append((x, y, torch.zeros(M_ * N_, device="cuda"), G.grouped_splits(Kd, M=M_, N=N_)))
+        refs.append(x.double().t() @ y.double())
+    try:
+        G.gemm_tn_grouped(jobs)
+    finally:
+        G.WIDE8_MIN_K = min_k
+    flush_reductions()
+    for c in (4, 5):
+        mine = [j for j in jobs if G._tile_class(j[0].shape[1], j[1].shape[1]) == c]
+        sps = G.fill_splits(mine, c)
+        assert len(set(sps)) == 1 and 56 % sps[0] == 0
+        for (x, y, out, _), sp in zip(mine, sps):
+            assert torch.equal(out.view(x.shape[1], y.shape[1]), G.gemm_tn(x, y, splits=sp))
+    for (x, y, out, _), ref in zip(jobs, refs):
+        assert (out.view(ref.shape).double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    on = G.WIDE8
+    try:
+        G.WIDE8 = False
+        assert [G._tile_class(M_, N_) for _, M_, N_ in shapes] == [0, 0, 0]
+    finally:
+        G.WIDE8 = on
+
+
 def test_grouped_weight_gradients_accumulate_in_place():
     """Large outputs with ONE K slice (FastVim-B: 3072 x 768, 768 x 1536) are added to the gradient by the grouped GEMM
     itself (splits = -1 of fv_gemm_bf16_tn_grouped: no partial, no reduction launch): bit for bit what the partial +
