@@ -340,6 +340,97 @@ __global__ __launch_bounds__(256) void scan_cl_bwd_kernel(ScanClParams p) {
 }
 
 
+typedef float sf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sf2 ssplat(float a) { sf2 o; o.x = a; o.y = a; return o; }
+__device__ __forceinline__ sf2 sfma2(sf2 a, sf2 b, sf2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ sf2 sexp2_2(sf2 a) { sf2 o; o.x = fv_exp2(a.x); o.y = fv_exp2(a.y); return o; }
+
+// a * {b.lo, b.lo} and a * {b.lo, b.lo} + c on packed pairs
+__device__ __forceinline__ sf2 pk_mul_lo(sf2 a, sf2 b) {
+  sf2 o;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+__device__ __forceinline__ sf2 pk_fma_lo(sf2 a, sf2 b, sf2 c) {
+  sf2 o;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+  return o;
+}
+
+// One step of the adjoint sweep of the register-resident backward kernels (short and chunked), for a lane = (channel, state
+// quad) holding its four states as two packed pairs.  In: the step's B / C values of the quad, the table row {delta, u, dy,
+// sigmoid}, the states after this step (xs) and before it (xp).  Out: the 8 values whose sums over the wave's 16 channels
+// are d B / d C of the step, as pairs {dB01, dB23, dC01, dC23}; du_acc / ddraw for the channel.
+//   a   = exp2(A2 delta)                    (re-derived: keeping it would cost a wave of occupancy)
+//   dx  = C dy + dxa                        adjoint of the state after the step
+//   dxa = a dx                              ... carried to the step before
+//   pj  = dxa x_{t-1}                       (= dx a x_{t-1}: one product fewer than forming a x_{t-1} first)
+struct AdjStep { float du_acc, ddraw; };
+template <bool FIRST>
+__device__ __forceinline__ AdjStep adjoint_step(const float4 Bv, const float4 Cv, const float4 cv, const sf2 (&A2)[2],
+                                                const sf2 (&Araw)[2], const sf2 (&xs)[2], const sf2 (&xp)[2], sf2 (&dxa)[2],
+                                                sf2 (&dA)[2], sf2 (&vals)[4]) {
+  const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
+  // the per-channel scalars multiply packed state pairs: as the LOW half of the register pair they were loaded into they
+  // feed both halves of a packed op (op_sel_hi = 0) -- left to the compiler, the splats were built with v_mov pairs
+  const sf2 ds = {cv.x, cv.y}, gs = {cv.z, cv.w};          // {delta, u}, {dy, sigmoid}
+  const float uu = cv.y, sg = cv.w;
+  sf2 tu;                                                   // {delta u, delta u}
+  asm("v_pk_mul_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(tu) : "v"(ds));
+  sf2 du2 = {0.f, 0.f}, dd2 = {0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const sf2 a = sexp2_2(pk_mul_lo(A2[h], ds));
+    const sf2 dx = pk_fma_lo(Cn[h], gs, dxa[h]);
+    dxa[h] = a * dx;
+    du2 = sfma2(dx, Bn[h], du2);
+    if (!FIRST) {                                  // x_{-1} = 0 in the short kernel's first step
+      const sf2 pj = dxa[h] * xp[h];
+      dd2 = sfma2(Araw[h], pj, dd2);
+      dA[h] = pk_fma_lo(pj, ds, dA[h]);
+    }
+    vals[h] = pk_mul_lo(dx, tu);                   // dB[4q + 2h ..]
+    vals[2 + h] = pk_mul_lo(xs[h], gs);            // dC[4q + 2h ..]
+  }
+  AdjStep o;
+  o.du_acc = quad_sum(du2.x + du2.y);
+  const float dd_acc = quad_sum(dd2.x + dd2.y);
+  // d delta = sum_n dx (B u + A a x_prev) = u * sum_n dx B + sum_n A dx a x_prev;  through the softplus: * sigmoid
+  o.ddraw = fmaf(uu, o.du_acc, dd_acc) * sg;
+  return o;
+}
+
+// Sum of the 8 values of `adjoint_step` over the wave's 16 channels: three reduce-scatter levels on packed pairs (one
+// v_pk_add_f32 per two sums; lane bits 5 and 4 by the cross-row swaps), the last two inside a 16-lane row as DPP adds
+// whose bank masks pick the half that keeps each value -- no select.  EVERY lane ends with a total: value (lane >> 3) & 7 of
+// quad q, the same in lanes i and i ^ 4, so the caller's store needs no lane predicate (a same-address LDS write costs
+// what a plain one does: tools/probe/valu_cost.hip) and the step stays one basic block.
+__device__ __forceinline__ float chan_sum8(const sf2 (&v)[4]) {
+  sf2 r[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                    // lane bit 5: dB pair <-> dC pair
+    auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[h].x), __float_as_uint(v[2 + h].x), false, false);
+    auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[h].y), __float_as_uint(v[2 + h].y), false, false);
+    const sf2 lo = {__uint_as_float(sx[0]), __uint_as_float(sy[0])}, hi = {__uint_as_float(sx[1]), __uint_as_float(sy[1])};
+    r[h] = lo + hi;
+  }
+  auto tx = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0].x), __float_as_uint(r[1].x), false, false);   // lane bit 4
+  auto ty = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0].y), __float_as_uint(r[1].y), false, false);
+  const sf2 lo = {__uint_as_float(tx[0]), __uint_as_float(ty[0])}, hi = {__uint_as_float(tx[1]), __uint_as_float(ty[1])};
+  const sf2 t = lo + hi;
+  // lane bit 3 (row_ror:8 == lane ^ 8): lanes with the bit clear (banks 0, 1) keep t.x, the others t.y;
+  // lane bit 2: lanes with the bit clear (banks 0, 2) add lane i + 4 (row_ror:12), the others lane i - 4 (row_ror:4)
+  float u, w;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %1, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(u), "=&v"(w) : "v"(t.x), "v"(t.y));
+  return w;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Backward for SHORT pooled lengths (Lc <= 16: the 224 / 256 px grids, BASELINE configs 2 and 3).
 //
@@ -398,10 +489,6 @@ __device__ __forceinline__ int opaque_tid() {
   return t;
 }
 
-typedef float sf2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ sf2 ssplat(float a) { sf2 o; o.x = a; o.y = a; return o; }
-__device__ __forceinline__ sf2 sfma2(sf2 a, sf2 b, sf2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ sf2 sexp2_2(sf2 a) { sf2 o; o.x = fv_exp2(a.x); o.y = fv_exp2(a.y); return o; }
 
 #ifdef FASTVIM_TUNING_HOOKS
 extern "C" unsigned long long* fv_debug_get_stamps();
@@ -428,6 +515,10 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef ShortLds<RQ, LCT> LD;
   constexpr int RQP = LD::RQP, RT = LD::RT, WP = LD::WP;
+  // d dt_bias[ch] = sum_t d delta_raw[t][ch] rides in the d Wdt product: the staged dt_low rows carry a column of ones in
+  // their zero padding (r = 4 RQ >= dt_rank; it meets zero weights in the two other products), so the sum arrives as
+  // column 4 RQ of the accumulator tile instead of one add per lane and step of the sweep.  dt_rank 48 has no padding.
+  constexpr bool BIAS_MM = RQP > RQ;
   float* s_dbl = smem + LD::o_dbl;
   float* s_ch = smem + LD::o_ch;
   float* s_dr = smem + LD::o_dr;
@@ -529,6 +620,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
           if (c < 4 * RQP) {
             const int qq = c / RQP, i = c - qq * RQP, r = qq + 4 * i;
             if (i < RQ && r < p.R) v = io<T>::ld(dbl + (size_t)l * W + r);
+            if (BIAS_MM && c == RQ) v = 1.f;      // r = 4 RQ: the ones column (BIAS_MM)
           } else {
             v = io<T>::ld(dbl + (size_t)l * W + p.R + (c - 4 * RQP));
           }
@@ -602,49 +694,41 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     float* my_part = s_part + (wv * 4 + q) * 8 + (lane >> 3);
     float* my_dr = s_dr + ch;
     float* my_du = s_du + ch;
+    // the step's three LDS words are requested one step ahead (the compiler barrier keeps them above the step's
+    // arithmetic): with three waves per SIMD the read latency of every step was otherwise exposed
+    float4 nB = *reinterpret_cast<const float4*>(my_bc + (LCT - 1) * WP);
+    float4 nC = *reinterpret_cast<const float4*>(my_bc + (LCT - 1) * WP + N);
+    float4 nc = *reinterpret_cast<const float4*>(my_ch + (LCT - 1) * (SH_CH * 4));
+    sf2 pv[4];
 #pragma unroll
     for (int s = LCT - 1; s >= 0; --s) {
+      const float4 Bv = nB, Cv = nC, cv = nc;
+      if (s > 0) {
+        nB = *reinterpret_cast<const float4*>(my_bc + (s - 1) * WP);
+        nC = *reinterpret_cast<const float4*>(my_bc + (s - 1) * WP + N);
+        nc = *reinterpret_cast<const float4*>(my_ch + (s - 1) * (SH_CH * 4));
+      }
       asm volatile("" ::: "memory");
       if (EXACT || s < Lc) {         // uniform
-        const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
-        const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
-        const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (SH_CH * 4));
-        const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
-        const float dt = cv.x, uu = cv.y, g = cv.z, sg = cv.w;
-        const float dtu = dt * uu;
-        float vals[8];
-        sf2 du2 = {0.f, 0.f}, dd2 = {0.f, 0.f};
+        sf2 vals[4];
+        AdjStep st;
+        if (s > 0) st = adjoint_step<false>(Bv, Cv, cv, A2, Araw, xs[s], xs[s > 0 ? s - 1 : 0], dxa, dA, vals);
+        else st = adjoint_step<true>(Bv, Cv, cv, A2, Araw, xs[s], xs[s], dxa, dA, vals);
+        if constexpr (!BIAS_MM) dbias += st.ddraw;
+        my_dr[s * SH_DRS] = st.ddraw;              // (identical in the four lanes of a channel: no lane predicate, no branch)
+        my_du[s * SH_CH] = cv.x * st.du_acc;
+        if constexpr (EXACT) {
+          // the channel sums of step s + 1 (a chain of dependent cross-lane operations) are taken here, in the same
+          // scheduling region as this step's independent arithmetic, so the wave has something to issue under their latency
+          if (s < LCT - 1) my_part[(s + 1) * (SH_NWV * 4 * 8)] = chan_sum8(pv);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const sf2 a = sexp2_2(A2[h] * dt);
-          const sf2 dx = sfma2(Cn[h], ssplat(g), dxa[h]);
-          sf2 pj = {0.f, 0.f};
-          if (s > 0) pj = dx * (a * xs[s > 0 ? s - 1 : 0][h]);   // dx * a_t * x_{t-1}
-          du2 = sfma2(dx, Bn[h], du2);
-          dd2 = sfma2(Araw[h], pj, dd2);
-          dA[h] = sfma2(pj, ssplat(dt), dA[h]);
-          const sf2 vb = dx * dtu, vc = xs[s][h] * g;
-          vals[2 * h] = vb.x; vals[2 * h + 1] = vb.y;            // dB[4q + 2h ..]
-          vals[4 + 2 * h] = vc.x; vals[5 + 2 * h] = vc.y;        // dC[4q + 2h ..]
-          dxa[h] = a * dx;
+          for (int e = 0; e < 4; ++e) pv[e] = vals[e];
+        } else {
+          my_part[s * (SH_NWV * 4 * 8)] = chan_sum8(vals);
         }
-        const float du_acc = quad_sum(du2.x + du2.y);
-        const float dd_acc = quad_sum(dd2.x + dd2.y);
-        // d delta = sum_n dx (B u + A a x_prev) = u * sum_n dx B + sum_n A dx a x_prev;  through the softplus: * sigmoid
-        const float ddraw = fmaf(uu, du_acc, dd_acc) * sg;
-        dbias += ddraw;
-        if (q == 0) {
-          my_dr[s * SH_DRS] = ddraw;
-          my_du[s * SH_CH] = dt * du_acc;
-        }
-        // sum over the wave's 16 channels: three reduce-scatter levels leave value (lane >> 3) & 7, the last level adds
-        rs_swap32<4, 8>(vals);
-        rs_swap16<2, 8>(vals);
-        rs_row8<1, 8>(vals, lane);
-        const float tot = add_dpp<0x12C>(vals[0]);             // + lane i + 4 (the channel with bit 0 set)
-        if ((lane & 4) == 0) my_part[s * (SH_NWV * 4 * 8)] = tot;
       }
     }
+    if constexpr (EXACT) my_part[0] = chan_sum8(pv);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -855,7 +939,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
       base[(size_t)d * N + q * 4 + 2 * h] = v.x;
       base[(size_t)d * N + q * 4 + 2 * h + 1] = v.y;
     }
-    if (q == 0) base[(size_t)p.d_in * (N + p.R) + d] = dbias;           // identical in the four lanes of a channel
+    if (!BIAS_MM && q == 0) base[(size_t)p.d_in * (N + p.R) + d] = dbias;           // identical in the four lanes of a channel
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -863,6 +947,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     for (int r = 0; r < 4; ++r) {
       const int dw = ch0 + wv * 16 + 4 * tg + r, rr = 16 * rt + cm;
       if (dw < p.d_in && rr < p.R) base[(size_t)p.d_in * N + (size_t)dw * p.R + rr] = accW[rt][r];
+      if (BIAS_MM && dw < p.d_in && rr == 4 * RQ) base[(size_t)p.d_in * (N + p.R) + dw] = accW[rt][r];
     }
 }
 
@@ -924,6 +1009,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
   }
   sf2 dA[2] = {{0.f, 0.f}, {0.f, 0.f}};
   float dbias = 0.f;
+  constexpr bool BIAS_MM = RQP > RQ;      // d dt_bias out of the d Wdt product (ones column in the staged rows: see the short kernel)
   f32x4_t accW[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -961,6 +1047,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
         if (col < 4 * RQP) {
           const int qq = col / RQP, i = col - qq * RQP, r = qq + 4 * i;
           if (i < RQ && r < p.R) v = io<T>::ld(dbl + (size_t)l * W + r);
+          if (BIAS_MM && col == RQ) v = 1.f;      // r = 4 RQ: the ones column
         } else {
           v = io<T>::ld(dbl + (size_t)l * W + p.R + (col - 4 * RQP));
         }
@@ -1115,37 +1202,12 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
           const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
           const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
           const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (CH * 4));
-          const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
-          const float dt = cv.x, uu = cv.y, g = cv.z, sg = cv.w;
-          const float dtu = dt * uu;
-          float vals[8];
-          sf2 du2 = {0.f, 0.f}, dd2 = {0.f, 0.f};
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const sf2 a = sexp2_2(A2[h] * dt);
-            const sf2 dx = sfma2(Cn[h], ssplat(g), dxa[h]);
-            const sf2 pj = dx * (a * (s > 0 ? xs[s > 0 ? s - 1 : 0][h] : entry[h]));   // dx * a_t * x_{t-1}
-            du2 = sfma2(dx, Bn[h], du2);
-            dd2 = sfma2(Araw[h], pj, dd2);
-            dA[h] = sfma2(pj, ssplat(dt), dA[h]);
-            const sf2 vb = dx * dtu, vc = xs[s][h] * g;
-            vals[2 * h] = vb.x; vals[2 * h + 1] = vb.y;            // dB[4q + 2h ..]
-            vals[4 + 2 * h] = vc.x; vals[5 + 2 * h] = vc.y;        // dC[4q + 2h ..]
-            dxa[h] = a * dx;
-          }
-          const float du_acc = quad_sum(du2.x + du2.y);
-          const float dd_acc = quad_sum(dd2.x + dd2.y);
-          const float ddraw = fmaf(uu, du_acc, dd_acc) * sg;
-          dbias += ddraw;
-          if (q == 0) {
-            my_dr[s * DRS] = ddraw;
-            my_du[s * CH] = dt * du_acc;
-          }
-          rs_swap32<4, 8>(vals);
-          rs_swap16<2, 8>(vals);
-          rs_row8<1, 8>(vals, lane);
-          const float tot = add_dpp<0x12C>(vals[0]);             // + lane i + 4 (the channel with bit 0 set)
-          if ((lane & 4) == 0) my_part[s * (NWV * 4 * 8)] = tot;
+          sf2 vals[4];
+          const AdjStep st = adjoint_step<false>(Bv, Cv, cv, A2, Araw, xs[s], s > 0 ? xs[s > 0 ? s - 1 : 0] : entry, dxa, dA, vals);
+          if constexpr (!BIAS_MM) dbias += st.ddraw;
+          my_dr[s * DRS] = st.ddraw;
+          my_du[s * CH] = cv.x * st.du_acc;
+          my_part[s * (NWV * 4 * 8)] = chan_sum8(vals);
         } else if (q == 0) {
           my_dr[s * DRS] = 0.f;        // rows past the sequence feed the K / M padding of the MFMAs below
         }
@@ -1233,7 +1295,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
       base[(size_t)d * N + q * 4 + 2 * h] = v.x;
       base[(size_t)d * N + q * 4 + 2 * h + 1] = v.y;
     }
-    if (q == 0) base[(size_t)p.d_in * (N + p.R) + d] = dbias;           // identical in the four lanes of a channel
+    if (!BIAS_MM && q == 0) base[(size_t)p.d_in * (N + p.R) + d] = dbias;           // identical in the four lanes of a channel
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -1241,6 +1303,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
     for (int r = 0; r < 4; ++r) {
       const int dw = ch0 + wv * 16 + 4 * tg + r, rr = 16 * rt + cm;
       if (dw < p.d_in && rr < p.R) base[(size_t)p.d_in * N + (size_t)dw * p.R + rr] = accW[rt][r];
+      if (BIAS_MM && dw < p.d_in && rr == 4 * RQ) base[(size_t)p.d_in * (N + p.R) + dw] = accW[rt][r];
     }
 }
 
