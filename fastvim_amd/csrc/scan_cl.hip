@@ -1195,6 +1195,32 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
       float* my_part = s_part + (wv * 4 + q) * 8 + (lane >> 3);
       float* my_dr = s_dr + ch;
       float* my_du = s_du + ch;
+      if (valid == LCT) {
+        // a full chunk: the short kernel's schedule -- LDS words a step ahead, the channel sums a step behind, no branch
+        float4 nB = *reinterpret_cast<const float4*>(my_bc + (LCT - 1) * WP);
+        float4 nC = *reinterpret_cast<const float4*>(my_bc + (LCT - 1) * WP + N);
+        float4 nc = *reinterpret_cast<const float4*>(my_ch + (LCT - 1) * (CH * 4));
+        sf2 pv[4];
+#pragma unroll
+        for (int s = LCT - 1; s >= 0; --s) {
+          const float4 Bv = nB, Cv = nC, cv = nc;
+          if (s > 0) {
+            nB = *reinterpret_cast<const float4*>(my_bc + (s - 1) * WP);
+            nC = *reinterpret_cast<const float4*>(my_bc + (s - 1) * WP + N);
+            nc = *reinterpret_cast<const float4*>(my_ch + (s - 1) * (CH * 4));
+          }
+          asm volatile("" ::: "memory");
+          sf2 vals[4];
+          const AdjStep st = adjoint_step<false>(Bv, Cv, cv, A2, Araw, xs[s], s > 0 ? xs[s > 0 ? s - 1 : 0] : entry, dxa, dA, vals);
+          if constexpr (!BIAS_MM) dbias += st.ddraw;
+          my_dr[s * DRS] = st.ddraw;
+          my_du[s * CH] = cv.x * st.du_acc;
+          if (s < LCT - 1) my_part[(s + 1) * (NWV * 4 * 8)] = chan_sum8(pv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pv[e] = vals[e];
+        }
+        my_part[0] = chan_sum8(pv);
+      } else {
 #pragma unroll
       for (int s = LCT - 1; s >= 0; --s) {
         asm volatile("" ::: "memory");
@@ -1211,6 +1237,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanCl
         } else if (q == 0) {
           my_dr[s * DRS] = 0.f;        // rows past the sequence feed the K / M padding of the MFMAs below
         }
+      }
       }
       wave_sync();
 
