@@ -1686,7 +1686,7 @@ __global__ __launch_bounds__(SH_THREADS) void xproj_scan_fwd_short_kernel(ScanCl
             acc2 = sfma2(Cn[h], st[h], acc2);
           }
           const float acc = quad_sum(acc2.x + acc2.y);
-          if (q == 0) s_y[s * SH_CH + chl] = acc;
+          s_y[s * SH_CH + chl] = acc;              // (the four lanes of a channel hold the same sum: no predicate, no branch)
         }
       }
     }
