@@ -516,11 +516,14 @@ int vec_combine(int d_in, int tpp) {
 int vec_convpool(int d_in) { return (d_in % 128 == 0 && d_in <= 12 * 128) ? 2 : 1; }
 int persistent_blocks(long nrows, int rg) {
   long groups = (nrows + rg - 1) / rg;
-  // one block per CU: measured best for the persistent backward kernels (conv_pool_bwd at FastVim-T 32.6 us with 256
-  // blocks vs 37.8 with 448, 36.9 with 384, 33.3 with 224, 46.0 with 299) -- no CU carries two blocks while others
-  // carry one, and the per-block gradient partials halve
+  // at most one block per CU: measured best for the persistent backward kernels (conv_pool_bwd at FastVim-T 32.6 us with 256
+  // blocks vs 37.8 with 448, 36.9 with 384, 46.0 with 299) -- no CU carries two blocks while others carry one, and the
+  // per-block gradient partials halve.  Below that cap the grid is the one that deals the row groups out EVENLY: 448 groups
+  // (FastVim-T: 1 792 pooling rows, 4 per block and iteration) are 2 iterations of 224 blocks, not 1.75 of 256 (round 5,
+  // same box, step 5.39 -> 5.36 ms; in round 2 the same 224 measured 33.3 against 32.6 us)
   static const int cap = fv_tune("FASTVIM_BWD_GRID", 256);   // tuning hook
-  return (int)(groups < cap ? groups : cap);
+  const long per = (groups + cap - 1) / cap;
+  return (int)((groups + per - 1) / per);
 }
 
 template <typename T, int VEC>
