@@ -743,10 +743,11 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
     char* my = smem + wv * (32 * RS);
     bf16_t* Cb = (bf16_t*)p.C + zoff;
 #pragma unroll
-    for (int h = 0; h < MB / 2; ++h) {
+    for (int h = 0; h < (MB + 1) / 2; ++h) {          // (an odd MB leaves a 16-row half slab at the end)
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
         const int b = 2 * h + bb;
+        if (b >= MB) continue;
 #pragma unroll
         for (int a = 0; a < NB; ++a) {
           const f32x4 v = acc[a][b];
@@ -760,7 +761,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, int block_id
       for (int i = 0; i < NB; ++i) {
         const int idx = i * 64 + lane, r = idx / CH, ch = idx - r * CH;
         const int m = m0 + wm * WMR + h * 32 + r, n = n0 + wn * WNC + ch * 8;
-        if (m < p.M && n < p.N) {
+        if (m < p.M && n < p.N && h * 32 + r < WMR) {
           const u32x4 q = *reinterpret_cast<const u32x4*>(my + r * RS + ch * 16);
           bf16_t* dst = Cb + (long)m * p.ldc + n;
           if (n + 8 <= p.N && (((uintptr_t)dst) & 15) == 0) {
@@ -1525,6 +1526,21 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   static const bool big = (fv_tune("FASTVIM_GEMM_BIG", 1) != 0);   // tuning hook
   if (big && !tall && AMODE == KC && BMODE == KC && p.N % 256 == 0 && p.N >= 2048 && p.K >= 512 && p.M >= 4096 && whole_k)
     return launch_k<AMODE, BMODE, 2, 4, true, 4, 8>(p, splits, st);
+  // 160 x 128 tiles where they save rounds of workgroups: the per-tile launches run in rounds of 512 resident workgroups
+  // (two per CU), so a launch costs about rounds x tile area.  FastVim-T in_proj forward (M = 25 088, N = 768, K = 192):
+  // 1 176 tiles of 128 x 128 = 2.3 -> 3 rounds, 942 tiles of 160 x 128 = 1.84 -> 2 rounds at 1.25 x the area: 3.0 -> 2.5
+  // (step 5.343 -> 5.305 ms, same box); FastVim-B out_proj forward (N = 768, K = 1536): 3.0 (either 128-row shape) -> 2.5;
+  // S-width out_proj forward (N = 384): one round of 128 x 192 = 1.5 -> one round of 160 x 128 = 1.25
+  static const int m160 = fv_tune("FASTVIM_GEMM_M160", 1);   // tuning hook
+  if (m160 && !tall && AMODE == KC && BMODE == KC && whole_k && splits == 1 && p.N % 128 == 0 && p.M >= 4096) {
+    const long slots = 2L * fv_cu_count();
+    auto cost = [&](long bm, long bn) { return fv_cdiv((long)fv_cdiv(p.M, bm) * (p.N / bn), slots) * bm * bn; };
+    const bool wide_ok = p.N % 192 == 0 && p.N >= 384 && !(p.N == 768 && p.K <= 192);
+    const bool n96_ok = p.N % 96 == 0 && p.N < 384;
+    long best = cost(128, 128);
+    if (wide_ok && cost(128, 192) < best) best = cost(128, 192);
+    if (!n96_ok && cost(160, 128) < best) return launch_k<AMODE, BMODE, 2, 2, true, 4, 5>(p, splits, st);
+  }
   // N = 192 (FastVim-T: out_proj forward, in_proj data gradient, patch embed): two 96-wide tiles cover it exactly,
   // two 128-wide ones compute and load a quarter too much
   static const int n96 = fv_tune("FASTVIM_GEMM_N96", 1);   // tuning hook (out_proj forward 11.2 -> 10.1 us, in_proj dgrad 18.0 -> 16.9)

@@ -29,6 +29,26 @@ def test_gemm_nt_nn(M, N, K):
     assert (c2.double().cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(25088, 768, 192),     # FastVim-T in_proj forward: 942 tiles of 160 x 128 (two rounds) instead of 1 176 of 128 x 128
+                                   (25000, 768, 192),     # ragged last tile (40 of its 160 rows)
+                                   (24999, 384, 128),     # ... and an odd row count
+                                   (32768, 768, 192)])    # no round saved: stays on 128 x 128
+def test_gemm_tall_tiles_that_save_a_round(M, N, K):
+    """Forward GEMMs with a short K loop take 160 x 128 tiles where that saves a round of resident workgroups (the bf16
+    epilogue's odd 16-row half slab): against fp64 at the bf16 rounding of the result, and row for row against the same
+    product computed in two row blocks that do NOT take the tall tiles."""
+    from fastvim_amd.gemm import gemm_nt
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    w = torch.randn(N, K, device="cuda").bfloat16()
+    ref = _ref(a, w.t())
+    c = gemm_nt(a, w)
+    assert (c.double().cpu() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    half = 2048                                    # M < 4096: the 128 x 128 kernel
+    for r0 in (0, M - half):
+        assert torch.equal(c[r0:r0 + half], gemm_nt(a[r0:r0 + half], w))
+
+
 @pytest.mark.parametrize("kind,M,N,K", [("nt", 100352, 1536, 384),    # FastChannelVim-S in_proj forward: 2352 tiles of 256 x 256
                                         ("nt", 25088, 3072, 768),     # FastVim-B in_proj forward
                                         ("nt", 65500, 1024, 384),     # ragged last row tile
