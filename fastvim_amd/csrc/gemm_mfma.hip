@@ -1530,9 +1530,11 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
   // (two per CU), so a launch costs about rounds x tile area.  FastVim-T in_proj forward (M = 25 088, N = 768, K = 192):
   // 1 176 tiles of 128 x 128 = 2.3 -> 3 rounds, 942 tiles of 160 x 128 = 1.84 -> 2 rounds at 1.25 x the area: 3.0 -> 2.5
   // (step 5.343 -> 5.305 ms, same box); FastVim-B out_proj forward (N = 768, K = 1536): 3.0 (either 128-row shape) -> 2.5;
-  // S-width out_proj forward (N = 384): one round of 128 x 192 = 1.5 -> one round of 160 x 128 = 1.25
+  // S-width out_proj forward (N = 384): one round of 128 x 192 = 1.5 -> one round of 160 x 128 = 1.25.  The data gradients
+  // (B as stored, transposing reads) that the streaming and phased kernels do not take follow the same rule: FastVim-B
+  // in_proj data gradient (N = 768, K = 3072) 3.0 -> 2.5, the channel model's (M = 100 352) 6.0 -> 5.0 / 10.5 -> 10.0
   static const int m160 = fv_tune("FASTVIM_GEMM_M160", 1);   // tuning hook
-  if (m160 && !tall && AMODE == KC && BMODE == KC && whole_k && splits == 1 && p.N % 128 == 0 && p.M >= 4096) {
+  if (m160 && !tall && AMODE == KC && whole_k && splits == 1 && p.N % 128 == 0 && p.M >= 4096) {
     const long slots = 2L * fv_cu_count();
     auto cost = [&](long bm, long bn) { return fv_cdiv((long)fv_cdiv(p.M, bm) * (p.N / bn), slots) * bm * bn; };
     const bool wide_ok = p.N % 192 == 0 && p.N >= 384 && !(p.N == 768 && p.K <= 192);

@@ -47,6 +47,13 @@ def test_gemm_tall_tiles_that_save_a_round(M, N, K):
     half = 2048                                    # M < 4096: the 128 x 128 kernel
     for r0 in (0, M - half):
         assert torch.equal(c[r0:r0 + half], gemm_nt(a[r0:r0 + half], w))
+    # the data-gradient form (B as stored, transposing reads) follows the same rule
+    from fastvim_amd.gemm import gemm_nn
+    b = w.t().contiguous()
+    cn = gemm_nn(a, b)
+    assert (cn.double().cpu() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    for r0 in (0, M - half):
+        assert torch.equal(cn[r0:r0 + half], gemm_nn(a[r0:r0 + half], b))
 
 
 @pytest.mark.parametrize("kind,M,N,K", [("nt", 100352, 1536, 384),    # FastChannelVim-S in_proj forward: 2352 tiles of 256 x 256
