@@ -1569,6 +1569,37 @@ __global__ __launch_bounds__(SH_THREADS) void xproj_scan_fwd_short_kernel(ScanCl
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int dir = blockIdx.y, b = blockIdx.x;
   const size_t bd = ((size_t)dir * p.B + b) * Lc;
+  // per-chunk parameters of a lane (dt_proj weights and bias of its matrix-role channel, A of its scan-role channel): the first
+  // two chunks' are requested HERE, in front of the row staging, and arrive under it and under the x_proj phase -- loaded at
+  // the top of a chunk they were an L2 round trip on every wave's critical path, twice per chunk (60 VGPRs before: room)
+  struct ChunkPar { float w[RQP]; float bias; float al[4]; };
+  auto load_par = [&](int ch0, ChunkPar& c) {
+    const int dm = ch0 + wv * 16 + (lane & 15), tg_ = lane >> 4;
+    const bool actm = dm < d_in;
+    const int ddm = actm ? dm : 0;
+    c.bias = p.dtb[dir][ddm];
+#pragma unroll
+    for (int kg = 0; kg < RQP; ++kg) {
+      const int r = 4 * kg + tg_;
+      c.w[kg] = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
+    }
+    const int d = ch0 + wv * 16 + (lane >> 2), dd = d < d_in ? d : 0;
+    const float4 a4 = *reinterpret_cast<const float4*>(p.Alog[dir] + (size_t)dd * N + (lane & 3) * 4);
+    c.al[0] = a4.x; c.al[1] = a4.y; c.al[2] = a4.z; c.al[3] = a4.w;
+  };
+  ChunkPar par0, par1;
+  load_par(0, par0);
+  if (SH_CH < d_in) load_par(SH_CH, par1);
+  // ... and so are the x_proj weight fragments of this wave's first K step
+  sc_bf16x8 bw0[7];
+  {
+    const int r = lane & 15, kc = lane >> 4;
+    const bf16_t* Wd = Wx2 + (size_t)dir * W * d_in;
+    const int k0 = min(wv, d_in / 32 - 1) * 32 + kc * 8;
+#pragma unroll
+    for (int nt = 0; nt < 7; ++nt)
+      if (nt < NT) bw0[nt] = *reinterpret_cast<const sc_bf16x8*>(Wd + (size_t)min(nt * 16 + r, W - 1) * d_in + k0);
+  }
   // ---- stage the pooled rows in scan order (row s = memory row l(s)); rows past Lc zero
   {
     const bf16_t* xc = (const bf16_t*)p.xc + bd * d_in;
@@ -1599,7 +1630,7 @@ __global__ __launch_bounds__(SH_THREADS) void xproj_scan_fwd_short_kernel(ScanCl
       for (int nt = 0; nt < 7; ++nt) {
         if (nt < NT) {
           const int n = min(nt * 16 + r, W - 1);
-          const sc_bf16x8 bw = *reinterpret_cast<const sc_bf16x8*>(Wd + (size_t)n * d_in + k0);
+          const sc_bf16x8 bw = ks == wv ? bw0[nt] : *reinterpret_cast<const sc_bf16x8*>(Wd + (size_t)n * d_in + k0);
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, a, acc[nt], 0, 0, 0);    // rows = n, cols = t
         }
       }
@@ -1629,21 +1660,19 @@ __global__ __launch_bounds__(SH_THREADS) void xproj_scan_fwd_short_kernel(ScanCl
   // ---- chunks of 192 channels: no workgroup barrier from here on
   const int q = lane & 3, cm = lane & 15, tg = lane >> 4;
   const float* my_bc = s_dbl + 4 * RQP + q * 4;
-  for (int ch0 = 0; ch0 < d_in; ch0 += SH_CH) {
+  auto chunk = [&](int ch0, const ChunkPar& par) {
     // matrix role: delta_raw[t][ch] = sum_r dt_low[t][r] Wdt[ch][r]
     {
       const int dm = ch0 + wv * 16 + cm;
       const bool actm = dm < d_in;
       const int ddm = actm ? dm : 0;
-      const float bias_m = p.dtb[dir][ddm];
+      const float bias_m = par.bias;
       f32x4_t D = {0.f, 0.f, 0.f, 0.f};
       const int ta = min(cm, LCT - 1);
 #pragma unroll
       for (int kg = 0; kg < RQP; ++kg) {
         const float a = s_dbl[ta * WP + tg * RQP + kg];
-        const int r = 4 * kg + tg;
-        const float w = (actm && r < p.R) ? p.Wdt[dir][(size_t)ddm * p.R + r] : 0.f;
-        D = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(a, par.w[kg], D, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1665,10 +1694,11 @@ __global__ __launch_bounds__(SH_THREADS) void xproj_scan_fwd_short_kernel(ScanCl
       const bool act = d < d_in;
       const int dd = act ? d : 0;
       sf2 A2[2], st[2] = {{0.f, 0.f}, {0.f, 0.f}};
+      (void)dd;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        A2[h].x = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h]) * FV_LOG2E;
-        A2[h].y = -__expf(p.Alog[dir][(size_t)dd * N + q * 4 + 2 * h + 1]) * FV_LOG2E;
+        A2[h].x = -__expf(par.al[2 * h]) * FV_LOG2E;
+        A2[h].y = -__expf(par.al[2 * h + 1]) * FV_LOG2E;
       }
       const float* my_ch = s_ch + (size_t)chl * 2;
 #pragma unroll
@@ -1706,6 +1736,13 @@ __global__ __launch_bounds__(SH_THREADS) void xproj_scan_fwd_short_kernel(ScanCl
       }
     }
     __builtin_amdgcn_wave_barrier();      // the next chunk overwrites this wave's table columns
+  };
+  chunk(0, par0);
+  if (SH_CH < d_in) chunk(SH_CH, par1);
+  for (int ch0 = 2 * SH_CH; ch0 < d_in; ch0 += SH_CH) {      // wider models: the further chunks fetch theirs at the top
+    ChunkPar pc;
+    load_par(ch0, pc);
+    chunk(ch0, pc);
   }
 }
 
