@@ -432,8 +432,8 @@ TRACE_NAMES = {
     "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 4>",
     "xproj_bwd": "xproj_bwd_kernel", "combine_out_proj_addnorm_fwd": "combine_out_proj_addnorm_kernel",
 }
-PMC_TRAFFIC_JSON = "r05_v3_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
-STEP_TRACE_CSV = "r05_v3_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r05_v3 (profiles/README.md)
+PMC_TRAFFIC_JSON = "r05_v4_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
+STEP_TRACE_CSV = "r05_v4_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r05_v4 (profiles/README.md)
 
 
 def in_step_trace_us():

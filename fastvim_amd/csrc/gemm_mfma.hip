@@ -1539,9 +1539,10 @@ int launch_shape(const GemmParams& p, int splits, hipStream_t st) {
     auto cost = [&](long bm, long bn) { return fv_cdiv((long)fv_cdiv(p.M, bm) * (p.N / bn), slots) * bm * bn; };
     const bool wide_ok = p.N % 192 == 0 && p.N >= 384 && !(p.N == 768 && p.K <= 192);
     const bool n96_ok = p.N % 96 == 0 && p.N < 384;
-    long best = cost(128, 128);
-    if (wide_ok && cost(128, 192) < best) best = cost(128, 192);
-    if (!n96_ok && cost(160, 128) < best) return launch_k<AMODE, BMODE, 2, 2, true, 4, 5>(p, splits, st);
+    // against the shape that would run otherwise (128 x 192 where the width allows it), with 8 % in hand for the taller
+    // tile's larger L2 -> LDS fill per flop
+    const long cur = wide_ok ? cost(128, 192) : cost(128, 128);
+    if (!n96_ok && cost(160, 128) * 27 / 25 < cur) return launch_k<AMODE, BMODE, 2, 2, true, 4, 5>(p, splits, st);
   }
   // N = 192 (FastVim-T: out_proj forward, in_proj data gradient, patch embed): two 96-wide tiles cover it exactly,
   // two 128-wide ones compute and load a quarter too much
