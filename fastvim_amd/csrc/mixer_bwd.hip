@@ -526,6 +526,26 @@ int persistent_blocks(long nrows, int rg) {
   return (int)((groups + per - 1) / per);
 }
 
+// Grid of the conv + pool adjoint.  Channel-wise tokenization (tokens_per_patch 8) runs the cell-walking kernel, whose blocks
+// are four waves -- `groups` of them per row over blockIdx.y, two resident per CU (convpool_bwd_row.hip): the launch costs
+// (rounds of resident blocks) x (iterations per block), so a grid that keeps all blocks resident in ONE round can beat one
+// block per CU in x: FastChannelVim-S (896 rows, 3 groups) 224 x 3 blocks x 2 iterations = 2 rounds x 2 -> 150 x 3 x 3 =
+// 1 round x 3; 177 -> 166 us (profiles/r05_hook_sweep_final_tree.log).  Everything else: persistent_blocks.
+int conv_pool_bwd_blocks(long nrows, int d_in, int tpp) {
+  const int VEC = vec_convpool(d_in), rg = rg_convpool(d_in, VEC);
+  const int base = persistent_blocks(nrows, rg);
+  if (tpp != 8 || VEC != 2 || d_in % 128) return base;
+  const int nch = d_in / 128;
+  int groups = (nch + 1) / 2;
+  while (nch % groups) ++groups;
+  const int rgr = 4 / (nch / groups);
+  const long rgroups = (nrows + rgr - 1) / rgr, slots = 2L * fv_cu_count();
+  auto even = [&](long cap) { const long per = (rgroups + cap - 1) / cap; return (rgroups + per - 1) / per; };
+  auto cost = [&](long x) { return ((x * groups + slots - 1) / slots) * ((rgroups + x - 1) / x); };
+  const long one_round = even(slots / groups > 0 ? slots / groups : 1);
+  return cost(one_round) < cost(base) ? (int)one_round : base;
+}
+
 template <typename T, int VEC>
 int launch_combine_bwd(const BwdParams& p, hipStream_t st) {
   const int nch = fv_cdiv(p.d_in, 64 * VEC);
@@ -553,7 +573,7 @@ int launch_conv_pool_bwd(const BwdParams& p, hipStream_t st) {
   const int nch = fv_cdiv(p.d_in, 64 * VEC);
   FV_CHECK(nch <= (VEC == 1 ? 16 : 12), "mixer_conv_pool_bwd: d_inner %d too large for the VEC=%d row walker", p.d_in, VEC);
   const int rg = rg_convpool(p.d_in, VEC);
-  dim3 grid(persistent_blocks((long)p.B * p.geo.rows, rg)), block(64 * nch * rg);
+  dim3 grid(conv_pool_bwd_blocks((long)p.B * p.geo.rows, p.d_in, p.geo.tpp)), block(64 * nch * rg);
   size_t smem = (size_t)12 * p.d_in * 4;
   FV_CHECK(smem <= 160 * 1024, "mixer_conv_pool_bwd: d_inner %d too large", p.d_in);
   if (smem > 64 * 1024) {     // opt in to > 64 KiB of dynamic LDS (once per instantiation; not a stream operation)
@@ -628,7 +648,7 @@ extern "C" int fv_mixer_bwd_blocks(int batch, int rows, int d_inner, int tokens_
     if (wb) return wb;
   }
   return which == 0 ? persistent_blocks(n, rg_combine(d_inner, vec_combine(d_inner, tokens_per_patch)))
-                    : persistent_blocks(n, rg_convpool(d_inner, vec_convpool(d_inner)));
+                    : conv_pool_bwd_blocks(n, d_inner, tokens_per_patch);
 }
 
 extern "C" int fv_mixer_combine_bwd(const void* dg, const void* xz, const void* skip, const float* yc,
