@@ -629,6 +629,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     opt = FlatAdamW(flat, model, lr=lr, betas=betas, weight_decay=0.05, no_decay=no_decay, ema_decay=0.9999)
     torch.manual_seed(5678 + rank)             # per-rank DropPath streams
     criterion = SoftTargetCrossEntropy()
+    loss_seed = torch.ones((), device=dev, dtype=torch.float32)      # d loss / d loss, allocated once outside the graph
 
     def fwd_bwd():
         flat.zero_grad()
@@ -639,7 +640,7 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
                 logits = model(x)
         if not is_mae:
             loss = criterion(logits, tgt)      # SoftTargetCrossEntropy (supervised_imagenet.py:83), fused value + gradient
-        loss.backward()
+        loss.backward(gradient=loss_seed)      # (the seed autograd would otherwise fill inside the captured step: a library launch)
         flat.finish_backward()
         return loss.detach()
 

@@ -43,6 +43,7 @@ class SegmentedTrainStep:
         self._gscale = 1.0 / self.exchange.world_size
         self.use_graph = use_graph
         self.loss = None
+        self._seed = torch.ones((), device=x.device, dtype=torch.float32)      # d loss / d loss, allocated once outside the graphs
         self._cuts = None
         self._exposed = []                               # (event before finish, event after) of the timed steps
         self.graphs = None
@@ -88,7 +89,8 @@ class SegmentedTrainStep:
         i = self.K - 1 - k                      # forward index
         outs = self._cuts[i][1]
         if k == 0:
-            torch.autograd.backward(outs[0])
+            seed = self._seed if (outs[0].dim() == 0 and outs[0].dtype == self._seed.dtype and outs[0].device == self._seed.device) else None
+            torch.autograd.backward(outs[0], seed)      # (the seed autograd would otherwise fill inside the captured graph)
         else:
             nxt = self._cuts[i + 1][0]
             torch.autograd.backward(list(outs), [t.grad for t in nxt])
