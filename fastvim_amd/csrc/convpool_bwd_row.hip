@@ -294,7 +294,10 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
       };
       // pooled gradients (x pool_scale): every slot of this row, the slots of row i+1 that its first three tokens
       // pool into (forward conv halo) and the slots of row i-1 that its last three tokens pool into (backward halo)
+      // (CHAN: the six halo slot gradients are used in the first / last cell of a row only; they wait in a lane-private LDS
+      //  slot instead of 12 registers that the allocator would otherwise spill to scratch at 256 VGPRs)
       f2 dcf[NS], dcb[NS], dcf_dn[NH], dcb_up[NH];
+      f2* park = reinterpret_cast<f2*>(smem + 12 * nch * 128) + wv * ((2 * NH + 2 * NS) * 64) + lane;
       {
         const float* dq = p.dxc + ((size_t)b * g.rows + i) * NS * p.d_in + c0;
 #pragma unroll
@@ -308,6 +311,17 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
         for (int k = 0; k < NH; ++k) {
           dcf_dn[k] = *reinterpret_cast<const f2*>(dn + (size_t)k * p.d_in) * (p.pool_scale * m_dn);
           dcb_up[k] = *reinterpret_cast<const f2*>(du + (size_t)(NS - NH + k) * p.d_in) * (p.pool_scale * m_up);
+          if constexpr (CHAN) {
+            park[k * 64] = dcf_dn[k];
+            park[(NH + k) * 64] = dcb_up[k];
+          }
+        }
+        if constexpr (CHAN) {
+#pragma unroll
+          for (int c = 0; c < NS; ++c) {
+            park[(2 * NH + c) * 64] = dcf[c];
+            park[(2 * NH + NS + c) * 64] = dcb[c];
+          }
         }
       }
       // body arrays: X / DO / PF index = position - (TPP*j - 3); PB index = position - (TPP*j - 6)
@@ -352,6 +366,17 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
       for (int j = 0; j <= pcols; ++j) {
         const bool tail = j == pcols, first = j == 0;
         const float e3 = tail ? m_dn : 1.f;
+        f2 hcf[NH], hcb[NH];        // slot gradients of the first three steps of this body
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+          if constexpr (CHAN) {
+            hcf[k] = park[(tail ? k : 2 * NH + k) * 64];
+            hcb[k] = park[(first ? NH + k : 2 * NH + NS + TPP - 3 + k) * 64];
+          } else {
+            hcf[k] = tail ? dcf_dn[k] : dcf[0];
+            hcb[k] = first ? dcb_up[k] : dcb[0];
+          }
+        }
 #pragma unroll
         for (int c = 0; c < TPP; ++c) {
           if (c < 3 || !tail) {
@@ -369,8 +394,14 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
             const int c3 = c < 3 ? c : 0;
             const int sf = CHAN ? c : 0, sf_dn = CHAN ? c3 : 0;
             const int sb = CHAN ? (c < 3 ? TPP - 3 + c3 : c - 3) : 0, sb_up = CHAN ? c3 : 0;
-            const f2 cfs = (c < 3 && tail) ? dcf_dn[sf_dn] : dcf[sf];
-            const f2 cbs = (c < 3 && first) ? dcb_up[sb_up] : dcb[sb];
+            f2 cfs, cbs;
+            if constexpr (CHAN) {
+              cfs = c < 3 ? hcf[sf_dn] : park[(2 * NH + sf) * 64];
+              cbs = c < 3 ? hcb[sb_up] : park[(2 * NH + NS + sb) * 64];
+            } else {
+              cfs = c < 3 ? hcf[sf_dn] : dcf[sf];
+              cbs = c < 3 ? hcb[sb_up] : dcb[sb];
+            }
             const float e0 = (c < 3 && first) ? m_up : 1.f;
             const f2 nf = fma2(Dfh, DO[c + 3], cfs) * dsf * e3;
             const f2 nb = fma2(Dbh, DO[c], cbs) * dsb * e0;
@@ -493,6 +524,7 @@ int fvi::conv_pool_bwd_row(const BwdParams& p, int nch, int rg, int grid, size_t
     nchg = nch / groups;
     rgr = t_rg > 0 ? t_rg : 4 / nchg;
     smem = (size_t)12 * nchg * 128 * 4;           // a block accumulates its own channels only
+    if (chan8) smem += (size_t)nchg * rgr * ((2 * 3 + 2 * 8) * 64) * 8;      // + the waves' parked slot gradients (11 KB per wave)
   } else {
     static const int r_groups = fv_tune("FASTVIM_BWD_ROW_GROUPS", 0), r_rg = fv_tune("FASTVIM_BWD_ROW_RG", 0);   // tuning hooks
     for (groups = 1; groups <= nch; ++groups) {

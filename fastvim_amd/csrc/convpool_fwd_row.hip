@@ -250,7 +250,8 @@ int pick_np(const FwdParams& p, int pool_max, hipStream_t st) {
   static const int force = fv_tune("FASTVIM_FWD_NP", 0);   // tuning hook
   // one channel pair per lane measured fastest (12.8 vs 16.5 us with three pairs on FastVim-T): more, shorter waves
   if ((force == 0 || force == 1) && p.d_in % 128 == 0 && p.d_in <= 16 * 128) return launch_row<T, NT, 1>(p, pool_max, st);
-  if ((force == 0 || force == 3) && p.d_in % 384 == 0 && p.d_in <= 8 * 384) return launch_row<T, NT, 3>(p, pool_max, st);
+  // (three pairs per lane -- d_inner 2304 ... 3072 only -- spilled 26-62 registers at 256 and served no model: those widths
+  //  take the generic kernel)
   if ((force == 0 || force == 2) && p.d_in % 256 == 0 && p.d_in <= 8 * 256) return launch_row<T, NT, 2>(p, pool_max, st);
   return FV_ERR_UNSUPPORTED;
 }

@@ -980,8 +980,10 @@ struct ChunkLds {
 };
 
 constexpr int CK_HOIST_MAX_RQ = 12;
+// (four-wave workgroups at dt_rank 48 are launched where the grid leaves at most two of them per CU -- ck_waves -- and at
+//  three per CU, 168 VGPRs, the hoisted dt_proj weights spilled 9-11 registers: two per CU, no spill)
 template <typename T, int RQ, int NWV, bool CK_GIVEN>
-__global__ __launch_bounds__(64 * NWV, 3) void scan_cl_bwd_chunked_kernel(ScanClParams p) {
+__global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_cl_bwd_chunked_kernel(ScanClParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef ChunkLds<RQ, NWV> LD;
   constexpr int RQP = LD::RQP, RT = LD::RT, WP = LD::WP, LCT = 16, CH = LD::CH, DRS = LD::DRS, NTH = 64 * NWV;

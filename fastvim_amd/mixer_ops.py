@@ -331,18 +331,24 @@ def scan_bwd_xproj(xc, x_dbl, dt_w, dt_b, A_log, dt_w_b, dt_b_b, A_log_b, dyc, W
 
 
 def chunk_rows_bf16(jobs):
-    """jobs: [(dx_dbl_chunks (nchunks, 2, M, W) fp32, out (2, M, WP) bf16)], all of one shape: out = bf16(sum over the
-    chunks), pad columns zero -- ONE launch for up to 64 mixers (fv_chunk_rows_bf16)."""
+    """jobs: [(dx_dbl_chunks (nchunks, 2, M, W) fp32, out (2, M, WP) bf16)]: out = bf16(sum over the chunks), pad columns
+    zero -- ONE launch per job shape for up to 64 mixers (fv_chunk_rows_bf16).  The queue of a backward pass holds every
+    block's job: on a non-square grid (224 x 256 px: 14 pooled rows on even layers, 16 on the rotated ones) or with
+    micro-batches of different sizes the shapes differ, so jobs are bucketed by shape, in queue order inside a bucket."""
     lib = L.lib()
-    for lo in range(0, len(jobs), 64):
-        grp = jobs[lo:lo + 64]
-        nchunks, _, Mrows, W = grp[0][0].shape
-        assert all(j[0].shape == grp[0][0].shape and j[1].dtype == torch.bfloat16 and j[1].is_contiguous() for j in grp)
-        k = len(grp)
-        ins = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in grp])
-        outs = (ctypes.c_void_p * k)(*[j[1].data_ptr() for j in grp])
-        rc = lib.fv_chunk_rows_bf16(ins, outs, L.i32(k), L.i32(nchunks), ctypes.c_long(2 * Mrows), L.i32(W), L.stream_of(grp[0][0]))
-        L.check(rc, "chunk_rows_bf16")
+    buckets = {}
+    for j in jobs:
+        assert j[1].dtype == torch.bfloat16 and j[1].is_contiguous() and j[0].dtype == torch.float32 and j[0].is_contiguous()
+        buckets.setdefault((tuple(j[0].shape), tuple(j[1].shape)), []).append(j)
+    for (ishape, _), bjobs in buckets.items():
+        nchunks, _, Mrows, W = ishape
+        for lo in range(0, len(bjobs), 64):
+            grp = bjobs[lo:lo + 64]
+            k = len(grp)
+            ins = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in grp])
+            outs = (ctypes.c_void_p * k)(*[j[1].data_ptr() for j in grp])
+            rc = lib.fv_chunk_rows_bf16(ins, outs, L.i32(k), L.i32(nchunks), ctypes.c_long(2 * Mrows), L.i32(W), L.stream_of(grp[0][0]))
+            L.check(rc, "chunk_rows_bf16")
 
 
 def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed,

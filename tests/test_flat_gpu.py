@@ -148,3 +148,36 @@ def test_backward_allreduce_step_without_finish_backward():
             opt.step()
             outs.append(flat.param_flat.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_non_square_grid_flat_state_step_with_folded_xproj():
+    """on a 224 x 256 px grid (14 x 16 patches) the even layers pool to 14 rows and the rotated ones to 16, so the
+    queue of one backward pass holds d x_dbl row jobs of TWO shapes; they used to meet an all-one-shape assert in
+    ``chunk_rows_bf16``.  The flat-state step must run (chained blocks, x_proj adjoint folded into the scan backward) and give
+    the gradients of the same model stepped without the flat state."""
+    from fastvim_amd.flat import FlatTrainingState
+    torch.manual_seed(0)
+    base = _model(depth=4, img=(224, 256))
+    x = torch.randn(32, 3, 224, 256, device="cuda")       # batch a multiple of 32: the grouped x_proj weight gradient path
+    g = torch.randn(32, 50, device="cuda")
+
+    def loss(m):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return (m(x).float() * g).sum()
+
+    m = copy.deepcopy(base)
+    with FlatTrainingState(m) as flat:
+        flat.zero_grad()
+        loss(m).backward()
+        flat.finish_backward()
+        torch.cuda.synchronize()
+        got = flat.grad_flat.clone()
+        names, offs = flat.names, flat.offsets
+    ref_m = copy.deepcopy(base)
+    loss(ref_m).backward()
+    params = dict(ref_m.named_parameters())
+    assert torch.isfinite(got).all()
+    for n in names:
+        o, k = offs[n], params[n].numel()
+        a, b = got[o:o + k], params[n].grad.reshape(-1).float()
+        assert (a - b).abs().max().item() <= 5e-3 * max(1e-3, b.abs().max().item()), n

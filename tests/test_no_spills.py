@@ -1,0 +1,99 @@
+"""No register spills / scratch on any BASELINE path (CPU test: reads the code-object notes of the built library).
+
+The instantiations a configuration dispatches are taken from the committed rocprofv3 traces of its graph-replayed
+training step (profiles/*_graph_step_kernel_stats.csv: FastVim-T = BASELINE configs[1], cfg3 / cfg4 / cfg5 and the Vim-T
+baseline); every one of them must have `.vgpr_spill_count == 0` and `.private_segment_fixed_size == 0`.  Kernels off those
+paths that still spill are an explicit allowlist: a NEW spilling kernel anywhere fails the second test until it is either
+fixed or acknowledged here."""
+import csv
+import glob
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_meta  # noqa: E402
+
+# instantiations that are known to spill and are dispatched by no BASELINE configuration (fp32 storage, 16-row grids of
+# the un-folded short scan, twelve-wave chunked scans at dt_rank 48, the generic whole-row conv adjoint in fp32)
+KNOWN_SPILLS = {
+    "conv_pool_bwd_chan_kernel<float, 8, false>",
+    "conv_pool_bwd_chan_kernel<float, 8, true>",
+    "conv_pool_bwd_kernel<float, 1, 17, false, false>",
+    "conv_pool_bwd_kernel<float, 2, 17, false, false>",
+    "scan_cl_bwd_chunked_kernel<bf16, 12, 12, false>",
+    "scan_cl_bwd_chunked_kernel<bf16, 12, 12, true>",
+    "scan_cl_bwd_chunked_kernel<float, 12, 12, false>",
+    "scan_cl_bwd_chunked_kernel<float, 12, 12, true>",
+    "scan_cl_bwd_short_kernel<bf16, 12, 16, true, false>",
+    "scan_cl_bwd_short_kernel<bf16, 3, 16, true, false>",
+    "scan_cl_bwd_short_kernel<float, 12, 16, true, false>",
+    "scan_cl_bwd_short_kernel<float, 3, 16, true, false>",
+    "xproj_bwd_kernel<float, 112, 16, true>",
+    "xproj_bwd_kernel<float, 80, 16, true>",
+    "xproj_bwd_kernel<float, 80, 8, true>",
+    "xproj_bwd_kernel<float, 96, 16, true>",
+}
+
+
+def _latest_traces():
+    """The newest committed step trace per configuration: rNN_vK (FastVim-T), rNN_cfg3 / cfg4 / cfg5, rNN_vim (Vim-T)."""
+    import re
+    best = {}
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_graph_step_kernel_stats.csv")):
+        m = re.match(r"r(\d+)_(v(\d+)|cfg3|cfg4|cfg5|vim)_graph_step_kernel_stats\.csv$", os.path.basename(f))
+        if not m:
+            continue
+        cfg = "T" if m.group(3) else m.group(2)
+        key = (int(m.group(1)), int(m.group(3) or 0))
+        if cfg not in best or key > best[cfg][0]:
+            best[cfg] = (key, f)
+    return {cfg: f for cfg, (_, f) in best.items()}
+
+
+def _dispatched():
+    out = {}
+    for cfg, f in _latest_traces().items():
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                n = row["Name"]
+                if n.startswith(("at::", "__amd", "void at::", "void rocprim", "rocprim", "void hipcub", "Cijk", "ncclDev")):
+                    continue
+                out.setdefault(kernel_meta.short(n), set()).add(cfg)
+    return out
+
+
+@pytest.fixture(scope="module")
+def meta():
+    if not os.path.exists(kernel_meta.LIB):
+        pytest.skip("library not built")
+    return {kernel_meta.short(r["name"]): r for r in kernel_meta.kernels()}
+
+
+def test_baseline_path_kernels_do_not_spill(meta):
+    disp = _dispatched()
+    assert {"T", "cfg3", "cfg4", "cfg5"} <= set().union(*disp.values()), "step traces of the BASELINE configurations are missing"
+    bad, unknown = [], []
+    for name, cfgs in sorted(disp.items()):
+        r = meta.get(name)
+        if r is None:
+            unknown.append((name, sorted(cfgs)))      # a trace older than the tree: the instantiation was renamed / retired
+            continue
+        if kernel_meta.spills(r):
+            bad.append((name, sorted(cfgs), r.get("vgpr_spill_count"), r.get("private_segment_fixed_size")))
+    assert not bad, f"kernels on BASELINE paths spill: {bad}"
+    # every hot kernel of the traces must still be found (a rename would silently empty this test)
+    assert len(unknown) <= len(disp) // 4, f"too many traced kernels are not in the library: {unknown}"
+
+
+def test_spilling_kernels_are_the_acknowledged_ones(meta):
+    now = {n for n, r in meta.items() if kernel_meta.spills(r)}
+    new = sorted(now - KNOWN_SPILLS)
+    if now:
+        print("kernels with spills / scratch (none on a BASELINE path):")
+        for n in sorted(now):
+            r = meta[n]
+            print(f"  {n}: {r.get('vgpr_spill_count', 0)} VGPRs, {r.get('private_segment_fixed_size', 0)} B scratch")
+    assert not new, f"new spilling kernels: {new}"
