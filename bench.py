@@ -429,7 +429,7 @@ TRACE_NAMES = {
     "conv_pool_fwd": "conv_pool_fwd_row_kernel", "scan_fwd": "xproj_scan_fwd_short_kernel", "combine_fwd": "combine_fwd_wave_kernel",
     "combine_bwd": "combine_bwd_wave_kernel", "scan_bwd": "scan_cl_bwd_short_kernel", "conv_pool_bwd": "conv_pool_bwd_row_kernel",
     "add_rmsnorm_fwd": "add_norm_fwd3_kernel", "gemm_out_proj_addnorm_fwd": "gemm_addnorm_kernel",
-    "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 4>",
+    "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 5>",
     "xproj_bwd": "xproj_bwd_kernel", "combine_out_proj_addnorm_fwd": "combine_out_proj_addnorm_kernel",
 }
 PMC_TRAFFIC_JSON = "r05_v4_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
@@ -713,6 +713,19 @@ def run_training_steps(model_name, img, batch, channels, dtype, steps, warmup, r
     extras = {"params": n_params}
     if world > 1:
         ex = getattr(flat, "exchange", None)
+        # what every rank ran on, gathered so that the first SCALE record is self-describing: device index, device name,
+        # the collective library's version as torch reports it (torch.cuda.nccl.version() IS RCCL's on ROCm)
+        try:
+            ccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:
+            ccl = None
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", 0)), "device_index": torch.cuda.current_device(),
+                "device": torch.cuda.get_device_name(), "pid": os.getpid()}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
+        extras["ddp_ranks"] = ranks_info
+        extras["ddp_lib"] = {"collective_library": "rccl" if (ccl and torch.version.hip) else dist.get_backend(), "version": ccl,
+                             "torch": torch.__version__, "hip": torch.version.hip, "native": True}
         extras["ddp"] = {
             "backend": dist.get_backend(), "ranks": dist.get_world_size(), "overlapped": seg is not None,
             "buckets": len(ex.bounds) if ex is not None else 1,
@@ -1007,6 +1020,8 @@ def main():
         }
         if "ddp" in extras:
             out["ddp"] = extras["ddp"]
+            out["ddp"]["ranks_on"] = extras.get("ddp_ranks")
+            out["ddp"]["library"] = extras.get("ddp_lib")
         if args.segmented:
             out["config"]["segmented_step"] = args.buckets
         if not args.no_kernels and args.model not in ("V", "M", "MV", "CV"):
