@@ -59,7 +59,6 @@ def build(force=False, verbose=False, tuning=False):
     was = os.path.exists(stamp)
     if was != tuning:
         force = True
-        (open(stamp, "w").close() if tuning else os.remove(stamp))
     if tuning and "-DFASTVIM_TUNING_HOOKS" not in FLAGS:
         FLAGS.append("-DFASTVIM_TUNING_HOOKS")
     if not tuning and "-DFASTVIM_TUNING_HOOKS" in FLAGS:
@@ -70,8 +69,13 @@ def build(force=False, verbose=False, tuning=False):
     fstamp = os.path.join(OBJ, ".flags")
     if not os.path.exists(fstamp) or open(fstamp).read() != sig:
         force = True
-        with open(fstamp, "w") as f:
-            f.write(sig)
+    if force:
+        # the stamps describe what the OBJECTS were built with: they are withdrawn now and written again only after every
+        # compile job and the link have succeeded -- an interrupted or failed rebuild leaves no stamp, so the next run
+        # rebuilds everything instead of linking objects of two flag sets into one library (round 5, advisor)
+        for st_ in (fstamp, stamp):
+            if os.path.exists(st_):
+                os.remove(st_)
     hdr_m = _deps_mtime()
     jobs, objs = [], []
     for src in _sources():
@@ -87,6 +91,11 @@ def build(force=False, verbose=False, tuning=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if not os.path.exists(fstamp):
+        with open(fstamp, "w") as f:
+            f.write(sig)
+    if tuning and not os.path.exists(stamp):
+        open(stamp, "w").close()
     return LIB
 
 

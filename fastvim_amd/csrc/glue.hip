@@ -166,6 +166,34 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const T* __restrict__ x
 
 bool dt_ok(int dt) { return dt == FV_F32 || dt == FV_BF16; }
 
+
+// Transposed bf16 shadows of up to 64 equal-shape weights in one launch: dst[j] (cols, rows) = src[j] (rows, cols)^T,
+// 32 x 32 tiles through LDS (both sides coalesced).  in_proj.weight (2 d_inner, d_model) -> (d_model, 2 d_inner): the
+// K-contiguous operand fv_mixer_conv_pool_bwd_dgrad streams into MFMA registers.
+constexpr int TRJ_MAX = 64;
+struct TransposeJobs {
+  const uint16_t* src[TRJ_MAX];
+  uint16_t* dst[TRJ_MAX];
+  int rows, cols;
+};
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(TransposeJobs J) {
+  __shared__ uint16_t t[32][33];
+  const uint16_t* src = J.src[blockIdx.z];
+  uint16_t* dst = J.dst[blockIdx.z];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    t[ty + 8 * i][tx] = (r < J.rows && c < J.cols) ? src[(size_t)r * J.cols + c] : (uint16_t)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < J.rows && c < J.cols) dst[(size_t)c * J.rows + r] = t[tx][ty + 8 * i];
+  }
+}
+
 }  // namespace
 
 extern "C" int fv_patch_unfold(const void* img, int img_dtype, void* out, int out_dtype, int batch, int chans, int height,
@@ -246,6 +274,22 @@ extern "C" int fv_column_sum(const void* x, int dtype, float* out, int rows, int
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FV_F32) hipLaunchKernelGGL(column_sum_kernel<float>, grid, block, 0, st, (const float*)x, out, rows, cols, accumulate);
   else hipLaunchKernelGGL(column_sum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, out, rows, cols, accumulate);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
+}
+
+extern "C" int fv_transpose_bf16_batched(const void* const* srcs, void* const* dsts, int njobs, int rows, int cols,
+                                         fv_stream_t stream) {
+  FV_CHECK(srcs && dsts && njobs > 0 && njobs <= TRJ_MAX, "transpose_bf16_batched: 1..%d jobs", TRJ_MAX);
+  FV_CHECK(rows > 0 && cols > 0 && fv_cdiv(rows, 32) <= 65535, "transpose_bf16_batched: bad shape (%d, %d)", rows, cols);
+  TransposeJobs J{};
+  for (int j = 0; j < njobs; ++j) {
+    FV_CHECK(srcs[j] && dsts[j], "transpose_bf16_batched: null pointer in job %d", j);
+    J.src[j] = (const uint16_t*)srcs[j];
+    J.dst[j] = (uint16_t*)dsts[j];
+  }
+  J.rows = rows; J.cols = cols;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(fv_cdiv(cols, 32), fv_cdiv(rows, 32), njobs), dim3(256), 0, (hipStream_t)stream, J);
   FV_LAUNCH_CHECK();
   return FV_OK;
 }

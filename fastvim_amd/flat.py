@@ -138,6 +138,19 @@ class FlatTrainingState:
         pe = getattr(model, "pos_embed", None)
         if isinstance(pe, torch.nn.Parameter) and pe.requires_grad:
             pe._fv_direct = True                     # (the patch projection's per-token table gradient)
+        # transposed bf16 shadows of the in_proj weights the fused conv-adjoint + data-gradient launch streams into MFMA
+        # registers (fv_mixer_conv_pool_bwd_dgrad: d_model 192, d_inner 384); re-made by ONE launch after every shadow refresh
+        self._t_src, self._t_dst, self._t_params = [], [], []
+        if shadow_dtype == torch.bfloat16 and dev.type == "cuda":
+            for mod in mixers.values():
+                w = mod.in_proj.weight
+                if tuple(w.shape) == (768, 192) and w.requires_grad and getattr(w, "_fv_shadow", None) is not None:
+                    wt = torch.empty(192, 768, device=dev, dtype=shadow_dtype)
+                    w._fv_shadow_t = wt
+                    w._fv_shadow_t_version = -1
+                    self._t_src.append(w._fv_shadow)
+                    self._t_dst.append(wt)
+                    self._t_params.append(w)
         self.refresh_shadow()
         # ``model.load_state_dict`` writes the fp32 masters in place: re-cast the shadow right away (the version check in
         # ``_shadow`` would also catch it at the next forward, but a captured HIP graph never runs that check again)
@@ -207,6 +220,16 @@ class FlatTrainingState:
         self.shadow_flat.copy_(self.param_flat)
         for p in self._params:
             p._fv_shadow_version = p._version
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        """Re-make the transposed in_proj shadows from ``shadow_flat`` (one launch; called after every shadow refresh:
+        here and by the fused optimizer step)."""
+        if self._t_src:
+            from .mixer_ops import transpose_bf16_batched
+            transpose_bf16_batched(self._t_src, self._t_dst)
+            for p in self._t_params:
+                p._fv_shadow_t_version = p._version
 
     @property
     def world_size(self):
@@ -355,6 +378,7 @@ class FlatAdamW:
             ctypes.c_float(self.weight_decay), ctypes.c_float(self.ema_decay), ctypes.c_float(grad_scale),
             ctypes.c_size_t(f.param_flat.numel()), L.stream_of(f.param_flat))
         L.check(rc, "adamw_flat")
+        f.refresh_transposed()      # (the kernel above has just re-cast the bf16 shadows)
 
 
 def save_checkpoint(path, model, opt, prefix="backbone.", **extra):

@@ -34,6 +34,22 @@ def _shadow(w, cdt):
     return w.to(cdt)
 
 
+def _shadow_t(w, cdt):
+    """The TRANSPOSED compute-dtype copy of a 2-D weight (in_proj.weight (2 d_inner, d) -> (d, 2 d_inner), K-contiguous for
+    the data gradient that streams it into MFMA registers: fv_mixer_conv_pool_bwd_dgrad).  FlatTrainingState keeps one per
+    eligible in_proj and re-transposes them in one launch after every fused optimizer step (``refresh_transposed``); any
+    other in-place write to the parameter is caught by the version counter, like ``_shadow``.  Without a flat training
+    state: a fresh transpose."""
+    wt = getattr(w, "_fv_shadow_t", None)
+    if wt is not None and wt.dtype == cdt:
+        if w._version != w._fv_shadow_t_version:
+            with torch.no_grad():
+                wt.copy_(_shadow(w, cdt).t())
+            w._fv_shadow_t_version = w._version
+        return wt
+    return _shadow(w, cdt).t().contiguous()
+
+
 def _direct_grad(w):
     """The preallocated .grad view my kernels may accumulate into (flat training state), or None."""
     g = w.grad
@@ -313,6 +329,7 @@ class _Ctx:
 
 
 COMBINE_IN_OUT_PROJ = True      # combine (expand + LayerNorm + gate) as the A-tile producer of the out_proj + add + norm launch (A/B switch)
+CONV_IN_DGRAD = True            # the conv + pool adjoint as the A-tile producer of the in_proj data gradient + norm adjoint (A/B switch)
 
 
 def resolve_combine(pack):
@@ -454,7 +471,22 @@ class ChainedBlockFn(torch.autograd.Function):
             L.check(rc, "gemm_bf16_dgrad_addnorm_bwd")
             out.update(dx=dx, dres_in=dres_in, pw=pw, nb=nb, dg_prev=dg_prev)
 
+        def fused_conv_dgrad(xz, d_o, dxc, dxc2, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed, scaling, conv_grad_out):
+            """The conv + pool adjoint AND the launch above in one (fv_mixer_conv_pool_bwd_dgrad); returns the conv
+            parameter-gradient sums (None when accumulated into ``conv_grad_out``)."""
+            gg = dres_out.reshape(Mrows, d).contiguous() if dres_out is not None else None
+            d_prev = g_prev.shape[2]
+            W2 = _shadow(W_out_prev, cdt) if d_prev % 128 == 0 else None
+            W_in_t = _shadow_t(ctx.W_in, cdt)                # (held across the launch, see _out_proj_add_norm_fwd)
+            p2, dx, dres_in, pw, nb, dg_prev = M.conv_pool_bwd_dgrad(
+                xz, d_o, dxc, dxc2, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed, scaling, W_in_t, gg, r, rstd,
+                w32, row_scale, ctx.rows_per_scale, W2=W2, conv_grad_out=conv_grad_out)
+            out.update(dx=dx, dres_in=dres_in, pw=pw, nb=nb, dg_prev=dg_prev)
+            return p2
+
         fctx.fused_in_dgrad = fused_in_dgrad
+        if (CONV_IN_DGRAD and cdt == torch.bfloat16 and d == 192 and ctx.W_in.shape[0] == 768 and (row_scale is None or row_scale.dtype == torch.float32)):
+            fctx.fused_conv_dgrad = fused_conv_dgrad
         grads = FastVimMixerFn.backward(fctx, dg)
         with torch.autocast("cuda", enabled=False):
             gd = _direct_grad(ctx.w_param)
@@ -658,12 +690,23 @@ class FastVimMixerFn(torch.autograd.Function):
                     fv["Wx2_grad"].add_(dWx2)
                     dWx2 = (None, None)
                 dxc = dxc.view(2, B * rows * tpp, d_in) + gemm_any_bnn(dx_dbl, Wx2.float(), out_dtype=torch.float32)   # + dx_dbl @ Wx
-            p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
-                                 pool_max, scaling, grad_out=fv.get("conv_grad") if cb is not None and cb_b is not None else None,
-                                 tpp=tpp, amax=amax, dxc2=dxc2)
+            conv_grad = fv.get("conv_grad") if cb is not None and cb_b is not None else None
+            fused_cd = getattr(ctx, "fused_conv_dgrad", None)
             dxz2 = dxz.view(B * Ltok, 2 * d_in)
-            fused_dgrad = getattr(ctx, "fused_in_dgrad", None)
-            if fused_dgrad is not None:
+            if (fused_cd is not None and amax is None and dxc.dtype == torch.float32 and dxc.is_contiguous()
+                    and M.conv_pool_bwd_dgrad_ok(xz, rows, cols, tpp, d, pool_max)):
+                # ChainedBlockFn, FastVim-T: the conv + pool adjoint is the A-tile producer of the in_proj data gradient,
+                # whose epilogue is the norm's adjoint (one launch instead of two; the x half of dxz is still written --
+                # the weight gradient below reads it)
+                p2 = fused_cd(xz, d_o, dxc, dxc2, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed, scaling, conv_grad)
+                fused_dgrad = "done"
+            else:
+                p2 = M.conv_pool_bwd(xz, d_o, dxc, cw2, cb, cwb2, cb_b, D, D_b, dxz, rows, cols, transposed,
+                                     pool_max, scaling, grad_out=conv_grad, tpp=tpp, amax=amax, dxc2=dxc2)
+                fused_dgrad = getattr(ctx, "fused_in_dgrad", None)
+            if fused_dgrad == "done":
+                dhidden = None
+            elif fused_dgrad is not None:
                 fused_dgrad(dxz2)          # ChainedBlockFn: the data gradient goes straight into the norm's adjoint
                 dhidden = None
             else:

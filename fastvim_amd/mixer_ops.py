@@ -373,6 +373,65 @@ def conv_pool_bwd(xz, d_o, dxc, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz,
     return reduce_partials(part, nb)
 
 
+def conv_pool_bwd_dgrad_ok(xz, rows, cols, tpp, d_model, pool_max):
+    """Is the conv + pool adjoint built as the A-tile producer of the in_proj data gradient + norm adjoint for this shape?"""
+    B, Ltok, two_d = xz.shape
+    return bool(xz.dtype == torch.bfloat16 and xz.is_contiguous() and
+                L.lib().fv_mixer_conv_pool_bwd_dgrad_ok(L.i32(B), L.i32(rows), L.i32(cols), L.i32(tpp), L.i32(two_d // 2),
+                                                        L.i32(d_model), L.i32(int(bool(pool_max))), L.i32(L.FV_BF16)))
+
+
+def conv_pool_bwd_dgrad(xz, d_o, dxc, dxc2, conv_w, conv_b, conv_w_b, conv_b_b, D, D_b, dxz, rows, cols, transposed, scaling,
+                        W_in_t, dres_out, r, rstd, norm_w32, row_scale, rows_per_scale, W2=None, conv_grad_out=None):
+    """``conv_pool_bwd`` (x half of ``dxz`` written, its z half read) AND ``fv_gemm_bf16_dgrad_addnorm_bwd2`` on the result in
+    one launch (fv_mixer_conv_pool_bwd_dgrad).  ``W_in_t`` (d, 2 d_in) bf16 = in_proj.weight^T.  Returns
+    (conv parameter-gradient sums or None when accumulated into ``conv_grad_out``, dx (M, d) bf16, dres_in (M, d) fp32,
+    pw (nb, d) partial sums of the norm weight's gradient, nb, dg_prev (M, N2) bf16 or None)."""
+    B, Ltok, two_d = xz.shape
+    d_in = two_d // 2
+    d = W_in_t.shape[0]
+    Mrows = B * Ltok
+    s_i, s_j = _geo(rows, cols, transposed)
+    lib = L.lib()
+    dev = xz.device
+    nb = lib.fv_mixer_conv_pool_bwd_dgrad_blocks(L.i32(B), L.i32(rows))
+    part = torch.empty(nb, 12 * d_in, device=dev, dtype=torch.float32)
+    dx = torch.empty(Mrows, d, device=dev, dtype=torch.bfloat16)
+    dres_in = torch.empty(Mrows, d, device=dev, dtype=torch.float32)
+    pw = torch.empty(nb, d, device=dev, dtype=torch.float32)
+    N2 = W2.shape[1] if W2 is not None else 0
+    dg_prev = torch.empty(Mrows, N2, device=dev, dtype=torch.bfloat16) if W2 is not None else None
+    assert dxc2 is None or (dxc2.dtype == xz.dtype and dxc2.shape == dxc.shape and dxc2.is_contiguous())
+    assert W_in_t.dtype == torch.bfloat16 and W_in_t.stride(1) == 1 and W_in_t.shape[1] == two_d
+    rc = lib.fv_mixer_conv_pool_bwd_dgrad(
+        L.ptr(xz), L.ptr(d_o), L.ptr(dxc), L.ptr(dxc2), L.ptr(conv_w), L.ptr(conv_b), L.ptr(conv_w_b), L.ptr(conv_b_b),
+        L.ptr(D), L.ptr(D_b), L.ptr(dxz), L.ptr(part), L.i32(B), L.i32(rows), L.i32(cols), L.i32(s_i), L.i32(s_j),
+        f32(scaling), L.ptr(W_in_t), ctypes.c_long(W_in_t.stride(0)), L.ptr(dres_out), L.ptr(r), L.ptr(rstd), L.ptr(norm_w32),
+        L.ptr(row_scale), L.i32(rows_per_scale), L.ptr(dx), L.ptr(dres_in), L.ptr(pw), L.ptr(W2), L.ptr(dg_prev), L.i32(N2),
+        ctypes.c_long(W2.stride(0) if W2 is not None else 0), L.stream_of(xz))
+    L.check(rc, "mixer_conv_pool_bwd_dgrad")
+    if conv_grad_out is not None:
+        reduce_partials(part, nb, out=conv_grad_out, accumulate=True)
+        p2 = None
+    else:
+        p2 = reduce_partials(part, nb)
+    return p2, dx, dres_in, pw, nb, dg_prev
+
+
+def transpose_bf16_batched(srcs, dsts):
+    """dsts[j] (cols, rows) = srcs[j] (rows, cols)^T, bf16, equal shapes, one launch per 64 matrices."""
+    lib = L.lib()
+    rows, cols = srcs[0].shape
+    for lo in range(0, len(srcs), 64):
+        a, b = srcs[lo:lo + 64], dsts[lo:lo + 64]
+        assert all(t.dtype == torch.bfloat16 and t.is_contiguous() and tuple(t.shape) == (rows, cols) for t in a)
+        assert all(t.dtype == torch.bfloat16 and t.is_contiguous() and tuple(t.shape) == (cols, rows) for t in b)
+        k = len(a)
+        ins = (ctypes.c_void_p * k)(*[t.data_ptr() for t in a])
+        outs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in b])
+        L.check(lib.fv_transpose_bf16_batched(ins, outs, L.i32(k), L.i32(rows), L.i32(cols), L.stream_of(a[0])), "transpose_bf16_batched")
+
+
 XPROJ_WIDTHS = (44, 56, 80, 96, 112, 34, 36, 38, 64)
 
 

@@ -38,8 +38,9 @@ const char* fv_last_error(void);
  *   2  round 4 changed fv_mixer_scan_bwd_segments / fv_mixer_scan_bwd_seg_partials (a d_inner argument was inserted)
  *      without bumping the number; round 5 bumps it for that break, removes the opt-in fv_mixer_mid_fwd(_ok) and
  *      fv_gemm_bf16_addnorm_rw(_ok), and adds fv_mixer_scan_bwd_xproj(_ok), fv_mixer_conv_pool_bwd2(_ok),
- *      fv_chunk_rows_bf16. */
-#define FV_ABI_VERSION 2
+ *      fv_chunk_rows_bf16.
+ *   3  round 6 adds fv_mixer_conv_pool_bwd_dgrad(_ok, _blocks), fv_transpose_bf16_batched (nothing removed or changed). */
+#define FV_ABI_VERSION 3
 int fv_version(void);
 
 /* ------------------------------------------------------------------------
@@ -416,6 +417,39 @@ int fv_mixer_combine_out_proj_addnorm(const void* xz, const void* skip, const fl
                                       const float* residual, const float* norm_weight, const float* row_scale,
                                       int rows_per_scale, void* y, float* residual_out, float* rstd, float eps,
                                       fv_stream_t stream);
+
+/* fv_mixer_conv_pool_bwd2 + fv_gemm_bf16_dgrad_addnorm_bwd2 in ONE launch (round 6): the backward mirror of
+ * fv_mixer_combine_out_proj_addnorm.  A workgroup owns four pooling rows of one image: it runs the conv + pool adjoint on
+ * them (reference: FastVim_MambaInnerFnNoOutProj_withoutZ.backward, selective_scan_interface.py:607-776 -- causal_conv1d_bwd
+ * of both directions, the mean-pool adjoint, the D-skip adjoint), writes the x half of dxz (batch, L, 768) once -- the
+ * in_proj weight gradient reads it -- and keeps it in LDS as the A operand of the in_proj data gradient
+ * `dxz @ in_proj.weight` (mamba_simple_faster.py:189-193; the z half of dxz, written by fv_mixer_combine_bwd, is read
+ * here), whose epilogue is the block's residual add + RMSNorm adjoint (models/fastvim.py:168-190) and whose second phase
+ * is the previous block's out_proj data gradient C2 = dx @ W2 -- arguments from `W_in_t` on as in
+ * fv_gemm_bf16_dgrad_addnorm_bwd2, except that the weight is given TRANSPOSED: W_in_t (192, ldwt) bf16 row-major =
+ * in_proj.weight^T (fv_transpose_bf16_batched), so that a lane's MFMA fragment is 16 contiguous bytes.
+ * conv_partials (fv_mixer_conv_pool_bwd_dgrad_blocks(batch, rows), 12 * 384) and partial_dw (same row count, 192) are
+ * per-workgroup partial rows for fv_reduce_partials: [dw | dw_b | db | db_b | dD | dD_b] as fv_mixer_conv_pool_bwd writes
+ * them, and the norm weight's gradient.  dx / dresidual_in / C2 and the x half of dxz are bit-identical to the two
+ * launches' (tests/test_convpool_dgrad_gpu.py); the parameter-gradient sums group rows differently (fp32 rounding).
+ * Built for bf16, d_inner 384, d_model 192, cols 14 or 16, tokens_per_patch 1, mean pooling
+ * (fv_mixer_conv_pool_bwd_dgrad_ok). */
+int fv_mixer_conv_pool_bwd_dgrad_ok(int batch, int rows, int cols, int tokens_per_patch, int d_inner, int d_model,
+                                    int pool_max, int dtype);
+int fv_mixer_conv_pool_bwd_dgrad_blocks(int batch, int rows);
+int fv_mixer_conv_pool_bwd_dgrad(const void* xz, const void* dskip, const float* dxc, const void* dxc2,
+                                 const float* conv_w, const float* conv_b, const float* conv_w_b, const float* conv_b_b,
+                                 const float* D, const float* D_b, void* dxz, float* conv_partials, int batch, int rows,
+                                 int cols, int tok_stride_row, int tok_stride_col, float scaling, const void* W_in_t,
+                                 long ldwt, const float* dresidual_out, const float* r, const float* rstd,
+                                 const float* norm_weight, const float* row_scale, int rows_per_scale, void* dx,
+                                 float* dresidual_in, float* partial_dw, const void* W2, void* C2, int N2, long ldw2,
+                                 fv_stream_t stream);
+
+/* dsts[j] (cols, rows) bf16 = srcs[j] (rows, cols)^T for up to 64 equal-shape matrices in one launch: the transposed
+ * bf16 shadows of in_proj.weight that fv_mixer_conv_pool_bwd_dgrad reads (refreshed once per optimizer step). */
+int fv_transpose_bf16_batched(const void* const* srcs, void* const* dsts, int njobs, int rows, int cols,
+                              fv_stream_t stream);
 
 /* fv_gemm_bf16_addnorm with a second GEMM phase: C2 (M, N2) bf16 = y @ W2^T, W2 (N2, N) bf16 row-major -- the block's
  * in_proj (mamba_simple_faster.py:189-193) computed from the normalised tile while it is still in LDS; bit-identical to

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.C_ABI_SYMBOLS) == declared
     # the library and the header it was built from agree on the ABI version (bumped with every signature change)
     hdr = open(os.path.join(ROOT, "include", "fastvim_hip.h")).read()
-    assert lib.fv_version() == int(re.search(r"#define\s+FV_ABI_VERSION\s+(\d+)", hdr).group(1)) == 2
+    assert lib.fv_version() == int(re.search(r"#define\s+FV_ABI_VERSION\s+(\d+)", hdr).group(1)) == 3
 
 
 def test_no_cpu_fallback():

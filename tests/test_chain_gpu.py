@@ -68,10 +68,11 @@ def test_chained_backbone_equals_block_by_block(drop_path):
     assert res[0][1].keys() == res[1][1].keys()
     for n in res[0][1]:
         a, b = res[0][1][n], res[1][1][n]
-        if n.endswith(".norm.weight"):
+        if n.endswith(".norm.weight") or ".conv1d" in n or n.endswith((".mixer.D", ".mixer.D_b")):
             # the chained backward sums d y * xhat over the rows per 64-row GEMM tile, the stand-alone kernel per
-            # persistent wave: same addends, different (fixed) grouping
-            assert torch.allclose(a, b, rtol=2e-5, atol=1e-6 * b.abs().max().item()), n
+            # persistent wave: same addends, different (fixed) grouping.  Round 6: the same holds for the conv / D
+            # gradients of the chained blocks (fv_mixer_conv_pool_bwd_dgrad sums per pooling-row tile)
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * b.abs().max().item()), n
         else:
             assert torch.equal(a, b), n
 

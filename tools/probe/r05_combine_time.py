@@ -4,7 +4,10 @@ usage: python tools/probe/r05_combine_time.py [sets]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from fastvim_amd import _lib as L_, mixer_ops as M
+from fastvim_amd import _lib as L_
+if os.environ.get("PROBE_LIB"):      # a scratch build of the library (tools/probe/r05_combine_phases.sh)
+    L_.LIB_PATH = os.environ["PROBE_LIB"]
+from fastvim_amd import mixer_ops as M
 
 B, rows, cols, d_in, d = 128, 14, 14, 384, 192
 Mrows = B * rows * cols
