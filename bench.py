@@ -31,6 +31,9 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if os.environ.get("PROBE_LIB"):      # A/B probes (tools/probe/*_variants.sh): a scratch build of the kernel library
+    import fastvim_amd._lib as _probe_lib
+    _probe_lib.LIB_PATH = os.environ["PROBE_LIB"]
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0

@@ -33,7 +33,13 @@ namespace {
 constexpr int CD_DI = 384, CD_N = 192, CD_K = 2 * CD_DI, CD_BM = 64, CD_NT = 256, CD_NCH = CD_DI / 128;
 constexpr int CD_RSA = CD_DI * 2 + 16;         // x panel row stride (bytes): = 4 dwords (mod 64), fragment reads conflict-free
 constexpr int CD_RSB = CD_N * 2 + 16;          // product tile row stride of the norm-adjoint epilogue (gemm_mfma.hip)
-constexpr int CD_PD = 4;                       // k steps of weight fragments in flight per wave (refilled in line pairs)
+#ifndef CD_PDEPTH
+#define CD_PDEPTH 4
+#endif
+#ifndef CD_W2_PIPE
+#define CD_W2_PIPE 1     // second phase: the next panel's first weight stage requested before this panel's epilogue
+#endif
+constexpr int CD_PD = CD_PDEPTH;               // k steps of weight fragments in flight per wave (refilled in line pairs)
 constexpr int CD_KS = CD_K / 32;               // 24 k steps; 0..11 the x half (panel), 12..23 the z half (ring)
 constexpr int CD_ZST = CD_BM * BK * 2;         // one z stage: 64 rows x 64 k, bf16, [row][64] with the KC chunk swizzle
 constexpr int CD_NZ = CD_DI / BK;              // 6 z stages
@@ -83,6 +89,17 @@ struct CdParams {
 __device__ __forceinline__ void cd_dma16(const void* base, uint32_t voff, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
+
+// Memory operations a wave issues between the DMA of z stage t (t >= 3: behind the MFMAs of the iteration that read stage
+// t - 3) and the wait for it at the top of stage t's iteration: per iteration in between, the weight refill (6 loads while
+// one exists) and the next stage's DMA (2).
+constexpr int cd_younger(int t) {
+  constexpr int KX = CD_DI / 32;
+  int n = 0;
+  for (int q = KX + 2 * (t - 3) + 2; q < KX + 2 * t; q += 2) n += (q + CD_PD < CD_KS ? 6 : 0) + ((q - KX) / 2 + 3 < CD_NZ ? 2 : 0);
+  return n;
+}
+static_assert(cd_younger(3) < 64 && cd_younger(4) < 64 && cd_younger(5) < 64, "vmcnt is a 6-bit counter");
 
 template <int NT, bool X2>
 __global__ __launch_bounds__(CD_NT, 2) void conv_pool_bwd_dgrad_kernel(CdParams p) {
@@ -336,22 +353,27 @@ __global__ __launch_bounds__(CD_NT, 2) void conv_pool_bwd_dgrad_kernel(CdParams 
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const char* afrag = smem + (lane & 15) * CD_RSA + (lane >> 4) * 16;
   static_assert(CD_PD % 2 == 0 && CD_KS % 2 == 0, "the weight ring is refilled in line pairs");
-#pragma unroll
-  for (int kp = 0; kp < (CD_DBG == 2 ? 0 : CD_KS); kp += 2) {
+  static_for<(CD_DBG == 2 ? 0 : CD_KS / 2)>([&](auto kp_c) {
+    constexpr int kp = 2 * decltype(kp_c)::value;
     constexpr int KX = CD_DI / 32;                 // 12: first k step of the z half
-    if (kp >= KX) {
+    if constexpr (kp >= KX) {
       // ---- z half: stage t holds k steps kp, kp + 1.  Stages 0..2 were requested before the x half; stage t + 3 is
       //      requested into stage t's buffer once every wave has read it.
-      const int t = (kp - KX) / 2;
-      if (t >= 3 || kp == KX) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of the stage have landed
-      if (t >= 3 || kp == KX) __builtin_amdgcn_s_barrier();                        // ... and everyone's
+      //      Loads return in order, so "my pieces of stage t have landed" is a COUNTED wait: the operations this wave
+      //      has issued behind DMA(t) may stay in flight -- the weight refills of the k-step pairs in between (6 loads each,
+      //      while a refill exists: kp + CD_PD < CD_KS) and the two later stages' DMAs (2 each).  Stages 0..2 are older
+      //      than weight fragments the x half has already consumed: no wait at all.  (vmcnt(0) here stalled every wave on
+      //      its youngest weight refill, an L2 round trip per stage.)
+      constexpr int t = (kp - KX) / 2;
+      if constexpr (t >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cd_younger(t)) : "memory");
+      if (t >= 3 || kp == KX) __builtin_amdgcn_s_barrier();      // ... and everyone's
     }
     bf16x8 cur[2][3];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int nb = 0; nb < 3; ++nb) cur[h][nb] = fb[(kp + h) % CD_PD][nb];
-    if (kp + CD_PD < CD_KS) {
+    if constexpr (kp + CD_PD < CD_KS) {
 #pragma unroll
       for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
@@ -362,11 +384,11 @@ __global__ __launch_bounds__(CD_NT, 2) void conv_pool_bwd_dgrad_kernel(CdParams 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       bf16x8 fa[4];
-      if (kp < KX) {
+      if constexpr (kp < KX) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) fa[mb] = *reinterpret_cast<const bf16x8*>(afrag + mb * 16 * CD_RSA + (kp + h) * 64);
       } else {
-        const int t = (kp - KX) / 2;
+        constexpr int t = (kp - KX) / 2;
         const char* st = smem + CD_O_RING + (t % 3) * CD_ZST;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) fa[mb] = frag<KC, CD_BM>(st, mb, h, lane);
@@ -376,15 +398,15 @@ __global__ __launch_bounds__(CD_NT, 2) void conv_pool_bwd_dgrad_kernel(CdParams 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[h][a], fa[b], acc[a][b], 0, 0, 0);
     }
-    if (kp >= KX) {
-      const int t = (kp - KX) / 2;
-      if (t + 3 < CD_NZ) {
+    if constexpr (kp >= KX) {
+      constexpr int t = (kp - KX) / 2;
+      if constexpr (t + 3 < CD_NZ) {
         __builtin_amdgcn_s_barrier();        // every wave is done reading stage t
         issue_z(t + 3);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-  }
+  });
   // the residual-stream gradient rows of the epilogue: requested here, used at the end of each row's arithmetic
   float4 ne_g[2][2][3];
 #pragma unroll
@@ -507,7 +529,8 @@ __global__ __launch_bounds__(CD_NT, 2) void conv_pool_bwd_dgrad_kernel(CdParams 
   // ================= phase 4: the previous block's out_proj data gradient d g = d x @ W_out from the tile in LDS =================
   if (p.W2 && CD_DBG != 4) {
     __syncthreads();
-    tile_times_w2_rows<CD_BM, CD_RSB, KS>(smem, smem + CD_O_B, smem + CD_O_S, p.W2, p.ldw2, p.N2, p.C2, tok_of, tid);
+    tile_times_w2_rows<CD_BM, CD_RSB, KS, decltype(tok_of), CD_W2_PIPE != 0>(smem, smem + CD_O_B, smem + CD_O_S, p.W2, p.ldw2, p.N2,
+                                                                              p.C2, tok_of, tid);
   }
 }
 

@@ -107,6 +107,18 @@ struct GldsPlan {
       __builtin_amdgcn_global_load_lds((gptr)(src[i] + (long)k0 * kstep), (lptr)(lds + (i * NT + wv * 64) * 16), 16, 0, 0);
     }
   }
+  // The same as opaque inline asm: the compiler orders every LDS access it can see behind ALL outstanding builtin DMA
+  // loads; issued this way a stage can stay in flight across LDS reads and writes of other regions.  Completion is the
+  // caller's to wait for (s_waitcnt vmcnt) before the barrier that publishes the stage.
+  __device__ __forceinline__ void issue_asm(char* lds, int k0, int tid) const {
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t wvo = (uint32_t)__builtin_amdgcn_readfirstlane((tid >> 6) * 64 * 16);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bf16_t* a = src[i] + (long)k0 * kstep;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a), "s"(base + wvo + (uint32_t)(i * NT * 16)) : "memory");
+    }
+  }
 };
 
 // fragment of a 16-wide block `blk` (rows for KC, cols for KS) at k-step ks (32 k) of the staged tile
@@ -201,15 +213,24 @@ struct KsFrags {
 // (a weight as stored, used forward: C2 = T @ W2^T).
 // rowof(tile row) = row of C2, or -1 for a tile row that is not stored (the pooling-row tiles of convpool_dgrad.hip map
 // their rows to scattered memory tokens; the GEMM kernels' tiles are runs of consecutive rows).
-template <int BMT, int RSB, int WMODE, class RowOf>
+// PIPE: the W2 stages are issued as opaque DMA (GldsPlan::issue_asm) and the first stage of the NEXT 128-column panel is
+// requested before this panel's epilogue, so it arrives under the slab round trip and the C2 stores instead of costing an
+// exposed L2 round trip per panel (three per launch at N2 = 384); same values.
+template <int BMT, int RSB, int WMODE, class RowOf, bool PIPE = false>
 __device__ __forceinline__ void tile_times_w2_rows(const char* tile, char* ldsB, char* slabs, const bf16_t* W2, long ldw2, int N2,
                                                    bf16_t* C2, RowOf rowof, int tid) {
-  constexpr int MB2 = BMT / 32, NB2 = 4, K2 = 192, STG = 128 * BK * 2;
+  constexpr int MB2 = BMT / 32, NB2 = 4, K2 = 192, STG = 128 * BK * 2, NKT = K2 / BK;
   const int lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   KsFrags<128, WMODE == KS ? NB2 : 1> kb;
   if constexpr (WMODE == KS) kb.init(ldsB, wn * NB2, lane);
   constexpr int RS = 64 * 2 + 16, CH = 64 / 8;            // epilogue slab: 32 rows x 64 columns per wave
   char* my = slabs + wv * (32 * RS);
+  int par = 0;                                            // PIPE: ring buffer of the next stage to be consumed
+  if constexpr (PIPE) {
+    GldsPlan<WMODE, 128, 256> g0;
+    g0.init(W2, ldw2, 0, N2, tid);
+    g0.issue_asm(ldsB, 0, tid);
+  }
   for (int n0 = 0; n0 < N2; n0 += 128) {
     GldsPlan<WMODE, 128, 256> gb;
     gb.init(W2, ldw2, n0, N2, tid);
@@ -218,12 +239,21 @@ __device__ __forceinline__ void tile_times_w2_rows(const char* tile, char* ldsB,
     for (int a = 0; a < NB2; ++a)
 #pragma unroll
       for (int b = 0; b < MB2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gb.issue(ldsB, 0, tid);
+    if constexpr (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else gb.issue(ldsB, 0, tid);
     __syncthreads();
 #pragma unroll
-    for (int kt = 0; kt < K2 / BK; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < K2 / BK) gb.issue(ldsB + (cur ^ 1) * STG, (kt + 1) * BK, tid);
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int cur = PIPE ? par : (kt & 1);
+      if constexpr (PIPE) {
+        if (kt + 1 < NKT) gb.issue_asm(ldsB + (cur ^ 1) * STG, (kt + 1) * BK, tid);
+        else if (n0 + 128 < N2) {
+          GldsPlan<WMODE, 128, 256> gn;
+          gn.init(W2, ldw2, n0 + 128, N2, tid);
+          gn.issue_asm(ldsB + (cur ^ 1) * STG, 0, tid);
+        }
+        par = cur ^ 1;
+      } else if (kt + 1 < NKT) gb.issue(ldsB + (cur ^ 1) * STG, (kt + 1) * BK, tid);
       if constexpr (WMODE == KS) {
         kb.read(cur * STG);
         kb.wait();
@@ -245,7 +275,14 @@ __device__ __forceinline__ void tile_times_w2_rows(const char* tile, char* ldsB,
 #pragma unroll
           for (int b = 0; b < MB2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[a], fa[b], acc[a][b], 0, 0, 0);
       }
-      __syncthreads();
+      if constexpr (PIPE) {
+        // the next stage of THIS panel is needed right away; the next panel's first stage is waited for at the top of
+        // its loop (the buffer this k tile read is overwritten only behind that barrier)
+        if (kt + 1 < NKT) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
+      } else __syncthreads();
     }
     // bf16 through the wave's slab: 16-byte stores, whole 128-byte row segments
 #pragma unroll
