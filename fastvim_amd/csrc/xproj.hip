@@ -10,7 +10,7 @@
 // emit per-slice partials of the weight gradient for the fixed-order reduction (no atomics).
 #include <stdlib.h>
 
-#include "common.h"
+#include "rowwalk.h"
 
 namespace {
 
@@ -100,6 +100,117 @@ __global__ __launch_bounds__(256) void xproj_bwd_kernel(XprojParams p) {
     float* dst = p.dW_part + (((size_t)slice * 2 + dir) * W) * p.d_in + d;
 #pragma unroll
     for (int c = 0; c < W; ++c) dst[(size_t)c * p.d_in] = acc[c];
+  }
+}
+
+// ---- the data half of the adjoint on the fp32 matrix cores (round 6; taken when the weight gradient is computed elsewhere
+// -- the grouped launch of the flat training state -- i.e. DW = false above).  The lane-per-channel kernel spends W FMAs
+// and W / 4 LDS broadcast reads per (row, channel) on the vector pipe: 37 us at FastVim-B (M = 3 584 pooled rows, 1 536
+// channels, W = 80), 49 us on the un-pooled Vim-T, for a product of 0.9 GFLOP.  v_mfma_f32_16x16x4_f32 is an exact fp32 FMA
+// chain (the scan kernels' dt_proj uses it the same way), so the values keep fp32 operands and fp32 accumulation:
+//     dxc[m][d] += sum_w G[m][w] Wx[w][d],   G = sum over the channel-chunk partials of d x_dbl (fixed order)
+// A workgroup owns 64 rows: G is staged once in LDS (row stride = 4 (mod 64) words x odd: the 16 x 4 operand reads of a k
+// step hit 64 banks); its four waves own 64 channels each of a 256-channel block and walk `cbw` such blocks; the weight
+// operand needs no transposition in this layout -- lane (k = lane >> 4, n = lane & 15) reads Wx[k][n], 64 contiguous bytes per
+// k row -- and comes straight from L2.  The weight rides in the A slot, so a lane ends with four consecutive channels of one
+// row: d xc is read and written 16 bytes per lane.
+typedef float xm_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int W>
+__global__ __launch_bounds__(256, 2) void xproj_bwd_mm_kernel(XprojParams p, int cbw) {
+  constexpr int KQ = (W + 3) / 4, W4 = 4 * KQ, WS = (W4 / 4) % 2 ? W4 : W4 + 4;
+  extern __shared__ __attribute__((aligned(16))) float s_g[];      // 64 * WS
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dir = blockIdx.z, m0 = blockIdx.y * 64;
+  const int nr = min(64, p.M - m0);
+  // stage the rows, summing the channel-chunk partials in fixed order (six in flight per lane, like the kernel above)
+  for (int e = tid; e < 64 * W4; e += 256) {
+    const int r = e / W4, c = e - r * W4;
+    float t = 0.f;
+    if (r < nr && c < W) {
+      for (int c0 = 0; c0 < p.nchunks; c0 += 6) {
+        float v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const bool on = c0 + u < p.nchunks;
+          v[u] = on ? p.dxdbl_part[(((size_t)(c0 + u) * 2 + dir) * p.M + m0 + r) * W + c] : 0.f;
+        }
+        t += ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
+      }
+    }
+    s_g[r * WS + c] = t;
+  }
+  __syncthreads();
+  if (p.dxdbl_out && blockIdx.x == 0) {      // one channel block publishes the summed rows (bf16, padded row stride)
+    constexpr int WP = (W + 7) / 8 * 8;
+    bf16_t* o = (bf16_t*)p.dxdbl_out + ((size_t)dir * p.M + m0) * WP;
+    for (int e = tid; e < nr * WP; e += 256) {
+      const int r = e / WP, c = e - r * WP;
+      o[e] = __float2bfloat16(c < W ? s_g[r * WS + c] : 0.f);
+    }
+  }
+  const int mr = lane & 15, kq = lane >> 4;
+  // Buffer addressing (rowwalk.h): 32-bit lane offsets -- with flat pointers every one of the 144 loads of a channel block
+  // carried its own 64-bit address pair and the kernel spilled.  The whole offset is in the LANE part (the range check
+  // does not see a scalar offset): rows past the slice's end and weight rows past W lie beyond their descriptors, so loads
+  // return zero and stores are dropped -- no branch, no clamp.
+  const __amdgpu_buffer_rsrc_t bw_ = fv_make_buf(p.Wx[dir], (size_t)W * p.d_in * 4);
+  const __amdgpu_buffer_rsrc_t bd_ = fv_make_buf(p.dxc + ((size_t)dir * p.M + m0) * p.d_in, (size_t)nr * p.d_in * 4);
+  const int row4 = 4 * p.d_in * 4;              // bytes between k steps of the weight / row quads of d xc
+  for (int cb = 0; cb < cbw; ++cb) {
+    const int n0 = (blockIdx.x * cbw + cb) * 256 + wv * 64;
+    if (n0 >= p.d_in) break;                  // uniform per wave (d_in is a multiple of 64: a wave's 64 channels are all live)
+    xm_f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (xm_f32x4){0.f, 0.f, 0.f, 0.f};
+    int wof[4], dof[4];                       // weight: row kq of a k step, channel n0 + 16 b + mr; d xc: row mr of a row block, channels n0 + 16 b + 4 kq ..
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      wof[b] = (kq * p.d_in + n0 + b * 16 + mr) * 4;
+      dof[b] = (mr * p.d_in + n0 + b * 16 + 4 * kq) * 4;
+    }
+    // EVERY weight value of this channel block is requested before the first MFMA (left to the compiler, a k step's four
+    // loads were issued one step ahead and waited for in place: an L2 round trip per k step)
+    float bw[KQ][4];
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint32_t t[1];
+        fv_buf_load_words<1>(bw_, wof[b] + ks * row4, 0, t);
+        bw[ks][b] = __uint_as_float(t[0]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KQ; ++ks) {
+      float av[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = s_g[(a * 16 + mr) * WS + 4 * ks + kq];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[ks][b], av[a], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // acc[a][b][j] = product[row 16 a + mr][channel n0 + 16 b + 4 kq + j] (the weight rides in the A slot, as in
+    // gemm_mfma.hip: a lane ends with four consecutive channels of one row -- 16-byte accesses).  d xc is read and written a
+    // row block at a time, its four loads in flight together: as `*q += v` through one pointer the read-modify-writes are
+    // a chain of dependent HBM round trips to the compiler, which cannot tell the addresses apart
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      uint32_t base[4][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fv_buf_load_words<4>(bd_, dof[b] + a * 16 * (p.d_in * 4), 0, base[b]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __float_as_uint(__uint_as_float(base[b][j]) + acc[a][b][j]);
+        fv_buf_store_words<4>(bd_, dof[b] + a * 16 * (p.d_in * 4), 0, o);
+      }
+    }
   }
 }
 
@@ -232,6 +343,41 @@ extern "C" int fv_mixer_xproj_bwd2(const float* dx_dbl_partials, int nchunks, co
   XprojParams p{};
   p.dxdbl_part = dx_dbl_partials; p.xc = xc; p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.dxc = dxc;
   p.dW_part = dW_partials; p.dxdbl_out = dx_dbl_bf16; p.nchunks = nchunks; p.M = M; p.d_in = d_inner; p.rows_per_block = xproj_rows();
+  static const bool mm = (fv_tune("FASTVIM_XPROJ_BWD_MM", 1) != 0);   // tuning hook
+  // (same-box A/B, profiles/r06_ab_xproj_bwd_mm.log: FastVim-B 224 px -0.4 ... -0.6 %, channel model -0.25 %, 2048 px even; at
+  //  d_inner 384 -- un-pooled Vim-T, 51 200 pooled rows -- the lane-per-channel kernel already sits on the 157 MB d xc
+  //  round trip and the matrix-core form is 0.3-0.5 % slower: taken from d_inner 768 up)
+  if (!dW_partials && mm && d_inner % 64 == 0 && d_inner >= 768 && (size_t)M * d_inner * 4 < 0x7fffffffull) {
+    // the data half on the fp32 matrix cores: 64-row workgroups walking `cbw` blocks of 256 channels -- as many as keep
+    // about two workgroups per CU's worth of them (fewer, longer workgroups re-stage the rows less often)
+    const int slices = fv_cdiv(M, 64), cblocks = fv_cdiv(d_inner, 256);
+    int cbw = 1;
+    while (cbw < cblocks && (long)slices * 2 * fv_cdiv(cblocks, cbw * 2) >= 2 * fv_cu_count()) cbw *= 2;
+    const dim3 mgrid(fv_cdiv(cblocks, cbw), slices, 2);
+    hipStream_t mst = (hipStream_t)stream;
+#define FV_XM(WW)                                                                                              \
+  do {                                                                                                         \
+    constexpr int KQ_ = (WW + 3) / 4, W4_ = 4 * KQ_, WS_ = (W4_ / 4) % 2 ? W4_ : W4_ + 4;                       \
+    hipLaunchKernelGGL((xproj_bwd_mm_kernel<WW>), mgrid, dim3(256), (size_t)64 * WS_ * 4, mst, p, cbw);        \
+  } while (0)
+    switch (width) {
+      case 44: FV_XM(44); break;
+      case 56: FV_XM(56); break;
+      case 80: FV_XM(80); break;
+      case 96: FV_XM(96); break;
+      case 112: FV_XM(112); break;
+      case 34: FV_XM(34); break;
+      case 36: FV_XM(36); break;
+      case 38: FV_XM(38); break;
+      case 64: FV_XM(64); break;
+      default:
+        fv_set_error("mixer_xproj_bwd: x_dbl width %d is not built", width);
+        return FV_ERR_UNSUPPORTED;
+    }
+#undef FV_XM
+    FV_LAUNCH_CHECK();
+    return FV_OK;
+  }
   const int bs = d_inner >= 256 ? 128 : 64;
   static const int rb = fv_tune("FASTVIM_XPROJ_RB", 8);   // tuning hook (rows of loads in flight; 8: 25.7 vs 26.8 us)
   dim3 grid(fv_cdiv(d_inner, bs), fv_mixer_xproj_bwd_slices(M), 2), block(bs);
