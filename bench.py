@@ -413,8 +413,29 @@ def kernel_table(B, rows, cols, d, depth, dtype, tpp=1):
                 del C_
             gemm_row("gemm_out_proj_addnorm_fwd", fused_fwd, ("g2", "resid", "y", "ro", "rs"), F_,
                      Mt * (d_in * e + d * (4 + 4 + e) + 4), 2.0 * Mt * d * d_in, 1 if fuse_c else depth - 1)
+            fuse_cd = tpp == 1 and M.conv_pool_bwd_dgrad_ok(T["xz"], rows, cols, 1, d, False)
             gemm_row("gemm_in_proj_dgrad_addnorm_bwd", fused_bwd, ("xz2", "gg", "resid", "rstd", "y", "ro", "pw", "dg"), F_,
-                     Mt * (2 * d_in * e + d * (4 + 4 + 4 + e) + 4 + d_in * e), 2.0 * Mt * d * 3 * d_in, depth - 1)
+                     Mt * (2 * d_in * e + d * (4 + 4 + 4 + e) + 4 + d_in * e), 2.0 * Mt * d * 3 * d_in, 0 if fuse_cd else depth - 1)
+            if fuse_cd:
+                # round 6: the conv + pool adjoint is the A-tile producer of that launch in every chained block
+                # (fv_mixer_conv_pool_bwd_dgrad); the two rows it replaces stay in the table with the launches they keep (the
+                # first block's conv adjoint; no stand-alone data gradient + norm adjoint).  Algorithmic bytes: x, d_o read
+                # and the x half of dxz written (3U) + pooled gradients (+ the second addend) + the z half of dxz read (U)
+                # + the norm adjoint's rows (residual gradient in / out, saved input, d hidden) + the previous block's d g
+                # written (U); the x half of dxz is NOT read back
+                CD_ = dict(T, gg=F_["gg"], resid=F_["resid"], rstd=F_["rstd"])
+                if "dxc2" not in CD_:
+                    CD_["dxc2"] = torch.randn(2, B, prow, d_in, device=dev, generator=g).to(dtype)
+                W_in_T = W_in.t().contiguous()
+
+                def fused_cd(s):
+                    return M.conv_pool_bwd_dgrad(s["xz"], s["d_o"], s["dxc"], s["dxc2"], cw, cb, cwb, cbb, D, Db, s["dxz"], rows, cols,
+                                                 False, 1.0, W_in_T, s["gg"], s["resid"], s["rstd"], nw_, sc_, L, W2=W_out)
+                gemm_row("conv_pool_bwd_dgrad_addnorm_bwd", fused_cd, ("xz", "d_o", "dxc", "dxc2", "dxz", "gg", "resid", "rstd"), CD_,
+                         5 * U + 2 * small * 4 + 2 * small * e + Mt * (d * (4 + 4 + 4 + e) + 4), 2.0 * Mt * d * 3 * d_in, depth - 1)
+                out["conv_pool_bwd"]["launches_per_step"] = 1
+                out["conv_pool_bwd"]["us_per_step"] = out["conv_pool_bwd"]["us"]
+                del CD_
             del F_
             for k_ in ("add_rmsnorm_fwd",):
                 out[k_]["launches_per_step"], out[k_]["us_per_step"] = 2, round(out[k_]["us"] * 2, 1)
@@ -434,9 +455,10 @@ TRACE_NAMES = {
     "add_rmsnorm_fwd": "add_norm_fwd3_kernel", "gemm_out_proj_addnorm_fwd": "gemm_addnorm_kernel",
     "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 5>",
     "xproj_bwd": "xproj_bwd_kernel", "combine_out_proj_addnorm_fwd": "combine_out_proj_addnorm_kernel",
+    "conv_pool_bwd_dgrad_addnorm_bwd": "conv_pool_bwd_dgrad_kernel",
 }
-PMC_TRAFFIC_JSON = "r05_v4_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
-STEP_TRACE_CSV = "r05_v4_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r05_v4 (profiles/README.md)
+PMC_TRAFFIC_JSON = "r06_v2_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
+STEP_TRACE_CSV = "r06_v2_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r05_v4 (profiles/README.md)
 
 
 def in_step_trace_us():
@@ -454,6 +476,38 @@ def in_step_trace_us():
                 out[key] = round(float(r["AverageNs"]) / 1e3, 2)
                 break
     return out
+
+
+def step_trace_breakdown(top=40):
+    """Every kernel of the replayed FastVim-T step from the committed rocprofv3 trace, per step: the rows of the kernel table
+    AND what the table does not time by itself (partial-sum reductions, the bf16 d x_dbl rows, patch unfold, optimizer, the
+    library nodes of the captured step) -- so that the rows sum to the step.  Steps in the trace = launches of the optimizer
+    kernel.  None when the file is absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", STEP_TRACE_CSV)
+    if not os.path.exists(path):
+        return None
+    rows = list(csv.DictReader(open(path)))
+    steps = next((int(r["Calls"]) for r in rows if r["Name"].startswith("adamw_flat_kernel")), 0)
+    if steps <= 0:
+        return None
+    table_prefixes = tuple(TRACE_NAMES.values()) + ("gemm_bf16_grouped_kernel", "gemm_stream_kernel", "gemm_bf16_kernel",
+                                                    "add_norm_bwd3_kernel")
+    out_rows, total, tail = [], 0.0, 0.0
+    for r in rows:
+        name = r["Name"]
+        if name.startswith("__amd_rocclr_copyBuffer"):       # set-up copies (flattening the parameters): none inside a replayed step
+            continue
+        per_step = float(r["TotalDurationNs"]) / steps / 1e3
+        total += per_step
+        in_table = name.startswith(table_prefixes)
+        if not in_table:
+            tail += per_step
+        out_rows.append({"kernel": name[:96], "launches_per_step": round(int(r["Calls"]) / steps, 2),
+                         "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "us_per_step": round(per_step, 1), "in_kernel_table": in_table})
+    out_rows.sort(key=lambda r: -r["us_per_step"])
+    return {"file": STEP_TRACE_CSV, "steps_in_trace": steps, "kernel_us_per_step": round(total, 1),
+            "tail_us_per_step_outside_kernel_table": round(tail, 1), "rows": out_rows[:top]}
 
 
 def step_roofline(kt, ms_per_step):
@@ -1065,6 +1119,15 @@ def main():
                                              if kt[dom].get("us_warm") else None)}
             out["roofline"]["committed_profile"] = profile_stamp()
             out["roofline_step"] = step_roofline(kt, ms)
+            if (args.model, args.img, args.batch, args.dtype) == ("T", 224, 128, "bf16"):
+                # kernel_rows_us sums the HBM-COLD stand-alone timings of the table (cold inputs overstate kernels whose input
+                # the previous launch has just written, the scans above all); the in-step sum comes from the committed trace
+                # and includes the launches the table does not time (reductions, patch unfold, optimizer, library nodes)
+                out["roofline_step"]["kernel_rows_us_source"] = "hbm_cold_stand_alone_timings_of_this_run"
+                stb = step_trace_breakdown()
+                if stb is not None:
+                    out["roofline_step"]["kernel_us_per_step_in_committed_trace"] = stb["kernel_us_per_step"]
+                    out["step_trace"] = stb
             try:      # plain elementwise kernels on cold tensors of the same size: what a 10-15 us launch can reach at all
                 out["roofline"]["elementwise_floor_same_size_cold"] = stream_floor(args.batch, gs * gs * (args.channels if args.model == "C" else 1), 2 * d, amp_dtype)
             except Exception as e_:

@@ -71,4 +71,8 @@ for _ in range(n):
                                                  L_.ptr(sc_), L_.i32(L), L_.ptr(y_), L_.ptr(ro_), L_.ptr(pw_), L_.i32(Mtok), L_.i32(d),
                                                  L_.i32(2 * d_in), ctypes.c_long(2 * d_in), ctypes.c_long(d), L_.ptr(W_out), L_.ptr(dg_),
                                                  L_.i32(d_in), ctypes.c_long(d_in), L_.stream_of(xz2)), "dgrad_addnorm_bwd")
+    # round 6: the conv + pool adjoint as the A-tile producer of that launch
+    if M.conv_pool_bwd_dgrad_ok(xz, rows, cols, 1, d, False) and M.scan_bwd_xproj_ok(xc, Wdt, False, rows, cols, 1):
+        M.conv_pool_bwd_dgrad(xz, d_o, dxc_a, dxc_b, cw, cb, cwb, cbb, D, Db, dxz, rows, cols, False, 1.0, W_in.t().contiguous(),
+                              gg_, resid, rstd_, nw_, sc_, L, W2=W_out)
 torch.cuda.synchronize()
