@@ -27,7 +27,7 @@ C_ABI_SYMBOLS = (
     "fv_add_norm_blocks", "fv_add_norm_fwd", "fv_add_norm_bwd", "fv_gemm_bf16", "fv_gemm_bf16_tn_grouped", "fv_gemm_bf16_tn_grouped_ld", "fv_mixer_xproj_fwd", "fv_mixer_xproj_bwd_slices", "fv_mixer_xproj_bwd", "fv_mixer_xproj_bwd2", "fv_adamw_flat", "fv_soft_target_ce",
     "fv_patch_unfold", "fv_gemm_bf16_rowbias", "fv_mean_pool_fwd", "fv_mean_pool_bwd", "fv_droppath_table", "fv_scale_cast",
     "fv_column_sum", "fv_gemm_bf16_addnorm", "fv_gemm_bf16_dgrad_addnorm_blocks", "fv_gemm_bf16_dgrad_addnorm_bwd", "fv_gemm_bf16_dgrad_addnorm_bwd2", "fv_gemm_bf16_addnorm2", "fv_mixer_combine_out_proj_addnorm_ok", "fv_mixer_combine_out_proj_addnorm", "fv_gemm_f32",
-    "fv_mixer_conv_pool_bwd_dgrad_ok", "fv_mixer_conv_pool_bwd_dgrad_blocks", "fv_mixer_conv_pool_bwd_dgrad", "fv_transpose_bf16_batched",
+    "fv_mixer_conv_pool_bwd_dgrad_ok", "fv_mixer_conv_pool_bwd_dgrad_blocks", "fv_mixer_conv_pool_bwd_dgrad", "fv_transpose_bf16_batched", "fv_gemm_bf16_tn_grouped_wide8",
 )
 
 

@@ -1482,6 +1482,19 @@ extern "C" int fv_gemm_bf16_dgrad_addnorm_bwd2(const void* A, const void* W, con
 // Grouped weight gradients: problem i is x_i (Kd_i, M_i)^T @ y_i (Kd_i, N_i) -> parts_i (splits_i, M_i, N_i) fp32,
 // both operands K-slow (rows = tokens), split-K over whole 64-deep tiles -- the arithmetic and fixed split order of
 // fv_gemm_bf16(a_k_slow = b_k_slow = 1, c_fp32 = 1), which launches them one at a time.
+// Tile class of an S-width weight gradient (d_model 384: in_proj 1536 x 384 -> 4 = 256 x 192 tiles, out_proj 384 x 768 -> 5 =
+// 192 x 256 tiles, eight waves, one workgroup per CU), 0 = not taken.  The eight-wave tiles pay from long K loops on
+// (FastChannelVim-S, 100 352 tokens: step 44.35 -> 43.51 ms; FastVim-S at 224 px, 25 088 tokens: 12.55 -> 12.62, stays on
+// 128 x 128; profiles/r05_ab_wgrad_s_width_tiles.log).  The host (fastvim_amd/gemm.py: _tile_class, split-K factors) and
+// the launcher below both ask THIS function.
+extern "C" int fv_gemm_bf16_tn_grouped_wide8(int M, int N, int Kd) {
+  static const int wide8 = fv_tune("FASTVIM_WGRAD_WIDE8", 1);   // tuning hook
+  if (!wide8 || Kd < 50000) return 0;
+  if (M % 256 == 0 && N % 192 == 0 && N % 256 != 0 && (long)M * N >= 1024 * 384) return 4;
+  if (M % 192 == 0 && N % 256 == 0 && M % 256 != 0 && (long)M * N >= 384 * 768) return 5;
+  return 0;
+}
+
 extern "C" int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
                                        const int* M, const int* N, const int* splits, int count, fv_stream_t stream) {
   return fv_gemm_bf16_tn_grouped_ld(x, y, parts, Kd, M, N, nullptr, nullptr, splits, count, stream);
@@ -1584,12 +1597,14 @@ extern "C" int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* cons
     // tile moves 32 KB per 2.1 MFLOP of K step, these 56 KB per 6.3 -- 0.59 x the fill (gemm.py puts the two shapes in
     // launches of their own)
     {
-      static const int wide8 = fv_tune("FASTVIM_WGRAD_WIDE8", 1);   // tuning hook
-      bool c4 = dma && wide8 && tile_env != 1, c5 = c4;
+      // ONE rule decides (fv_gemm_bf16_tn_grouped_wide8: the host groups problems and picks split-K factors by it too --
+      // round 5 had the K threshold on the Python side only, so a launch Python had classed for 128 x 128 tiles could run
+      // on these with the wrong split factors)
+      bool c4 = dma && tile_env != 1, c5 = c4;
       for (int i = 0; i < n; ++i) {
-        const GemmParams& q = G.p[i];
-        c4 = c4 && q.M % 256 == 0 && q.N % 192 == 0 && q.N % 256 != 0 && (long)q.M * q.N >= 1024 * 384;
-        c5 = c5 && q.M % 192 == 0 && q.N % 256 == 0 && q.M % 256 != 0 && (long)q.M * q.N >= 384 * 768;
+        const int w8 = fv_gemm_bf16_tn_grouped_wide8(G.p[i].M, G.p[i].N, G.p[i].K);
+        c4 = c4 && w8 == 4;
+        c5 = c5 && w8 == 5;
       }
       if (c4 || c5) {
         const int tm = c4 ? 256 : 192, tn = c4 ? 192 : 256;

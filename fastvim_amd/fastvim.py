@@ -466,10 +466,18 @@ class VisionMamba(nn.Module):
                 # previous out_proj + this block's add + norm + mixer as ONE autograd node: its backward can hand the
                 # in_proj data gradient straight to the norm's adjoint
                 ChainedBlockFn.pending_in = pack
-                ChainedBlockFn.defer = msf.COMBINE_IN_OUT_PROJ
+                # a deferred combine leaves saved tensors UNWRITTEN until the next block's launch fills them: anything that
+                # reads saved tensors when they are saved (torch.autograd.graph.save_on_cpu, non-reentrant checkpointing --
+                # both are saved-tensor hooks) would copy garbage, so deferral is off while such hooks are active.  The
+                # hand-over (pending_in / pending_out / defer) is class state of one host thread: single-threaded by design
+                ChainedBlockFn.defer = msf.COMBINE_IN_OUT_PROJ and torch._C._autograd._top_saved_tensors_default_hooks(True) is None
+                ChainedBlockFn.pending_out = None
                 try:
                     g, residual = ChainedBlockFn.apply(pend[0], pend[1], residual, blk.norm.weight, float(blk.norm.eps), scale,
                                                        *blk.mixer.mixer_fn_args(cdt, rot, defer_out_proj=True))
+                except BaseException:
+                    ChainedBlockFn.pending_out = None      # (a failed apply must not leave its pack for the next caller)
+                    raise
                 finally:
                     ChainedBlockFn.pending_in, ChainedBlockFn.defer = None, False
                 pack, ChainedBlockFn.pending_out = ChainedBlockFn.pending_out, None

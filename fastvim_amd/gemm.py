@@ -226,11 +226,12 @@ def _tile_class(M, N, Kd=None):
     224 px, 25 088 tokens: 12.55 -> 12.62, stays on 128 x 128; profiles/r05_ab_wgrad_s_width_tiles.log)."""
     if M % 256 == 0 and N % 256 == 0 and M * N >= 512 * 512:
         return 3          # large outputs (FastVim-B: 3072 x 768, 768 x 1536): 256 x 256 tiles on 8 waves halve the L2 traffic
-    if WIDE8 and (Kd is None or Kd >= WIDE8_MIN_K):             # S-width outputs (1536 x 384, 384 x 768): 256 x 192 / 192 x 256 tiles on 8 waves (csrc/gemm_mfma.hip)
-        if M % 256 == 0 and N % 192 == 0 and N % 256 and M * N >= 1024 * 384:
-            return 4
-        if M % 192 == 0 and N % 256 == 0 and M % 256 and M * N >= 384 * 768:
-            return 5
+    # S-width outputs (1536 x 384, 384 x 768): 256 x 192 / 192 x 256 tiles on 8 waves -- the C dispatcher's own rule
+    # (fv_gemm_bf16_tn_grouped_wide8, K threshold included), so that the class the problems are grouped and split by is
+    # the tile the launch runs on
+    w8 = L.lib().fv_gemm_bf16_tn_grouped_wide8(L.i32(M), L.i32(N), L.i32(Kd if Kd is not None else 1 << 30))
+    if w8:
+        return int(w8)
     best = 0
     for c in (1, 2):
         if _padded(M, N, c) < _padded(M, N, best):
@@ -239,8 +240,6 @@ def _tile_class(M, N, Kd=None):
 
 
 DIRECT_ACC = True      # False: every grouped problem writes partials that a reduction launch adds to the gradient
-WIDE8 = True           # False: S-width weight gradients on 128 x 128 tiles (A/B knob)
-WIDE8_MIN_K = 50000    # tokens from which the 8-wave S-width tiles are used
 _SLOTS = (512, 512, 512, 256, 256, 256)     # workgroups of the grouped kernel the chip holds at once, per tile class (two per CU;
                                   # one of the 8-wave 256 x 256 tiles)
 FILL = True      # False: the factors of grouped_splits whatever the group (a segmented step then sums every weight

@@ -39,7 +39,8 @@ const char* fv_last_error(void);
  *      without bumping the number; round 5 bumps it for that break, removes the opt-in fv_mixer_mid_fwd(_ok) and
  *      fv_gemm_bf16_addnorm_rw(_ok), and adds fv_mixer_scan_bwd_xproj(_ok), fv_mixer_conv_pool_bwd2(_ok),
  *      fv_chunk_rows_bf16.
- *   3  round 6 adds fv_mixer_conv_pool_bwd_dgrad(_ok, _blocks), fv_transpose_bf16_batched (nothing removed or changed). */
+ *   3  round 6 adds fv_mixer_conv_pool_bwd_dgrad(_ok, _blocks), fv_transpose_bf16_batched, fv_gemm_bf16_tn_grouped_wide8
+ *      (nothing removed or changed). */
 #define FV_ABI_VERSION 3
 int fv_version(void);
 
@@ -472,6 +473,11 @@ int fv_gemm_bf16_tn_grouped(const void* const* x, const void* const* y, float* c
 int fv_gemm_bf16_tn_grouped_ld(const void* const* x, const void* const* y, float* const* parts, const int* Kd,
                                const int* M, const int* N, const int* ldx, const int* ldy, const int* splits, int count,
                                fv_stream_t stream);
+
+/* Tile class the grouped launch runs an (M, N) weight gradient over Kd tokens on when every problem of the launch agrees:
+ * 4 = 256 x 192 tiles, 5 = 192 x 256 tiles (eight waves; the d_model-384 outputs from 50 000 tokens on), 0 = not taken.  The
+ * host groups problems per launch and picks their split-K factors by the same answer. */
+int fv_gemm_bf16_tn_grouped_wide8(int M, int N, int Kd);
 
 /* x_proj of both directions, bf16: x_dbl (2, M, width) = xc (2, M, d_inner) @ x_proj_w2 (2, width, d_inner)^T, fp32
  * accumulate (mamba_simple_faster.py:321-327; the F.linear behind `self.x_proj` / `self.x_proj_b`).  M = batch*Lc,

@@ -95,3 +95,28 @@ def test_chained_backbone_with_and_without_the_fused_combine(monkeypatch):
     assert res[0][0] == res[1][0]
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+def test_deferred_combine_is_off_under_saved_tensor_hooks():
+    """a deferred combine leaves g / mean / rstd UNWRITTEN when they are saved for backward (the next block's
+    launch fills them); a saved-tensor hook that copies at save time (save_on_cpu, non-reentrant checkpointing) would copy
+    garbage.  Under such hooks the chain runs the combine as its own launch: logits and gradients equal the plain run's."""
+    from fastvim_amd.fastvim import VisionMamba
+    torch.manual_seed(0)
+    m = VisionMamba(img_size=224, depth=4, embed_dim=192, num_classes=20, rms_norm=True, residual_in_fp32=True,
+                    fused_add_norm=True, final_pool_type="mean", if_abs_pos_embed=True, drop_path_rate=0.0).cuda().train()
+    x = torch.randn(4, 3, 224, 224, device="cuda")
+    res = []
+    for hooked in (False, True):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if hooked:
+                with torch.autograd.graph.save_on_cpu():
+                    y = m(x)
+            else:
+                y = m(x)
+        y.float().square().mean().backward()
+        res.append((y.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
