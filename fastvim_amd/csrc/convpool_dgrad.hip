@@ -36,6 +36,9 @@ constexpr int CD_RSB = CD_N * 2 + 16;          // product tile row stride of the
 #ifndef CD_PDEPTH
 #define CD_PDEPTH 4
 #endif
+#ifndef CD_SB_EVERY
+#define CD_SB_EVERY 1    // conv steps per scheduling region (1: the stand-alone kernel's step-by-step order)
+#endif
 #ifndef CD_W2_PIPE
 #define CD_W2_PIPE 1     // second phase: the next panel's first weight stage requested before this panel's epilogue
 #endif
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(CD_NT, 2) void conv_pool_bwd_dgrad_kernel(CdParams 
             fv_buf_store_words<1>(bo, voff, (m_row + n * g.s_j) * tok_x, pk);
             *reinterpret_cast<uint32_t*>(prow + n * CD_RSA + voff) = pk[0];      // bank = 4 n + 64 c + lane: conflict-free
           }
-          __builtin_amdgcn_sched_barrier(0);
+          if ((n + 3) % CD_SB_EVERY == CD_SB_EVERY - 1) __builtin_amdgcn_sched_barrier(0);
         }
         cf_dn_raw = pooled(2, false, c0n, more);
       }
