@@ -60,3 +60,28 @@ __device__ __forceinline__ void chan_reduce_scatter(float (&v)[PV], int lane) {
   rs_row4<PV / 16, PV>(v, lane);
 }
 
+
+// Value `v` of lane i plus that of lane i ^ 4 (the last level of a channel reduce whose values are already scattered: both
+// lanes end with the total).  Two DPP adds whose bank masks pick the direction: lanes with bit 2 clear (banks 0, 2) read
+// lane i + 4 (row_ror:12), the others lane i - 4 (row_ror:4).
+__device__ __forceinline__ float add_lane_xor4(float v) {
+  float w;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(w) : "v"(v));
+  return w;
+}
+// lane k of every quad's value, in all four lanes of the quad (quad_perm [k, k, k, k])
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, true));
+}
+// Sum of 8 values per lane over the 16 channel lanes of a wave: three reduce-scatter levels (lane bits 5, 4, 3) and one
+// plain level (bit 2).  Every lane returns the total of value index (lane >> 3) & 7, the same in lanes i and i ^ 4.
+__device__ __forceinline__ float chan_sum8_plain(float (&v)[8], int lane) {
+  rs_swap32<4, 8>(v);
+  rs_swap16<2, 8>(v);
+  rs_row8<1, 8>(v, lane);
+  return add_lane_xor4(v[0]);
+}

@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "lane_reduce.h"
+#include "scan_step.h"
 
 namespace {
 
@@ -74,7 +75,7 @@ struct ScanParams {
   float *last_state;
   float *dB_part, *dC_part;              // variable: (S, batch, G, N, L); constant: unused
   float *pA, *pD, *pbias, *pBc, *pCc;    // per-batch partials (batch, dim[, N])
-  float* ckpt;                           // short-sequence backward: states entering every 4-step segment
+  float* ckpt;                           // short-sequence backward: states entering every 16-step chunk (L > 16)
   int batch, dim, L, N, G, S;
   int B_var, C_var, softplus;
 };
@@ -460,11 +461,11 @@ __global__ __launch_bounds__(64) void scan_bdl_bwd_kernel(ScanParams p, int ntil
 // Short sequences use the mapping of the fused mixer scan (scan_cl.hip) instead: the recurrence runs serially in
 // registers and parallelism comes from batch x channels x state quads -- a lane owns 4 of the 16 states of one
 // channel (sums over states = two DPP quad adds), B_t / C_t are LDS broadcasts, a 256-thread block covers 64
-// channels of one batch element.  Backward: a forward sweep checkpoints the state entering every 4-step segment,
-// segments are walked high-to-low (recompute 4 states, adjoint), dB / dC are reduced over the 16 channel lanes of
-// a wave by the swap/DPP reduce-scatter, over waves through LDS, over 64-channel chunks by reduce_leading.
+// channels of one batch element.  Backward (round 6): 16-step chunks recomputed into registers from the state entering
+// them (no checkpoint at all up to 16 steps), the fused mixer's packed adjoint step, dB / dC reduced over the 16 channel
+// lanes of a wave by the swap/DPP reduce-scatter, over waves through LDS, over 64-channel chunks by reduce_leading.
 // Requires d_state == 16, variable B and C, and whole 64-channel chunks per group.
-constexpr int SN = 16, SCPB = 64, SKS = 4;
+constexpr int SN = 16, SCPB = 64;
 
 static const bool g_short_on = (fv_tune("FASTVIM_SCAN_SHORT", 1) != 0);   // tuning hook
 inline bool short_path(int L, int N, int dim, int G, int Bv, int Cv) {
@@ -513,9 +514,12 @@ __global__ __launch_bounds__(256) void scan_short_fwd_kernel(ScanParams p) {
   const int d = g * cpg + cx * SCPB + (tid >> 2);
   stage_bc<T>(p, b, g, smem);
   __syncthreads();
-  float A2[4], st[4] = {0.f, 0.f, 0.f, 0.f};
+  sf2 A2[2], st[2] = {{0.f, 0.f}, {0.f, 0.f}};       // the 4 states of a lane as two packed pairs (scan_step.h)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) A2[j] = p.A[(size_t)d * SN + q * 4 + j] * FV_LOG2E;
+  for (int h = 0; h < 2; ++h) {
+    A2[h].x = p.A[(size_t)d * SN + q * 4 + 2 * h] * FV_LOG2E;
+    A2[h].y = p.A[(size_t)d * SN + q * 4 + 2 * h + 1] * FV_LOG2E;
+  }
   const float Dd = p.D ? p.D[d] : 0.f, bias = p.delta_bias ? p.delta_bias[d] : 0.f;
   const size_t row = ((size_t)b * p.dim + d) * p.L;
   const T* u = (const T*)p.u + row;
@@ -523,36 +527,39 @@ __global__ __launch_bounds__(256) void scan_short_fwd_kernel(ScanParams p) {
   const T* z = p.z ? (const T*)p.z + row : nullptr;
   T* out = (T*)p.out + row;
   for (int l0 = 0; l0 < p.L; l0 += 4) {
-    float uv[4], dv[4], zv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {          // the group's loads first, then the arithmetic
-      const int l = min(l0 + k, p.L - 1);
-      uv[k] = io<T>::ld(u + l);
-      dv[k] = io<T>::ld(dl + l);
-      zv[k] = z ? io<T>::ld(z + l) : 0.f;
-    }
+    // Groups of four steps: quad lane q loads step l0 + q's u / delta / z and evaluates softplus(delta + bias), delta u,
+    // D u and SiLU(z) for it -- once per (channel, step) instead of once per quad lane (round 6; the four lanes of a channel
+    // used to issue the same twelve loads and the same eight transcendentals per group) -- and the quad reads them by DPP
+    // broadcast.  No barrier, no LDS: the table form of this (profiles/r06_ab_scan_op_table_forward.log) lost to its barriers.
+    const int lq = min(l0 + q, p.L - 1);
+    const float uq = io<T>::ld(u + lq);
+    float dq = io<T>::ld(dl + lq) + bias;
+    const float zq = z ? io<T>::ld(z + lq) : 0.f;
+    if (p.softplus) dq = fv_softplus(dq);
+    const float duq = dq * uq, skq = Dd * uq, szq = z ? fv_silu(zq) : 1.f;
+    const float dt4[4] = {quad_bcast<0>(dq), quad_bcast<1>(dq), quad_bcast<2>(dq), quad_bcast<3>(dq)};
+    const float du4[4] = {quad_bcast<0>(duq), quad_bcast<1>(duq), quad_bcast<2>(duq), quad_bcast<3>(duq)};
+    const float sk4[4] = {quad_bcast<0>(skq), quad_bcast<1>(skq), quad_bcast<2>(skq), quad_bcast<3>(skq)};
+    const float sz4[4] = {quad_bcast<0>(szq), quad_bcast<1>(szq), quad_bcast<2>(szq), quad_bcast<3>(szq)};
+    float yq = 0.f;                         // lane q keeps step l0 + q's output
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (l0 + k < p.L) {
-        const float* r = smem + (l0 + k) * 2 * SN;
-        float dt = dv[k] + bias;
-        if (p.softplus) dt = fv_softplus(dt);
-        const float du = dt * uv[k];
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], du * r[q * 4 + j]);
-          acc = fmaf(r[SN + q * 4 + j], st[j], acc);
-        }
-        float y = quad_sum(acc) + Dd * uv[k];
-        if (z) y *= fv_silu(zv[k]);
-        if (q == 0) io<T>::st(out + l0 + k, y);
+        const float4 Bv = *reinterpret_cast<const float4*>(smem + (l0 + k) * 2 * SN + q * 4);
+        const float4 Cv = *reinterpret_cast<const float4*>(smem + (l0 + k) * 2 * SN + SN + q * 4);
+        const float dt = dt4[k], du = du4[k];
+        st[0] = sfma2(sexp2_2(A2[0] * dt), st[0], sf2{Bv.x, Bv.y} * du);
+        st[1] = sfma2(sexp2_2(A2[1] * dt), st[1], sf2{Bv.z, Bv.w} * du);
+        const sf2 t = sfma2(sf2{Cv.x, Cv.y}, st[0], sf2{Cv.z, Cv.w} * st[1]);
+        const float y = (quad_sum(t.x + t.y) + sk4[k]) * sz4[k];
+        if (q == k) yq = y;
       }
     }
+    if (l0 + q < p.L) io<T>::st(out + l0 + q, yq);      // four consecutive steps of the row, one per quad lane
   }
   if (p.last_state) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p.last_state[((size_t)b * p.dim + d) * SN + q * 4 + j] = st[j];
+    float* ls = p.last_state + ((size_t)b * p.dim + d) * SN + q * 4;
+    ls[0] = st[0].x; ls[1] = st[0].y; ls[2] = st[1].x; ls[3] = st[1].y;
   }
 }
 
@@ -655,180 +662,227 @@ __global__ __launch_bounds__(GTHR) void scan_short_fwd_seg_kernel(ScanParams p) 
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void scan_short_bwd_kernel(ScanParams p) {
+// Backward, REGISTER-resident chunks (round 6).  The round-1 kernel this replaces checkpointed the state entering every
+// 4-step segment in global memory (50 MB written and re-read at config 3's shape: 3.6 x the op's algorithmic bytes by the
+// counters; 5.3 x at config 5's), recomputed a segment at a time, paid two workgroup barriers and a 16-value reduce-scatter
+// (8 of them zero) per segment, and evaluated softplus / sigmoid in all four state-quad lanes of a channel: 3 249 vector
+// instructions per wave for 14 steps, 1 896 now; traffic 100.9 -> 48.5 MB at config 3's shape, 302 -> 145 MB at config 5's
+// (profiles/r06_scan_op_cfg*_pmc.json; same-box timings profiles/r06_ab_scan_op_round6.log: forward + backward 141 -> 90 us
+// at config 3's shape, 312 -> 223 at config 5's).  Time is cut into chunks of 16 steps whose trajectory fits a lane's
+// registers -- the fused mixer's kernels (scan_cl.hip) do the same, and the adjoint step IS theirs (scan_step.h: packed
+// state pairs, channel reduce-scatter):
+//   * sequences of up to 16 steps (the 14- / 16-row pooled grids, BASELINE configs 2 and 3) are ONE chunk: no checkpoint at
+//     all; longer ones keep the state entering every chunk (a quarter of the old checkpoints) from one forward sweep;
+//   * per chunk: the 16 x 4 states recomputed into registers, the decay factors re-derived in the adjoint sweep (one
+//     v_exp_f32 each), no barrier inside the sweeps, two per chunk for the sum over the four waves;
+//   * softplus(delta + bias), its sigmoid, sigmoid(z) and SiLU'(z) are evaluated once per (channel, step): quad lane q does
+//     step 4 i + q of a group of four and the quad reads them by DPP broadcast;
+//   * the output tiles take the places of the input tiles in LDS (44 KB per block instead of 69: three blocks per CU).
+template <typename T, bool ONE>      // ONE: L <= 16, a single chunk (no forward sweep, no checkpoint, one window)
+__global__ __launch_bounds__(256, ONE ? 3 : 2) void scan_short_bwd_reg_kernel(ScanParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int PV = 16, NWV = 4, TILE = SCPB * SWLP;
+  constexpr int LM = 16, NWV = 4, TILE = SCPB * SWLP;
+  const int L = p.L;
   float* s_bc = smem;                              // L * 32
-  float* s_part = s_bc + p.L * 2 * SN;             // SKS * NWV * 4 * PV
-  float* s_u = s_part + SKS * NWV * 4 * PV;        // input tiles u, delta, dout, z; output tiles du, ddelta, dz
+  float* s_part = s_bc + L * 2 * SN;               // LM * NWV * 4 * 8
+  // input tiles u, delta, dout, z (a window of 32 steps); the output tiles take their places -- d u over u and d z over z
+  // (an entry is read by its quad, then written by the quad's lane 0: one wave, program order), d delta over delta (delta
+  // lives in registers by then)
+  float* s_u = s_part + LM * NWV * 4 * 8;
   float* s_d = s_u + TILE;
   float* s_g = s_d + TILE;
   float* s_z = s_g + TILE;
-  float* s_du = s_z + TILE;
-  float* s_dd = s_du + TILE;
-  float* s_dz = s_dd + TILE;
   const int tid = threadIdx.x, q = tid & 3, lane = tid & 63, wv = tid >> 6, cl = tid >> 2;
   const int cpg = p.dim / p.G, chunks = cpg / SCPB;
   const int g = blockIdx.x / chunks, cx = blockIdx.x - g * chunks, b = blockIdx.y;
   const int d0 = g * cpg + cx * SCPB, d = d0 + cl;
-  const int nseg = (p.L + SKS - 1) / SKS;
+  const size_t row0 = ((size_t)b * p.dim + d0) * L;
+  const bool has_z = p.z != nullptr;
+  const int nwin = ONE ? 1 : (L + SWL - 1) / SWL, nck = ONE ? 1 : (L + LM - 1) / LM;
+  float* ck = p.ckpt + (((size_t)b * nck) * p.dim + d) * SN + q * 4;      // + chunk * dim * SN: state entering the chunk
+  const size_t ck_c = (size_t)p.dim * SN;
   stage_bc<T>(p, b, g, s_bc);
-  float A2[4], Ar[4];
+  // the 4 states of a lane are two packed pairs (scan_step.h)
+  sf2 A2[2], Araw[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    Ar[j] = p.A[(size_t)d * SN + q * 4 + j];
-    A2[j] = Ar[j] * FV_LOG2E;
+  for (int h = 0; h < 2; ++h) {
+    Araw[h].x = p.A[(size_t)d * SN + q * 4 + 2 * h];
+    Araw[h].y = p.A[(size_t)d * SN + q * 4 + 2 * h + 1];
+    A2[h] = Araw[h] * FV_LOG2E;
   }
   const float Dd = p.D ? p.D[d] : 0.f, bias = p.delta_bias ? p.delta_bias[d] : 0.f;
-  const size_t row0 = ((size_t)b * p.dim + d0) * p.L;
-  const bool has_z = p.z != nullptr;
-  float* ck = p.ckpt + (((size_t)b * nseg) * p.dim + d) * SN + q * 4;
-  const size_t ck_seg = (size_t)p.dim * SN;
-  const int nwin = (p.L + SWL - 1) / SWL;
-
-  {  // forward sweep: state entering every segment but the first (windows ascending; a single window stays staged)
-    float st[4] = {0.f, 0.f, 0.f, 0.f};
+  float* my_u = s_u + cl * SWLP;
+  float* my_d = s_d + cl * SWLP;
+  const float* my_g = s_g + cl * SWLP;
+  float* my_z = s_z + cl * SWLP;
+  const float* my_bc = s_bc + q * 4;                 // this quad lane's B states of step 0 (C: + SN)
+  // delta of the 16 steps of a chunk (window-local first step lb, global first step g0), once per (channel, step): lane q
+  // of the quad evaluates step 4 i + q; dt_own keeps the lane's own four (a select chain over dtv by q would turn into a
+  // dynamic index and put the array in scratch)
+  float dtv[LM], dt_own[LM / 4];
+  auto chunk_delta = [&](int lb, int g0) {
+#pragma unroll
+    for (int i = 0; i < LM / 4; ++i) {
+      const int l = 4 * i + q;
+      float dt = 0.f;                                // steps past the sequence: delta = 0, an identity step
+      if (g0 + l < L) {
+        dt = my_d[lb + l] + bias;
+        if (p.softplus) dt = fv_softplus(dt);
+      }
+      dt_own[i] = dt;
+      dtv[4 * i + 0] = quad_bcast<0>(dt);
+      dtv[4 * i + 1] = quad_bcast<1>(dt);
+      dtv[4 * i + 2] = quad_bcast<2>(dt);
+      dtv[4 * i + 3] = quad_bcast<3>(dt);
+    }
+  };
+  if (nck > 1) {
+    // ---- forward sweep over the chunks before the last: the state entering every later chunk
+    sf2 st[2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int w = 0; w < nwin; ++w) {
-      const int w0 = w * SWL, wl = min(SWL, p.L - w0);
+      const int w0 = w * SWL, wl = min(SWL, L - w0);
       if (w) __syncthreads();
-      tile_ld<T>((const T*)p.u + row0, p.L, w0, wl, s_u);
-      tile_ld<T>((const T*)p.delta + row0, p.L, w0, wl, s_d);
+      tile_ld<T>((const T*)p.u + row0, L, w0, wl, s_u);
+      tile_ld<T>((const T*)p.delta + row0, L, w0, wl, s_d);
       if (nwin == 1) {
-        tile_ld<T>((const T*)p.dout + row0, p.L, w0, wl, s_g);
-        if (has_z) tile_ld<T>((const T*)p.z + row0, p.L, w0, wl, s_z);
+        tile_ld<T>((const T*)p.dout + row0, L, w0, wl, s_g);
+        if (has_z) tile_ld<T>((const T*)p.z + row0, L, w0, wl, s_z);
       }
       __syncthreads();
-      for (int l = 0; l < wl; ++l) {
-        const int gl = w0 + l;
-        if (gl % SKS == 0 && gl > 0)
-          *reinterpret_cast<float4*>(ck + (size_t)(gl / SKS) * ck_seg) = make_float4(st[0], st[1], st[2], st[3]);
-        if (gl >= (nseg - 1) * SKS) break;       // the last segment's states are recomputed, not checkpointed
-        const float* r = s_bc + gl * 2 * SN;
-        float dt = s_d[cl * SWLP + l] + bias;
-        if (p.softplus) dt = fv_softplus(dt);
-        const float dub = dt * s_u[cl * SWLP + l];
+      for (int cc = 0; cc < SWL / LM; ++cc) {
+        const int c = w * (SWL / LM) + cc;
+        if (c + 1 >= nck) break;                     // (the last chunk's states are recomputed in the backward pass)
+        chunk_delta(cc * LM, c * LM);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st[j] = fmaf(fv_exp2(dt * A2[j]), st[j], dub * r[q * 4 + j]);
+        for (int l = 0; l < LM; ++l) {
+          asm volatile("" ::: "memory");
+          const float4 Bv = *reinterpret_cast<const float4*>(my_bc + (c * LM + l) * 2 * SN);
+          const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
+          const float dt = dtv[l], dtu = dt * my_u[cc * LM + l];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+        }
+        *reinterpret_cast<float4*>(ck + (size_t)(c + 1) * ck_c) = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
       }
     }
+  } else {
+    tile_ld<T>((const T*)p.u + row0, L, 0, L, s_u);
+    tile_ld<T>((const T*)p.delta + row0, L, 0, L, s_d);
+    tile_ld<T>((const T*)p.dout + row0, L, 0, L, s_g);
+    if (has_z) tile_ld<T>((const T*)p.z + row0, L, 0, L, s_z);
+    __syncthreads();
   }
-  float dxa[4] = {0.f, 0.f, 0.f, 0.f}, dA[4] = {0.f, 0.f, 0.f, 0.f}, dD_acc = 0.f, dbias_acc = 0.f;
-  const int s_chunk = cx;                           // split index of the dB / dC partials
+  // ---- backward over the chunks, last first
+  sf2 dxa[2] = {{0.f, 0.f}, {0.f, 0.f}}, dA[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float dD_acc = 0.f, dbias_acc = 0.f;
+  float* my_part = s_part + (wv * 4 + q) * 8 + ((lane >> 3) & 7);
   for (int w = nwin - 1; w >= 0; --w) {
-    const int w0 = w * SWL, wl = min(SWL, p.L - w0);
+    const int w0 = w * SWL, wl = min(SWL, L - w0);
     if (nwin > 1) {
       __syncthreads();                              // the previous window's output tiles are out
-      tile_ld<T>((const T*)p.u + row0, p.L, w0, wl, s_u);
-      tile_ld<T>((const T*)p.delta + row0, p.L, w0, wl, s_d);
-      tile_ld<T>((const T*)p.dout + row0, p.L, w0, wl, s_g);
-      if (has_z) tile_ld<T>((const T*)p.z + row0, p.L, w0, wl, s_z);
+      tile_ld<T>((const T*)p.u + row0, L, w0, wl, s_u);
+      tile_ld<T>((const T*)p.delta + row0, L, w0, wl, s_d);
+      tile_ld<T>((const T*)p.dout + row0, L, w0, wl, s_g);
+      if (has_z) tile_ld<T>((const T*)p.z + row0, L, w0, wl, s_z);
       __syncthreads();
     }
-    for (int seg = (w0 + wl - 1) / SKS; seg * SKS >= w0; --seg) {      // SWL is a multiple of SKS: segments do not straddle windows
-      const int s0 = seg * SKS, ns = min(SKS, p.L - s0);
-      float uv[SKS], dv[SKS], gq[SKS], zv[SKS];
+    for (int cc = SWL / LM - 1; cc >= 0; --cc) {
+      const int c = w * (SWL / LM) + cc, g0 = c * LM, lb = cc * LM;
+      if (g0 >= L) continue;                         // uniform
+      const int valid = min(LM, L - g0);
+      float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c > 0) e4 = *reinterpret_cast<const float4*>(ck + (size_t)c * ck_c);
+      chunk_delta(lb, g0);
+      // ---- the chunk's states from the state entering it
+      const sf2 entry[2] = {{e4.x, e4.y}, {e4.z, e4.w}};
+      sf2 xs[LM][2];
+      {
+        sf2 st[2] = {entry[0], entry[1]};
 #pragma unroll
-      for (int k = 0; k < SKS; ++k) {
-        const int l = min(s0 + k, p.L - 1) - w0;
-        uv[k] = s_u[cl * SWLP + l];
-        dv[k] = s_d[cl * SWLP + l];
-        gq[k] = s_g[cl * SWLP + l];
-        zv[k] = has_z ? s_z[cl * SWLP + l] : 0.f;
-      }
-      float cur[4] = {0.f, 0.f, 0.f, 0.f};
-      if (seg > 0) {
-        const float4 c4 = *reinterpret_cast<const float4*>(ck + (size_t)seg * ck_seg);
-        cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
-      }
-      float xs[SKS][4], aq[SKS][4], dtv[SKS];
+        for (int l = 0; l < LM; ++l) {
+          asm volatile("" ::: "memory");             // (keeps the scheduler from hoisting every step's LDS reads to the top)
+          if (l < valid) {      // uniform
+            const float4 Bv = *reinterpret_cast<const float4*>(my_bc + (g0 + l) * 2 * SN);
+            const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
+            const float dt = dtv[l], dtu = dt * my_u[lb + l];
 #pragma unroll
-      for (int k = 0; k < SKS; ++k) {
-        const float* r = s_bc + min(s0 + k, p.L - 1) * 2 * SN;
-        const bool on = k < ns;
-        const float raw = dv[k] + bias;
-        const float dt = p.softplus ? fv_softplus(raw) : raw;
-        dtv[k] = on ? dt : 0.f;                      // delta = 0: the step is an identity
-        if (!on) gq[k] = 0.f;
-        const float dub = dtv[k] * uv[k];
+            for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+          }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          aq[k][j] = fv_exp2(dtv[k] * A2[j]);
-          cur[j] = fmaf(aq[k][j], cur[j], dub * r[q * 4 + j]);
-          xs[k][j] = cur[j];
+          for (int h = 0; h < 2; ++h) xs[l][h] = st[h];
         }
       }
+      // ---- adjoint sweep, high to low, in groups of four steps (the per-step scalars of a group come from its quad lanes)
 #pragma unroll
-      for (int k = SKS - 1; k >= 0; --k) {
-        if (k < ns) {          // uniform across the block
-          const int l = s0 + k, lw = l - w0;
-          const float* r = s_bc + l * 2 * SN;
-          float gk = gq[k];
-          if (has_z) {         // out = y * silu(z): gradient wrt y and wrt z
-            float ypre = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ypre = fmaf(r[SN + q * 4 + j], xs[k][j], ypre);
-            ypre = quad_sum(ypre) + Dd * uv[k];
-            const float sg = fv_sigmoid(zv[k]);
-            if (q == 0) s_dz[cl * SWLP + lw] = gq[k] * ypre * sg * (1.f + zv[k] * (1.f - sg));
-            gk = gq[k] * zv[k] * sg;
+      for (int i = LM / 4 - 1; i >= 0; --i) {
+        if (4 * i < valid) {      // uniform
+          // lane q: step 4 i + q -- sigmoid of the softplus argument (= 1 - exp(-softplus)), gate value and derivative
+          const int lq = min(4 * i + q, valid - 1);
+          const float sp_q = p.softplus ? 1.f - __expf(-dt_own[i]) : 1.f;
+          float zs_q = 1.f, zd_q = 0.f;
+          if (has_z) {
+            const float zv = my_z[lb + lq], sg = fv_sigmoid(zv);
+            zs_q = zv * sg;                              // SiLU(z)
+            zd_q = sg * (1.f + zv * (1.f - sg));         // SiLU'(z)
           }
-          float vals[PV];
+          const float sp4[4] = {quad_bcast<0>(sp_q), quad_bcast<1>(sp_q), quad_bcast<2>(sp_q), quad_bcast<3>(sp_q)};
+          const float zs4[4] = {quad_bcast<0>(zs_q), quad_bcast<1>(zs_q), quad_bcast<2>(zs_q), quad_bcast<3>(zs_q)};
+          const float zd4[4] = {quad_bcast<0>(zd_q), quad_bcast<1>(zd_q), quad_bcast<2>(zd_q), quad_bcast<3>(zd_q)};
 #pragma unroll
-          for (int e = 0; e < PV; ++e) vals[e] = 0.f;
-          float du_acc = 0.f, ddt_acc = 0.f;
-          const float dtu = dtv[k] * uv[k];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float Bn = r[q * 4 + j], Cn = r[SN + q * 4 + j];
-            const float dx = fmaf(gk, Cn, dxa[j]);
-            const float ax = xs[k][j] - dtu * Bn;               // a_t * x_{t-1}
-            du_acc = fmaf(dx, Bn, du_acc);
-            ddt_acc += dx * fmaf(Ar[j], ax, Bn * uv[k]);
-            dA[j] = fmaf(dx * dtv[k], ax, dA[j]);
-            vals[j] = dx * dtu;                                  // dB[4q+j]
-            vals[4 + j] = gk * xs[k][j];                         // dC[4q+j]
-            dxa[j] = aq[k][j] * dx;
+          for (int k = 3; k >= 0; --k) {
+            const int l = 4 * i + k;
+            asm volatile("" ::: "memory");
+            if (l < valid) {      // uniform
+              const float4 Bv = *reinterpret_cast<const float4*>(my_bc + (g0 + l) * 2 * SN);
+              const float4 Cv = *reinterpret_cast<const float4*>(my_bc + (g0 + l) * 2 * SN + SN);
+              const float uv = my_u[lb + l], gq = my_g[lb + l], dt = dtv[l];
+              float gk = gq;
+              if (has_z) {       // out = y * silu(z): gradient wrt y and wrt z
+                const sf2 t = sfma2(sf2{Cv.x, Cv.y}, xs[l][0], sf2{Cv.z, Cv.w} * xs[l][1]);
+                const float ypre = quad_sum(t.x + t.y) + Dd * uv;
+                if (q == 0) my_z[lb + l] = gq * ypre * zd4[k];      // d z (over z: this group's z was read at its top)
+                gk = gq * zs4[k];
+              }
+              // the fused mixer's adjoint step (scan_step.h): {delta, u, dy, sigmoid} = {dt, u, gk, d softplus}; the state
+              // before the chunk's first step is its entry state (zero for the first chunk: the products with it vanish)
+              const float4 cv = make_float4(dt, uv, gk, sp4[k]);
+              sf2 vals[4];
+              const AdjStep st = adjoint_step<false>(Bv, Cv, cv, A2, Araw, xs[l], l > 0 ? xs[l > 0 ? l - 1 : 0] : entry, dxa, dA, vals);
+              if (q == 0) {
+                dbias_acc += st.ddraw;
+                dD_acc = fmaf(gk, uv, dD_acc);
+                my_u[lb + l] = fmaf(dt, st.du_acc, Dd * gk);         // d u (over u)
+                my_d[lb + l] = st.ddraw;                             // d delta (over delta)
+              }
+              my_part[l * (NWV * 4 * 8)] = chan_sum8(vals);
+            }
           }
-          du_acc = quad_sum(du_acc);
-          ddt_acc = quad_sum(ddt_acc);
-          // d softplus: sigmoid(raw) = 1 - exp(-softplus(raw))
-          const float ddraw = p.softplus ? ddt_acc * (1.f - __expf(-dtv[k])) : ddt_acc;
-          if (q == 0) {
-            dbias_acc += ddraw;
-            dD_acc = fmaf(gk, uv[k], dD_acc);
-            s_du[cl * SWLP + lw] = fmaf(dtv[k], du_acc, Dd * gk);
-            s_dd[cl * SWLP + lw] = ddraw;
-          }
-          chan_reduce_scatter<PV>(vals, lane);
-          s_part[((k * NWV + wv) * 4 + q) * PV + (lane >> 2)] = vals[0];
         }
       }
       __syncthreads();
       // the 4 waves in fixed order -> this chunk's partial of dB / dC, layout (split, batch, G, N, L)
-      for (int e = tid; e < ns * 4 * PV; e += blockDim.x) {
-        const int k = e / (4 * PV), rem = e - k * 4 * PV;
-        const int qq = rem / PV, v = rem - qq * PV;
-        if (v < 8) {
-          float t = 0.f;
+      for (int e = tid; e < valid * 32; e += 256) {
+        const int l = e >> 5, qq = (e >> 3) & 3, v = e & 7;
+        float t = 0.f;
 #pragma unroll
-          for (int ww = 0; ww < NWV; ++ww) t += s_part[((k * NWV + ww) * 4 + qq) * PV + v];
-          const int n = qq * 4 + (v & 3);
-          float* dst = (v < 4 ? p.dB_part : p.dC_part) + ((((size_t)s_chunk * p.batch + b) * p.G + g) * SN + n) * p.L;
-          dst[s0 + k] = t;
-        }
+        for (int ww = 0; ww < NWV; ++ww) t += s_part[((l * NWV + ww) * 4 + qq) * 8 + v];
+        const int n = qq * 4 + (v & 3);
+        float* dst = (v < 4 ? p.dB_part : p.dC_part) + ((((size_t)cx * p.batch + b) * p.G + g) * SN + n) * L;
+        dst[g0 + l] = t;
       }
-      __syncthreads();
+      if (cc > 0 && g0 > 0) __syncthreads();       // the window's other chunk reuses the wave partials
     }
-    // (the loop's last barrier also orders the output tiles' writes before the copies below)
-    tile_st<T>((T*)p.du + row0, p.L, w0, wl, s_du);
-    tile_st<T>((T*)p.ddelta + row0, p.L, w0, wl, s_dd);
-    if (has_z && p.dz) tile_st<T>((T*)p.dz + row0, p.L, w0, wl, s_dz);
+    // (the chunk loop's barrier also orders the output tiles' writes before the copies below)
+    tile_st<T>((T*)p.du + row0, L, w0, wl, s_u);
+    tile_st<T>((T*)p.ddelta + row0, L, w0, wl, s_d);
+    if (has_z && p.dz) tile_st<T>((T*)p.dz + row0, L, w0, wl, s_z);
   }
-  // per-(batch, channel) partials, one row per batch element: [dA (dim*N) | dD (dim) | d delta_bias (dim)]
   const size_t bd = (size_t)b * p.dim + d;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) p.pA[bd * SN + q * 4 + j] = dA[j];
+  for (int h = 0; h < 2; ++h) {
+    p.pA[bd * SN + q * 4 + 2 * h] = dA[h].x;
+    p.pA[bd * SN + q * 4 + 2 * h + 1] = dA[h].y;
+  }
   if (q == 0) {
     if (p.pD) p.pD[bd] = dD_acc;
     if (p.pbias) p.pbias[bd] = dbias_acc;
@@ -873,7 +927,7 @@ BwdWs bwd_ws(int batch, int dim, int L, int N, int G, int Bv, int Cv) {
   w.pCc = take(Cv ? 0 : (size_t)batch * dim * N);
   w.dBp = take((Bv && S > 1) ? (size_t)S * batch * G * N * L : 0);
   w.dCp = take((Cv && S > 1) ? (size_t)S * batch * G * N * L : 0);
-  w.ckpt = take(sp ? (size_t)batch * ((L + SKS - 1) / SKS) * dim * N : 0);
+  w.ckpt = take(sp && L > 16 ? (size_t)batch * ((L + 15) / 16) * dim * N : 0);      // state entering every 16-step chunk
   w.total = o;
   return w;
 }
@@ -930,13 +984,10 @@ int launch_short(const ScanParams& p, int bwd, hipStream_t st) {
       hipLaunchKernelGGL((scan_short_fwd_kernel<T>), grid, block, (size_t)p.L * 2 * SN * 4, st, p);
     }
   } else {
-    const size_t smem = ((size_t)p.L * 2 * SN + SKS * 4 * 4 * 16 + 7 * SCPB * SWLP) * 4;
-    static FvOncePerDevice done;   
-    if (smem > 64 * 1024 && done.first()) {
-      (void)hipFuncSetAttribute((const void*)scan_short_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)0;     
-    }
-    hipLaunchKernelGGL((scan_short_bwd_kernel<T>), grid, block, smem, st, p);
+    // 16-step chunks in registers (one chunk, no checkpoint, on the 14- / 16-row grids)
+    const size_t smr = ((size_t)p.L * 2 * SN + 16 * 4 * 4 * 8 + 4 * SCPB * SWLP) * 4;      // <= 58 KB at L = 128
+    if (p.L <= 16) hipLaunchKernelGGL((scan_short_bwd_reg_kernel<T, true>), grid, block, smr, st, p);
+    else hipLaunchKernelGGL((scan_short_bwd_reg_kernel<T, false>), grid, block, smr, st, p);
   }
   FV_LAUNCH_CHECK();
   return FV_OK;

@@ -7,7 +7,9 @@ import json
 import re
 import sys
 
-KEYS = (("conv_pool_bwd_dgrad_addnorm_bwd", "conv_pool_bwd_dgrad_kernel"), ("conv_pool_fwd", "conv_pool_fwd"), ("scan_fwd", "scan_cl_fwd"), ("combine_out_proj_addnorm_fwd", "combine_out_proj_addnorm_kernel"),
+KEYS = (("scan_op_fwd", "scan_short_fwd"), ("scan_op_bwd", "scan_short_bwd"), ("scan_op_fwd_wave", "scan_bdl_fwd"), ("scan_op_bwd_wave", "scan_bdl_bwd"),
+        ("scan_op_reduce", "reduce_leading"),
+        ("conv_pool_bwd_dgrad_addnorm_bwd", "conv_pool_bwd_dgrad_kernel"), ("conv_pool_fwd", "conv_pool_fwd"), ("scan_fwd", "scan_cl_fwd"), ("combine_out_proj_addnorm_fwd", "combine_out_proj_addnorm_kernel"),
         ("combine_fwd", "combine_fwd"),
         ("combine_bwd", "combine_bwd"), ("scan_bwd_xproj", "14, true, true>"), ("scan_bwd", "scan_cl_bwd"),
         ("conv_pool_bwd_two_addends", "conv_pool_bwd_row_kernel<__hip_bfloat16, 14, true>"), ("conv_pool_bwd", "conv_pool_bwd"),
