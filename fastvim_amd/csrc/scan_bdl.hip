@@ -974,10 +974,11 @@ int launch_short(const ScanParams& p, int bwd, hipStream_t st) {
   FV_CHECK(p.batch <= 65535, "selective_scan: batch %d exceeds the launch grid", p.batch);
   if (!bwd) {
     static const bool seg_on = (fv_tune("FASTVIM_SCAN_SHORT_SEG", 1) != 0);   // tuning hook
-    // 32 < L <= 128 on FEW rows (config 4: 8 x 1536 rows = 768 serial waves, under one per SIMD): four time segments per
-    // block, 27 instead of 40 us there.  With two or more serial waves per SIMD already (config 5: 64 x 768 rows) the
-    // second pass costs more than the shorter chain gives (82 vs 61 us): the serial kernel stays.
-    if (seg_on && p.L > SWL && (long)(p.dim / GCH) * p.batch < 2 * 4 * fv_cu_count()) {
+    // 32 < L <= 128 on FEW rows: four time segments per block -- twice the arithmetic, a quarter of the dependent chain.
+    // Since the serial kernel shares its loads and transcendentals inside the quad (round 6) the segments pay only below
+    // about half a serial wave per SIMD (tools/probe/r06_seg_probe.py, warm: 24 / 48 / 96 blocks of 64 channels 15.5 / 15.9 /
+    // 19.1 us segmented against 22.7 / 23.0 / 23.2 serial; 192 blocks -- config 4's shape -- 24.4 against 23.7)
+    if (seg_on && p.L > SWL && (long)(p.dim / SCPB) * p.batch <= 128) {
       const size_t smem = ((size_t)p.L * 2 * SN + (p.z ? 4 : 3) * GCH * (p.L + 1) + GSEG * GCH * SN + GSEG * GCH) * 4;
       hipLaunchKernelGGL((scan_short_fwd_seg_kernel<T>), dim3(p.dim / GCH, p.batch), dim3(GTHR), smem, st, p);
     } else {

@@ -191,13 +191,16 @@ def test_scan_errors():
         selective_scan_fn(u.cpu(), u.cpu(), A[:, :8].cpu(), torch.randn(2, 8, 8), torch.randn(2, 8, 8))
 
 
-@pytest.mark.parametrize("Bsz,D,L", [(2, 64, 33), (2, 128, 37), (1, 64, 128), (3, 64, 112), (2, 96, 100), (2, 64, 64)])
+@pytest.mark.parametrize("Bsz,D,L", [(2, 64, 33), (2, 128, 37), (1, 64, 128), (3, 64, 112), (2, 96, 100), (2, 64, 64),
+                                     (3, 3072, 40), (130, 64, 35)])
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
 def test_short_scan_segmented_forward_vs_oracle(Bsz, D, L, itype):
-    """32 < L <= 128 with d_state 16 takes the time-segmented forward kernel (scan_short_fwd_seg_kernel: a block's four
-    waves scan four consecutive segments -- end states from zero, a fold over the earlier segments, a second scan from
-    the true entry state; ragged last segment when L % 4 != 0): output, gate, skip, bias, softplus and last state against
-    the fp64 oracle, and the gradients through the (unchanged) backward kernel."""
+    """32 < L <= 128 with d_state 16 on FEW rows (at most 128 blocks of 64 channels) takes the time-segmented forward
+    kernel (scan_short_fwd_seg_kernel: a block's four waves scan four consecutive segments -- end states from zero, a fold
+    over the earlier segments, a second scan from the true entry state; ragged last segment when L % 4 != 0); the last two
+    shapes (144 / 130 blocks) take the serial quad-sharing kernel at those lengths (round 6: the threshold moved): output,
+    gate, skip, bias, softplus and last state against the fp64 oracle, and the gradients through the chunked backward
+    kernel (three and two chunks: checkpoints, ragged last chunk)."""
     from fastvim_amd.selective_scan_interface import selective_scan_fn
     from oracle import selective_scan_oracle
     g = torch.Generator().manual_seed(Bsz * 1000 + D + L)
