@@ -86,12 +86,13 @@ struct Lane {
     bias = p.dtb[dir][dd];
   }
   // softplus(dt_proj(dt_low) + bias) -- each quad lane sums its r = q, q+4, ... then quad add
-  __device__ __forceinline__ float delta(const float* row) const {
+  __device__ __forceinline__ float delta_raw(const float* row) const {
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < RQ; ++i) acc = fmaf(wdt[i], row[q + 4 * i], acc);   // row padded with zeros to 4*RQ
-    return fv_softplus(quad_sum(acc) + bias);
+    return quad_sum(acc) + bias;
   }
+  __device__ __forceinline__ float delta(const float* row) const { return fv_softplus(delta_raw(row)); }
 };
 
 // stage x_dbl rows of this (dir, b) into LDS as fp32, row stride WP (dt_low part padded to 4*RQ)
@@ -122,21 +123,31 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_kernel(ScanClParams p) {
   float* y = p.yc + ((size_t)ln.dir * p.B + ln.b) * p.Lc * p.d_in + dd;
   float st[4] = {0.f, 0.f, 0.f, 0.f};
   for (int s0 = 0; s0 < p.Lc; s0 += 4) {
-    // the 4 loads of the group are issued together, ahead of the arithmetic
-    float uv[4];
+    // Groups of four steps; the quad shares what is per (channel, step) (round 6, as in the op-level kernel): lane q loads
+    // step s0 + q's u and takes the softplus of ITS step's dt_proj sum -- every lane has all four sums after the quad adds
+    // -- and the four lanes read delta and delta u of a step by DPP broadcast: a quarter of the loads and softplus
+    // evaluations.
     int lk[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int step = min(s0 + k, p.Lc - 1);
       lk[k] = ln.dir ? p.Lc - 1 - step : step;       // backward direction: descending rows
-      uv[k] = io<T>::ld(u + (size_t)lk[k] * p.d_in);
     }
+    const int lkq = ln.q == 0 ? lk[0] : ln.q == 1 ? lk[1] : ln.q == 2 ? lk[2] : lk[3];
+    const float uq = io<T>::ld(u + (size_t)lkq * p.d_in);
+    float raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[k] = ln.delta_raw(smem + lk[k] * WP);
+    const float dtq = fv_softplus(ln.q == 0 ? raw[0] : ln.q == 1 ? raw[1] : ln.q == 2 ? raw[2] : raw[3]);
+    const float duq = dtq * uq;
+    const float dt4[4] = {quad_bcast<0>(dtq), quad_bcast<1>(dtq), quad_bcast<2>(dtq), quad_bcast<3>(dtq)};
+    const float du4[4] = {quad_bcast<0>(duq), quad_bcast<1>(duq), quad_bcast<2>(duq), quad_bcast<3>(duq)};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (s0 + k < p.Lc) {
         const float* row = smem + lk[k] * WP;
-        const float dt = ln.delta(row);
-        const float du = dt * uv[k];
+        const float dt = dt4[k];
+        const float du = du4[k];
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
