@@ -23,6 +23,7 @@
 #include "common.h"
 #include "lane_reduce.h"
 #include "scan_step.h"
+#include <type_traits>
 
 namespace {
 
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_c
 // structure with C dy in the place of B delta u (scan_cl_bwd_chunked_kernel then runs each segment from its true incoming
 // adjoint state).
 template <typename T, int RQ, int MODE = 0>
-__global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p) {
+__global__ __launch_bounds__(256, RQ <= 6 ? 6 : 5) void scan_cl_fwd_chunked_kernel(ScanClParams p) {
   constexpr bool STATE_ONLY = MODE != 0, ADJ = MODE == 2;
   constexpr int NWV = 4, CH = 64, LCT = 16, NTH = 256;
   constexpr int RQP = (RQ + 3) / 4 * 4, WP = 4 * RQP + 2 * N;
@@ -1319,28 +1320,38 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
   float* ck = p.ckpt ? p.ckpt + (((size_t)dir * p.B + b) * nchunk * p.d_in + dd) * N + q * 4 : nullptr;
 
   float pre[NST], um[4];
+  // staging plan of this thread, the same for every chunk: staged element e = tid + i NTH is (step row, column) of the
+  // [dt_low by quad | B | C] row; its source column in x_dbl, and whether it is a real value at all
+  int st_row[NST], st_src[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = tid + i * NTH;
+    const int srow = e / WP, col = e - srow * WP;
+    int src = p.R + (col - 4 * RQP);
+    bool ok = e < LCT * WP;
+    if (col < 4 * RQP) {
+      const int qq = col / RQP, k = col - qq * RQP, r = qq + 4 * k;
+      src = r;
+      ok = ok && k < RQ && r < p.R;
+    }
+    st_row[i] = ok ? srow : -1;
+    st_src[i] = ok ? src : 0;
+  }
+  // every load is issued unconditionally from a clamped address and its value selected afterwards: a load behind a
+  // branch is a basic block of its own, and the join waits for every load issued before it
   auto fetch = [&](int c) {            // chunk c's rows (this thread's share) and inputs into registers
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      const int e = tid + i * NTH;
-      const int srow = e / WP, col = e - srow * WP;
-      const int sg = c * LCT + srow;
-      const int l = dir ? Lc - 1 - sg : sg;
-      float v = 0.f;
-      if (e < LCT * WP && sg < Lc) {
-        if (col < 4 * RQP) {
-          const int qq = col / RQP, k = col - qq * RQP, r = qq + 4 * k;
-          if (k < RQ && r < p.R) v = io<T>::ld(dbl + (size_t)l * W + r);
-        } else {
-          v = io<T>::ld(dbl + (size_t)l * W + p.R + (col - 4 * RQP));
-        }
-      }
-      pre[i] = v;
+      const int sg = c * LCT + st_row[i];
+      const bool ok = st_row[i] >= 0 && sg < Lc;
+      const int l = ok ? (dir ? Lc - 1 - sg : sg) : 0;
+      const float v = io<T>::ld(dbl + (size_t)l * W + st_src[i]);
+      pre[i] = ok ? v : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int sg = min(c * LCT + 4 * tg + r, Lc - 1), l = dir ? Lc - 1 - sg : sg;
-      if constexpr (ADJ) um[r] = actm ? gy[(size_t)l * p.d_in] : 0.f;          // the output gradient of the step
+      if constexpr (ADJ) um[r] = gy[(size_t)l * p.d_in];          // the output gradient of the step (channel clamped: masked below)
       else um[r] = io<T>::ld(u + (size_t)l * p.d_in);
     }
   };
@@ -1351,6 +1362,7 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
       if (e < LCT * WP) s_dbl[buf][e] = pre[i];
     }
   };
+  const bool whole = ch0 + CH <= p.d_in;          // every lane of the workgroup owns a channel (uniform)
   const int cfirst = ADJ ? c1 - 1 : c0, cstep = ADJ ? -1 : 1;      // the adjoint recurrence walks the chunks last to first
   fetch(cfirst);
   put(cfirst & 1);
@@ -1378,7 +1390,7 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
         const int s = 4 * tg + r;
         const float dt = (actm && s < valid) ? fv_softplus(D[r] + bias_m) : 0.f;
         // {delta, delta * u}; adjoint pass: {delta, dy} (dy of a step past the sequence is masked: its C row is zero)
-        *reinterpret_cast<float2*>(s_ch + ((size_t)s * CH + wv * 16 + cm) * 2) = make_float2(dt, ADJ ? um[r] : dt * um[r]);
+        *reinterpret_cast<float2*>(s_ch + ((size_t)s * CH + wv * 16 + cm) * 2) = make_float2(dt, ADJ ? (actm ? um[r] : 0.f) : dt * um[r]);
       }
     }
     if (more) fetch(c + cstep);          // in flight under the recurrence
@@ -1388,35 +1400,53 @@ __global__ __launch_bounds__(256) void scan_cl_fwd_chunked_kernel(ScanClParams p
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const float* my_bc = s_dbl[buf] + 4 * RQP + q * 4;
     const float* my_ch = s_ch + (size_t)ch * 2;
+    // FULL: a whole chunk on whole channel blocks -- ONE basic block (no per-step bound check, no predicated store: the
+    // scheduler sees all sixteen steps, the LDS words of a step are requested under the arithmetic of the one before);
+    // the outputs of four steps are collected across the quad (lane q keeps step 4 g + q) and leave in one store
+    auto sweep = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      [[maybe_unused]] float ykeep = 0.f;
+      [[maybe_unused]] float* yp = y + (size_t)(dir ? Lc - 1 - (c * LCT + q) : c * LCT + q) * p.d_in;
+      [[maybe_unused]] const long ystep = (long)(dir ? -4 : 4) * p.d_in;
 #pragma unroll
-    for (int si = 0; si < LCT; ++si) {
-      const int s = ADJ ? LCT - 1 - si : si;
-      if (s < valid) {          // uniform
-        const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
-        const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
-        const float2 cv = *reinterpret_cast<const float2*>(my_ch + s * (CH * 2));
-        const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
-        if constexpr (ADJ) {
-          sdt += cv.x;
+      for (int si = 0; si < LCT; ++si) {
+        const int s = ADJ ? LCT - 1 - si : si;
+        if (FULL || s < valid) {          // uniform
+          const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+          const float4 Cv = *reinterpret_cast<const float4*>(my_bc + s * WP + N);
+          const float2 cv = *reinterpret_cast<const float2*>(my_ch + s * (CH * 2));
+          const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}}, Cn[2] = {{Cv.x, Cv.y}, {Cv.z, Cv.w}};
+          if constexpr (ADJ) {
+            sdt += cv.x;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) st[h] = sexp2_2(A2[h] * cv.x) * sfma2(Cn[h], ssplat(cv.y), st[h]);      // a (C dy + dxa)
-        } else if constexpr (STATE_ONLY) {
-          sdt += cv.x;
+            for (int h = 0; h < 2; ++h) st[h] = sexp2_2(A2[h] * cv.x) * sfma2(Cn[h], ssplat(cv.y), st[h]);      // a (C dy + dxa)
+          } else if constexpr (STATE_ONLY) {
+            sdt += cv.x;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
-        } else {
-          sf2 acc = {0.f, 0.f};
+            for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
+          } else {
+            sf2 acc = {0.f, 0.f};
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
-            acc = sfma2(Cn[h], st[h], acc);
+            for (int h = 0; h < 2; ++h) {
+              st[h] = sfma2(sexp2_2(A2[h] * cv.x), st[h], Bn[h] * cv.y);
+              acc = sfma2(Cn[h], st[h], acc);
+            }
+            const float yv = quad_sum(acc.x + acc.y);
+            if constexpr (FULL) {
+              ykeep = (s & 3) == q ? yv : ykeep;
+              if ((s & 3) == 3) {
+                *yp = ykeep;
+                yp += ystep;
+              }
+            } else {
+              const int sg = c * LCT + s, l = dir ? Lc - 1 - sg : sg;
+              if (act && q == 0) y[(size_t)l * p.d_in] = yv;
+            }
           }
-          const float yv = quad_sum(acc.x + acc.y);
-          const int sg = c * LCT + s, l = dir ? Lc - 1 - sg : sg;
-          if (act && q == 0) y[(size_t)l * p.d_in] = yv;
         }
       }
-    }
+    };
+    if (valid == LCT && whole) sweep(std::true_type{}); else sweep(std::false_type{});
     if (!STATE_ONLY && ck && c + 1 < nchunk && act)
       *reinterpret_cast<float4*>(ck + (size_t)(c + 1) * p.d_in * N) = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
     if (more) put(buf ^ 1);          // the other buffer's readers passed the barrier of the previous chunk
