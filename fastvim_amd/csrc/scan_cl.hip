@@ -960,23 +960,31 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_c
   }
 
   // stage the x_dbl rows of chunk c of (dir, b) in scan order: fp32, dt_low regrouped by quad lane, rows past Lc zero
+  // (every load unconditional from a clamped address, the value selected afterwards: a load behind a branch is a basic
+  //  block of its own and its join waits for every load issued before it)
   auto stage = [&](size_t bd, int c) {
     const T* dbl = (const T*)p.xdbl + bd * W;
-    for (int e = opaque_tid(); e < LCT * WP; e += NTH) {
+    constexpr int NIT = (LCT * WP + NTH - 1) / NTH;
+    const int t0 = opaque_tid();
+    float v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = min(t0 + it * NTH, LCT * WP - 1);
       const int srow = e / WP, col = e - srow * WP;
       const int sg = c * LCT + srow;
-      const int l = dir ? Lc - 1 - sg : sg;
-      float v = 0.f;
-      if (sg < Lc) {
-        if (col < 4 * RQP) {
-          const int qq = col / RQP, i = col - qq * RQP, r = qq + 4 * i;
-          if (i < RQ && r < p.R) v = io<T>::ld(dbl + (size_t)l * W + r);
-          if (BIAS_MM && col == RQ) v = 1.f;      // r = 4 RQ: the ones column
-        } else {
-          v = io<T>::ld(dbl + (size_t)l * W + p.R + (col - 4 * RQP));
-        }
-      }
-      s_dbl[e] = v;
+      const int qq = col / RQP, i = col - qq * RQP, r = qq + 4 * i;
+      const bool low = col < 4 * RQP;
+      const bool ok = sg < Lc && (!low || (i < RQ && r < p.R));
+      const int l = ok ? (dir ? Lc - 1 - sg : sg) : 0;
+      const int src = ok ? (low ? r : p.R + (col - 4 * RQP)) : 0;
+      const float x = io<T>::ld(dbl + (size_t)l * W + src);
+      v[it] = ok ? x : 0.f;
+      if (BIAS_MM && col == RQ && sg < Lc) v[it] = 1.f;      // r = 4 RQ: the ones column
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = t0 + it * NTH;
+      if (e < LCT * WP) s_dbl[e] = v[it];
     }
   };
   // delta_raw of the staged chunk on the matrix cores, softplus (and sigmoid) once per (step, channel), the table row
@@ -1046,15 +1054,23 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_c
         __syncthreads();
         table(um, gm, bias_m, LCT);
         wave_sync();
+        {         // the LDS words of a step are requested a step ahead (as in the adjoint sweep below)
+          float4 nB = *reinterpret_cast<const float4*>(my_bc);
+          float2 nc = *reinterpret_cast<const float2*>(my_ch);
 #pragma unroll
-        for (int s = 0; s < LCT; ++s) {
-          asm volatile("" ::: "memory");
-          const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
-          const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (CH * 4));
-          const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
-          const float dt = cv.x, dtu = cv.x * cv.y;
+          for (int s = 0; s < LCT; ++s) {
+            const float4 Bv = nB;
+            const float2 cv = nc;
+            if (s + 1 < LCT) {
+              nB = *reinterpret_cast<const float4*>(my_bc + (s + 1) * WP);
+              nc = *reinterpret_cast<const float2*>(my_ch + (s + 1) * (CH * 4));
+            }
+            asm volatile("" ::: "memory");
+            const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
+            const float dt = cv.x, dtu = cv.x * cv.y;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+            for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+          }
         }
         if (act) *reinterpret_cast<float4*>(ck + (size_t)(c + 1) * ck_c) = make_float4(st[0].x, st[0].y, st[1].x, st[1].y);
         __syncthreads();        // every wave is done with the staged rows
@@ -1099,19 +1115,41 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_c
       sf2 xs[LCT][2];
       {
         sf2 st[2] = {entry[0], entry[1]};
+        if (valid == LCT) {        // a full chunk: no bound check per step, the LDS words a step ahead
+          float4 nB = *reinterpret_cast<const float4*>(my_bc);
+          float2 nc = *reinterpret_cast<const float2*>(my_ch);
 #pragma unroll
-        for (int s = 0; s < LCT; ++s) {
-          asm volatile("" ::: "memory");
-          if (s < valid) {          // uniform
-            const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
-            const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (CH * 4));
+          for (int s = 0; s < LCT; ++s) {
+            const float4 Bv = nB;
+            const float2 cv = nc;
+            if (s + 1 < LCT) {
+              nB = *reinterpret_cast<const float4*>(my_bc + (s + 1) * WP);
+              nc = *reinterpret_cast<const float2*>(my_ch + (s + 1) * (CH * 4));
+            }
+            asm volatile("" ::: "memory");
             const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
             const float dt = cv.x, dtu = cv.x * cv.y;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+            for (int h = 0; h < 2; ++h) {
+              st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+              xs[s][h] = st[h];
+            }
           }
+        } else {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) xs[s][h] = st[h];
+          for (int s = 0; s < LCT; ++s) {
+            asm volatile("" ::: "memory");
+            if (s < valid) {          // uniform
+              const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
+              const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (CH * 4));
+              const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
+              const float dt = cv.x, dtu = cv.x * cv.y;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) st[h] = sfma2(sexp2_2(A2[h] * dt), st[h], Bn[h] * dtu);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xs[s][h] = st[h];
+          }
         }
       }
 
