@@ -962,11 +962,10 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_c
   // stage the x_dbl rows of chunk c of (dir, b) in scan order: fp32, dt_low regrouped by quad lane, rows past Lc zero
   // (every load unconditional from a clamped address, the value selected afterwards: a load behind a branch is a basic
   //  block of its own and its join waits for every load issued before it)
-  auto stage = [&](size_t bd, int c) {
+  constexpr int NIT = (LCT * WP + NTH - 1) / NTH;
+  auto stage_load = [&](size_t bd, int c, float (&v)[NIT]) {
     const T* dbl = (const T*)p.xdbl + bd * W;
-    constexpr int NIT = (LCT * WP + NTH - 1) / NTH;
     const int t0 = opaque_tid();
-    float v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = min(t0 + it * NTH, LCT * WP - 1);
@@ -981,11 +980,19 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_c
       v[it] = ok ? x : 0.f;
       if (BIAS_MM && col == RQ && sg < Lc) v[it] = 1.f;      // r = 4 RQ: the ones column
     }
+  };
+  auto stage_put = [&](const float (&v)[NIT]) {
+    const int t0 = opaque_tid();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = t0 + it * NTH;
       if (e < LCT * WP) s_dbl[e] = v[it];
     }
+  };
+  auto stage = [&](size_t bd, int c) {
+    float v[NIT];
+    stage_load(bd, c, v);
+    stage_put(v);
   };
   // delta_raw of the staged chunk on the matrix cores, softplus (and sigmoid) once per (step, channel), the table row
   // {delta, u, dy, sigmoid} of this wave's 16 channels to LDS
@@ -1083,29 +1090,36 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_c
       const float4 h0 = *reinterpret_cast<const float4*>(p.hin + ((((size_t)dir * p.B + b) * nseg + sgi) * p.d_in + dd) * N + q * 4);
       dxa[0].x = h0.x; dxa[0].y = h0.y; dxa[1].x = h0.z; dxa[1].y = h0.w;
     }
+    // a chunk's inputs (the state entering it, u / dy of this lane's table rows, its share of the x_dbl rows) are requested
+    // when the PREVIOUS chunk's adjoint sweep is over -- in flight under its dt_proj adjoint, the workgroup barrier and
+    // the twelve-wave sums -- instead of at the top of their own iteration, where every wave of the CU waited for them
+    float um[4], gm[4], sv[NIT], bias_m;
+    float4 e4;
+    auto fetch_chunk = [&](int c) {
+      e4 = *reinterpret_cast<const float4*>(ck + (size_t)c * ck_c);      // (chunk 0's slot is never written: masked below)
+      const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + cm;
+      const int ddm = dm < p.d_in ? dm : 0;
+      bias_m = p.dtb[dir][ddm];
+      const T* u = (const T*)p.xc + bd * p.d_in + ddm;
+      const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + ddm;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s = 4 * tg + r, sg = min(c * LCT + s, Lc - 1), l = dir ? Lc - 1 - sg : sg;
+        um[r] = io<T>::ld(u + (size_t)l * p.d_in);
+        gm[r] = gy[(size_t)l * p.d_in];
+      }
+      stage_load(bd, c, sv);
+    };
+    fetch_chunk(c_hi - 1);
     for (int c = c_hi - 1; c >= c_lo; --c) {
       const int valid = min(LCT, Lc - c * LCT);
-      // the state entering the chunk (requested first: it is needed after the staging barrier)
-      float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c > 0 && act) e4 = *reinterpret_cast<const float4*>(ck + (size_t)c * ck_c);
-      float um[4], gm[4];
-      float bias_m;
+      if (c == 0 || !act) e4 = make_float4(0.f, 0.f, 0.f, 0.f);      // the state entering the sequence
       {
-        const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + cm;
-        const bool actm = dm < p.d_in;
-        const int ddm = actm ? dm : 0;
-        bias_m = p.dtb[dir][ddm];
-        const T* u = (const T*)p.xc + bd * p.d_in + ddm;
-        const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + ddm;
+        const int t2 = opaque_tid(), tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + (t2 & 15);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int s = 4 * tg + r, sg = min(c * LCT + s, Lc - 1), l = dir ? Lc - 1 - sg : sg;
-          um[r] = io<T>::ld(u + (size_t)l * p.d_in);
-          const float gv = gy[(size_t)l * p.d_in];
-          gm[r] = (actm && s < valid) ? gv : 0.f;
-        }
+        for (int r = 0; r < 4; ++r) gm[r] = (dm < p.d_in && 4 * tg + r < valid) ? gm[r] : 0.f;
       }
-      stage(bd, c);
+      stage_put(sv);
       __syncthreads();      // rows staged; the previous chunk's readers of s_part / s_pd are done as well
       table(um, gm, bias_m, valid);
       wave_sync();
@@ -1202,6 +1216,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && RQ > 6) ? 2 : 3) void scan_c
       }
       }
       wave_sync();
+      fetch_chunk(max(c - 1, c_lo));      // unconditional: behind a branch the old values would stay live across the sweeps
 
       // ---- dt_proj adjoint on the matrix cores, from this wave's 16 columns of the d delta_raw table
       {
