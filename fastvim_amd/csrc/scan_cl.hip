@@ -509,45 +509,58 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     }
   }
 
+  // An element's inputs -- u and dy of this lane's four table rows, its share of the x_dbl rows (fp32, dt_low regrouped by
+  // quad lane, rows past Lc zero) -- are requested when the PREVIOUS element's adjoint sweep is over and arrive under its
+  // dt_proj / x_proj adjoints, barriers and wave sums (round 6; unconditionally, with the element index clamped: behind a
+  // branch the old values stay live around the loop and spill).  Every load comes from a clamped address, the value is
+  // selected afterwards.
+  constexpr int NIT = (LCT * WP + SH_THREADS - 1) / SH_THREADS;
+  float um[4], gm[4], sv[NIT], bias_m;
+  auto fetch_elem = [&](int bi) {
+    const int b = blockIdx.y * p.NBB + bi;
+    const size_t bd = ((size_t)dir * p.B + b) * Lc;
+    const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + cm;
+    const int ddm = dm < p.d_in ? dm : 0;
+    bias_m = p.dtb[dir][ddm];
+    const T* u = (const T*)p.xc + bd * p.d_in + ddm;
+    const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + ddm;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = 4 * tg + r, sc = min(s, Lc - 1), l = dir ? Lc - 1 - sc : sc;
+      um[r] = io<T>::ld(u + l * p.d_in);
+      gm[r] = gy[l * p.d_in];
+    }
+    const T* dbl = (const T*)p.xdbl + bd * W;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = min(t2 + it * SH_THREADS, LCT * WP - 1);
+      const int srow = e / WP, c = e - srow * WP;
+      const int qq = c / RQP, i = c - qq * RQP, r = qq + 4 * i;
+      const bool low = c < 4 * RQP;
+      const bool ok = (EXACT || srow < Lc) && (!low || (i < RQ && r < p.R));
+      const int l = ok ? (dir ? Lc - 1 - srow : srow) : 0;
+      const int src = ok ? (low ? r : p.R + (c - 4 * RQP)) : 0;
+      const float x = io<T>::ld(dbl + (size_t)l * W + src);
+      sv[it] = ok ? x : 0.f;
+      if (BIAS_MM && c == RQ && (EXACT || srow < Lc)) sv[it] = 1.f;      // r = 4 RQ: the ones column (BIAS_MM)
+    }
+  };
+  // (dt_rank 24 on the 14-row grid has no register left for it: two dwords would go to scratch -- it fetches at the top)
+  constexpr bool PREF = !(RQ == 6 && LCT == 14 && EXACT);
+  if constexpr (PREF) fetch_elem(0);
   for (int bi = 0; bi < p.NBB; ++bi) {
     const int b = blockIdx.y * p.NBB + bi;
     const size_t bd = ((size_t)dir * p.B + b) * Lc;
     SC_STAMP(bi, 0);
-    // matrix role: u and dy of this lane's 4 steps (requested before the staging barrier)
-    float um[4], gm[4];
-    float bias_m;
+    if constexpr (!PREF) fetch_elem(bi);
     {
-      const int t2 = opaque_tid(), cm = t2 & 15, tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + cm;
-      const bool actm = dm < p.d_in;
-      const int ddm = actm ? dm : 0;
-      bias_m = p.dtb[dir][ddm];
-      const T* u = (const T*)p.xc + bd * p.d_in + ddm;
-      const float* gy = p.dyc + (size_t)dir * p.dyc_dir + (size_t)b * Lc * p.d_in + ddm;
+      const int t2 = opaque_tid(), tg = (t2 >> 4) & 3, dm = ch0 + (t2 >> 6) * 16 + (t2 & 15);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int s = 4 * tg + r, sc = min(s, Lc - 1), l = dir ? Lc - 1 - sc : sc;
-        um[r] = io<T>::ld(u + l * p.d_in);
-        const float gv = gy[l * p.d_in];
-        gm[r] = (actm && s < Lc) ? gv : 0.f;
-      }
-    }
-    // stage the x_dbl rows of (dir, b) in scan order: fp32, dt_low regrouped by quad lane, rows past Lc zero
-    {
-      const T* dbl = (const T*)p.xdbl + bd * W;
-      for (int e = tid; e < LCT * WP; e += SH_THREADS) {
-        const int srow = e / WP, c = e - srow * WP;
-        const int l = dir ? Lc - 1 - srow : srow;
-        float v = 0.f;
-        if (EXACT || srow < Lc) {
-          if (c < 4 * RQP) {
-            const int qq = c / RQP, i = c - qq * RQP, r = qq + 4 * i;
-            if (i < RQ && r < p.R) v = io<T>::ld(dbl + (size_t)l * W + r);
-            if (BIAS_MM && c == RQ) v = 1.f;      // r = 4 RQ: the ones column (BIAS_MM)
-          } else {
-            v = io<T>::ld(dbl + (size_t)l * W + p.R + (c - 4 * RQP));
-          }
-        }
-        s_dbl[e] = v;
+      for (int r = 0; r < 4; ++r) gm[r] = (dm < p.d_in && 4 * tg + r < Lc) ? gm[r] : 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e = t2 + it * SH_THREADS;
+        if (e < LCT * WP) s_dbl[e] = sv[it];
       }
     }
     __syncthreads();      // rows staged; the previous element's readers of s_part / s_pd are done as well
@@ -592,14 +605,22 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     sf2 xs[LCT][2];
     {
       sf2 st[2] = {{0.f, 0.f}, {0.f, 0.f}};
+      // the LDS words of a step are requested one step ahead, as in the adjoint sweep (round 6: the read latency of every
+      // step was exposed here too)
+      float4 nB = *reinterpret_cast<const float4*>(my_bc);
+      float2 nc = *reinterpret_cast<const float2*>(my_ch);
 #pragma unroll
       for (int s = 0; s < LCT; ++s) {
+        const float4 Bv = nB;
+        const float2 cv = nc;
+        if (s + 1 < LCT) {
+          nB = *reinterpret_cast<const float4*>(my_bc + (s + 1) * WP);
+          nc = *reinterpret_cast<const float2*>(my_ch + (s + 1) * (SH_CH * 4));
+        }
         // a compiler memory barrier per step keeps the scheduler from hoisting every step's LDS reads to the top of the
         // unrolled loop (it spilled 145 VGPRs)
         asm volatile("" ::: "memory");
         if (EXACT || s < Lc) {
-          const float4 Bv = *reinterpret_cast<const float4*>(my_bc + s * WP);
-          const float4 cv = *reinterpret_cast<const float4*>(my_ch + s * (SH_CH * 4));
           const sf2 Bn[2] = {{Bv.x, Bv.y}, {Bv.z, Bv.w}};
           const float dt = cv.x, dtu = cv.x * cv.y;
 #pragma unroll
@@ -654,6 +675,7 @@ __global__ __launch_bounds__(SH_THREADS, 3) void scan_cl_bwd_short_kernel(ScanCl
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (PREF) fetch_elem(min(bi + 1, p.NBB - 1));      // the last element fetches itself again: see fetch_elem
 
     SC_STAMP(bi, 4);
     // x_proj adjoint: this wave's B operand fragments -- Wx[k][its 16 channels of this chunk | its 16 of the other one],
