@@ -363,7 +363,12 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
           DO[3 + c] = dc[c].get(0);
         }
       }
-      for (int j = 0; j <= pcols; ++j) {
+      // One body per cell; xn / dn = the packed cell j + 1, consumed at the end of the body and refilled THERE with cell
+      // j + 3.  The two packed buffers alternate between bodies (the loop below is unrolled by two): as `xr1 = xr2; xr2 =
+      // load` the rotation is a parallel copy at the end of the loop body, the load lands in temporaries, and the copy out
+      // of them waits for every load of the iteration that issued it -- the cell "two ahead" was waited for at once
+      // (round 6, ISA: `s_waitcnt vmcnt(15) ... vmcnt(0)` over 16 `v_mov`s at the bottom of the loop).
+      auto body = [&](int j, P (&xn)[TPP], P (&dn)[TPP]) {
         const bool tail = j == pcols, first = j == 0;
         const float e3 = tail ? m_dn : 1.f;
         f2 hcf[NH], hcb[NH];        // slot gradients of the first three steps of this body
@@ -442,20 +447,22 @@ __global__ __launch_bounds__(512) void conv_pool_bwd_chan_kernel(BwdParams p, in
           }
 #pragma unroll
           for (int c = 0; c < TPP; ++c) {
-            X[3 + c] = xr1[c].get(0) * m_nx;
-            DO[3 + c] = dr1[c].get(0);
-            xr1[c] = xr2[c];
-            dr1[c] = dr2[c];
+            X[3 + c] = xn[c].get(0) * m_nx;
+            DO[3 + c] = dn[c].get(0);
           }
           m_prev = m_cur;
           m_cur = cell(j + 1);
           const int m3 = cell(j + 3 > pcols ? pcols : j + 3);
 #pragma unroll
           for (int c = 0; c < TPP; ++c) {
-            xr2[c].load(bx, voff, (m3 + c * ts) * tok_x);
-            dr2[c].load(bd, voff, (m3 + c * ts) * tok_d);
+            xn[c].load(bx, voff, (m3 + c * ts) * tok_x);
+            dn[c].load(bd, voff, (m3 + c * ts) * tok_d);
           }
         }
+      };
+      for (int j = 0; j <= pcols; j += 2) {
+        body(j, xr1, dr1);
+        if (j + 1 <= pcols) body(j + 1, xr2, dr2);
       }
     }
   }

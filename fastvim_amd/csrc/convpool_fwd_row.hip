@@ -149,7 +149,12 @@ __global__ __launch_bounds__(512) void conv_pool_fwd_chan_kernel(FwdParams p) {
 #pragma unroll
     for (int c = 0; c < TPP; ++c) cur[c] = rc[c].get(0);
   }
-  for (int j = 0; j < ncell; ++j) {
+  // One body per cell; rn = the packed cell j + 1, consumed at the end of the body and refilled there with cell j + 3.
+  // The two packed buffers alternate between bodies (loop unrolled by two): written as `r1 = r2; r2 = load` the rotation
+  // is a parallel copy at the bottom of the loop, the loads land in temporaries and the copies out of them wait for
+  // every load of the iteration that issued it (round 6, ISA of the backward twin: the cell "two ahead" was waited for
+  // at once).
+  auto body = [&](int j, P (&rn)[TPP]) {
     // window of cell j: prev[0..2] | cur[0..TPP) | next[0..2]
     const float m_nx = (j + 1 < ncell || down) ? 1.f : 0.f;
     f2 xw[TPP + 6];
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(512) void conv_pool_fwd_chan_kernel(FwdParams p) {
 #pragma unroll
     for (int c = 0; c < TPP; ++c) xw[3 + c] = cur[c];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) xw[3 + TPP + k] = r1[k].get(0) * m_nx;
+    for (int k = 0; k < 3; ++k) xw[3 + TPP + k] = rn[k].get(0) * m_nx;
     const int mc = cell(j);
 #pragma unroll
     for (int c = 0; c < TPP; ++c) {
@@ -186,12 +191,14 @@ __global__ __launch_bounds__(512) void conv_pool_fwd_chan_kernel(FwdParams p) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) prev[k] = cur[TPP - 3 + k];
 #pragma unroll
-    for (int c = 0; c < TPP; ++c) cur[c] = r1[c].get(0) * m_nx;
-#pragma unroll
-    for (int c = 0; c < TPP; ++c) r1[c] = r2[c];
+    for (int c = 0; c < TPP; ++c) cur[c] = rn[c].get(0) * m_nx;
     const int m3 = cell(j + 3 > ncell ? ncell : j + 3);
 #pragma unroll
-    for (int c = 0; c < TPP; ++c) r2[c].load(bx, voff, (m3 + c * ts) * tok_x);
+    for (int c = 0; c < TPP; ++c) rn[c].load(bx, voff, (m3 + c * ts) * tok_x);
+  };
+  for (int j = 0; j < ncell; j += 2) {
+    body(j, r1);
+    if (j + 1 < ncell) body(j + 1, r2);
   }
   T* xc = (T*)p.xc;
   const size_t dstride = (size_t)p.B * g.rows * NS * p.d_in;
