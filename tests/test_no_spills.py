@@ -17,10 +17,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import kernel_meta  # noqa: E402
 
 # instantiations that are known to spill and are dispatched by no BASELINE configuration (fp32 storage, 16-row grids of
-# the un-folded short scan, twelve-wave chunked scans at dt_rank 48, the generic whole-row conv adjoint in fp32)
+# the un-folded short scan, twelve-wave chunked scans at dt_rank 48, the generic whole-row conv adjoint in fp32; 13 of 576
+# after the cell-walking conv adjoints stopped rotating their prefetch buffers through a parallel copy)
 KNOWN_SPILLS = {
-    "conv_pool_bwd_chan_kernel<float, 8, false>",
-    "conv_pool_bwd_chan_kernel<float, 8, true>",
     "conv_pool_bwd_kernel<float, 1, 17, false, false>",
     "conv_pool_bwd_kernel<float, 2, 17, false, false>",
     "scan_cl_bwd_chunked_kernel<bf16, 12, 12, false>",
@@ -29,7 +28,6 @@ KNOWN_SPILLS = {
     "scan_cl_bwd_chunked_kernel<float, 12, 12, true>",
     "scan_cl_bwd_short_kernel<bf16, 12, 16, true, false>",
     "scan_cl_bwd_short_kernel<bf16, 3, 16, true, false>",
-    "scan_cl_bwd_short_kernel<float, 12, 16, true, false>",
     "scan_cl_bwd_short_kernel<float, 3, 16, true, false>",
     "xproj_bwd_kernel<float, 112, 16, true>",
     "xproj_bwd_kernel<float, 80, 16, true>",
