@@ -5,7 +5,7 @@ source vS was the destination of a global / buffer load issued within the previo
 temporary and the copy into the loop-carried register waits for it."""
 import re, sys, glob, subprocess
 def demangle(n):
-    try: return subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', n], capture_output=True, text=True).stdout.strip()[:110]
+    try: return subprocess.run(['c++filt', n], capture_output=True, text=True).stdout.strip()[:110]
     except Exception: return n
 for f in sorted(glob.glob('/tmp/isa/all_*.s')):
     lines=open(f).read().split('\n')
