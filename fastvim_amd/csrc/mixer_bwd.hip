@@ -292,25 +292,24 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
           VecIO<T, VEC>::load(dob_b + (size_t)m * p.d_in + c0, dw[k]);
         }
       }
-      // Chunks of CH tokens; the NEXT chunk's tokens are requested before this chunk's arithmetic (round 6: they were loaded
-      // at the top of their own chunk, behind a branch per token, and used at once).  Two packed buffers alternate over a
-      // loop unrolled by two -- rotated through a copy the loads would land in temporaries and the copy would wait for
-      // them (see conv_pool_bwd_chan_kernel).  Loads are unconditional from a clamped token, the value selected after.
-      auto load_chunk = [&](int n0, RawVec<T, VEC> (&xp)[CH], RawVec<T, VEC> (&dp)[CH]) {
+      for (int n0 = -3; n0 < g.cols; n0 += CH) {
+        RawVec<T, VEC> xp[CH], dp[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {                    // token n0 + c + 3
           const int j3 = n0 + c + 3, sp = s_row + j3;
-          const bool ok = sp < g.L && j3 < g.cols + 3;
-          const int m = tok_mem<TP>(g, ok ? sp : s_row);
-          xp[c].load(xz_b + (size_t)m * 2 * p.d_in + (act ? c0 : 0));
-          dp[c].load(dob_b + (size_t)m * p.d_in + (act ? c0 : 0));      // (masked where it is used: see `chunk`)
+          if (act && sp < g.L && j3 < g.cols + 3) {
+            const int m = tok_mem<TP>(g, sp);
+            xp[c].load(xz_b + (size_t)m * 2 * p.d_in + c0);
+            dp[c].load(dob_b + (size_t)m * p.d_in + c0);
+          } else {
+            xp[c].zero();
+            dp[c].zero();
+          }
         }
-      };
-      auto chunk = [&](int n0, RawVec<T, VEC> (&xp)[CH], RawVec<T, VEC> (&dp)[CH]) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
         const int n = n0 + c;
-        if (n >= g.cols) return;
+        if (n >= g.cols) break;
         // shift the windows by one token and bring in token n+3
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -326,10 +325,6 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
         const bool v0 = s_row + n >= 0;                   // token n exists
         xp[c].get(xw[3]);
         dp[c].get(dw[3]);
-        if (!(act && v3 && n + 3 < g.cols + 3)) {         // token n+3 was read from a clamped address
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) xw[3][v] = dw[3][v] = 0.f;
-        }
         const int r3 = (n + 3 >= g.cols) ? 2 : 1;         // row of token n+3 relative to i-1
         const int r0 = (n < 0) ? 0 : 1;                   // row of token n
         const bool own3 = n + 3 < g.cols;                 // token n+3 belongs to this row (n+3 >= 0 always)
@@ -412,22 +407,6 @@ __global__ __launch_bounds__(VEC == 1 ? 1024 : 768) void conv_pool_bwd_kernel(Bw
           }
           if (act) VecIO<T, VEC>::store(dxz_b + (size_t)tok_mem<TP>(g, s_row + n) * 2 * p.d_in + c0, dx);
         }
-        }
-      };
-      if constexpr (CH <= 8 && !PM && sizeof(T) == 2) {
-        RawVec<T, VEC> xa[CH], da[CH], xb[CH], db[CH];
-        load_chunk(-3, xa, da);
-        for (int n0 = -3; n0 < g.cols; n0 += 2 * CH) {
-          load_chunk(n0 + CH, xb, db);
-          chunk(n0, xa, da);
-          load_chunk(n0 + 2 * CH, xa, da);
-          chunk(n0 + CH, xb, db);
-        }
-      } else {          // whole rows in one chunk (CH = 17), max pooling, fp32 storage: no register room for a second buffer
-        for (int n0 = -3; n0 < g.cols; n0 += CH) {
-          RawVec<T, VEC> xa[CH], da[CH];
-          load_chunk(n0, xa, da);
-          chunk(n0, xa, da);
         }
       }
     }
