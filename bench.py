@@ -992,6 +992,8 @@ def main():
                     help="A/B: the x_proj adjoint as its own launch instead of inside the short scan backward (round 5)")
     ap.add_argument("--no-conv-dgrad", action="store_true",
                     help="A/B: the conv + pool adjoint as its own launch instead of inside the in_proj data gradient + norm adjoint (round 6)")
+    ap.add_argument("--no-xproj-two-addends", action="store_true",
+                    help="A/B: wide models add the x_proj adjoint's product to the fp32 d xc instead of handing it to the conv adjoint as a second bf16 addend (round 6)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few-step runs of BASELINE configs 3, 4, 5 and the Vim-T baseline (default FastVim-T run only)")
     ap.add_argument("--vim-2048", action="store_true", help="only the Vim-vs-FastVim block at 2048 px (SURVEY row f2), as JSON")
@@ -1045,6 +1047,9 @@ def main():
     if args.no_conv_dgrad:
         import fastvim_amd.mamba_simple_faster as _msf
         _msf.CONV_IN_DGRAD = False
+    if args.no_xproj_two_addends:
+        import fastvim_amd.mamba_simple_faster as _msf
+        _msf.XPROJ_TWO_ADDENDS = False
     use_graph = not args.no_graph
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trace = os.environ.get("FASTVIM_BENCH_TRACE") == "1"      # debugging aid: per-step loss (adds a sync per step)

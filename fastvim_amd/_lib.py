@@ -24,7 +24,7 @@ C_ABI_SYMBOLS = (
     "fv_mixer_conv_pool_fwd", "fv_mixer_scan_fwd", "fv_mixer_xproj_scan_fwd_ok", "fv_mixer_xproj_scan_fwd", "fv_mixer_combine_fwd",
     "fv_mixer_bwd_blocks", "fv_mixer_combine_bwd", "fv_mixer_scan_bwd_chunks", "fv_mixer_scan_bwd_chunks_b",
     "fv_mixer_scan_bwd_ckpt_floats", "fv_mixer_scan_bwd_partials", "fv_mixer_scan_bwd", "fv_mixer_scan_bwd_dir", "fv_mixer_scan_bwd_ckpt", "fv_mixer_scan_bwd_segments", "fv_mixer_scan_bwd_seg_floats", "fv_mixer_scan_bwd_seg_partials", "fv_mixer_scan_bwd_seg_chunks", "fv_mixer_scan_bwd_seg", "fv_mixer_scan_fwd_ckpt", "fv_mixer_scan_ckpt_floats", "fv_mixer_scan_fwd_segments", "fv_mixer_scan_fwd_seg_floats", "fv_mixer_scan_fwd_seg", "fv_rows_segment_sum", "fv_rows_gather", "fv_mixer_conv_pool_bwd", "fv_mixer_conv_pool_bwd2_ok", "fv_mixer_conv_pool_bwd2", "fv_mixer_scan_bwd_xproj_ok", "fv_mixer_scan_bwd_xproj", "fv_chunk_rows_bf16", "fv_reduce_partials", "fv_reduce_partials_multi",
-    "fv_add_norm_blocks", "fv_add_norm_fwd", "fv_add_norm_bwd", "fv_gemm_bf16", "fv_gemm_bf16_tn_grouped", "fv_gemm_bf16_tn_grouped_ld", "fv_mixer_xproj_fwd", "fv_mixer_xproj_bwd_slices", "fv_mixer_xproj_bwd", "fv_mixer_xproj_bwd2", "fv_adamw_flat", "fv_soft_target_ce",
+    "fv_add_norm_blocks", "fv_add_norm_fwd", "fv_add_norm_bwd", "fv_gemm_bf16", "fv_gemm_bf16_tn_grouped", "fv_gemm_bf16_tn_grouped_ld", "fv_mixer_xproj_fwd", "fv_mixer_xproj_bwd_slices", "fv_mixer_xproj_bwd", "fv_mixer_xproj_bwd2", "fv_mixer_xproj_bwd3_ok", "fv_mixer_xproj_bwd3", "fv_adamw_flat", "fv_soft_target_ce",
     "fv_patch_unfold", "fv_gemm_bf16_rowbias", "fv_mean_pool_fwd", "fv_mean_pool_bwd", "fv_droppath_table", "fv_scale_cast",
     "fv_column_sum", "fv_gemm_bf16_addnorm", "fv_gemm_bf16_dgrad_addnorm_blocks", "fv_gemm_bf16_dgrad_addnorm_bwd", "fv_gemm_bf16_dgrad_addnorm_bwd2", "fv_gemm_bf16_addnorm2", "fv_mixer_combine_out_proj_addnorm_ok", "fv_mixer_combine_out_proj_addnorm", "fv_gemm_f32",
     "fv_mixer_conv_pool_bwd_dgrad_ok", "fv_mixer_conv_pool_bwd_dgrad_blocks", "fv_mixer_conv_pool_bwd_dgrad", "fv_transpose_bf16_batched", "fv_gemm_bf16_tn_grouped_wide8",

@@ -685,7 +685,7 @@ extern "C" int fv_mixer_conv_pool_bwd(const void* xz, const void* d_o, const flo
 }
 
 extern "C" int fv_mixer_conv_pool_bwd2_ok(int rows, int cols, int tokens_per_patch, int d_inner, int pool_max) {
-  return !pool_max && tokens_per_patch == 1 && (cols == 14 || cols == 16) && rows > 0 && d_inner % 128 == 0 && d_inner <= 1024;
+  return !pool_max && tokens_per_patch == 1 && (cols == 14 || cols == 16) && rows > 0 && d_inner % 128 == 0 && d_inner <= 2048;
 }
 
 extern "C" int fv_mixer_conv_pool_bwd2(const void* xz, const void* d_o, const float* dxc, const void* dxc2,

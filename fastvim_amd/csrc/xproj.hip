@@ -21,6 +21,8 @@ struct XprojParams {
   float* dxc;                // (2, M, d_in) fp32: in = through-the-scan part, out = total
   float* dW_part;            // (nslices, 2, W, d_in) fp32 (null: the weight gradient is computed elsewhere)
   void* dxdbl_out;           // (2, M, WP) bf16, WP = W rounded up to 8, pad columns zero (nullable): summed dx_dbl
+  const void* Wxt;           // (2, d_in, W) bf16: the TRANSPOSED compute-dtype shadow of both weights (xproj_bwd_mmb_kernel)
+  void* dxc2_out;            // (2, M, d_in) bf16 (nullable): the product is WRITTEN here instead of added to dxc
   int nchunks, M, d_in, rows_per_block;
 };
 
@@ -124,6 +126,8 @@ __global__ __launch_bounds__(256, 2) void xproj_bwd_mm_kernel(XprojParams p, int
   const int dir = blockIdx.z, m0 = blockIdx.y * 64;
   const int nr = min(64, p.M - m0);
   // stage the rows, summing the channel-chunk partials in fixed order (six in flight per lane, like the kernel above)
+  {
+#pragma clang fp reassociate(off) contract(off)      // (the published rows are the same bits in every form of this kernel)
   for (int e = tid; e < 64 * W4; e += 256) {
     const int r = e / W4, c = e - r * W4;
     float t = 0.f;
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void xproj_bwd_mm_kernel(XprojParams p, int
       }
     }
     s_g[r * WS + c] = t;
+  }
   }
   __syncthreads();
   if (p.dxdbl_out && blockIdx.x == 0) {      // one channel block publishes the summed rows (bf16, padded row stride)
@@ -198,6 +203,154 @@ __global__ __launch_bounds__(256, 2) void xproj_bwd_mm_kernel(XprojParams p, int
     // gemm_mfma.hip: a lane ends with four consecutive channels of one row -- 16-byte accesses).  d xc is read and written a
     // row block at a time, its four loads in flight together: as `*q += v` through one pointer the read-modify-writes are
     // a chain of dependent HBM round trips to the compiler, which cannot tell the addresses apart
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      uint32_t base[4][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fv_buf_load_words<4>(bd_, dof[b] + a * 16 * (p.d_in * 4), 0, base[b]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __float_as_uint(__uint_as_float(base[b][j]) + acc[a][b][j]);
+        fv_buf_store_words<4>(bd_, dof[b] + a * 16 * (p.d_in * 4), 0, o);
+      }
+    }
+  }
+}
+
+// The same data half on the BF16 matrix cores (round 6): bf16(summed d x_dbl) times the bf16 shadow weight -- the operands the
+// reference's autocast backward multiplies (selective_scan_interface.py:726-734), fp32 accumulate, fp32 d xc.  The fp32 form
+// above spends 4.3 us of matrix time per 256-channel block (20 k steps x 16 `v_mfma_f32_16x16x4_f32` per wave); here a
+// block is 3 k steps x 16 `v_mfma_f32_16x16x32_bf16`, and the launch sits on the round trip of d xc.  The weight rides in
+// the A slot (a lane ends with four consecutive channels of one row: 16-byte read-modify-writes), so a lane needs eight
+// consecutive k of ONE channel per fragment: the weight comes TRANSPOSED, (d_in, W) bf16 -- one 16-byte load per
+// fragment -- from the shadow the flat training state re-makes after every optimizer step.  W % 8 == 0; a row of the
+// transposed weight is W values, the k padding up to 32 KS reads on into the next channel's row (finite; it meets the
+// zero padding of the d x_dbl rows) or beyond the descriptor (zero).
+typedef __bf16 xm_bf16x8 __attribute__((ext_vector_type(8)));
+template <int W>
+__global__ __launch_bounds__(256, 2) void xproj_bwd_mmb_kernel(XprojParams p, int cbw) {
+  static_assert(W % 8 == 0, "transposed weight rows must be 16-byte multiples");
+  constexpr int KS = (W + 31) / 32, KP = 32 * KS, WS = KP + 4;      // row stride of the staged rows: KP + 4 floats
+  extern __shared__ __attribute__((aligned(16))) float s_g[];      // 64 * WS
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dir = blockIdx.z, m0 = blockIdx.y * 64;
+  const int nr = min(64, p.M - m0);
+  const int mr = lane & 15, kq = lane >> 4;
+  // the weight fragments of the workgroup's FIRST channel block (usually its only one) are requested before the rows
+  // are staged: the block is a chain of dependent round trips -- rows, barrier, weights, product, store -- and this
+  // takes the weights off it
+  const __amdgpu_buffer_rsrc_t bw_ = fv_make_buf((const bf16_t*)p.Wxt + (size_t)dir * p.d_in * W, (size_t)p.d_in * W * 2);
+  auto load_aw = [&](int n0, xm_bf16x8 (&aw)[4][KS]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint32_t t[4];
+        fv_buf_load_words<4>(bw_, ((n0 + b * 16 + mr) * W + 32 * ks + 8 * kq) * 2, 0, t);
+        aw[b][ks] = __builtin_bit_cast(xm_bf16x8, *reinterpret_cast<fv_u32x4*>(t));
+      }
+  };
+  xm_bf16x8 aw[4][KS];
+  load_aw(blockIdx.x * cbw * 256 + wv * 64, aw);
+  // stage the rows, summing the channel-chunk partials in fixed order; columns W .. KP and rows past the slice zero
+  if (p.nchunks == 1) {
+    // already summed (the wide models pre-sum their eight chunks): every 16-byte piece of the 64 rows requested at once
+    // -- the general loop below has ONE load in flight per lane and iteration with a single chunk, twenty-four dependent
+    // round trips in front of the barrier (round 6: that loop was most of the kernel's 20 us)
+    constexpr int NV = (64 * (KP / 4) + 255) / 256;
+    const float* src = p.dxdbl_part + ((size_t)dir * p.M + m0) * W;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * 256, r = e / (KP / 4), c4 = e - r * (KP / 4);
+      const bool ok = e < 64 * (KP / 4) && r < nr && 4 * c4 < W;
+      v[i] = *reinterpret_cast<const float4*>(src + (ok ? r * W + 4 * c4 : 0));
+      if (!ok) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * 256, r = e / (KP / 4), c4 = e - r * (KP / 4);
+      if (e < 64 * (KP / 4)) *reinterpret_cast<float4*>(s_g + r * WS + 4 * c4) = v[i];
+    }
+  } else {
+  {
+#pragma clang fp reassociate(off) contract(off)      // (the published rows are the same bits in every form of this kernel)
+  for (int e = tid; e < 64 * KP; e += 256) {
+    const int r = e / KP, c = e - r * KP;
+    float t = 0.f;
+    if (r < nr && c < W) {
+      for (int c0 = 0; c0 < p.nchunks; c0 += 6) {
+        float v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const bool on = c0 + u < p.nchunks;
+          v[u] = on ? p.dxdbl_part[(((size_t)(c0 + u) * 2 + dir) * p.M + m0 + r) * W + c] : 0.f;
+        }
+        t += ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
+      }
+    }
+    s_g[r * WS + c] = t;
+  }
+  }
+  }
+  __syncthreads();
+  if (p.dxdbl_out && blockIdx.x == 0) {      // one channel block publishes the summed rows (bf16; W is a multiple of 8)
+    bf16_t* o = (bf16_t*)p.dxdbl_out + ((size_t)dir * p.M + m0) * W;
+    for (int e = tid; e < nr * W; e += 256) {
+      const int r = e / W, c = e - r * W;
+      o[e] = __float2bfloat16(s_g[r * WS + c]);
+    }
+  }
+  // this lane's B operands, the same for every channel block: rows 16 a + mr, k = 32 ks + 8 kq .. + 7 (rounded to bf16 as
+  // the published rows are)
+  xm_bf16x8 bv[4][KS];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* q = s_g + (a * 16 + mr) * WS + 32 * ks + 8 * kq;
+      const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
+      uint32_t w4[4] = {pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y), pack_bf16x2(hi.z, hi.w)};
+      bv[a][ks] = __builtin_bit_cast(xm_bf16x8, *reinterpret_cast<fv_u32x4*>(w4));
+    }
+  const __amdgpu_buffer_rsrc_t bd_ = fv_make_buf(p.dxc + ((size_t)dir * p.M + m0) * p.d_in, (size_t)nr * p.d_in * 4);
+  const __amdgpu_buffer_rsrc_t b2_ = fv_make_buf((bf16_t*)p.dxc2_out + ((size_t)dir * p.M + m0) * p.d_in, p.dxc2_out ? (size_t)nr * p.d_in * 2 : 0);
+  for (int cb = 0; cb < cbw; ++cb) {
+    const int n0 = (blockIdx.x * cbw + cb) * 256 + wv * 64;
+    if (n0 >= p.d_in) break;                  // uniform per wave (d_in is a multiple of 64)
+    xm_f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (xm_f32x4){0.f, 0.f, 0.f, 0.f};
+    int dof[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dof[b] = (mr * p.d_in + n0 + b * 16 + 4 * kq) * 4;
+    if (cb > 0) load_aw(n0, aw);              // (further blocks: every fragment requested before the first MFMA)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[b][ks], bv[a][ks], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // acc[a][b][j] = product[row 16 a + mr][channel n0 + 16 b + 4 kq + j]
+    if (p.dxc2_out) {
+      // the product leaves as its own bf16 tensor -- the conv + pool adjoint takes the pooled gradient as two addends
+      // (fv_mixer_conv_pool_bwd2) -- instead of a read-modify-write of the fp32 d xc: 2 bytes per element instead of 8
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const uint32_t o[2] = {pack_bf16x2(acc[a][b][0], acc[a][b][1]), pack_bf16x2(acc[a][b][2], acc[a][b][3])};
+          fv_buf_store_words<2>(b2_, (dof[b] + a * 16 * (p.d_in * 4)) >> 1, 0, o);
+        }
+      continue;
+    }
+    // d xc is read and written a row block at a time
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       uint32_t base[4][4];
@@ -331,6 +484,48 @@ extern "C" int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, con
                                   int width, int dtype, fv_stream_t stream) {
   return fv_mixer_xproj_bwd2(dx_dbl_partials, nchunks, xc, x_proj_w, x_proj_w_b, dxc, dW_partials, nullptr, M, d_inner,
                              width, dtype, stream);
+}
+
+// the data half with the transposed bf16 shadow weights (2, d_inner, width): bf16 matrix cores where the matrix-core form
+// applies (fv_mixer_xproj_bwd3_ok), else fv_mixer_xproj_bwd2
+extern "C" int fv_mixer_xproj_bwd3_ok(int M, int d_inner, int width, int dtype) {
+  static const bool on = (fv_tune("FASTVIM_XPROJ_BWD_MMB", 1) != 0);   // tuning hook
+  const bool built = width == 56 || width == 80 || width == 96 || width == 112 || width == 64;
+  return on && built && dtype == FV_BF16 && d_inner % 64 == 0 && d_inner >= 768 && M > 0 &&
+         (size_t)M * d_inner * 4 < 0x7fffffffull && (size_t)d_inner * width * 2 < 0x7fffffffull;
+}
+extern "C" int fv_mixer_xproj_bwd3(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
+                                   const float* x_proj_w_b, const void* x_proj_w_t_bf16, float* dxc, void* dxc2_bf16,
+                                   void* dx_dbl_bf16, int M, int d_inner, int width, int dtype, fv_stream_t stream) {
+  const bool ok = x_proj_w_t_bf16 && dx_dbl_bf16 && fv_mixer_xproj_bwd3_ok(M, d_inner, width, dtype);
+  if (!ok) {
+    FV_CHECK(!dxc2_bf16, "mixer_xproj_bwd3: a separate bf16 product needs the bf16 matrix-core form (fv_mixer_xproj_bwd3_ok)");
+    return fv_mixer_xproj_bwd2(dx_dbl_partials, nchunks, xc, x_proj_w, x_proj_w_b, dxc, nullptr, dx_dbl_bf16, M, d_inner,
+                               width, dtype, stream);
+  }
+  FV_CHECK(dx_dbl_partials && xc && (dxc || dxc2_bf16), "mixer_xproj_bwd3: null pointer");
+  FV_CHECK(nchunks > 0, "mixer_xproj_bwd3: empty dimension");
+  XprojParams p{};
+  p.dxdbl_part = dx_dbl_partials; p.xc = xc; p.Wx[0] = x_proj_w; p.Wx[1] = x_proj_w_b; p.dxc = dxc; p.dxc2_out = dxc2_bf16;
+  p.dxdbl_out = dx_dbl_bf16; p.Wxt = x_proj_w_t_bf16; p.nchunks = nchunks; p.M = M; p.d_in = d_inner;
+  const int slices = fv_cdiv(M, 64), cblocks = fv_cdiv(d_inner, 256);
+  int cbw = 1;
+  while (cbw < cblocks && (long)slices * 2 * fv_cdiv(cblocks, cbw * 2) >= 2 * fv_cu_count()) cbw *= 2;
+  const dim3 mgrid(fv_cdiv(cblocks, cbw), slices, 2);
+#define FV_XB(WW)                                                                                              \
+  hipLaunchKernelGGL((xproj_bwd_mmb_kernel<WW>), mgrid, dim3(256), (size_t)64 * (32 * ((WW + 31) / 32) + 4) * 4, \
+                     (hipStream_t)stream, p, cbw)
+  switch (width) {
+    case 56: FV_XB(56); break;
+    case 80: FV_XB(80); break;
+    case 96: FV_XB(96); break;
+    case 112: FV_XB(112); break;
+    case 64: FV_XB(64); break;
+    default: return FV_ERR_UNSUPPORTED;
+  }
+#undef FV_XB
+  FV_LAUNCH_CHECK();
+  return FV_OK;
 }
 
 extern "C" int fv_mixer_xproj_bwd2(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,

@@ -151,6 +151,26 @@ class FlatTrainingState:
                     self._t_src.append(w._fv_shadow)
                     self._t_dst.append(wt)
                     self._t_params.append(w)
+        # ... and of the x_proj weight pairs of the wide models (d_inner >= 768), (2, W, d_inner) -> (2, d_inner, W): the
+        # x_proj adjoint's data half streams them K-contiguous into the bf16 matrix cores (fv_mixer_xproj_bwd3)
+        self._tx_src, self._tx_dst, self._tx_params = [], [], []
+        if shadow_dtype == torch.bfloat16 and dev.type == "cuda":
+            for mod in mixers.values():
+                fv = mod.__dict__.get("_fv", {})
+                ws = fv.get("Wx2_shadow")
+                if ws is None or ws.dtype != torch.bfloat16:
+                    continue
+                _, Wd, d_in = ws.shape
+                if d_in >= 768 and d_in % 64 == 0 and Wd % 8 == 0:
+                    wt = torch.empty(2, d_in, Wd, device=dev, dtype=shadow_dtype)
+                    fv["Wx2_shadow_t"] = wt
+                    fv["Wx2_t_params"] = (mod.x_proj.weight, mod.x_proj_b.weight)
+                    for k in range(2):
+                        self._tx_src.append(ws[k])
+                        self._tx_dst.append(wt[k])
+                    for w in fv["Wx2_t_params"]:
+                        w._fv_shadow_t_version = -1
+                        self._tx_params.append(w)
         self.refresh_shadow()
         # ``model.load_state_dict`` writes the fp32 masters in place: re-cast the shadow right away (the version check in
         # ``_shadow`` would also catch it at the next forward, but a captured HIP graph never runs that check again)
@@ -225,11 +245,13 @@ class FlatTrainingState:
     def refresh_transposed(self):
         """Re-make the transposed in_proj shadows from ``shadow_flat`` (one launch; called after every shadow refresh:
         here and by the fused optimizer step)."""
-        if self._t_src:
-            from .mixer_ops import transpose_bf16_batched
-            transpose_bf16_batched(self._t_src, self._t_dst)
-            for p in self._t_params:
-                p._fv_shadow_t_version = p._version
+        from .mixer_ops import transpose_bf16_batched
+        for src, dst, params in ((self._t_src, self._t_dst, self._t_params),
+                                 (getattr(self, "_tx_src", []), getattr(self, "_tx_dst", []), getattr(self, "_tx_params", []))):
+            if src:
+                transpose_bf16_batched(src, dst)
+                for p in params:
+                    p._fv_shadow_t_version = p._version
 
     @property
     def world_size(self):

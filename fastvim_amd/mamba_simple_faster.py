@@ -50,6 +50,24 @@ def _shadow_t(w, cdt):
     return _shadow(w, cdt).t().contiguous()
 
 
+def _wx2_shadow_t(fv):
+    """The transposed bf16 shadow (2, d_inner, W) of a mixer's x_proj weight pair kept by FlatTrainingState for the wide
+    models, or None.  Re-made by the flat state after every optimizer step; an in-place write to either weight since then
+    (version counters) is caught here and the pair re-transposed from the (already re-cast) plain shadow."""
+    if fv is None:
+        return None
+    wt = fv.get("Wx2_shadow_t")
+    if wt is None:
+        return None
+    params = fv["Wx2_t_params"]
+    if any(w._version != w._fv_shadow_t_version for w in params):
+        with torch.no_grad():
+            for k, w in enumerate(params):
+                wt[k].copy_(_shadow(w, wt.dtype).t())
+                w._fv_shadow_t_version = w._version
+    return wt
+
+
 def _direct_grad(w):
     """The preallocated .grad view my kernels may accumulate into (flat training state), or None."""
     g = w.grad
@@ -330,6 +348,7 @@ class _Ctx:
 
 COMBINE_IN_OUT_PROJ = True      # combine (expand + LayerNorm + gate) as the A-tile producer of the out_proj + add + norm launch (A/B switch)
 CONV_IN_DGRAD = True            # the conv + pool adjoint as the A-tile producer of the in_proj data gradient + norm adjoint (A/B switch)
+XPROJ_TWO_ADDENDS = True        # wide models: the x_proj adjoint's product as a second (bf16) addend of the pooled gradient (A/B switch)
 
 
 def resolve_combine(pack):
@@ -673,7 +692,14 @@ class FastVimMixerFn(torch.autograd.Function):
             elif grouped_x:
                 # the weight gradient dx_dbl^T xc joins the grouped launch at the end of backward (bf16 dx_dbl, as in
                 # the reference's autocast backward); the kernel only adds dx_dbl @ Wx to dxc
-                dxb = M.xproj_bwd(dx_dbl, xc, Wx2[0], Wx2[1], dxc, dw=False)
+                # wide models (flat training state): the product runs on the bf16 matrix cores from the transposed shadow
+                # weight, and where the conv + pool adjoint takes a second addend (14- / 16-column grids) it is written
+                # as its own bf16 tensor instead of a read-modify-write of the fp32 d xc
+                wt = _wx2_shadow_t(fv)
+                if (wt is not None and amax is None and XPROJ_TWO_ADDENDS and M.xproj_bwd3_ok(Mrows, d_in, W_, xc.dtype)
+                        and M.conv_pool_bwd2_ok(rows, cols, tpp, d_in, pool_max)):
+                    dxc2 = torch.empty(dxc.shape, device=dxc.device, dtype=xc.dtype)
+                dxb = M.xproj_bwd(dx_dbl, xc, Wx2[0], Wx2[1], dxc, dw=False, Wx2_t=wt, dxc2=dxc2)
                 xc2 = xc.view(2, Mrows, d_in)
                 for k_ in range(2):
                     _GroupedWgrad.add(dxb[k_][:, :W_], xc2[k_], fv["Wx2_grad"][k_].reshape(-1))

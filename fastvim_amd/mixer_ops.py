@@ -459,11 +459,22 @@ _XPROJ_PRESUM = 8       # chunk count from which dx_dbl is summed by the reducti
                         # channels; same box 30.85 -> 30.78 ms per step, twice; 16 in round 2)
 
 
-def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True):
+def xproj_bwd3_ok(Mrows, d_in, W, dtype):
+    return bool(dtype == torch.bfloat16 and L.lib().fv_mixer_xproj_bwd3_ok(L.i32(Mrows), L.i32(d_in), L.i32(W), L.i32(L.dtype_code(dtype))))
+
+
+def conv_pool_bwd2_ok(rows, cols, tpp, d_in, pool_max):
+    """The conv + pool adjoint takes the pooled gradient as two addends (fp32 dxc + storage-dtype dxc2) at this shape."""
+    return bool(L.lib().fv_mixer_conv_pool_bwd2_ok(L.i32(rows), L.i32(cols), L.i32(tpp), L.i32(d_in), L.i32(int(pool_max))))
+
+
+def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True, Wx2_t=None, dxc2=None):
     """dxc (2, B, Lc, d_in) fp32 += dx_dbl @ Wx (in place); returns d x_proj weights (2, W, d_in) fp32, or
     accumulates them into ``grad_out`` (flat view of that shape) and returns None.  ``dw=False``: the weight gradient
     is left to the caller (grouped GEMM); returns the summed dx_dbl rows as bf16, (2, M, W rounded up to 8) with zero
-    pad columns."""
+    pad columns.  ``Wx2_t`` (2, d_in, W) bf16, with ``dw=False``: the transposed compute-dtype shadow of both weights --
+    the product then runs on the bf16 matrix cores where that form is built (fv_mixer_xproj_bwd3); with ``dxc2`` (bf16,
+    dxc's shape; only where ``xproj_bwd3_ok``) it is WRITTEN there and dxc is left alone."""
     nchunks, _, Mrows, W = dx_dbl_chunks.shape
     d_in = xc.shape[-1]
     lib = L.lib()
@@ -476,9 +487,17 @@ def xproj_bwd(dx_dbl_chunks, xc, Wx, Wx_b, dxc, grad_out=None, dw=True):
     if not dw:
         WP = (W + 7) // 8 * 8
         dxb = torch.empty(2, Mrows, WP, device=xc.device, dtype=torch.bfloat16)
-        rc = lib.fv_mixer_xproj_bwd2(L.ptr(dx_dbl_chunks), L.i32(nchunks), L.ptr(xc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(dxc),
-                                     None, L.ptr(dxb), L.i32(Mrows), L.i32(d_in), L.i32(W),
-                                     L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
+        if Wx2_t is not None:
+            assert Wx2_t.dtype == torch.bfloat16 and Wx2_t.is_contiguous() and tuple(Wx2_t.shape) == (2, d_in, W)
+            assert dxc2 is None or (dxc2.dtype == torch.bfloat16 and dxc2.is_contiguous() and dxc2.numel() == dxc.numel())
+            rc = lib.fv_mixer_xproj_bwd3(L.ptr(dx_dbl_chunks), L.i32(nchunks), L.ptr(xc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(Wx2_t),
+                                         L.ptr(dxc), L.ptr(dxc2), L.ptr(dxb), L.i32(Mrows), L.i32(d_in), L.i32(W),
+                                         L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
+        else:
+            assert dxc2 is None
+            rc = lib.fv_mixer_xproj_bwd2(L.ptr(dx_dbl_chunks), L.i32(nchunks), L.ptr(xc), L.ptr(Wx), L.ptr(Wx_b), L.ptr(dxc),
+                                         None, L.ptr(dxb), L.i32(Mrows), L.i32(d_in), L.i32(W),
+                                         L.i32(L.dtype_code(xc.dtype)), L.stream_of(xc))
         L.check(rc, "mixer_xproj_bwd")
         return dxb
     ns = lib.fv_mixer_xproj_bwd_slices(L.i32(Mrows))

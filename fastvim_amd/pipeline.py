@@ -111,7 +111,7 @@ class SegmentedTrainStep:
         f, o = self.flat, self.opt
         # every tensor attribute of the optimizer (moments, EMA, step count, lr, decay mask, ...) and the state's own buffers:
         # whatever a warm-up step may advance is put back, not a hand-picked list
-        bufs = [f.param_flat, f.shadow_flat] + list(getattr(f, "_t_dst", []))      # (+ the transposed in_proj shadows)
+        bufs = [f.param_flat, f.shadow_flat] + list(getattr(f, "_t_dst", [])) + list(getattr(f, "_tx_dst", []))   # (+ the transposed in_proj / x_proj shadows)
         for v in vars(o).values():
             if torch.is_tensor(v) and v.is_cuda and all(v is not b for b in bufs):
                 bufs.append(v)

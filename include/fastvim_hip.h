@@ -502,6 +502,18 @@ int fv_mixer_xproj_bwd(const float* dx_dbl_partials, int nchunks, const void* xc
 int fv_mixer_xproj_bwd2(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
                         const float* x_proj_w_b, float* dxc, float* dW_partials, void* dx_dbl_bf16, int M, int d_inner,
                         int width, int dtype, fv_stream_t stream);
+/* The data half of fv_mixer_xproj_bwd2 (dW_partials == NULL; `dx_dbl_bf16` required) with the TRANSPOSED bf16 copy of both
+ * weights, `x_proj_w_t_bf16` (2, d_inner, width): bf16(summed dx_dbl) @ bf16(weight) on the bf16 matrix cores, fp32
+ * accumulate -- the operands of the reference's autocast backward (selective_scan_interface.py:726-734).  The product is
+ * added to `dxc` (fp32, in place), or, with `dxc2_bf16` (2, M, d_inner) non-NULL, WRITTEN there in bf16 and `dxc` left alone
+ * (the conv + pool adjoint then takes both: fv_mixer_conv_pool_bwd2).  Built where fv_mixer_xproj_bwd3_ok says so (bf16
+ * storage, d_inner a multiple of 64 from 768 up, width 56 / 64 / 80 / 96 / 112); any other call, or a NULL transposed
+ * weight, is fv_mixer_xproj_bwd2 with the fp32 weights (and refuses `dxc2_bf16`).  (Added in round 6; ABI version
+ * unchanged: new symbols.) */
+int fv_mixer_xproj_bwd3_ok(int M, int d_inner, int width, int dtype);
+int fv_mixer_xproj_bwd3(const float* dx_dbl_partials, int nchunks, const void* xc, const float* x_proj_w,
+                        const float* x_proj_w_b, const void* x_proj_w_t_bf16, float* dxc, void* dxc2_bf16,
+                        void* dx_dbl_bf16, int M, int d_inner, int width, int dtype, fv_stream_t stream);
 
 /* Soft-target cross-entropy, value and gradient in one call (replaces timm.loss.SoftTargetCrossEntropy as the
  * reference trainer uses it, imagenet_classification/supervised_imagenet.py:83, 109-115, and its autograd):
