@@ -101,12 +101,25 @@ template <typename T>
 __device__ __forceinline__ void stage_dbl(const ScanClParams& p, int dir, int b, float* s_dbl, int RP) {
   const int W = p.R + 2 * N, WP = RP + 2 * N;
   const T* dbl = (const T*)p.xdbl + ((size_t)dir * p.B + b) * p.Lc * W;
-  for (int e = threadIdx.x; e < p.Lc * WP; e += blockDim.x) {
-    const int l = e / WP, c = e - l * WP;
-    float v = 0.f;
-    if (c < p.R) v = io<T>::ld(dbl + (size_t)l * W + c);
-    else if (c >= RP) v = io<T>::ld(dbl + (size_t)l * W + p.R + (c - RP));
-    s_dbl[e] = v;
+  // four elements per lane and trip, their loads issued together from clamped addresses (round 6: one conditional load per
+  // trip was a dependent L2 round trip per trip in front of the barrier -- five of them at FastVim-B's 14 x 80 rows)
+  const int n = p.Lc * WP;
+  for (int e0 = threadIdx.x; e0 < n; e0 += 4 * blockDim.x) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + u * (int)blockDim.x, n - 1);
+      const int l = e / WP, c = e - l * WP;
+      const bool ok = c < p.R || c >= RP;
+      const int src = c < p.R ? c : p.R + (c - RP);
+      const float x = io<T>::ld(dbl + (size_t)l * W + (ok ? src : 0));
+      v[u] = ok ? x : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * (int)blockDim.x;
+      if (e < n) s_dbl[e] = v[u];
+    }
   }
 }
 
