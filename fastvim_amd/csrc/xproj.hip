@@ -126,6 +126,25 @@ __global__ __launch_bounds__(256, 2) void xproj_bwd_mm_kernel(XprojParams p, int
   const int dir = blockIdx.z, m0 = blockIdx.y * 64;
   const int nr = min(64, p.M - m0);
   // stage the rows, summing the channel-chunk partials in fixed order (six in flight per lane, like the kernel above)
+  if (W % 4 == 0 && p.nchunks == 1) {
+    // already summed: every 16-byte piece of the 64 rows requested at once (see xproj_bwd_mmb_kernel: the general loop has
+    // one load in flight per lane and trip with a single chunk)
+    constexpr int NV = (64 * (W4 / 4) + 255) / 256;
+    const float* src = p.dxdbl_part + ((size_t)dir * p.M + m0) * W;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * 256, r = e / (W4 / 4), c4 = e - r * (W4 / 4);
+      const bool ok = e < 64 * (W4 / 4) && r < nr && 4 * c4 < W;
+      v[i] = *reinterpret_cast<const float4*>(src + (ok ? r * W + 4 * c4 : 0));
+      if (!ok) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * 256, r = e / (W4 / 4), c4 = e - r * (W4 / 4);
+      if (e < 64 * (W4 / 4)) *reinterpret_cast<float4*>(s_g + r * WS + 4 * c4) = v[i];
+    }
+  } else {
   {
 #pragma clang fp reassociate(off) contract(off)      // (the published rows are the same bits in every form of this kernel)
   for (int e = tid; e < 64 * W4; e += 256) {
@@ -143,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void xproj_bwd_mm_kernel(XprojParams p, int
       }
     }
     s_g[r * WS + c] = t;
+  }
   }
   }
   __syncthreads();
@@ -275,25 +295,43 @@ __global__ __launch_bounds__(256, 2) void xproj_bwd_mmb_kernel(XprojParams p, in
       if (e < 64 * (KP / 4)) *reinterpret_cast<float4*>(s_g + r * WS + 4 * c4) = v[i];
     }
   } else {
-  {
+    // four elements per lane and trip, each with up to six chunk partials in flight (one element per trip left a single
+    // dependent round trip per chunk group and trip: sixteen trips at the channel model's four chunks)
 #pragma clang fp reassociate(off) contract(off)      // (the published rows are the same bits in every form of this kernel)
-  for (int e = tid; e < 64 * KP; e += 256) {
-    const int r = e / KP, c = e - r * KP;
-    float t = 0.f;
-    if (r < nr && c < W) {
+    for (int e0 = tid; e0 < 64 * KP; e0 += 4 * 256) {
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      int off[4];
+      bool ok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j * 256, r = e / KP, c = e - r * KP;
+        ok[j] = e < 64 * KP && r < nr && c < W;
+        off[j] = ok[j] ? r * W + c : 0;
+      }
       for (int c0 = 0; c0 < p.nchunks; c0 += 6) {
-        float v[6];
+        float v[4][6];
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
           const bool on = c0 + u < p.nchunks;
-          v[u] = on ? p.dxdbl_part[(((size_t)(c0 + u) * 2 + dir) * p.M + m0 + r) * W + c] : 0.f;
+          const float* src = p.dxdbl_part + (((size_t)(on ? c0 + u : 0) * 2 + dir) * p.M + m0) * W;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x = src[off[j]];
+            v[j][u] = on ? x : 0.f;
+          }
         }
-        t += ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] += ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3])) + (v[j][4] + v[j][5]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j * 256;
+        if (e < 64 * KP) {
+          const int r = e / KP, c = e - r * KP;
+          s_g[r * WS + c] = ok[j] ? t[j] : 0.f;
+        }
       }
     }
-    s_g[r * WS + c] = t;
-  }
-  }
   }
   __syncthreads();
   if (p.dxdbl_out && blockIdx.x == 0) {      // one channel block publishes the summed rows (bf16; W is a multiple of 8)
