@@ -716,15 +716,18 @@ extern "C" int fv_mixer_conv_pool_bwd2(const void* xz, const void* d_o, const fl
 
 // Several independent fixed-order reductions in ONE launch (gradient partials of different kernels /
 // layers whose sums are only needed before the optimizer step).
-constexpr int MAXJOBS = 96;      // 96 x 32 bytes of job table + prefix stay under the 4 KiB kernel-argument limit
+// 144 x 26 bytes of job table + prefix = 3 752 bytes: under the 4 KiB kernel-argument segment less the 256 bytes of implicit
+// arguments (round 6: 96 x 32 before -- a FastVim-T step's 197 jobs are two launches now, not three)
+constexpr int MAXJOBS = 144;
 struct ReduceJobs {
   const float* in[MAXJOBS];
   float* out[MAXJOBS];
-  int S[MAXJOBS];
-  long n[MAXJOBS];
-  int blk_end[MAXJOBS];   // exclusive prefix of blocks per job
+  unsigned n[MAXJOBS];           // elements per partial (< 2^32: checked at the launch)
+  int blk_end[MAXJOBS];          // exclusive prefix of blocks per job
+  unsigned short S[MAXJOBS];     // partials (<= 65 535: checked at the launch)
   int njobs, accumulate;
 };
+static_assert(sizeof(ReduceJobs) <= 4096 - 256, "job table must fit the kernel-argument segment");
 
 __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J) {
   __shared__ float s_acc[8][33];
@@ -763,7 +766,8 @@ extern "C" int fv_reduce_partials_multi(const float* const* partials, float* con
   int blocks = 0;
   for (int j = 0; j < njobs; ++j) {
     FV_CHECK(partials[j] && outs[j] && n_partials[j] > 0, "reduce_partials_multi: bad job %d", j);
-    J.in[j] = partials[j]; J.out[j] = outs[j]; J.S[j] = n_partials[j]; J.n[j] = (long)ns[j];
+    FV_CHECK(n_partials[j] <= 65535 && ns[j] < 0xffffffffull, "reduce_partials_multi: job %d too large for the packed table", j);
+    J.in[j] = partials[j]; J.out[j] = outs[j]; J.S[j] = (unsigned short)n_partials[j]; J.n[j] = (unsigned)ns[j];
     blocks += fv_cdiv((long)ns[j], n_partials[j] <= FLAT_S ? 256 : 32);
     J.blk_end[j] = blocks;
   }

@@ -105,12 +105,12 @@ def combine_fwd(xz, skip, yc, ln_w, ln_b, eps, rows, cols, transposed, tpp=1, ou
 
 class _Deferred:
     """Gradient-partial reductions whose results are only needed before the optimizer step are queued
-    (flat training state only) and issued up to 96 at a time by ONE launch (fv_reduce_partials_multi).
+    (flat training state only) and issued up to 144 at a time by ONE launch (fv_reduce_partials_multi).
     ``side = True`` issues them on a second HIP stream (forked after the producers, joined in
     ``flush_reductions``; partial buffers stay referenced until the join): measured 3 % SLOWER under graph
     replay on MI355X (9.54 vs 9.28 ms/step), like the weight-gradient side stream, so it is off by default."""
     enabled = False
-    max_jobs = 96        # per launch (the C side's table size)
+    max_jobs = 144       # per launch (the C side's table size)
     side = False         # second-stream issue: measured slower (see above)
     jobs = []
     stream = None

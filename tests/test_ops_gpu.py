@@ -320,7 +320,7 @@ def test_xproj_fwd_kernel_vs_torch(Mrows, d_in, W):
 
 
 def test_deferred_partial_reductions_match_single_launches():
-    """fv_reduce_partials_multi (up to 96 queued gradient-partial reductions in one launch) against fp64 and against
+    """fv_reduce_partials_multi (up to 144 queued gradient-partial reductions in one launch) against fp64 and against
     the one-job kernel, which shares its summation code (bitwise equal: an eager model and one on the flat training
     state stay in lock-step); a repeat is bitwise identical."""
     from fastvim_amd import mixer_ops as M
@@ -382,3 +382,26 @@ def test_soft_target_cross_entropy_vs_oracle(B, C, dtype):
         loss2 = SoftTargetCrossEntropy()(x, t)
         (loss2 * 2.5).backward()
         assert torch.equal(loss, loss2) and torch.equal(g1, x.grad)
+
+
+def test_deferred_reductions_across_the_job_table_boundary():
+    """200 queued reductions (more than one launch's packed table of 144 jobs) of mixed shapes: every sum is the single-job
+    kernel's, bit for bit."""
+    from fastvim_amd import mixer_ops as M
+    torch.manual_seed(3)
+    shapes = [(6, 1024), (64, 352), (12, 96), (130, 132), (1, 40), (9, 260)]
+    parts = [torch.randn(*shapes[k % len(shapes)], device="cuda") for k in range(200)]
+    base = [torch.randn(p.shape[1], device="cuda") for p in parts]
+    single = [b.clone() for b in base]
+    for p, o in zip(parts, single):
+        M.reduce_partials(p, p.shape[0], out=o, accumulate=True, defer=False)
+    multi = [b.clone() for b in base]
+    M.defer_reductions(True)
+    try:
+        for p, o in zip(parts, multi):
+            M.reduce_partials(p, p.shape[0], out=o, accumulate=True)
+        M.flush_reductions()
+    finally:
+        M.defer_reductions(False)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(single, multi))

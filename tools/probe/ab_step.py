@@ -22,6 +22,8 @@ if "--wgrad-splits" in a:       # --wgrad-splits IN,OUT: split-K factors of the 
         return _orig(Kd, target, M, N)
     _g2.grouped_splits = _gs
     import fastvim_amd.mamba_simple_faster as _msf
+if "--max-jobs" in a:           # jobs per deferred-reduction launch (96 until round 6, 144 since)
+    mixer_ops._Deferred.max_jobs = int(a[a.index("--max-jobs") + 1])
 if "--presum" in a:
     mixer_ops._XPROJ_PRESUM = int(a[a.index("--presum") + 1])
 torch.cuda.set_device(0)
