@@ -716,12 +716,16 @@ extern "C" int fv_mixer_conv_pool_bwd2(const void* xz, const void* d_o, const fl
 
 // Several independent fixed-order reductions in ONE launch (gradient partials of different kernels /
 // layers whose sums are only needed before the optimizer step).
-// 144 x 26 bytes of job table + prefix = 3 752 bytes: under the 4 KiB kernel-argument segment less the 256 bytes of implicit
-// arguments (round 6: 96 x 32 before -- a FastVim-T step's 197 jobs are two launches now, not three)
-constexpr int MAXJOBS = 144;
+// The job table rides in the kernel arguments: 4 KiB less 256 bytes of implicit arguments.  Round 6 packs a job into 18
+// bytes -- both pointers as 32-bit FLOAT offsets from the lowest pointer of the launch (16 GB of reach; a launch whose
+// buffers lie further apart is cut in two), 32-bit lengths, 16-bit partial counts -- 208 jobs per launch instead of 96: a
+// FastVim-T step's 197 jobs are ONE launch (three before), and the big and small jobs of a launch fill each other's gaps.
+constexpr int MAXJOBS = 208;
 struct ReduceJobs {
-  const float* in[MAXJOBS];
-  float* out[MAXJOBS];
+  const float* in_base;
+  float* out_base;
+  unsigned in_off[MAXJOBS];      // partials = in_base + in_off (floats)
+  unsigned out_off[MAXJOBS];     // out = out_base + out_off (floats)
   unsigned n[MAXJOBS];           // elements per partial (< 2^32: checked at the launch)
   int blk_end[MAXJOBS];          // exclusive prefix of blocks per job
   unsigned short S[MAXJOBS];     // partials (<= 65 535: checked at the launch)
@@ -738,11 +742,12 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J
   }
   const int job = lo;
   const int blk = blockIdx.x - (job ? J.blk_end[job - 1] : 0);
-  const float* __restrict__ in = J.in[job];
+  const float* __restrict__ in = J.in_base + J.in_off[job];
+  float* __restrict__ out = J.out_base + J.out_off[job];
   const int S = J.S[job];
   const size_t n = (size_t)J.n[job];
   if (S <= FLAT_S) {
-    flat_sum(in, J.out[job], S, n, (size_t)blk * 256 + threadIdx.x, J.accumulate);
+    flat_sum(in, out, S, n, (size_t)blk * 256 + threadIdx.x, J.accumulate);
     return;
   }
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
@@ -753,29 +758,52 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += s_acc[k][c];
-    float* out = J.out[job];
     out[i] = J.accumulate ? out[i] + t : t;
   }
+}
+
+static int reduce_multi_launch(const float* const* partials, float* const* outs, const int* n_partials, const size_t* ns,
+                               int njobs, int accumulate, hipStream_t st) {
+  uintptr_t in_lo = ~(uintptr_t)0, in_hi = 0, out_lo = ~(uintptr_t)0, out_hi = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const uintptr_t a = (uintptr_t)partials[j], b = (uintptr_t)outs[j];
+    in_lo = a < in_lo ? a : in_lo; in_hi = a > in_hi ? a : in_hi;
+    out_lo = b < out_lo ? b : out_lo; out_hi = b > out_hi ? b : out_hi;
+  }
+  const uintptr_t reach = (uintptr_t)0xffffffffull * 4;
+  if (njobs > 1 && (in_hi - in_lo > reach || out_hi - out_lo > reach)) {      // buffers too far apart for 32-bit offsets
+    const int h = njobs / 2;
+    int rc = reduce_multi_launch(partials, outs, n_partials, ns, h, accumulate, st);
+    if (rc) return rc;
+    return reduce_multi_launch(partials + h, outs + h, n_partials + h, ns + h, njobs - h, accumulate, st);
+  }
+  ReduceJobs J{};
+  J.in_base = (const float*)in_lo; J.out_base = (float*)out_lo;
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    J.in_off[j] = (unsigned)(((uintptr_t)partials[j] - in_lo) >> 2);
+    J.out_off[j] = (unsigned)(((uintptr_t)outs[j] - out_lo) >> 2);
+    J.S[j] = (unsigned short)n_partials[j]; J.n[j] = (unsigned)ns[j];
+    blocks += fv_cdiv((long)ns[j], n_partials[j] <= FLAT_S ? 256 : 32);
+    J.blk_end[j] = blocks;
+  }
+  J.njobs = njobs; J.accumulate = accumulate;
+  if (blocks == 0) return FV_OK;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, st, J);
+  FV_LAUNCH_CHECK();
+  return FV_OK;
 }
 
 extern "C" int fv_reduce_partials_multi(const float* const* partials, float* const* outs, const int* n_partials,
                                         const size_t* ns, int njobs, int accumulate, fv_stream_t stream) {
   FV_CHECK(partials && outs && n_partials && ns && njobs > 0 && njobs <= MAXJOBS,
            "reduce_partials_multi: 1..%d jobs", MAXJOBS);
-  ReduceJobs J{};
-  int blocks = 0;
   for (int j = 0; j < njobs; ++j) {
     FV_CHECK(partials[j] && outs[j] && n_partials[j] > 0, "reduce_partials_multi: bad job %d", j);
     FV_CHECK(n_partials[j] <= 65535 && ns[j] < 0xffffffffull, "reduce_partials_multi: job %d too large for the packed table", j);
-    J.in[j] = partials[j]; J.out[j] = outs[j]; J.S[j] = (unsigned short)n_partials[j]; J.n[j] = (unsigned)ns[j];
-    blocks += fv_cdiv((long)ns[j], n_partials[j] <= FLAT_S ? 256 : 32);
-    J.blk_end[j] = blocks;
+    FV_CHECK((((uintptr_t)partials[j] | (uintptr_t)outs[j]) & 3) == 0, "reduce_partials_multi: job %d is not float-aligned", j);
   }
-  J.njobs = njobs; J.accumulate = accumulate;
-  if (blocks == 0) return FV_OK;
-  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
-  FV_LAUNCH_CHECK();
-  return FV_OK;
+  return reduce_multi_launch(partials, outs, n_partials, ns, njobs, accumulate, (hipStream_t)stream);
 }
 
 extern "C" int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n, int accumulate,

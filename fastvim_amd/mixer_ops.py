@@ -110,7 +110,8 @@ class _Deferred:
     ``flush_reductions``; partial buffers stay referenced until the join): measured 3 % SLOWER under graph
     replay on MI355X (9.54 vs 9.28 ms/step), like the weight-gradient side stream, so it is off by default."""
     enabled = False
-    max_jobs = 144       # per launch (the C side's table size)
+    max_jobs = 144       # per launch (the C side's table takes 208: one launch for a FastVim-T step's 197 jobs measured 5.216 ms
+                         # against 5.209 with two, 5.237 with the three of a 96-job table -- profiles/r06_ab_reduce_one_launch.log)
     side = False         # second-stream issue: measured slower (see above)
     jobs = []
     stream = None

@@ -321,7 +321,7 @@ int fv_mixer_conv_pool_bwd2(const void* xz, const void* d_o, const float* dxc, c
  * adds into `out` (gradient accumulation straight into a parameter's .grad). */
 int fv_reduce_partials(const float* partials, float* out, int n_partials, size_t n, int accumulate,
                        fv_stream_t stream);
-/* Up to 144 such reductions in one launch (host arrays of device pointers / sizes; at most 65 535 partials of fewer
+/* Up to 208 such reductions in one launch (host arrays of device pointers / sizes; at most 65 535 partials of fewer
  * than 2^32 elements each; 96 until round 6). */
 int fv_reduce_partials_multi(const float* const* partials, float* const* outs, const int* n_partials,
                              const size_t* ns, int njobs, int accumulate, fv_stream_t stream);

@@ -320,7 +320,7 @@ def test_xproj_fwd_kernel_vs_torch(Mrows, d_in, W):
 
 
 def test_deferred_partial_reductions_match_single_launches():
-    """fv_reduce_partials_multi (up to 144 queued gradient-partial reductions in one launch) against fp64 and against
+    """fv_reduce_partials_multi (up to 208 queued gradient-partial reductions in one launch) against fp64 and against
     the one-job kernel, which shares its summation code (bitwise equal: an eager model and one on the flat training
     state stay in lock-step); a repeat is bitwise identical."""
     from fastvim_amd import mixer_ops as M
@@ -385,12 +385,12 @@ def test_soft_target_cross_entropy_vs_oracle(B, C, dtype):
 
 
 def test_deferred_reductions_across_the_job_table_boundary():
-    """200 queued reductions (more than one launch's packed table of 144 jobs) of mixed shapes: every sum is the single-job
+    """260 queued reductions (more than one launch's packed table of 208 jobs) of mixed shapes: every sum is the single-job
     kernel's, bit for bit."""
     from fastvim_amd import mixer_ops as M
     torch.manual_seed(3)
     shapes = [(6, 1024), (64, 352), (12, 96), (130, 132), (1, 40), (9, 260)]
-    parts = [torch.randn(*shapes[k % len(shapes)], device="cuda") for k in range(200)]
+    parts = [torch.randn(*shapes[k % len(shapes)], device="cuda") for k in range(260)]
     base = [torch.randn(p.shape[1], device="cuda") for p in parts]
     single = [b.clone() for b in base]
     for p, o in zip(parts, single):
