@@ -457,8 +457,8 @@ TRACE_NAMES = {
     "xproj_bwd": "xproj_bwd_kernel", "combine_out_proj_addnorm_fwd": "combine_out_proj_addnorm_kernel",
     "conv_pool_bwd_dgrad_addnorm_bwd": "conv_pool_bwd_dgrad_kernel",
 }
-PMC_TRAFFIC_JSON = "r06_v3_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
-STEP_TRACE_CSV = "r06_v3_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r05_v4 (profiles/README.md)
+PMC_TRAFFIC_JSON = "r06_v4_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
+STEP_TRACE_CSV = "r06_v4_graph_step_kernel_stats.csv"      # committed: bash tools/profile_step.sh r05_v4 (profiles/README.md)
 
 
 def in_step_trace_us():
