@@ -283,9 +283,13 @@ def kernel_table(B, rows, cols, d, depth, dtype, tpp=1):
         _, T["dxdbl_chunks"], _ = M.scan_bwd(T["xc"], T["x_dbl"], Wdt, bdt, A_log, Wdt, bdt, A_log, T["dyc"], keep_chunks=True)
         nch = T["dxdbl_chunks"].shape[0]
         if nch < M._XPROJ_PRESUM:
-            table["xproj_bwd"] = (lambda s: M.xproj_bwd(s["dxdbl_chunks"], s["xc"], Wx32[0], Wx32[1], s["dxc"], dw=False),
+            # as the flat training step issues it: where the bf16 matrix-core form is built (round 6, wide models) the
+            # product is taken from the transposed bf16 shadow weight
+            WxT = (Wx32.to(torch.bfloat16).transpose(1, 2).contiguous()
+                   if M.xproj_bwd3_ok(B * prow, d_in, W_, dtype) else None)
+            table["xproj_bwd"] = (lambda s: M.xproj_bwd(s["dxdbl_chunks"], s["xc"], Wx32[0], Wx32[1], s["dxc"], dw=False, Wx2_t=WxT),
                                   ("dxdbl_chunks", "dxc"),
-                                  nch * 2 * B * prow * W_ * 4 + 2 * (2 * small * 4) + 2 * W_ * d_in * 4
+                                  nch * 2 * B * prow * W_ * 4 + 2 * (2 * small * 4) + 2 * W_ * d_in * (2 if WxT is not None else 4)
                                   + 2 * B * prow * ((W_ + 7) // 8 * 8) * 2, 1)
     out = {}
     # the backward wrappers sum their per-block gradient partials right away when no flat gradient is attached; in
@@ -454,7 +458,7 @@ TRACE_NAMES = {
     "combine_bwd": "combine_bwd_wave_kernel", "scan_bwd": "scan_cl_bwd_short_kernel", "conv_pool_bwd": "conv_pool_bwd_row_kernel",
     "add_rmsnorm_fwd": "add_norm_fwd3_kernel", "gemm_out_proj_addnorm_fwd": "gemm_addnorm_kernel",
     "gemm_in_proj_dgrad_addnorm_bwd": "gemm_dgrad_addnorm_bwd_kernel", "gemm_in_proj_fwd": "gemm_bf16_kernel<0, 0, 2, 2, true, 4, 5>",
-    "xproj_bwd": "xproj_bwd_kernel", "combine_out_proj_addnorm_fwd": "combine_out_proj_addnorm_kernel",
+    "xproj_bwd": "xproj_bwd_mmb_kernel", "combine_out_proj_addnorm_fwd": "combine_out_proj_addnorm_kernel",
     "conv_pool_bwd_dgrad_addnorm_bwd": "conv_pool_bwd_dgrad_kernel",
 }
 PMC_TRAFFIC_JSON = "r06_v4_pmc_traffic.json"               # same script: three --pmc passes folded by tools/pmc_summary.py
